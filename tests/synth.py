@@ -1,0 +1,182 @@
+"""Deterministic test inputs (SURVEY.md section 8d generator) and the named parity cases.
+
+Used by tests/golden/make_golden.py (to feed the real reference) and by the tests
+(to feed the oracle and the HIP path the same bytes).  Fixtures under
+tests/golden/ hold only the reference's OUTPUTS for these inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_G = 0x4D49454B4B490001
+SEED_Q = 0x4D49454B4B490002
+SEED_M = 0x4D49454B4B490003
+_M64 = (1 << 64) - 1
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def splitmix64(z):
+    """Vectorised splitmix64 on uint64 arrays (wrap-around arithmetic)."""
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def splitmix64_int(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def genome_bases(g: int, off: int, n: int) -> bytes:
+    """n bases of synthetic genome g starting at position off."""
+    w0, w1 = off >> 5, (off + n + 31) >> 5
+    idx = np.arange(w0, w1, dtype=np.uint64)
+    words = splitmix64(np.uint64(SEED_G) ^ (np.uint64(g) << np.uint64(32)) ^ idx)
+    shifts = (np.uint64(62) - np.uint64(2) * np.arange(32, dtype=np.uint64))
+    codes = ((words[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+    lo = off - (w0 << 5)
+    return _ACGT[codes[lo:lo + n]].tobytes()
+
+
+def query_origin(q: int, G: int, L: int, qlen: int):
+    return q % G, splitmix64_int(SEED_Q ^ q) % (L - qlen)
+
+
+def mutate(seq: bytes, q: int, rate: float) -> bytes:
+    """Substitute round(rate*len) positions (position/base from SEED_M stream)."""
+    s = bytearray(seq)
+    for j in range(int(round(rate * len(s)))):
+        r = splitmix64_int(SEED_M ^ (q << 20) ^ j)
+        pos = r % len(s)
+        s[pos] = b"ACGT"[((b"ACGT".index(bytes([s[pos]])) if bytes([s[pos]]) in b"ACGT" else 0)
+                          + 1 + ((r >> 40) % 3)) % 4]
+    return bytes(s)
+
+
+def fasta(name: str, seq: bytes, width: int = 80) -> bytes:
+    lines = [b">" + name.encode()]
+    lines += [seq[i:i + width] for i in range(0, len(seq), width)]
+    return b"\n".join(lines) + b"\n"
+
+
+class Case:
+    """One named parity case: parameters + genome files + query records."""
+
+    def __init__(self, name, k, h, f, b, threshold):
+        self.name, self.k, self.h, self.f, self.b, self.threshold = name, k, h, f, b, threshold
+        self.genome_files = []   # (file name, file bytes, gzip?)
+        self.queries = []        # (header bytes incl '>', sequence bytes)
+
+    @property
+    def fp_bits(self):
+        return 5 + self.f
+
+    def genome_sequences(self):
+        """Concatenated non-'>' lines per file, as index_file_of_file builds them
+        (Miekki.cpp:559-567); files whose sequence is shorter than k are skipped (569)."""
+        out = []
+        for _, data, _ in self.genome_files:
+            seq = b"".join(l for l in data.split(b"\n") if not l.startswith(b">"))
+            if len(seq) >= self.k:
+                out.append(seq)
+        return out
+
+    def query_sequences(self):
+        """Records query_file keeps (Miekki.cpp:465): sequence at least k long."""
+        return [(h, s) for h, s in self.queries if len(s) >= self.k]
+
+
+def _std_queries(case, G, L, n, qlen=1000, start=0):
+    for q in range(start, start + n):
+        g, off = query_origin(q, G, L, qlen)
+        case.queries.append((f">q{q}_g{g}_p{off}".encode(), genome_bases(g, off, qlen)))
+
+
+def case_c1() -> Case:
+    """BASELINE config 1: 10 synthetic 5 Mb genomes, -k 31 -h 14, 100 x 1 kb queries."""
+    c = Case("c1", 31, 14, 3, 33, 200)
+    G, L = 10, 5_000_000
+    for g in range(G):
+        c.genome_files.append((f"genome{g}.fa", fasta(f"genome{g}", genome_bases(g, 0, L)), False))
+    _std_queries(c, G, L, 100)
+    # h=14 gives empty hit lists for 1 kb queries: add long ones
+    for q in range(100, 104):
+        g, off = query_origin(q, G, L, 50_000)
+        c.queries.append((f">long{q}_g{g}_p{off}".encode(), genome_bases(g, off, 50_000)))
+    return c
+
+
+def case_h20() -> Case:
+    """h=20 with every awkward query shape the reference accepts."""
+    c = Case("h20", 31, 20, 3, 32, 200)
+    G, L = 6, 1_000_000
+    for g in range(G):
+        c.genome_files.append((f"genome{g}.fa", fasta(f"genome{g}", genome_bases(g, 0, L)), g == 2))
+    _std_queries(c, G, L, 40)
+    for q in range(40, 50):                                  # non-genomic queries
+        c.queries.append((f">miss{q}".encode(), genome_bases(1_000_000 + q, 0, 1000)))
+    for q in range(50, 60):                                  # 1 % substitutions
+        g, off = query_origin(q, G, L, 1000)
+        c.queries.append((f">mut{q}_g{g}".encode(), mutate(genome_bases(g, off, 1000), q, 0.01)))
+    g, off = query_origin(60, G, L, 50_000)
+    c.queries.append((b">long60", genome_bases(g, off, 50_000)))
+    c.queries.append((b">whole_genome3", genome_bases(3, 0, L)))
+    s = bytearray(genome_bases(1, 1234, 1000))               # N and lower-case inside
+    s[100] = ord("N"); s[101] = ord("N"); s[500:520] = bytes(s[500:520]).lower(); s[700] = ord("n")
+    c.queries.append((b">with_N_and_lower", bytes(s)))
+    s = bytearray(genome_bases(1, 4321, 1000)); s[3] = ord("N")  # non-ACGT inside the k-1 seed
+    c.queries.append((b">N_in_seed", bytes(s)))
+    c.queries.append((b">len_k", genome_bases(0, 10, 31)))       # zero k-mers processed
+    c.queries.append((b">len_k_plus_1", genome_bases(0, 10, 32)))
+    c.queries.append((b">len_k_minus_1", genome_bases(0, 10, 30)))  # skipped by the driver
+    c.queries.append((b">len_k_plus_5", genome_bases(0, 777, 36)))
+    return c
+
+
+def case_w16() -> Case:
+    """2-byte fingerprints: reference built with minimizer=uint16_t, run with -f 11."""
+    c = Case("w16", 31, 17, 11, 33, 100)
+    G, L = 6, 500_000
+    for g in range(G):
+        c.genome_files.append((f"genome{g}.fa", fasta(f"genome{g}", genome_bases(g, 0, L)), False))
+    _std_queries(c, G, L, 30)
+    for q in range(30, 36):
+        c.queries.append((f">miss{q}".encode(), genome_bases(2_000_000 + q, 0, 1000)))
+    g, off = query_origin(36, G, L, 20_000)
+    c.queries.append((b">long36", genome_bases(g, off, 20_000)))
+    return c
+
+
+def case_messy() -> Case:
+    """k=21, h=12: multi-FASTA contigs, ragged/empty lines, lower-case and N in
+    genomes, a gzip'd genome, a too-short genome, many buckets shared per query."""
+    c = Case("messy", 21, 12, 3, 32, 20)
+    L = 60_000
+    a = genome_bases(50, 0, L)
+    c.genome_files.append(("multi.fa", b">c1 first\n" + a[:20_000] + b"\n\n>c2\n" + a[20_000:20_010]
+                           + b"\n" + a[20_010:45_000] + b"\n>c3\n" + a[45_000:] + b"\n", False))
+    bseq = bytearray(genome_bases(51, 0, L))
+    bseq[1000:1100] = bytes(bseq[1000:1100]).lower()
+    for p in (5, 3000, 3001, 3002, 40_000):
+        bseq[p] = ord("N")
+    c.genome_files.append(("lowerN.fa", fasta("lowerN", bytes(bseq), 70), True))
+    c.genome_files.append(("tiny.fa", b">tiny\nACGTACGT\n", False))          # < k: skipped
+    c.genome_files.append(("plain.fa", fasta("plain", genome_bases(52, 0, L), 61), False))
+    c.genome_files.append(("nohdr.fa", genome_bases(53, 0, 30_000) + b"\n", False))
+    srcs = [a, bytes(bseq), genome_bases(52, 0, L), genome_bases(53, 0, 30_000)]
+    for q in range(24):
+        src = srcs[q % 4]
+        off = splitmix64_int(SEED_Q ^ (7000 + q)) % (len(src) - 3000)
+        n = 300 + 100 * (q % 20)
+        c.queries.append((f">m{q}".encode(), src[off:off + n]))
+    c.queries.append((b">whole_multi", a))
+    c.queries.append((b">miss", genome_bases(3_000_000, 0, 2500)))
+    return c
+
+
+CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy}
