@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- query x genome fingerprint comparisons/s on MI355X.
+
+One "step" = one pass of the hot path (query sketch + Bloom gate + fingerprint
+scan + fused threshold filter, then -- for N > 1 -- the single RCCL gather of the
+per-query top candidates) over a batch of synthetic 1 kb queries that is already
+resident in HBM, against an index of synthetic 5 Mb genomes that was built on the
+device by the sketch kernels before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--genomes-per-gpu G] [--queries Q] [--h H] [--fp-bits 8|16]
+
+For N > 1 it is launched by torch.distributed.run, one rank per GPU; genomes are
+sharded by rank (rank r owns ids [r*G, (r+1)*G)), every rank scans all queries
+against its shard, and the candidate rows are gathered on rank 0 (weak scaling:
+per-GPU work is fixed, total genomes = N * G).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+GENOME_LEN = 5_000_000
+QUERY_LEN = 1000
+
+
+def cpu_baseline(h, rank0_cores):
+    """Reference scan timed on this host's cores on a bounded sample of the same
+    workload (oracle/_ref/ref_harness scanbench = the real reference's
+    query_sequences), or the oracle port when the reference build is absent."""
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    threads = max(1, min(rank0_cores, 16))
+    G_cpu, nq = 10_000, 201 * threads
+    if h >= 20:
+        G_cpu, nq = 2_000, 201 * threads
+    sample = f"reference query_sequences: {nq} synthetic 1 kb queries vs {G_cpu} genomes, -h {h}, saturated Bloom"
+    if os.path.exists(harness):
+        try:
+            out = subprocess.run([harness, "scanbench", str(h), str(G_cpu), str(nq), str(threads)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900).stdout.decode()
+            line = [l for l in out.splitlines() if l.startswith("{")][-1]
+            r = json.loads(line)
+            return {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
+                    "kind": "reference", "sample": sample}
+        except Exception as e:                       # fall through to the port
+            sys.stderr.write(f"reference scanbench unavailable: {e}\n")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import synth
+    from oracle import oracle as orc
+    Gp, nqp, hp = 64, 32, min(h, 17)
+    o = orc.OracleMiekki(31, hp, 8, 33, 200)
+    o.insert_sequences([synth.genome_bases(g, 0, 1_000_000) for g in range(Gp)])
+    qs = [synth.genome_bases(*synth.query_origin(q, Gp, 1_000_000, QUERY_LEN), QUERY_LEN) for q in range(nqp)]
+    act = sum(o.query_sequence(s)[1] for s in qs)
+    t0 = time.time()
+    o.query_sequences(qs)
+    dt = time.time() - t0
+    return {"value": act * Gp / dt, "unit": "comparisons/s", "cores": 1, "kind": "port",
+            "sample": f"oracle query_sequences: {nqp} queries vs {Gp} x 1 Mb genomes, -h {hp}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genomes-per-gpu", type=int, default=12_500)
+    ap.add_argument("--queries", type=int, default=100_000)
+    ap.add_argument("--h", type=int, default=20)
+    ap.add_argument("--fp-bits", type=int, default=8)
+    ap.add_argument("--cap", type=int, default=16, help="candidate slots per query per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libmiekki_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import miekki_amd
+    from miekki_amd import lib as L
+    lib = L.load_library()
+
+    G = args.genomes_per_gpu
+    G_total = G * world
+    Q = args.queries
+    W = args.fp_bits // 8
+    ix = miekki_amd.Miekki(31, args.h, args.fp_bits, 33, 200, device=local_rank, genome_id_base=rank * G)
+    ix.reserve(G)
+    t0 = time.time()
+    done = 0
+    while done < G:                                    # progress lines keep the runner's watchdog fed
+        n = min(2048, G - done)
+        ix.insert_synthetic(rank * G + done, n, GENOME_LEN)
+        done += n
+        if rank == 0:
+            sys.stderr.write(f"[bench] built {done}/{G} genomes in {time.time() - t0:.1f}s\n")
+    L.check(lib.mk_sync(ix._h))
+    build_s = time.time() - t0
+    bst = ix.stats()
+
+    qs = C.c_void_p()
+    L.check(lib.mk_qset_synthetic(ix._h, 0, Q, G_total, GENOME_LEN, QUERY_LEN, C.byref(qs)))
+    cap = args.cap
+    d_count = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    d_cand = torch.zeros(Q * cap * 24, dtype=torch.uint8, device="cuda")
+    if world > 1 and rank == 0:
+        g_count = [torch.zeros_like(d_count) for _ in range(world)]
+        g_cand = [torch.zeros_like(d_cand) for _ in range(world)]
+    min_score, min_inter = 10, 100.0                  # query_file's filter_results(.., 10, 10, 0.5*threshold)
+
+    def step():
+        L.check(lib.mk_qset_run(ix._h, qs, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
+        L.check(lib.mk_sync(ix._h))
+        if world > 1:                                 # the one exchange step: top candidates -> rank 0
+            dist.gather(d_count, g_count if rank == 0 else None, dst=0)
+            dist.gather(d_cand, g_cand if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    ix.reset_stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = ix.stats()
+    active = np.zeros(Q, np.uint32)
+    L.check(lib.mk_qset_active(ix._h, qs, active.ctypes.data))
+    a_sum = int(active.sum())
+    comparisons_step_rank = a_sum * G
+    comparisons_step = comparisons_step_rank * world
+    value = comparisons_step * args.steps / dt
+
+    # sanity: every query's own genome must be among its candidates on the owning rank
+    cnt = d_count.cpu().numpy()
+    n_hit = int((cnt > 0).sum())
+
+    if rank == 0:
+        launches = max(1, int(st["scan_launches"]))
+        algo_bytes_step = comparisons_step_rank * W + 4 * Q * G
+        algo_per_launch = algo_bytes_step * args.steps / launches
+        avg_launch_s = st["scan_ms"] / 1e3 / launches
+        achieved = algo_per_launch / avg_launch_s / 1e9
+        out = {
+            "metric": "query x genome fingerprint comparisons/sec at -h %d" % args.h,
+            "value": value, "unit": "comparisons/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8" if W == 1 else "u16", "data": "synthetic",
+            "config": {"workload": "%d synthetic 5 Mb genomes per GPU (%d total), -k 31 -h %d, %d-bit fingerprints, "
+                                   "%d x 1 kb queries scanned by every rank" % (G, G_total, args.h, args.fp_bits, Q),
+                       "genomes_per_gpu": G, "genomes_total": G_total, "queries": Q, "h": args.h,
+                       "active_partitions_per_query": a_sum / max(Q, 1), "parallelism": "genome-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                         "algo_bytes_per_launch": algo_per_launch},
+            "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
+                       "index_build_s": build_s, "index_sketches_per_s": G / build_s,
+                       "index_kmers_per_s": bst["build_kmers"] / build_s,
+                       "build_sketch_ms": bst["build_sketch_ms"], "build_finalize_ms": bst["build_finalize_ms"]},
+            "check": {"queries_with_candidates_on_rank0": n_hit},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.h, os.cpu_count() or 1)
+        print(json.dumps(out))
+    lib.mk_qset_free(ix._h, qs)
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

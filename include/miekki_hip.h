@@ -1,0 +1,174 @@
+/* miekki_hip.h -- C ABI of libmiekki_hip.so, the MI355X (gfx950) implementation of
+ * Miekki's sketch-build + fingerprint-intersection hot path.
+ *
+ * The reference has no FFI of its own: main.cpp calls Miekki's members directly.
+ * Each entry point below replaces one of those L3 -> L2 calls (citations are into
+ * the reference tree) and is what a binding in the
+ * reference would bind; INTEGRATION.md shows that binding.
+ *
+ * Conventions: plain C, opaque handle, every call returns 0 on success or a
+ * negative mk_status and leaves a message for mk_last_error() (thread-local).
+ * Host pointers unless a parameter name starts with `d_` (device memory of the
+ * context's GPU).  One context owns one GPU; calls on one context must not
+ * overlap.  There is no CPU fallback: without a usable HIP device mk_create
+ * fails.
+ */
+#ifndef MIEKKI_HIP_H
+#define MIEKKI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_ABI_VERSION 1
+
+typedef enum {
+    MK_OK = 0,
+    MK_ERR_ARG = -1,          /* bad argument */
+    MK_ERR_UNSUPPORTED = -2,  /* the reference's "not implemented" (Miekki.cpp:235-237, 893-895) */
+    MK_ERR_DEVICE = -3,       /* HIP runtime error / no GPU */
+    MK_ERR_NOMEM = -4,
+    MK_ERR_STATE = -5         /* call not valid in the context's current state */
+} mk_status;
+
+typedef struct mk_ctx mk_ctx;
+
+/* Constructor arguments of Miekki(k, h, bit_per_min, 5, 0, out, b, threshold, t)
+ * (Miekki.h:66-90, main.cpp:196). */
+typedef struct {
+    uint32_t k;               /* -k, 2..31 (offsetUpdatekmer = 1 << 2k, Miekki.h:76-77) */
+    uint32_t h;               /* -h, log2 of the number of partitions, 1..28 */
+    uint32_t fp_bits;         /* number_bit_minimizer = 5 + f: 8 (-f 3) or 16 (-f 11) */
+    uint32_t bloom_log2;      /* -b, >= 32 as in the reference */
+    uint32_t threshold;       /* -s truncated to u32 (main.cpp:196) */
+    int32_t device;           /* HIP device ordinal */
+    uint32_t genome_id_base;  /* id of this context's first genome (multi-GPU genome sharding) */
+    uint32_t reserved;
+} mk_params;
+
+/* Same layout as the reference's similarity_score (Miekki.h:27-31). */
+typedef struct {
+    uint32_t genome;
+    uint32_t matches;
+    double jaccard;
+    double intersection;
+} mk_hit;
+
+/* Device-time accounting of the last query call(s), from HIP events recorded on
+ * the context's stream around each kernel. */
+typedef struct {
+    double sketch_ms;         /* query sketch + Bloom gate */
+    double scan_ms;           /* fingerprint scan launches */
+    double filter_ms;         /* candidate ordering on device (0 when fused) */
+    uint64_t scan_launches;
+    uint64_t comparisons;     /* G * sum of active partitions */
+    uint64_t active_partitions;
+    uint64_t scan_algo_bytes; /* comparisons * W + 4 * queries * G */
+    double build_sketch_ms;   /* index build: k-mer hashing + minimizer selection */
+    double build_finalize_ms; /* transposed matrix write, sizes, Bloom insert */
+    uint64_t build_kmers;
+    uint64_t build_genomes;
+} mk_stats;
+
+const char *mk_last_error(void);
+uint32_t mk_abi_version(void);
+
+/* new Miekki(...)  (main.cpp:196) */
+int mk_create(const mk_params *params, mk_ctx **out);
+void mk_destroy(mk_ctx *ctx);
+
+/* Pre-size the fingerprint matrix for n_genomes rows per partition.  Optional;
+ * appending past the reservation re-lays the matrix out (needs 2x memory). */
+int mk_reserve(mk_ctx *ctx, uint32_t n_genomes);
+
+uint32_t mk_index_size(const mk_ctx *ctx);                 /* Miekki::index_size */
+int mk_get_params(const mk_ctx *ctx, mk_params *out);
+int mk_get_stats(const mk_ctx *ctx, mk_stats *out);
+int mk_reset_stats(mk_ctx *ctx);
+
+/* ---- index build --------------------------------------------------------- */
+
+/* Miekki::insert_sequences (Miekki.cpp:277-314; called from index_file_of_file,
+ * Miekki.cpp:572,580).  Genome ids follow call order.  Sequences shorter than k
+ * are rejected with MK_ERR_ARG (the driver filters them, Miekki.cpp:569). */
+int mk_index_append(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t n);
+
+/* Same, for the synthetic genomes of SURVEY.md 8d generated on the device
+ * (ids first_id .. first_id+n-1, `length` bases each): no PCIe traffic. */
+int mk_index_append_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length);
+
+/* ---- persistence: the payload of dump_disk / the loading constructor
+ * (Miekki.cpp:649-719), streamed in ranges so that the host never
+ * needs the whole matrix at once. --------------------------------------------- */
+
+/* columns [p_begin, p_end): (p_end-p_begin) * G * (fp_bits/8) bytes, partition-
+ * major, 16-bit values big-endian -- byte-for-byte what dump_disk writes. */
+int mk_index_export_columns(mk_ctx *ctx, uint32_t p_begin, uint32_t p_end, uint8_t *dst);
+int mk_index_export_sizes(mk_ctx *ctx, uint64_t *genome_size, uint32_t *sketch_size);
+/* Bloom bytes [begin, end) of the 2^(b-3)-byte table */
+int mk_index_export_bloom(mk_ctx *ctx, uint64_t begin, uint64_t end, uint8_t *dst);
+
+int mk_index_import_begin(mk_ctx *ctx, uint32_t n_genomes);    /* empties the index first */
+int mk_index_import_columns(mk_ctx *ctx, uint32_t p_begin, uint32_t p_end, const uint8_t *src);
+int mk_index_import_sizes(mk_ctx *ctx, const uint64_t *genome_size, const uint32_t *sketch_size);
+int mk_index_import_bloom(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *src);
+
+/* ---- queries --------------------------------------------------------------- */
+
+/* Miekki::query_sequences (Miekki.cpp:344-372): scores[nq][G], row-major u32. */
+int mk_query_scores(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t nq,
+                    uint32_t *scores);
+
+/* filter_results(query_sequences(batch), nresults, min_score, min_intersection)
+ * (Miekki.cpp:437; 376-422): hits[nq][nresults], nhits[nq]; each row descending by
+ * intersection with the reference's heap tie behaviour.  active[nq] (may be NULL)
+ * receives query_sequence's active_minimizer (Miekki.cpp:318-340). */
+int mk_query(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t nq,
+             uint32_t nresults, uint32_t min_score, double min_intersection,
+             mk_hit *hits, uint32_t *nhits, uint32_t *active);
+
+/* Pure host function: Miekki::filter_results (Miekki.cpp:376-397) over
+ * candidates that already passed both thresholds, given in ascending genome
+ * order.  Used by mk_query and by the multi-GPU merge on rank 0. */
+uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresults, mk_hit *out);
+
+/* ---- device-resident query sets (bench / multi-GPU path) ------------------- */
+
+typedef struct mk_qset mk_qset;
+
+/* Upload sequences once; they stay in HBM until mk_qset_free. */
+int mk_qset_upload(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t nq,
+                   mk_qset **out);
+/* SURVEY 8d synthetic queries first_id.. cut from synthetic genomes
+ * (id mod n_genomes_total, length genome_len), generated on the device. */
+int mk_qset_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t nq, uint64_t n_genomes_total,
+                      uint64_t genome_len, uint64_t query_len, mk_qset **out);
+void mk_qset_free(mk_ctx *ctx, mk_qset *qs);
+
+/* One pass of the hot path over the set: sketch + Bloom gate + scan + threshold
+ * filter.  Candidates (both thresholds passed) go to device memory owned by the
+ * caller: d_count[nq] (u32, may exceed cap when a row overflows) and
+ * d_cand[nq][cap] (mk_hit, ascending genome id per row).  Asynchronous on the
+ * context's stream; mk_sync waits. */
+int mk_qset_run(mk_ctx *ctx, mk_qset *qs, uint32_t min_score, double min_intersection,
+                uint32_t cap, uint32_t *d_count, mk_hit *d_cand);
+/* Raw scores of queries [q_begin, q_end) of the set into d_scores[(q_end-q_begin)][G]. */
+int mk_qset_scores(mk_ctx *ctx, mk_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t *d_scores);
+/* active partitions per query after the last run/scores call */
+int mk_qset_active(mk_ctx *ctx, mk_qset *qs, uint32_t *active);
+int mk_sync(mk_ctx *ctx);
+
+/* ---- exact mode (ground_truth_batch, Miekki.cpp:792-859) ------------------- */
+
+/* genome: contig sequences as ground_truth_batch delimits them (Miekki.cpp:803-822);
+ * for each query: |A n B| and |B| + |A \ B| over distinct canonical k-mers. */
+int mk_exact(mk_ctx *ctx, const char *const *contigs, const uint64_t *contig_lens,
+             uint32_t n_contigs, const char *const *queries, const uint64_t *query_lens,
+             uint32_t nq, uint64_t *inter, uint64_t *uni);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

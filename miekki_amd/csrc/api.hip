@@ -1,0 +1,724 @@
+// C ABI of libmiekki_hip.so: context, index build / import / export, query
+// pipeline.  Host-side orchestration only; the arithmetic lives in sketch.hip and
+// scan.hip.  There is deliberately no CPU fallback anywhere in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "mk_internal.hpp"
+
+namespace mk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+template <typename T>
+static int dev_alloc(T **p, uint64_t count)
+{
+    *p = nullptr;
+    if (!count) return MK_OK;
+    MK_HIP(hipMalloc((void **)p, count * sizeof(T)));
+    return MK_OK;
+}
+
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// ---- device timers -----------------------------------------------------------
+int timer_begin(mk_ctx *c, int kind, Timer &t)
+{
+    if (!c->free_timers.empty()) { t = c->free_timers.back(); c->free_timers.pop_back(); }
+    else { MK_HIP(hipEventCreate(&t.a)); MK_HIP(hipEventCreate(&t.b)); }
+    t.kind = kind;
+    MK_HIP(hipEventRecord(t.a, c->stream));
+    return MK_OK;
+}
+
+int timer_end(mk_ctx *c, Timer &t)
+{
+    MK_HIP(hipEventRecord(t.b, c->stream));
+    c->pending.push_back(t);
+    return MK_OK;
+}
+
+int drain_timers(mk_ctx *c)
+{
+    for (Timer &t : c->pending) {
+        MK_HIP(hipEventSynchronize(t.b));
+        float ms = 0;
+        MK_HIP(hipEventElapsedTime(&ms, t.a, t.b));
+        switch (t.kind) {
+        case 0: c->stats.sketch_ms += ms; break;
+        case 1: c->stats.scan_ms += ms; c->stats.scan_launches++; break;
+        case 2: c->stats.filter_ms += ms; break;
+        case 3: c->stats.build_sketch_ms += ms; break;
+        case 4: c->stats.build_finalize_ms += ms; break;
+        }
+        c->free_timers.push_back(t);
+    }
+    c->pending.clear();
+    return MK_OK;
+}
+
+struct ScopedTimer {
+    mk_ctx *c; Timer t; bool on;
+    ScopedTimer(mk_ctx *ctx, int kind) : c(ctx), on(false) { on = timer_begin(c, kind, t) == MK_OK; }
+    ~ScopedTimer() { if (on) (void)timer_end(c, t); }
+};
+
+static int use_device(const mk_ctx *c)
+{
+    MK_HIP(hipSetDevice(c->p.device));
+    return MK_OK;
+}
+
+// ---- matrix capacity -----------------------------------------------------------
+static int ensure_capacity(mk_ctx *c, uint32_t need)
+{
+    if (need <= c->capG) return MK_OK;
+    uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(256, (uint64_t)c->capG * 2));
+    cap = std::min<uint64_t>(cap, 0xffffff00ull);
+    const uint64_t ld = (cap * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
+    cap = ld / c->W;
+    uint8_t *nM = nullptr;
+    uint32_t *nss = nullptr;
+    uint64_t *ngs = nullptr;
+    MK_TRY(dev_alloc(&nM, (uint64_t)c->P * ld));
+    MK_TRY(dev_alloc(&nss, cap));
+    MK_TRY(dev_alloc(&ngs, cap));
+    MK_HIP(hipMemsetAsync(nM, 0, (uint64_t)c->P * ld, c->stream));
+    if (c->G) {
+        MK_HIP(hipMemcpy2DAsync(nM, ld, c->d_M, c->ld, (size_t)c->G * c->W, c->P, hipMemcpyDeviceToDevice,
+                                c->stream));
+        MK_HIP(hipMemcpyAsync(nss, c->d_sketch_size, (size_t)c->G * 4, hipMemcpyDeviceToDevice, c->stream));
+        MK_HIP(hipMemcpyAsync(ngs, c->d_genome_size, (size_t)c->G * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    MK_HIP(hipStreamSynchronize(c->stream));
+    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size);
+    c->d_M = nM; c->d_sketch_size = nss; c->d_genome_size = ngs;
+    c->ld = ld; c->capG = (uint32_t)cap;
+    return MK_OK;
+}
+
+// ---- index build ---------------------------------------------------------------
+static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes)
+{
+    if (!c->d_tables) {
+        const uint64_t budget = 1ull << 30;                       // table bytes per batch
+        c->build_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kBuildBatch, budget / ((uint64_t)c->P * 8)));
+        MK_TRY(dev_alloc(&c->d_tables, (uint64_t)c->build_batch * c->P));
+        MK_TRY(dev_alloc(&c->d_active, kBuildBatch));
+        MK_TRY(dev_alloc(&c->d_cardsum, kBuildBatch));
+        MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
+        if (c->d_bloom) {
+            MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
+            MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
+        }
+    }
+    if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
+    if (seq_bytes > c->seq_cap) {
+        dev_free(c->d_seq);
+        const uint64_t cap = std::max<uint64_t>(seq_bytes, c->seq_cap * 2);
+        MK_TRY(dev_alloc(&c->d_seq, cap + 64));
+        c->seq_cap = cap;
+    }
+    return MK_OK;
+}
+
+// genome_size / sketch_size of Miekki.cpp:303-311 from the device's exact sums
+static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t len)
+{
+    const double card = (double)cardsum / 2147483648.0;          // sum of 2^-exp, exact
+    const uint32_t sq = active * active;                         // u32 wrap-around, Miekki.cpp:306
+    const double est = 0.72134 * (double)sq / card;
+    if (est > (double)len) return len;
+    if (std::isnan(est)) return 0x8000000000000000ull;           // what the x86 conversion yields
+    return (uint64_t)est;
+}
+
+// sequences already in c->d_seq at offsets h_off[0..n]
+static int build_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n)
+{
+    MK_TRY(ensure_capacity(c, c->G + n));
+    MK_HIP(hipMemcpyAsync(c->d_seq_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MK_TRY(launch_seed_valid(c, c->d_seq, c->d_seq_off, n, c->d_seed_valid));
+    {
+        ScopedTimer t(c, 3);
+        MK_TRY(launch_genome_sketch(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables));
+    }
+    {
+        ScopedTimer t(c, 4);
+        MK_TRY(launch_finalize(c, c->d_tables, n, c->G));
+        MK_TRY(launch_bloom_insert(c, c->d_tables, c->d_seq, c->d_seq_off, c->d_seed_valid, n));
+    }
+    uint32_t act[kBuildBatch];
+    uint64_t card[kBuildBatch];
+    MK_HIP(hipMemcpyAsync(act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    uint64_t gsz[kBuildBatch];
+    for (uint32_t g = 0; g < n; ++g) {
+        const uint64_t len = h_off[g + 1] - h_off[g];
+        gsz[g] = estimate_genome_size(act[g], card[g], len);
+        c->h_sketch_size.push_back(act[g]);
+        c->h_genome_size.push_back(gsz[g]);
+        c->stats.build_kmers += len > c->p.k ? len - c->p.k : 0;
+    }
+    MK_HIP(hipMemcpy(c->d_sketch_size + c->G, act, n * 4, hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpy(c->d_genome_size + c->G, gsz, n * 8, hipMemcpyHostToDevice));
+    c->G += n;
+    c->stats.build_genomes += n;
+    return MK_OK;
+}
+
+// ---- query sets ------------------------------------------------------------------
+static void qset_release(mk_qset *qs)
+{
+    if (!qs) return;
+    dev_free(qs->d_seq); dev_free(qs->d_off); dev_free(qs->d_ent_off); dev_free(qs->d_entries);
+    dev_free(qs->d_nent);
+    delete qs;
+}
+
+static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **out)
+{
+    std::unique_ptr<mk_qset, void (*)(mk_qset *)> qs(new mk_qset(), qset_release);
+    qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
+    qs->d_nent = nullptr; qs->sketched = false; qs->total_active = 0; qs->short_max_nk = 0;
+    qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
+        if (lens[q] >= (1ull << 40)) { set_error("query too long"); return MK_ERR_ARG; }
+        qs->h_off[q + 1] = qs->h_off[q] + lens[q];
+        qs->h_ent_off[q + 1] = qs->h_ent_off[q] + std::min<uint64_t>(nk, c->P);
+        if (nk > kShortMax) qs->long_q.push_back(q);
+        else qs->short_max_nk = std::max<uint32_t>(qs->short_max_nk, (uint32_t)nk);
+    }
+    qs->total_len = qs->h_off[nq];
+    MK_TRY(dev_alloc(&qs->d_seq, qs->total_len + 64));
+    MK_TRY(dev_alloc(&qs->d_off, (uint64_t)nq + 1));
+    MK_TRY(dev_alloc(&qs->d_ent_off, (uint64_t)nq + 1));
+    MK_TRY(dev_alloc(&qs->d_entries, qs->h_ent_off[nq] + 1));
+    MK_TRY(dev_alloc(&qs->d_nent, (uint64_t)nq + 1));
+    MK_HIP(hipMemcpyAsync(qs->d_off, qs->h_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipMemcpyAsync(qs->d_ent_off, qs->h_ent_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice,
+                          c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    *out = qs.release();
+    return MK_OK;
+}
+
+static int qset_sketch(mk_ctx *c, mk_qset *qs)
+{
+    ScopedTimer t(c, 0);
+    MK_TRY(launch_query_sketch_short(c, qs));
+    if (!qs->long_q.empty()) {
+        if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
+        if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
+        for (uint32_t q : qs->long_q) MK_TRY(launch_query_sketch_long(c, qs, q));
+    }
+    qs->sketched = true;
+    return MK_OK;
+}
+
+static uint32_t ntiles_of(const mk_ctx *c)
+{
+    return (uint32_t)(((uint64_t)c->G * c->W + kTileBytes - 1) / kTileBytes);
+}
+
+// scan queries [q0, q1) of the set; scores and/or filtered candidates
+static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, bool filter,
+                     uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count, mk_hit *d_cand)
+{
+    if (q1 <= q0 || c->G == 0) return MK_OK;
+    const uint32_t nt = ntiles_of(c);
+    const uint32_t per_launch = std::max<uint32_t>(1, 0x7ffffff0u / nt);
+    for (uint32_t q = q0; q < q1; q += per_launch) {
+        const uint32_t n = std::min(per_launch, q1 - q);
+        ScanArgs a;
+        a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
+        a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_nent;
+        a.scores = d_scores ? d_scores + (uint64_t)(q - q0) * c->G : nullptr;
+        a.min_score = min_score; a.min_inter = min_inter;
+        a.sketch_size = c->d_sketch_size; a.genome_size = c->d_genome_size;
+        a.genome_id_base = c->p.genome_id_base; a.cap = cap;
+        a.count = d_count ? d_count + (q - q0) : nullptr;
+        a.cand = d_cand ? d_cand + (uint64_t)(q - q0) * cap : nullptr;
+        ScopedTimer t(c, 1);
+        MK_TRY(launch_scan(c, a, filter));
+    }
+    return MK_OK;
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+const char *mk_last_error(void) { return g_err; }
+uint32_t mk_abi_version(void) { return MK_ABI_VERSION; }
+
+int mk_create(const mk_params *p, mk_ctx **out)
+{
+    if (!p || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = nullptr;
+    if (p->fp_bits != 8 && p->fp_bits != 16) { set_error("not implemented"); return MK_ERR_UNSUPPORTED; }
+    if (p->k < 2 || p->k > 31) { set_error("k must be in [2,31]"); return MK_ERR_ARG; }
+    if (p->h < 1 || p->h > 28) { set_error("h must be in [1,28]"); return MK_ERR_ARG; }
+    if (p->bloom_log2 != 0 && (p->bloom_log2 < 32 || p->bloom_log2 > 40)) {
+        set_error("bloom_log2 must be 0 (no Bloom gate) or in [32,40]");
+        return MK_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device: libmiekki_hip has no CPU path");
+        return MK_ERR_DEVICE;
+    }
+    if (p->device < 0 || p->device >= ndev) { set_error("device %d out of range", p->device); return MK_ERR_ARG; }
+    std::unique_ptr<mk_ctx> c(new mk_ctx());
+    c->p = *p;
+    c->P = 1u << p->h; c->W = p->fp_bits / 8; c->f = p->fp_bits - kMantisBits;
+    c->empty = p->fp_bits == 8 ? 255u : 65535u;
+    c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
+    c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
+    c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
+    c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
+    c->cand_cap_q = 0; c->cand_cap = 0; c->d_long_table = nullptr; c->d_long_flags = nullptr;
+    c->d_long_counts = nullptr;
+    memset(&c->stats, 0, sizeof c->stats);
+    MK_HIP(hipSetDevice(p->device));
+    MK_HIP(hipStreamCreate(&c->stream));
+    c->bloom_bytes = p->bloom_log2 ? (1ull << p->bloom_log2) / 8 : 0;
+    c->bloom_dev_bytes = 0;
+    if (p->bloom_log2) {
+        // largest reachable cell: ((4^k - 1) + 1023) >> (b + 3)
+        const uint64_t top = ((1ull << (2 * p->k)) - 1) + 1023;
+        c->bloom_dev_bytes = std::min<uint64_t>(c->bloom_bytes, (top >> (p->bloom_log2 + 3)) + 1);
+        mk_ctx *cc = c.get();
+        MK_TRY(dev_alloc(&cc->d_bloom, c->bloom_dev_bytes));
+        MK_HIP(hipMemsetAsync(c->d_bloom, 0, c->bloom_dev_bytes, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
+    }
+    *out = c.release();
+    return MK_OK;
+}
+
+void mk_destroy(mk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)drain_timers(c);
+    for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
+    dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
+    dev_free(c->d_seed_valid); dev_free(c->d_seq); dev_free(c->d_seq_off); dev_free(c->d_scores);
+    dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_long_flags);
+    dev_free(c->d_long_counts);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mk_reserve(mk_ctx *c, uint32_t n)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return ensure_capacity(c, n);
+}
+
+uint32_t mk_index_size(const mk_ctx *c) { return c ? c->G : 0; }
+
+int mk_get_params(const mk_ctx *c, mk_params *out)
+{
+    if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = c->p;
+    return MK_OK;
+}
+
+int mk_sync(mk_ctx *c)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return drain_timers(c);
+}
+
+int mk_get_stats(const mk_ctx *cc, mk_stats *out)
+{
+    if (!cc || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    mk_ctx *c = const_cast<mk_ctx *>(cc);
+    MK_TRY(mk_sync(c));
+    *out = c->stats;
+    return MK_OK;
+}
+
+int mk_reset_stats(mk_ctx *c)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(mk_sync(c));
+    memset(&c->stats, 0, sizeof c->stats);
+    return MK_OK;
+}
+
+// ------------------------------------------------------------------ build
+int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t n)
+{
+    if (!c || (n && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    for (uint32_t g = 0; g < n; ++g)
+        if (lens[g] < c->p.k) { set_error("sequence %u shorter than k", g); return MK_ERR_ARG; }
+    MK_TRY(ensure_build_scratch(c, 0));
+    for (uint32_t g0 = 0; g0 < n; g0 += c->build_batch) {
+        const uint32_t nb = std::min(c->build_batch, n - g0);
+        uint64_t off[kBuildBatch + 1];
+        off[0] = 0;
+        for (uint32_t g = 0; g < nb; ++g) off[g + 1] = off[g] + lens[g0 + g];
+        MK_TRY(ensure_build_scratch(c, off[nb]));
+        for (uint32_t g = 0; g < nb; ++g)
+            MK_HIP(hipMemcpyAsync(c->d_seq + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice, c->stream));
+        MK_TRY(build_batch(c, off, nb));
+    }
+    return MK_OK;
+}
+
+int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    if (length < c->p.k) { set_error("sequence shorter than k"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_TRY(ensure_build_scratch(c, 0));
+    for (uint32_t g0 = 0; g0 < n; g0 += c->build_batch) {
+        const uint32_t nb = std::min(c->build_batch, n - g0);
+        uint64_t off[kBuildBatch + 1];
+        for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
+        MK_TRY(ensure_build_scratch(c, off[nb]));
+        MK_TRY(launch_synth_genomes(c, first_id + g0, nb, length, c->d_seq));
+        MK_TRY(build_batch(c, off, nb));
+    }
+    return MK_OK;
+}
+
+// ------------------------------------------------------------------ persistence
+static int staged_columns(mk_ctx *c, bool to_device, uint32_t pb, uint32_t pe, uint8_t *host)
+{
+    if (pb > pe || pe > c->P) { set_error("partition range out of bounds"); return MK_ERR_ARG; }
+    if (pb == pe || c->G == 0) return MK_OK;
+    const uint64_t row = (uint64_t)c->G * c->W;
+    const uint32_t rows_per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pe - pb, (256ull << 20) / row));
+    uint8_t *d_stage = nullptr;
+    MK_TRY(dev_alloc(&d_stage, (uint64_t)rows_per * row));
+    int rc = MK_OK;
+    for (uint32_t p = pb; p < pe && rc == MK_OK; p += rows_per) {
+        const uint32_t r = std::min(rows_per, pe - p);
+        uint8_t *h = host + (uint64_t)(p - pb) * row;
+        if (to_device) {
+            if (hipMemcpyAsync(d_stage, h, (size_t)r * row, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+            if (rc == MK_OK) rc = launch_convert_columns(c, true, p, p + r, d_stage);
+        } else {
+            rc = launch_convert_columns(c, false, p, p + r, d_stage);
+            if (rc == MK_OK && hipMemcpyAsync(h, d_stage, (size_t)r * row, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+        }
+        if (rc == MK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+    }
+    if (rc == MK_ERR_DEVICE) set_error("column transfer failed: %s", hipGetErrorString(hipGetLastError()));
+    dev_free(d_stage);
+    return rc;
+}
+
+int mk_index_export_columns(mk_ctx *c, uint32_t pb, uint32_t pe, uint8_t *dst)
+{
+    if (!c || !dst) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return staged_columns(c, false, pb, pe, dst);
+}
+
+int mk_index_export_sizes(mk_ctx *c, uint64_t *genome_size, uint32_t *sketch_size)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    if (genome_size) memcpy(genome_size, c->h_genome_size.data(), (size_t)c->G * 8);
+    if (sketch_size) memcpy(sketch_size, c->h_sketch_size.data(), (size_t)c->G * 4);
+    return MK_OK;
+}
+
+int mk_index_export_bloom(mk_ctx *c, uint64_t begin, uint64_t end, uint8_t *dst)
+{
+    if (!c || !dst) { set_error("null argument"); return MK_ERR_ARG; }
+    if (begin > end || end > c->bloom_bytes) { set_error("Bloom range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
+    if (begin < dev_end) MK_HIP(hipMemcpy(dst, c->d_bloom + begin, dev_end - begin, hipMemcpyDeviceToHost));
+    const uint64_t zfrom = std::max(begin, dev_end);
+    if (zfrom < end) memset(dst + (zfrom - begin), 0, end - zfrom);   // cells no k-mer can reach
+    return MK_OK;
+}
+
+int mk_index_import_begin(mk_ctx *c, uint32_t n)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    c->G = 0;
+    c->h_sketch_size.clear(); c->h_genome_size.clear();
+    MK_TRY(ensure_capacity(c, n));
+    c->G = n;
+    c->h_sketch_size.assign(n, 0); c->h_genome_size.assign(n, 0);
+    if (c->d_bloom) MK_HIP(hipMemset(c->d_bloom, 0, c->bloom_dev_bytes));
+    return MK_OK;
+}
+
+int mk_index_import_columns(mk_ctx *c, uint32_t pb, uint32_t pe, const uint8_t *src)
+{
+    if (!c || !src) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return staged_columns(c, true, pb, pe, const_cast<uint8_t *>(src));
+}
+
+int mk_index_import_sizes(mk_ctx *c, const uint64_t *genome_size, const uint32_t *sketch_size)
+{
+    if (!c || !genome_size || !sketch_size) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    c->h_genome_size.assign(genome_size, genome_size + c->G);
+    c->h_sketch_size.assign(sketch_size, sketch_size + c->G);
+    if (c->G) {
+        MK_HIP(hipMemcpy(c->d_genome_size, genome_size, (size_t)c->G * 8, hipMemcpyHostToDevice));
+        MK_HIP(hipMemcpy(c->d_sketch_size, sketch_size, (size_t)c->G * 4, hipMemcpyHostToDevice));
+    }
+    return MK_OK;
+}
+
+int mk_index_import_bloom(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *src)
+{
+    if (!c || !src) { set_error("null argument"); return MK_ERR_ARG; }
+    if (begin > end || end > c->bloom_bytes) { set_error("Bloom range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
+    if (begin < dev_end) MK_HIP(hipMemcpy(c->d_bloom + begin, src, dev_end - begin, hipMemcpyHostToDevice));
+    return MK_OK;
+}
+
+// ------------------------------------------------------------------ queries
+int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, mk_qset **out)
+{
+    if (!c || !out || (nq && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    mk_qset *qs = nullptr;
+    MK_TRY(qset_alloc(c, lens, nq, &qs));
+    // one pinned staging pass keeps the upload a single large copy
+    std::vector<char> host(qs->total_len);
+    for (uint32_t q = 0; q < nq; ++q) memcpy(host.data() + qs->h_off[q], seqs[q], lens[q]);
+    if (qs->total_len && hipMemcpy(qs->d_seq, host.data(), qs->total_len, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("query upload failed");
+        qset_release(qs);
+        return MK_ERR_DEVICE;
+    }
+    *out = qs;
+    return MK_OK;
+}
+
+int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
+                      mk_qset **out)
+{
+    if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    if (!G || qlen == 0 || L <= qlen) { set_error("bad synthetic query shape"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    std::vector<uint64_t> lens(nq, qlen);
+    mk_qset *qs = nullptr;
+    MK_TRY(qset_alloc(c, lens.data(), nq, &qs));
+    int rc = launch_synth_queries(c, first_id, nq, G, L, qlen, qs->d_seq);
+    if (rc != MK_OK) { qset_release(qs); return rc; }
+    *out = qs;
+    return MK_OK;
+}
+
+void mk_qset_free(mk_ctx *c, mk_qset *qs)
+{
+    if (c) { (void)hipSetDevice(c->p.device); (void)hipStreamSynchronize(c->stream); }
+    qset_release(qs);
+}
+
+int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count,
+                mk_hit *d_cand)
+{
+    if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_TRY(qset_sketch(c, qs));
+    MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream));
+    MK_TRY(qset_scan(c, qs, 0, qs->nq, nullptr, true, min_score, min_inter, cap, d_count, d_cand));
+    {
+        ScopedTimer t(c, 2);
+        MK_TRY(launch_sort_candidates(c, qs->nq, cap, d_count, d_cand));
+    }
+    return MK_OK;
+}
+
+int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores)
+{
+    if (!c || !qs || !d_scores) { set_error("null argument"); return MK_ERR_ARG; }
+    if (q0 > q1 || q1 > qs->nq) { set_error("query range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
+    return qset_scan(c, qs, q0, q1, d_scores, false, 0, 0.0, 0, nullptr, nullptr);
+}
+
+int mk_qset_active(mk_ctx *c, mk_qset *qs, uint32_t *active)
+{
+    if (!c || !qs || !active) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    if (qs->nq) MK_HIP(hipMemcpy(active, qs->d_nent, (size_t)qs->nq * 4, hipMemcpyDeviceToHost));
+    return MK_OK;
+}
+
+static int account(mk_ctx *c, mk_qset *qs, std::vector<uint32_t> &act)
+{
+    act.resize(qs->nq);
+    MK_TRY(mk_qset_active(c, qs, act.data()));
+    uint64_t a = 0;
+    for (uint32_t v : act) a += v;
+    c->stats.active_partitions += a;
+    c->stats.comparisons += a * c->G;
+    c->stats.scan_algo_bytes += a * c->G * c->W + 4ull * qs->nq * c->G;
+    return MK_OK;
+}
+
+int mk_query_scores(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t *scores)
+{
+    if (!c || (nq && (!seqs || !lens || !scores))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    if (!nq || !c->G) return MK_OK;
+    mk_qset *qs = nullptr;
+    MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
+    std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
+    MK_TRY(qset_sketch(c, qs));
+    const uint64_t per = std::max<uint64_t>(1, (1ull << 28) / c->G);       // <= 1 GiB of scores in flight
+    const uint64_t need = std::min<uint64_t>(per, nq) * c->G;
+    if (need > c->scores_cap) {
+        dev_free(c->d_scores);
+        MK_TRY(dev_alloc(&c->d_scores, need));
+        c->scores_cap = need;
+    }
+    for (uint64_t q0 = 0; q0 < nq; q0 += per) {
+        const uint32_t q1 = (uint32_t)std::min<uint64_t>(nq, q0 + per);
+        MK_TRY(qset_scan(c, qs, (uint32_t)q0, q1, c->d_scores, false, 0, 0.0, 0, nullptr, nullptr));
+        MK_HIP(hipMemcpyAsync(scores + q0 * c->G, c->d_scores, (size_t)(q1 - q0) * c->G * 4,
+                              hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
+    }
+    std::vector<uint32_t> act;
+    MK_TRY(account(c, qs, act));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return MK_OK;
+}
+
+// Miekki::filter_results (Miekki.cpp:376-397) on pre-thresholded candidates in
+// ascending genome order; same libstdc++ heap calls as the reference.
+uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresults, mk_hit *out)
+{
+    const auto compare = [](const mk_hit &a, const mk_hit &b) { return a.intersection > b.intersection; };
+    std::vector<mk_hit> heap;
+    heap.reserve((size_t)nresults + 1);
+    for (uint32_t i = 0; i < ncand; ++i) {
+        if (heap.size() >= nresults) {
+            if (heap.empty()) continue;
+            if (heap.front().intersection > cand[i].intersection) continue;   // ties replace
+            std::pop_heap(heap.begin(), heap.end(), compare);
+            heap.pop_back();
+        }
+        heap.push_back(cand[i]);
+        std::push_heap(heap.begin(), heap.end(), compare);
+    }
+    std::sort_heap(heap.begin(), heap.end(), compare);
+    std::copy(heap.begin(), heap.end(), out);
+    return (uint32_t)heap.size();
+}
+
+int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t nresults,
+             uint32_t min_score, double min_inter, mk_hit *hits, uint32_t *nhits, uint32_t *active)
+{
+    if (!c || (nq && (!seqs || !lens || !hits || !nhits))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    if (!nq) return MK_OK;
+    if (!c->G) {
+        memset(nhits, 0, (size_t)nq * 4);
+        if (active) memset(active, 0, (size_t)nq * 4);     // no column is ever compared
+        return MK_OK;
+    }
+    mk_qset *qs = nullptr;
+    MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
+    std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
+    const uint32_t cap = 256;
+    if ((uint64_t)nq > c->cand_cap_q) {
+        dev_free(c->d_count); dev_free(c->d_cand);
+        MK_TRY(dev_alloc(&c->d_count, (uint64_t)nq));
+        MK_TRY(dev_alloc(&c->d_cand, (uint64_t)nq * cap));
+        c->cand_cap_q = nq;
+    }
+    MK_TRY(mk_qset_run(c, qs, min_score, min_inter, cap, c->d_count, c->d_cand));
+    std::vector<uint32_t> cnt(nq);
+    std::vector<mk_hit> cand((size_t)nq * cap);
+    MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)nq * cap * sizeof(mk_hit), hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> act;
+    MK_TRY(account(c, qs, act));
+    if (active) memcpy(active, act.data(), (size_t)nq * 4);
+    std::vector<uint32_t> row;
+    std::vector<mk_hit> full;
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (cnt[q] <= cap) {
+            nhits[q] = mk_filter_candidates(cand.data() + (size_t)q * cap, cnt[q], nresults, hits + (size_t)q * nresults);
+            continue;
+        }
+        // more candidates than the device row holds: replay this query over its
+        // full score row with the reference's own arithmetic
+        if (c->scores_cap < c->G) {
+            dev_free(c->d_scores);
+            MK_TRY(dev_alloc(&c->d_scores, (uint64_t)c->G));
+            c->scores_cap = c->G;
+        }
+        row.resize(c->G);
+        MK_TRY(qset_scan(c, qs, q, q + 1, c->d_scores, false, 0, 0.0, 0, nullptr, nullptr));
+        MK_HIP(hipMemcpyAsync(row.data(), c->d_scores, (size_t)c->G * 4, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
+        full.clear();
+        for (uint32_t g = 0; g < c->G; ++g) {
+            if (row[g] < min_score) continue;
+            const double jac = (double)row[g] / c->h_sketch_size[g];
+            const double inter = jac * c->h_genome_size[g];
+            if (inter < min_inter) continue;
+            full.push_back(mk_hit{g + c->p.genome_id_base, row[g], jac, inter});
+        }
+        nhits[q] = mk_filter_candidates(full.data(), (uint32_t)full.size(), nresults, hits + (size_t)q * nresults);
+    }
+    return MK_OK;
+}
+
+int mk_exact(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,
+             const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter, uint64_t *uni)
+{
+    if (!c || (n_contigs && (!contigs || !contig_lens)) || (nq && (!queries || !query_lens || !inter || !uni))) {
+        set_error("null argument");
+        return MK_ERR_ARG;
+    }
+    MK_TRY(use_device(c));
+    return exact_sets(c, contigs, contig_lens, n_contigs, queries, query_lens, nq, inter, uni);
+}
+
+}  // extern "C"

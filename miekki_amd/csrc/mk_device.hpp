@@ -1,0 +1,102 @@
+// Shared device/host arithmetic of the sketch path (gfx950 only).
+// Reference citations: /root/reference/{utils.cpp,Miekki.cpp}; the algorithm is
+// restated from its definition in SURVEY.md section 8a, not translated.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MK_HD __host__ __device__ __forceinline__
+
+namespace mk {
+
+constexpr uint32_t kNumHash = 5;        // Miekki.h:79
+constexpr uint32_t kMantisBits = 5;     // main.cpp:196
+constexpr uint64_t kRevMul = 0xD6E8FEB86659FD93ULL;   // utils.cpp:180
+
+// utils.cpp:179-184
+MK_HD uint64_t revhash64(uint64_t x)
+{
+    x = ((x >> 32) ^ x) * kRevMul;
+    x = ((x >> 32) ^ x) * kRevMul;
+    return (x >> 32) ^ x;
+}
+
+// Forward code of a base outside the k-1 seed (nuc2int, utils.cpp:31-49):
+// C,G,T -> 1,2,3; anything else 0.
+MK_HD uint32_t fwd_code(uint8_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }
+// Reverse-strand code outside the seed (nuc2intrc, utils.cpp:107-125):
+// A,C,G -> 3,2,1; anything else (T included) 0.
+MK_HD uint32_t rc_code(uint8_t c) { return c == 'A' ? 3u : c == 'C' ? 2u : c == 'G' ? 1u : 0u; }
+// Seed characters (first k-1 of the sequence) go through str2numstrand
+// (utils.cpp:252-272): case-insensitive ACGT, 4 = invalid (whole seed becomes 0).
+MK_HD uint32_t seed_code(uint8_t c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2; case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+// Both 2-bit codes of sequence position j as the rolling state of
+// minhash_sketch_partition sees them (Miekki.cpp:158-164): positions inside the
+// seed contribute seed digits (all zero when the seed is invalid) and their
+// complement through rcb (Miekki.cpp:66-76); later positions go through
+// update_kmer / update_kmer_RC.  Returns fwd | rc << 2.
+MK_HD uint32_t pos_codes(uint8_t c, uint64_t j, uint32_t k, bool seed_valid)
+{
+    if (j < k - 1) {
+        uint32_t s = seed_valid ? seed_code(c) : 0u;
+        return s | ((3u - s) << 2);
+    }
+    return fwd_code(c) | (rc_code(c) << 2);
+}
+
+// HyperMinHash fingerprint (Miekki::mantis, Miekki.cpp:91-113) of the
+// (64-h)-bit remainder n, truncated to fp_bits; f = fp_bits - 5.
+MK_HD uint32_t mantis(uint64_t n, uint32_t h, uint32_t f, uint32_t empty)
+{
+    if (n == 0) return empty;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int prefix = 63 - __clzll((long long)n);
+#else
+    int prefix = 63 - __builtin_clzll(n);
+#endif
+    int e = prefix - 32 + (int)h;
+    if (e < 0) e = 0;
+    int off = prefix - (int)f;
+    if (off < 0) off = 0;
+    uint64_t suffix = (n - (1ULL << prefix)) >> off;
+    return (uint32_t)(suffix + ((uint64_t)e << f)) & empty;
+}
+
+// anc -> (bucket, fingerprint)  (Miekki.cpp:169-171)
+MK_HD void bucket_fp(uint64_t anc, uint32_t h, uint32_t f, uint32_t empty, uint32_t &bucket,
+                     uint32_t &fp)
+{
+    bucket = (uint32_t)(anc >> (64 - h));
+    fp = mantis(anc & ((1ULL << (64 - h)) - 1), h, f, empty);
+}
+
+// i-th Bloom position of a selected k-mer (universal_hash, utils.cpp:197-199,
+// shifted as in Miekki.cpp:124/138).  unrevhash64(revhash64(c)) == c, so the
+// first term is the canonical k-mer itself.
+MK_HD uint64_t bloom_pos(uint64_t canon, uint64_t anc, uint32_t i, uint32_t bloom_log2)
+{
+    return (canon + (((uint64_t)(i * 69u) * anc) % 1024u)) >> bloom_log2;
+}
+
+// splitmix64 and the synthetic genome generator of SURVEY.md 8d
+MK_HD uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t kSeedG = 0x4D49454B4B490001ULL;
+constexpr uint64_t kSeedQ = 0x4D49454B4B490002ULL;
+
+MK_HD uint64_t genome_word(uint64_t g, uint64_t word) { return splitmix64(kSeedG ^ (g << 32) ^ word); }
+
+}  // namespace mk

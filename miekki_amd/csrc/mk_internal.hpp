@@ -1,0 +1,147 @@
+// Internal declarations shared by the translation units of libmiekki_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/miekki_hip.h"
+#include "mk_device.hpp"
+
+namespace mk {
+
+void set_error(const char *fmt, ...);
+#define MK_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            mk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                          __LINE__);                                                          \
+            return e_ == hipErrorOutOfMemory ? MK_ERR_NOMEM : MK_ERR_DEVICE;                  \
+        }                                                                                     \
+    } while (0)
+#define MK_TRY(expr)                                                                          \
+    do {                                                                                      \
+        int s_ = (expr);                                                                      \
+        if (s_ != MK_OK) return s_;                                                           \
+    } while (0)
+
+constexpr uint32_t kShortMax = 4096;     // k-mers a query may have for the in-LDS sketch
+constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batch
+constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
+constexpr uint64_t kEmptyKey = ~0ULL;
+
+// packed query-sketch entry: partition in the low word, fingerprint in the high word
+__host__ __device__ inline uint64_t make_entry(uint32_t p, uint32_t fp) { return (uint64_t)p | ((uint64_t)fp << 32); }
+
+struct Timer {
+    hipEvent_t a, b;
+    int kind;            // 0 sketch, 1 scan, 2 filter, 3 build sketch, 4 build finalize
+};
+
+}  // namespace mk
+
+struct mk_ctx {
+    mk_params p;
+    uint32_t P, W, f, empty;
+    hipStream_t stream;
+    // fingerprint matrix, partition-major: row p at d_M + p * ld (bytes); 16-bit values native LE
+    uint8_t *d_M;
+    uint64_t ld;
+    uint32_t capG, G;
+    uint32_t *d_sketch_size;
+    uint64_t *d_genome_size;
+    std::vector<uint32_t> h_sketch_size;
+    std::vector<uint64_t> h_genome_size;
+    // Bloom filter: only the cells a 2k-bit k-mer can reach live on the device
+    uint8_t *d_bloom;
+    uint64_t bloom_dev_bytes, bloom_bytes;
+    uint64_t *d_bloom_order;       // first-writer arbitration keys (build only), lazily allocated
+    // build scratch (lazily allocated)
+    uint32_t build_batch;          // genomes per build batch (<= kBuildBatch, bounded by table memory)
+    uint64_t *d_tables;            // build_batch x P min-keys
+    uint32_t *d_active;            // per batch genome: non-empty partitions
+    uint64_t *d_cardsum;           // per batch genome: sum of 2^(31-exp)
+    uint32_t *d_seed_valid;
+    char *d_seq;                   // batch sequences, concatenated
+    uint64_t seq_cap;
+    uint64_t *d_seq_off;           // kBuildBatch + 1
+    // query scratch
+    uint32_t *d_scores;
+    uint64_t scores_cap;
+    uint32_t *d_count;
+    mk_hit *d_cand;
+    uint64_t cand_cap_q, cand_cap;
+    uint64_t *d_long_table;        // P keys, long-query path
+    uint8_t *d_long_flags;         // P
+    uint32_t *d_long_counts;
+    // stats
+    mk_stats stats;
+    std::vector<mk::Timer> pending;
+    std::vector<mk::Timer> free_timers;
+};
+
+struct mk_qset {
+    uint32_t nq;
+    char *d_seq;
+    uint64_t total_len;
+    uint64_t *d_off;               // nq + 1 offsets into d_seq
+    uint64_t *d_ent_off;           // nq + 1 offsets into d_entries (capacity max(len-k,0) each)
+    uint64_t *d_entries;
+    uint32_t *d_nent;              // active partitions per query
+    std::vector<uint64_t> h_off, h_ent_off;
+    std::vector<uint32_t> long_q;  // queries with more than kShortMax k-mers
+    uint32_t short_max_nk;         // longest short query (k-mers)
+    bool sketched;
+    uint64_t total_active;
+};
+
+namespace mk {
+
+// timing helpers (api.hip)
+int timer_begin(mk_ctx *c, int kind, Timer &t);
+int timer_end(mk_ctx *c, Timer &t);
+int drain_timers(mk_ctx *c);
+
+// ---- sketch.hip
+int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint32_t n, uint32_t *d_valid);
+int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
+                         const uint32_t *d_valid, uint32_t n, uint64_t *d_tables);
+int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0);
+int launch_bloom_insert(mk_ctx *c, const uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
+                        const uint32_t *d_valid, uint32_t n);
+int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
+int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
+int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, char *d_out);
+int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
+                         char *d_out);
+int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging);
+
+// ---- scan.hip
+struct ScanArgs {
+    const uint8_t *M;
+    uint64_t ld;
+    uint32_t G, ntiles, nq, q_begin;
+    const uint64_t *entries;
+    const uint64_t *ent_off;
+    const uint32_t *nent;
+    uint32_t *scores;              // [nq][G] or null
+    // fused threshold filter
+    uint32_t min_score;
+    double min_inter;
+    const uint32_t *sketch_size;
+    const uint64_t *genome_size;
+    uint32_t genome_id_base, cap;
+    uint32_t *count;
+    mk_hit *cand;
+};
+int launch_scan(mk_ctx *c, const ScanArgs &a, bool filter);
+int launch_sort_candidates(mk_ctx *c, uint32_t nq, uint32_t cap, const uint32_t *d_count, mk_hit *d_cand);
+
+// ---- exact.hip
+int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,
+               const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
+               uint64_t *uni);
+
+}  // namespace mk

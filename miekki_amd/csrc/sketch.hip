@@ -1,0 +1,544 @@
+// K1-K4: k-mer hashing, per-partition minimizer selection, matrix/Bloom update,
+// and the sparse query sketch.  gfx950 only.
+//
+// Replaces Miekki::minhash_sketch_partition (Miekki.cpp:150-197), the body of
+// insert_sequences (Miekki.cpp:287-311), insert_bloom/check_bloom
+// (Miekki.cpp:121-146) and minhash_sketch_partition_solid_kmers (Miekki.cpp:214-224).
+//
+// Selection rule restated: in every partition the winner is
+// the k-mer with the smallest fingerprint, earliest position first among equals,
+// and a fingerprint equal to the "empty" value can never be stored.  That is the
+// minimum of the key (fingerprint, position), which is what both paths compute:
+// genomes by 64-bit atomic minimum into a per-genome table in HBM, short queries
+// by an in-LDS sort of (partition, fingerprint, position) keys.
+#include "mk_internal.hpp"
+
+namespace mk {
+
+constexpr uint32_t kSegKmers = 4096;   // k-mers per workgroup of the genome sketch
+constexpr uint32_t kPerThread = 16;    // consecutive k-mers per thread (rolling update)
+constexpr int kPosBits = 40;           // key = fingerprint << 40 | position
+
+struct SketchParams {
+    uint32_t k, h, f, empty, bloom_log2, P;
+    uint64_t kmask;
+};
+
+static SketchParams make_sp(const mk_ctx *c)
+{
+    SketchParams s;
+    s.k = c->p.k; s.h = c->p.h; s.f = c->f; s.empty = c->empty; s.bloom_log2 = c->p.bloom_log2;
+    s.P = c->P;
+    s.kmask = (c->p.k < 32) ? ((1ULL << (2 * c->p.k)) - 1) : ~0ULL;
+    return s;
+}
+
+// canonical k-mer starting at sequence position i, read straight from the characters
+__device__ __forceinline__ uint64_t canon_at(const char *__restrict__ seq, uint64_t i, uint32_t k,
+                                             bool seed_valid)
+{
+    uint64_t S = 0, RC = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t cd = pos_codes((uint8_t)seq[i + j], i + j, k, seed_valid);
+        S = (S << 2) | (cd & 3u);
+        RC |= (uint64_t)(cd >> 2) << (2 * j);
+    }
+    return S < RC ? S : RC;
+}
+
+// ---------------------------------------------------------------- seed validity
+__global__ void seed_valid_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
+                                  uint32_t n, uint32_t k, uint32_t *__restrict__ valid)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const char *s = seq + off[g];
+    const uint64_t len = off[g + 1] - off[g];
+    uint32_t ok = 1;
+    for (uint32_t j = 0; j + 1 < k && j < len; ++j) ok &= seed_code((uint8_t)s[j]) != 4u;
+    valid[g] = ok;
+}
+
+int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint32_t n, uint32_t *d_valid)
+{
+    if (!n) return MK_OK;
+    hipLaunchKernelGGL(seed_valid_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_seq, d_off, n,
+                       c->p.k, d_valid);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- K1 genome sketch
+// grid = (segments of 4096 k-mers, genomes).  Each thread rolls 16 consecutive
+// k-mers from 2-bit codes staged in LDS and posts (fingerprint, position) keys to
+// the genome's table with a 64-bit atomic minimum, skipping keys that a (possibly
+// stale) plain read already shows to be losers.
+__global__ __launch_bounds__(256) void genome_sketch_kernel(const char *__restrict__ seq,
+                                                            const uint64_t *__restrict__ off,
+                                                            const uint32_t *__restrict__ valid,
+                                                            uint64_t *__restrict__ tables,
+                                                            SketchParams sp)
+{
+    __shared__ uint8_t codes[kSegKmers + 64];
+    const uint32_t g = blockIdx.y;
+    const uint64_t len = off[g + 1] - off[g];
+    const uint64_t nk = len > sp.k ? len - sp.k : 0;         // Miekki.cpp:162: last k-mer skipped
+    const uint64_t seg0 = (uint64_t)blockIdx.x * kSegKmers;
+    if (seg0 >= nk) return;
+    const uint32_t cnt = (uint32_t)min((uint64_t)kSegKmers, nk - seg0);
+    const char *__restrict__ s = seq + off[g];
+    const bool sv = valid[g] != 0;
+    const uint32_t nchar = cnt + sp.k - 1;
+    for (uint32_t j = threadIdx.x; j < nchar; j += 256)
+        codes[j] = (uint8_t)pos_codes((uint8_t)s[seg0 + j], seg0 + j, sp.k, sv);
+    __syncthreads();
+    const uint32_t i0 = threadIdx.x * kPerThread;
+    if (i0 >= cnt) return;
+    const uint32_t i1 = min(i0 + kPerThread, cnt);
+    uint64_t *__restrict__ table = tables + (uint64_t)g * sp.P;
+    uint64_t S = 0, RC = 0;
+    for (uint32_t j = 0; j + 1 < sp.k; ++j) {                // first k-1 digits of k-mer i0
+        const uint32_t cd = codes[i0 + j];
+        S = (S << 2) | (cd & 3u);
+        RC |= (uint64_t)(cd >> 2) << (2 * (j + 1));
+    }
+    const uint32_t topshift = 2 * sp.k - 2;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t cd = codes[i + sp.k - 1];
+        S = ((S << 2) | (cd & 3u)) & sp.kmask;               // update_kmer, Miekki.cpp:51-55
+        RC = (RC >> 2) | ((uint64_t)(cd >> 2) << topshift);  // update_kmer_RC, Miekki.cpp:59-62
+        const uint64_t anc = revhash64(S < RC ? S : RC);
+        uint32_t bucket, fp;
+        bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+        if (fp != sp.empty) {                                // `fp < 255` can never hold for 255
+            const uint64_t key = ((uint64_t)fp << kPosBits) | (seg0 + i);
+            if (key < table[bucket]) atomicMin((unsigned long long *)&table[bucket], (unsigned long long)key);
+        }
+    }
+}
+
+int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
+                         const uint32_t *d_valid, uint32_t n, uint64_t *d_tables)
+{
+    if (!n) return MK_OK;
+    uint64_t max_nk = 0;
+    for (uint32_t g = 0; g < n; ++g) {
+        const uint64_t len = h_off[g + 1] - h_off[g];
+        if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
+        if (len >= (1ULL << kPosBits)) { set_error("sequence too long"); return MK_ERR_ARG; }
+    }
+    MK_HIP(hipMemsetAsync(d_tables, 0xFF, (size_t)n * c->P * sizeof(uint64_t), c->stream));
+    if (!max_nk) return MK_OK;
+    const uint64_t segs = (max_nk + kSegKmers - 1) / kSegKmers;
+    if (segs > 0x7fffffffULL) { set_error("sequence too long"); return MK_ERR_ARG; }
+    hipLaunchKernelGGL(genome_sketch_kernel, dim3((uint32_t)segs, n), dim3(256), 0, c->stream, d_seq, d_off,
+                       d_valid, d_tables, make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- K2 finalize
+// tables[n][P] -> M[p][g0 .. g0+n) (transposed through LDS), plus per-genome
+// active count and HyperLogLog-style cardinality sum (Miekki.cpp:290-301).  The
+// sum of 2^-exp is kept as an exact integer multiple of 2^-31.
+constexpr uint32_t kFinRows = 64;        // partitions per tile
+constexpr uint32_t kFinTiles = 16;       // tiles per workgroup
+
+template <int W>
+__global__ __launch_bounds__(256) void finalize_kernel(const uint64_t *__restrict__ tables, uint32_t n,
+                                                       uint32_t g0, uint8_t *__restrict__ M, uint64_t ld,
+                                                       uint32_t *__restrict__ active,
+                                                       unsigned long long *__restrict__ cardsum,
+                                                       SketchParams sp)
+{
+    using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
+    __shared__ fp_t tile[kFinRows][kBuildBatch + 2];
+    __shared__ uint32_t s_act[kBuildBatch];
+    __shared__ unsigned long long s_card[kBuildBatch];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < kBuildBatch) { s_act[threadIdx.x] = 0; s_card[threadIdx.x] = 0; }
+    __syncthreads();
+    for (uint32_t t = 0; t < kFinTiles; ++t) {
+        const uint32_t p0 = (blockIdx.x * kFinTiles + t) * kFinRows;
+        if (p0 >= sp.P) break;
+        for (uint32_t g = wave; g < n; g += 4) {
+            const uint32_t p = p0 + lane;
+            uint32_t fp = sp.empty;
+            if (p < sp.P) {
+                const uint64_t key = tables[(uint64_t)g * sp.P + p];
+                if (key != kEmptyKey) fp = (uint32_t)(key >> kPosBits);
+            }
+            tile[lane][g] = (fp_t)fp;
+            const bool act = fp != sp.empty;
+            unsigned long long term = act ? (1ull << (31u - (fp >> sp.f))) : 0ull;
+            uint32_t a = act ? 1u : 0u;
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_down(a, o);
+                term += __shfl_down(term, o);
+            }
+            if (lane == 0) { atomicAdd(&s_act[g], a); atomicAdd(&s_card[g], term); }
+        }
+        __syncthreads();
+        const uint32_t rows = min(kFinRows, sp.P - p0);
+        const uint64_t col0 = (uint64_t)g0 * W;
+        if (((col0 | ((uint64_t)n * W)) & 15u) == 0) {          // 16-byte row pieces
+            const uint32_t vec_per_row = n * W / 16;
+            for (uint32_t idx = threadIdx.x; idx < rows * vec_per_row; idx += 256) {
+                const uint32_t r = idx / vec_per_row, v = idx - r * vec_per_row;
+                alignas(16) fp_t tmp[16 / W];
+#pragma unroll
+                for (uint32_t e = 0; e < 16 / W; ++e) tmp[e] = tile[r][v * (16 / W) + e];
+                *reinterpret_cast<uint4 *>(M + (uint64_t)(p0 + r) * ld + col0 + v * 16) =
+                    *reinterpret_cast<const uint4 *>(tmp);
+            }
+        } else {
+            for (uint32_t idx = threadIdx.x; idx < rows * n; idx += 256) {
+                const uint32_t r = idx / n, g = idx - r * n;
+                *reinterpret_cast<fp_t *>(M + (uint64_t)(p0 + r) * ld + col0 + (uint64_t)g * W) = tile[r][g];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < n) {
+        atomicAdd(&active[threadIdx.x], s_act[threadIdx.x]);
+        atomicAdd(&cardsum[threadIdx.x], s_card[threadIdx.x]);
+    }
+}
+
+int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0)
+{
+    if (!n) return MK_OK;
+    MK_HIP(hipMemsetAsync(c->d_active, 0, kBuildBatch * sizeof(uint32_t), c->stream));
+    MK_HIP(hipMemsetAsync(c->d_cardsum, 0, kBuildBatch * sizeof(uint64_t), c->stream));
+    const uint32_t per_block = kFinRows * kFinTiles;
+    const uint32_t blocks = (c->P + per_block - 1) / per_block;
+    if (c->W == 1)
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
+                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, make_sp(c));
+    else
+        hipLaunchKernelGGL(finalize_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
+                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- K3 Bloom insert
+// insert_bloom (Miekki.cpp:121-131) sets a zero cell to 1 << (hash % 8) of its FIRST
+// inserter in (genome, partition, hash index) order.  Pass A posts that order as a
+// 64-bit key per still-zero cell with an atomic minimum; pass B lets the winner
+// write the byte and reset the key.  Cells already non-zero are never touched.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bloom_kernel(const uint64_t *__restrict__ tables,
+                                                    const char *__restrict__ seq,
+                                                    const uint64_t *__restrict__ off,
+                                                    const uint32_t *__restrict__ valid, uint8_t *bloom,
+                                                    uint64_t bloom_dev_bytes, uint64_t *order,
+                                                    SketchParams sp)
+{
+    const uint32_t g = blockIdx.y;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= sp.P) return;
+    const uint64_t key = tables[(uint64_t)g * sp.P + p];
+    if (key == kEmptyKey) return;
+    const uint64_t pos = key & ((1ULL << kPosBits) - 1);
+    const uint64_t canon = canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
+    const uint64_t anc = revhash64(canon);
+    for (uint32_t i = 0; i < kNumHash; ++i) {
+        const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
+        const uint64_t cell = hsh >> 3;
+        if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
+        const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (i << 4) | (uint32_t)(hsh & 7);
+        if (!WRITE) {
+            if (bloom[cell] == 0) atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+        } else {
+            if (order[cell] == okey) {
+                bloom[cell] = (uint8_t)(1u << (hsh & 7));
+                order[cell] = kEmptyKey;
+            }
+        }
+    }
+}
+
+int launch_bloom_insert(mk_ctx *c, const uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
+                        const uint32_t *d_valid, uint32_t n)
+{
+    if (!n || !c->d_bloom) return MK_OK;
+    dim3 grid((c->P + 255) / 256, n);
+    hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, make_sp(c));
+    hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+__device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                            uint64_t canon, uint64_t anc, uint32_t bloom_log2)
+{
+    // check_bloom, Miekki.cpp:135-146: `cell && mask[hit]` is a logical and -> byte != 0
+    for (uint32_t i = 0; i < kNumHash; ++i) {
+        const uint64_t cell = bloom_pos(canon, anc, i, bloom_log2) >> 3;
+        if (cell >= bloom_dev_bytes || bloom[cell] == 0) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- K4 query sketch (short)
+// One workgroup per query of at most kShortMax k-mers.  Keys
+// (partition << 34 | fingerprint << 18 | position) are sorted in LDS; the first
+// key of every partition run is that partition's winner.  Winners that pass the
+// Bloom gate are compacted, in ascending partition order, into the query's slice
+// of the entry list -- the sparse form of the reference's dense 2^h vector.
+__global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restrict__ seq,
+                                                           const uint64_t *__restrict__ off,
+                                                           const uint64_t *__restrict__ ent_off,
+                                                           uint64_t *__restrict__ entries,
+                                                           uint32_t *__restrict__ nent,
+                                                           const uint8_t *__restrict__ bloom,
+                                                           uint64_t bloom_dev_bytes, uint32_t npad_max,
+                                                           SketchParams sp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    uint8_t *codes = smem + (size_t)npad_max * sizeof(uint64_t);
+    __shared__ uint32_t s_seed_bad;
+    __shared__ uint32_t s_wave_tot[4];
+    const uint32_t q = blockIdx.x;
+    const uint64_t len = off[q + 1] - off[q];
+    const uint64_t nk64 = len > sp.k ? len - sp.k : 0;
+    if (nk64 > kShortMax) return;                            // long path handles it
+    const uint32_t nk = (uint32_t)nk64;
+    if (nk == 0) { if (threadIdx.x == 0) nent[q] = 0; return; }
+    const char *__restrict__ s = seq + off[q];
+    uint32_t npad = 256;
+    while (npad < nk) npad <<= 1;
+
+    if (threadIdx.x == 0) s_seed_bad = 0;
+    __syncthreads();
+    if (threadIdx.x + 1 < sp.k && seed_code((uint8_t)s[threadIdx.x]) == 4u) atomicOr(&s_seed_bad, 1u);
+    __syncthreads();
+    const bool sv = s_seed_bad == 0;
+    const uint32_t nchar = nk + sp.k - 1;
+    for (uint32_t j = threadIdx.x; j < nchar; j += 256) codes[j] = (uint8_t)pos_codes((uint8_t)s[j], j, sp.k, sv);
+    __syncthreads();
+
+    for (uint32_t i = threadIdx.x; i < npad; i += 256) {
+        uint64_t key = kEmptyKey;
+        if (i < nk) {
+            uint64_t S = 0, RC = 0;
+            for (uint32_t j = 0; j < sp.k; ++j) {
+                const uint32_t cd = codes[i + j];
+                S = (S << 2) | (cd & 3u);
+                RC |= (uint64_t)(cd >> 2) << (2 * j);
+            }
+            const uint64_t anc = revhash64(S < RC ? S : RC);
+            uint32_t bucket, fp;
+            bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+            if (fp != sp.empty) key = ((uint64_t)bucket << 34) | ((uint64_t)fp << 18) | i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+
+    for (uint32_t kk = 2; kk <= npad; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < npad; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = keys[i], b = keys[l];
+                    const bool up = (i & kk) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+
+    // each thread owns a contiguous run so that the compaction keeps partition order
+    const uint32_t per = npad / 256;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t out[kShortMax / 256];
+    uint32_t cnt = 0;
+    for (uint32_t e = 0; e < per; ++e) {
+        const uint32_t i = b0 + e;
+        const uint64_t key = keys[i];
+        if (key == kEmptyKey) continue;
+        const uint32_t bucket = (uint32_t)(key >> 34);
+        if (i > 0 && (uint32_t)(keys[i - 1] >> 34) == bucket) continue;   // not the run's first
+        const uint32_t pos = (uint32_t)(key & 0x3ffffu);
+        uint64_t S = 0, RC = 0;
+        for (uint32_t j = 0; j < sp.k; ++j) {
+            const uint32_t cd = codes[pos + j];
+            S = (S << 2) | (cd & 3u);
+            RC |= (uint64_t)(cd >> 2) << (2 * j);
+        }
+        const uint64_t canon = S < RC ? S : RC;
+        if (!bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2))
+            out[cnt++] = make_entry(bucket, (uint32_t)(key >> 18) & 0xffffu);
+    }
+    // exclusive scan of cnt over the workgroup
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave_tot[w];
+    const uint32_t total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    uint64_t *__restrict__ dst = entries + ent_off[q] + base + (incl - cnt);
+    for (uint32_t e = 0; e < cnt; ++e) dst[e] = out[e];
+    if (threadIdx.x == 0) nent[q] = total;
+}
+
+int launch_query_sketch_short(mk_ctx *c, mk_qset *qs)
+{
+    if (!qs->nq || qs->short_max_nk == 0) {
+        // queries without any k-mer still need a zero count
+        if (qs->nq) MK_HIP(hipMemsetAsync(qs->d_nent, 0, (size_t)qs->nq * sizeof(uint32_t), c->stream));
+        return MK_OK;
+    }
+    uint32_t npad = 256;
+    while (npad < qs->short_max_nk) npad <<= 1;
+    MK_HIP(hipMemsetAsync(qs->d_nent, 0, (size_t)qs->nq * sizeof(uint32_t), c->stream));
+    const size_t lds = (size_t)npad * sizeof(uint64_t) + npad + 64;
+    hipLaunchKernelGGL(query_sketch_kernel, dim3(qs->nq), dim3(256), lds, c->stream, qs->d_seq, qs->d_off,
+                       qs->d_ent_off, qs->d_entries, qs->d_nent, c->d_bloom, c->bloom_dev_bytes, npad,
+                       make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- K4' query sketch (long)
+// Whole-genome and other long queries reuse the genome path (one table in HBM),
+// then gate and compact the table.  Entry order is irrelevant to the scan, so the
+// compaction is a wave-aggregated append.
+__global__ __launch_bounds__(256) void long_compact_kernel(const uint64_t *__restrict__ table,
+                                                           const char *__restrict__ s,
+                                                           const uint32_t *__restrict__ seed_valid,
+                                                           const uint8_t *__restrict__ bloom,
+                                                           uint64_t bloom_dev_bytes,
+                                                           uint64_t *__restrict__ dst,
+                                                           uint32_t *__restrict__ count, SketchParams sp)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    uint32_t fp = 0;
+    if (p < sp.P) {
+        const uint64_t key = table[p];
+        if (key != kEmptyKey) {
+            fp = (uint32_t)(key >> kPosBits);
+            const uint64_t canon = canon_at(s, key & ((1ULL << kPosBits) - 1), sp.k, seed_valid[0] != 0);
+            keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2);
+        }
+    }
+    const uint64_t mask = __ballot(keep);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t slot0 = 0;
+    if (lane == leader) slot0 = atomicAdd(count, (uint32_t)__popcll(mask));
+    slot0 = __shfl(slot0, (int)leader);
+    if (keep) dst[slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_entry(p, fp);
+}
+
+int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q)
+{
+    const uint64_t one_off[2] = {qs->h_off[q], qs->h_off[q + 1]};
+    // table build on the single sequence: offsets are read from the set's own array
+    uint32_t *d_valid = c->d_seed_valid;
+    hipLaunchKernelGGL(seed_valid_kernel, dim3(1), dim3(64), 0, c->stream, qs->d_seq, qs->d_off + q, 1u,
+                       c->p.k, d_valid);
+    MK_TRY(launch_genome_sketch(c, qs->d_seq, qs->d_off + q, one_off, d_valid, 1, c->d_long_table));
+    hipLaunchKernelGGL(long_compact_kernel, dim3((c->P + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_long_table, qs->d_seq + qs->h_off[q], d_valid, c->d_bloom, c->bloom_dev_bytes,
+                       qs->d_entries + qs->h_ent_off[q], qs->d_nent + q, make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- synthetic inputs
+__global__ void synth_genomes_kernel(uint64_t first_id, uint32_t n, uint64_t len, char *__restrict__ out)
+{
+    const uint64_t words = (len + 31) / 32;
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.y;
+    if (w >= words || g >= n) return;
+    const uint64_t bits = genome_word(first_id + g, w);
+    char *dst = out + (uint64_t)g * len + w * 32;
+    const uint32_t m = (uint32_t)min((uint64_t)32, len - w * 32);
+    for (uint32_t i = 0; i < m; ++i) dst[i] = "ACGT"[(bits >> (62 - 2 * i)) & 3];
+}
+
+int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, char *d_out)
+{
+    if (!n || !len) return MK_OK;
+    const uint64_t words = (len + 31) / 32;
+    hipLaunchKernelGGL(synth_genomes_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->stream,
+                       first_id, n, len, d_out);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+__global__ void synth_queries_kernel(uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
+                                     char *__restrict__ out)
+{
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    const uint64_t id = first_id + q;
+    const uint64_t g = id % G;
+    const uint64_t o = splitmix64(kSeedQ ^ id) % (L - qlen);
+    for (uint64_t i = threadIdx.x; i < qlen; i += blockDim.x) {
+        const uint64_t pos = o + i;
+        const uint64_t bits = genome_word(g, pos >> 5);
+        out[(uint64_t)q * qlen + i] = "ACGT"[(bits >> (62 - 2 * (pos & 31))) & 3];
+    }
+}
+
+int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
+                         char *d_out)
+{
+    if (!nq) return MK_OK;
+    hipLaunchKernelGGL(synth_queries_kernel, dim3(nq), dim3(256), 0, c->stream, first_id, nq, G, L, qlen, d_out);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- column import / export
+// dense staging [rows][G*W] (reference byte order: 16-bit big-endian) <-> M rows
+template <int W, bool TO_DEVICE>
+__global__ void convert_columns_kernel(uint8_t *__restrict__ M, uint64_t ld, uint32_t G, uint32_t p_begin,
+                                       uint32_t rows, uint8_t *__restrict__ staging)
+{
+    const uint64_t total = (uint64_t)rows * G;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(idx / G), g = (uint32_t)(idx - (uint64_t)r * G);
+        uint8_t *m = M + (uint64_t)(p_begin + r) * ld + (uint64_t)g * W;
+        uint8_t *s = staging + idx * W;
+        if (W == 1) {
+            if (TO_DEVICE) *m = *s; else *s = *m;
+        } else {
+            if (TO_DEVICE) { m[0] = s[1]; m[1] = s[0]; } else { s[0] = m[1]; s[1] = m[0]; }
+        }
+    }
+}
+
+int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging)
+{
+    const uint32_t rows = p_end - p_begin;
+    if (!rows || !c->G) return MK_OK;
+    const uint64_t total = (uint64_t)rows * c->G;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 8192);
+#define MK_CONV(Wv, TD)                                                                                 \
+    hipLaunchKernelGGL((convert_columns_kernel<Wv, TD>), dim3(blocks), dim3(256), 0, c->stream, c->d_M, \
+                       c->ld, c->G, p_begin, rows, d_staging)
+    if (c->W == 1) { if (to_device) MK_CONV(1, true); else MK_CONV(1, false); }
+    else           { if (to_device) MK_CONV(2, true); else MK_CONV(2, false); }
+#undef MK_CONV
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+}  // namespace mk

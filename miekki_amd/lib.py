@@ -1,0 +1,100 @@
+"""ctypes binding of include/miekki_hip.h (libmiekki_hip.so)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmiekki_hip.so")
+
+
+class MiekkiHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libmiekki_hip: status {status}: {msg}")
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("h", C.c_uint32), ("fp_bits", C.c_uint32), ("bloom_log2", C.c_uint32),
+                ("threshold", C.c_uint32), ("device", C.c_int32), ("genome_id_base", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("genome", C.c_uint32), ("matches", C.c_uint32), ("jaccard", C.c_double),
+                ("intersection", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sketch_ms", C.c_double), ("scan_ms", C.c_double), ("filter_ms", C.c_double),
+                ("scan_launches", C.c_uint64), ("comparisons", C.c_uint64), ("active_partitions", C.c_uint64),
+                ("scan_algo_bytes", C.c_uint64), ("build_sketch_ms", C.c_double),
+                ("build_finalize_ms", C.c_double), ("build_kmers", C.c_uint64), ("build_genomes", C.c_uint64)]
+
+
+vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+PP = C.POINTER
+
+# name -> (restype, argtypes): every symbol include/miekki_hip.h declares
+SIGNATURES = {
+    "mk_last_error": (C.c_char_p, []),
+    "mk_abi_version": (u32, []),
+    "mk_create": (i32, [PP(Params), PP(vp)]),
+    "mk_destroy": (None, [vp]),
+    "mk_reserve": (i32, [vp, u32]),
+    "mk_index_size": (u32, [vp]),
+    "mk_get_params": (i32, [vp, PP(Params)]),
+    "mk_get_stats": (i32, [vp, PP(Stats)]),
+    "mk_reset_stats": (i32, [vp]),
+    "mk_index_append": (i32, [vp, vp, vp, u32]),
+    "mk_index_append_synthetic": (i32, [vp, u64, u32, u64]),
+    "mk_index_export_columns": (i32, [vp, u32, u32, vp]),
+    "mk_index_export_sizes": (i32, [vp, vp, vp]),
+    "mk_index_export_bloom": (i32, [vp, u64, u64, vp]),
+    "mk_index_import_begin": (i32, [vp, u32]),
+    "mk_index_import_columns": (i32, [vp, u32, u32, vp]),
+    "mk_index_import_sizes": (i32, [vp, vp, vp]),
+    "mk_index_import_bloom": (i32, [vp, u64, u64, vp]),
+    "mk_query_scores": (i32, [vp, vp, vp, u32, vp]),
+    "mk_query": (i32, [vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp]),
+    "mk_filter_candidates": (u32, [vp, u32, u32, vp]),
+    "mk_qset_upload": (i32, [vp, vp, vp, u32, PP(vp)]),
+    "mk_qset_synthetic": (i32, [vp, u64, u32, u64, u64, u64, PP(vp)]),
+    "mk_qset_free": (None, [vp, vp]),
+    "mk_qset_run": (i32, [vp, vp, u32, C.c_double, u32, vp, vp]),
+    "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
+    "mk_qset_active": (i32, [vp, vp, vp]),
+    "mk_sync": (i32, [vp]),
+    "mk_exact": (i32, [vp, vp, vp, u32, vp, vp, u32, vp, vp]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libmiekki_hip.so.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise MiekkiHipError(-3, f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                     "or `make -C miekki_amd/csrc lib` (there is no CPU fallback)")
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status: int):
+    if status != 0:
+        raise MiekkiHipError(status, load_library().mk_last_error().decode(errors="replace"))
+
+
+def seq_arrays(seqs):
+    n = len(seqs)
+    return (C.c_char_p * n)(*seqs), (C.c_uint64 * n)(*[len(s) for s in seqs])

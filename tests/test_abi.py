@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/miekki_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import miekki_amd
+from miekki_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "miekki_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mk_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("mk_create", "mk_index_append", "mk_query", "mk_query_scores", "mk_qset_run",
+                 "mk_index_export_columns", "mk_index_import_columns", "mk_exact", "mk_filter_candidates"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(L.library_path())
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/miekki_hip.h but not exported"
+    assert sorted(L.SIGNATURES) == declared_symbols()
+
+
+def test_abi_version_and_struct_layouts():
+    lib = L.load_library()
+    assert lib.mk_abi_version() == 1
+    assert ctypes.sizeof(L.Hit) == 24          # similarity_score, Miekki.h:27-31
+    assert ctypes.sizeof(L.Params) == 32
+
+
+def test_filter_candidates_is_the_reference_heap(golden_dir):
+    """mk_filter_candidates is pure host code: pin it to the reference's tie cases."""
+    import numpy as np
+    lib = L.load_library()
+    gold = np.load(os.path.join(golden_dir, "filter_ties.npz"))
+    off = gold["off"]
+    for c in range(int(gold["n"])):
+        G, nres, ms = (int(x) for x in gold[f"c{c}_par"])
+        mi = float(gold[f"c{c}_mi"])
+        ss, gs, sc = gold[f"c{c}_ss"], gold[f"c{c}_gs"], gold[f"c{c}_sc"]
+        cand = (L.Hit * max(G, 1))()
+        n = 0
+        for g in range(G):
+            if sc[g] < ms:
+                continue
+            jac = float(sc[g]) / float(ss[g]); inter = jac * float(gs[g])
+            if inter < mi:
+                continue
+            cand[n] = L.Hit(g, int(sc[g]), jac, inter); n += 1
+        out = (L.Hit * max(nres, 1))()
+        m = lib.mk_filter_candidates(cand, n, nres, out)
+        lo, hi = int(off[c]), int(off[c + 1])
+        assert [out[i].genome for i in range(m)] == list(gold["genome"][lo:hi]), c
+        assert [out[i].matches for i in range(m)] == list(gold["matches"][lo:hi]), c
+
+
+def test_unsupported_fingerprint_width_fails_like_the_reference():
+    # -f values other than 3 / 11: "not implemented" (Miekki.cpp:235-237); checked before any device use
+    lib = L.load_library()
+    p = L.Params(31, 14, 21, 33, 200, 0, 0, 0)
+    h = ctypes.c_void_p()
+    assert lib.mk_create(ctypes.byref(p), ctypes.byref(h)) == -2
+    assert b"not implemented" in lib.mk_last_error()
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.MiekkiHipError):
+        miekki_amd.Miekki(31, 14, 8, 33, 200)

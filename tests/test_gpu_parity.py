@@ -1,0 +1,222 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden fixtures
+of the real reference and against the CPU oracle on the same seeded inputs.
+
+Integer work must be bit-exact; Jaccard / intersection doubles within 1e-6
+relative (north-star tolerance; in practice they are identical).
+"""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+CASE_NAMES = ["messy", "h20", "w16", "c1"]
+RTOL = 1e-6
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import miekki_amd
+    return miekki_amd
+
+
+@pytest.fixture(scope="module")
+def built(hip, golden_dir):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            case = synth.CASES[name]()
+            gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+            ix = hip.Miekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+            seqs = case.genome_sequences()
+            for i in range(0, len(seqs), 11):
+                ix.insert_sequences(seqs[i:i + 11])
+            cache[name] = (case, gold, ix)
+        return cache[name]
+    yield get
+    for _, _, ix in cache.values():
+        ix.close()
+
+
+def stream_of(ix):
+    return b"".join(ix.serialize())
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_index_build_bit_exact(built, name):
+    case, gold, ix = built(name)
+    assert ix.index_size == int(gold["G"])
+    np.testing.assert_array_equal(ix.sketch_size, gold["sketch_size"])
+    np.testing.assert_array_equal(ix.genome_size, gold["genome_size"])
+    raw = bytearray(stream_of(ix))
+    assert len(raw) == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    G, W, P = ix.index_size, ix.W, ix.number_minimizer
+    cols = np.frombuffer(bytes(raw), np.uint8, P * G * W, 39).reshape(P, G * W)
+    np.testing.assert_array_equal(cols[:64], gold["cols_head"])
+    np.testing.assert_array_equal(cols[-64:], gold["cols_tail"])
+    for g in range(G):
+        assert sha(np.ascontiguousarray(cols[:, g * W:(g + 1) * W]).tobytes()) == str(gold["col_sha_per_genome"][g]), g
+    bloom = np.frombuffer(bytes(raw), np.uint8, ix.bloom_size // 8, 39 + P * G * W + 8 * G)
+    assert int(np.count_nonzero(bloom)) == int(gold["bloom_nonzero"])
+    idx = np.flatnonzero(bloom)[:256]
+    np.testing.assert_array_equal(idx.astype(np.uint64), gold["bloom_nonzero_idx_head"])
+    np.testing.assert_array_equal(bloom[idx], gold["bloom_nonzero_val_head"])
+    assert sha(bloom.tobytes()) == str(gold["bloom_sha"])
+    # the whole dump_disk payload, byte for byte
+    assert sha(bytes(raw)) == str(gold["stream_sha_masked"])
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_scores_bit_exact(built, name):
+    case, gold, ix = built(name)
+    qs = [s for _, s in case.query_sequences()]
+    scores = ix.query_sequences(qs)
+    np.testing.assert_array_equal(scores, gold["scores"])
+    _, active = ix.query(qs, 10, 10, 0.5 * case.threshold)
+    np.testing.assert_array_equal(active, gold["qseq_active"])
+
+
+PARAMS = {"approx": lambda t: (10, 10, 0.5 * t), "exact_a": lambda t: (5, 10, float(t)),
+          "exact_A": lambda t: (5, 5, float(t)), "loose": lambda t: (3, 0, 0.0),
+          "loose10": lambda t: (10, 1, 0.0)}
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("tag", list(PARAMS))
+def test_fused_query_hits(built, name, tag):
+    """mk_query = scan + fused threshold filter + reference heap."""
+    case, gold, ix = built(name)
+    nres, ms, mi = PARAMS[tag](case.threshold)
+    qs = [s for _, s in case.query_sequences()]
+    hits, _ = ix.query(qs, nres, ms, mi)
+    off = gold[f"hits_{tag}_off"]
+    for q in range(len(qs)):
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert [h.genome for h in hits[q]] == list(gold[f"hits_{tag}_genome"][lo:hi]), (q, tag)
+        assert [h.matches for h in hits[q]] == list(gold[f"hits_{tag}_matches"][lo:hi]), (q, tag)
+        np.testing.assert_allclose([h.jaccard for h in hits[q]], gold[f"hits_{tag}_jaccard"][lo:hi], rtol=RTOL, atol=0)
+        np.testing.assert_allclose([h.intersection for h in hits[q]], gold[f"hits_{tag}_inter"][lo:hi], rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_out_txt_matches_reference_cli(built, name, golden_dir, tmp_path):
+    case, gold, ix = built(name)
+    qf = tmp_path / "queries.fa"
+    qf.write_bytes(b"".join(h + b"\n" + s + b"\n" for h, s in case.queries))
+    with open(tmp_path / "out.txt", "wb") as out:
+        ix.query_file(str(qf), out)
+    assert (tmp_path / "out.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["messy", "w16"])
+def test_dump_and_load_round_trip(hip, built, name, tmp_path):
+    case, gold, ix = built(name)
+    path = str(tmp_path / "idx.gz")
+    ix.dump_disk(path)
+    raw = bytearray(gzip.decompress(open(path, "rb").read()))
+    raw[32] = 0; raw[38] = 0
+    assert sha(bytes(raw)) == str(gold["stream_sha_masked"])
+    back = hip.Miekki.load(path)
+    try:
+        assert back.index_size == ix.index_size and back.threshold == ix.threshold
+        qs = [s for _, s in case.query_sequences()]
+        np.testing.assert_array_equal(back.query_sequences(qs), gold["scores"])
+        assert stream_of(back) == stream_of(ix)
+    finally:
+        back.close()
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_exact_mode_matches_reference_cli(built, name, golden_dir):
+    case, gold, ix = built(name)
+    want = open(os.path.join(golden_dir, f"{name}_exact.txt"), "rb").read().decode().splitlines()
+    files = [(fn, data) for fn, data, _ in case.genome_files
+             if len(b"".join(l for l in data.split(b"\n") if not l.startswith(b">"))) >= case.k]
+    nres, ms, mi = PARAMS["exact_a"](case.threshold)
+    recs = [(hd, sq) for hd, sq in case.query_sequences() if sq[:1] in (b"A", b"C", b"G", b"T", b"N")]
+    hits, _ = ix.query([s for _, s in recs], nres, ms, mi)
+    per_file = {}
+    for (hd, sq), hs in zip(recs, hits):
+        for h in hs:
+            per_file.setdefault(h.genome, []).append((hd, sq, h))
+    got = []
+    for g, items in per_file.items():
+        fn, data = files[g]
+        inter, uni = ix.ground_truth_batch([sq for _, sq, _ in items], data)
+        for (hd, sq, h), ni, nu in zip(items, inter, uni):
+            if ni > 0:
+                got.append("%g\t%g\t%g\t%g\t%s\t%s" % (int(ni) / int(nu), h.jaccard, int(ni), h.intersection, hd.decode(), fn))
+    assert sorted(got) == sorted(want)
+
+
+def test_device_generator_matches_host_generator(hip):
+    """mk_index_append_synthetic / mk_qset_synthetic use the SURVEY 8d generator."""
+    k, h = 31, 12
+    a = hip.Miekki(k, h, 8, 33, 200)
+    b = hip.Miekki(k, h, 8, 33, 200)
+    try:
+        L_ = 100_003
+        a.insert_synthetic(7, 3, L_)
+        b.insert_sequences([synth.genome_bases(7 + g, 0, L_) for g in range(3)])
+        assert stream_of(a) == stream_of(b)
+    finally:
+        a.close(); b.close()
+
+
+def test_ragged_multi_tile_against_oracle(hip):
+    """G not a multiple of anything, several 1 KiB tiles, both widths, long and
+    empty queries: HIP scores == oracle scores on the same seeded inputs."""
+    from oracle import oracle as orc
+    for fpb, G in ((8, 2100), (16, 1030)):
+        k, h, L_ = 31, 10, 3000
+        seqs = [synth.genome_bases(900 + g, 0, L_ + (g % 7)) for g in range(G)]
+        o = orc.OracleMiekki(k, h, fpb, 32, 50)
+        o.insert_sequences(seqs)
+        ix = hip.Miekki(k, h, fpb, 32, 50)
+        try:
+            for i in range(0, G, 333):
+                ix.insert_sequences(seqs[i:i + 333])
+            np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+            np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+            qs = [seqs[5][100:1100], seqs[G - 1][:700], synth.genome_bases(5, 0, 1500), seqs[17],
+                  seqs[3][:k], seqs[3][:k + 1], seqs[1000][200:9000] if L_ > 9000 else seqs[1000]]
+            np.testing.assert_array_equal(ix.query_sequences(qs), o.query_sequences(qs))
+            hits, act = ix.query(qs, 10, 2, 0.0)
+            for q, s in enumerate(qs):
+                row, oact = o.query_sequence(s)
+                assert int(act[q]) == oact
+                want = o.filter_results(row, 10, 2, 0.0)
+                assert [(h_.genome, h_.matches) for h_ in hits[q]] == [(w[0], w[1]) for w in want], q
+        finally:
+            ix.close()
+
+
+def test_candidate_overflow_falls_back_to_full_row(hip):
+    """More passing genomes than the device candidate row holds (cap 256)."""
+    from oracle import oracle as orc
+    k, h, G = 21, 8, 700
+    base = synth.genome_bases(4242, 0, 4000)
+    seqs = [base[: 3000 + g] for g in range(G)]              # near-identical genomes: everything matches
+    o = orc.OracleMiekki(k, h, 8, 32, 0)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 32, 0)
+    try:
+        ix.insert_sequences(seqs)
+        q = base[500:2500]
+        hits, _ = ix.query([q], 10, 1, 0.0)
+        row, _ = o.query_sequence(q)
+        want = o.filter_results(row, 10, 1, 0.0)
+        assert [(h_.genome, h_.matches) for h_ in hits[0]] == [(w[0], w[1]) for w in want]
+    finally:
+        ix.close()
