@@ -1,0 +1,19 @@
+// Host-side I/O of the `miekki` binary: gzip-transparent text input and the
+// on-disk index format of the reference (Miekki.cpp:649-719),
+// streamed through the C ABI in partition ranges.  Plain zlib, no HIP.
+#pragma once
+#include <string>
+
+#include "miekki_hip.h"
+
+namespace mkhost {
+
+bool file_exists(const std::string &path);
+// whole file; gunzipped when it carries the gzip magic (zstr.hpp:157-167 semantics)
+bool read_text(const std::string &path, std::string &out);
+// dump_disk: gzip level 1 like zstr::ofstream (zstr.hpp:82)
+int dump_index(mk_ctx *ctx, const std::string &path, std::string &err);
+// Miekki(const string&): builds a context from the file's own header
+int load_index(const std::string &path, int device, mk_ctx **out, std::string &err);
+
+}  // namespace mkhost

@@ -1,0 +1,431 @@
+// `miekki` -- drop-in host driver for the -l / -i / -a / -A / -o / -d / -e command
+// line of the reference (main.cpp:125-238) on top of libmiekki_hip.so.
+//
+// Plain C++ above the C ABI of include/miekki_hip.h: flag parsing, FASTA reading,
+// batching, output formatting and the index file format stay on the host exactly
+// where the reference has them (file drivers Miekki.cpp:426-645, 723-788); every
+// sketch / scan / filter / exact-intersection computation is a call into the HIP
+// layer.  Differences from the reference, all deliberate:
+//   * genome ids follow list order and output follows query order (what the
+//     reference does at -t 1); -t is accepted and ignored,
+//   * `-i ... -e` reports that genome file names are not stored in an index
+//     instead of crashing,
+//   * no zlib re-compression of the in-memory columns (main.cpp:198): they live
+//     raw in HBM.
+#include <getopt.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "index_io.hpp"
+#include "miekki_hip.h"
+
+using namespace std;
+
+namespace {
+
+string int_to_string(uint64_t n)                 // utils.cpp:145-157: thousands separators
+{
+    string s = to_string(n), out;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (i && (s.size() - i) % 3 == 0) out += ',';
+        out += s[i];
+    }
+    return out;
+}
+
+void help()
+{
+    cout << "miekki (MI355X build): minhash index for k-mer intersection\n"
+            "Input\n"
+            "  -i <file>  load a constructed index from disk\n"
+            "  -l <file>  construct an index from a list of FASTA files\n"
+            "  -a <file>  query a FASTA file (one 2-line record per query)\n"
+            "  -A <file>  query every FASTA file of a list as one sequence\n"
+            "Output\n"
+            "  -o <file>  output file name (out.txt)\n"
+            "  -d <file>  dump the index on disk\n"
+            "Performances\n"
+            "  -h <int>   use 2^h minimizers per sequence (17)\n"
+            "  -k <int>   k-mer size (31)\n"
+            "  -s <num>   minimal estimated intersection to be reported (200)\n"
+            "  -t <int>   thread number of the CPU version; accepted and ignored\n"
+            "Advanced usage\n"
+            "  -f <int>   fingerprint size: 3 (1-byte) or 11 (2-byte)\n"
+            "  -b <int>   2^b bits used for the Bloom filter (33)\n"
+            "  -e         exact mode, real intersection is computed on hits\n";
+}
+
+void die(const string &what)
+{
+    cout << what << ": " << mk_last_error() << endl;
+    exit(1);
+}
+
+vector<string> split_lines(const string &text)   // getline semantics
+{
+    vector<string> lines;
+    size_t pos = 0;
+    while (pos <= text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == string::npos) e = text.size();
+        lines.emplace_back(text, pos, e - pos);
+        pos = e + 1;
+    }
+    return lines;
+}
+
+bool nucleotide_start(const string &s)           // Miekki.cpp:736, 771
+{
+    return !s.empty() && (s[0] == 'A' || s[0] == 'C' || s[0] == 'G' || s[0] == 'T' || s[0] == 'N');
+}
+
+struct Driver {
+    mk_ctx *ctx = nullptr;
+    uint32_t k = 31, threshold = 200;
+    vector<string> file_names;                   // Miekki.h:59, never persisted
+    ofstream out;
+
+    // ---- Miekki.cpp:540-588
+    void index_file_of_file(const string &list)
+    {
+        if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
+        string text;
+        mkhost::read_text(list, text);
+        vector<string> seqs, names;
+        uint64_t bytes = 0;
+        auto flush = [&]() {
+            if (seqs.empty()) return;
+            vector<const char *> p;
+            vector<uint64_t> l;
+            for (auto &s : seqs) { p.push_back(s.data()); l.push_back(s.size()); }
+            if (mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size()) != MK_OK) die("index build failed");
+            file_names.insert(file_names.end(), names.begin(), names.end());
+            seqs.clear(); names.clear(); bytes = 0;
+        };
+        for (const string &fn : split_lines(text)) {
+            if (fn.size() <= 3) continue;
+            if (!mkhost::file_exists(fn)) { cout << "Missed file: " << fn << endl; continue; }
+            string ftext, ref;
+            mkhost::read_text(fn, ftext);
+            for (const string &line : split_lines(ftext))
+                if (line.empty() || line[0] != '>') ref += line;       // contigs concatenated (563-566)
+            if (ref.size() >= k) {
+                bytes += ref.size();
+                seqs.push_back(std::move(ref)); names.push_back(fn);
+                if (seqs.size() >= 64 || bytes > (1ull << 30)) flush();
+                cout << "-" << flush_stream();
+            }
+        }
+        flush();
+        cout << endl;
+        cout << "Reference indexed: " << mk_index_size(ctx) << endl;
+        mk_params p;
+        mk_get_params(ctx, &p);
+        if (p.bloom_log2) cout << "BF size:" << int_to_string(1ull << p.bloom_log2) << endl;
+    }
+
+    static const char *flush_stream() { cout.flush(); return ""; }
+
+    // one output line of query_file / query_whole_file (Miekki.cpp:440-444, 503-505)
+    static string hit_text(const mk_hit *h, uint32_t n)
+    {
+        string s;
+        for (uint32_t i = 0; i < n; ++i)
+            s += to_string(h[i].genome) + "\t" + to_string(h[i].matches) + "\t" +
+                 to_string((unsigned)h[i].intersection) + "\t" + to_string(h[i].jaccard) + ";";
+        return s;
+    }
+
+    void run_query(const vector<const string *> &seqs, uint32_t nres, uint32_t min_score, double min_inter,
+                   vector<mk_hit> &hits, vector<uint32_t> &nhits)
+    {
+        vector<const char *> p;
+        vector<uint64_t> l;
+        for (auto s : seqs) { p.push_back(s->data()); l.push_back(s->size()); }
+        hits.assign((size_t)seqs.size() * nres + 1, mk_hit{});
+        nhits.assign(seqs.size() + 1, 0);
+        if (seqs.empty()) return;
+        if (mk_query(ctx, p.data(), l.data(), (uint32_t)seqs.size(), nres, min_score, min_inter, hits.data(),
+                     nhits.data(), nullptr) != MK_OK)
+            die("query failed");
+    }
+
+    // strict 2-line records (Miekki.cpp:458-464)
+    static void read_records(const string &path, vector<string> &heads, vector<string> &seqs)
+    {
+        string text;
+        mkhost::read_text(path, text);
+        vector<string> lines = split_lines(text);
+        for (size_t i = 0; i < lines.size(); i += 2) {
+            heads.push_back(std::move(lines[i]));
+            seqs.push_back(i + 1 < lines.size() ? std::move(lines[i + 1]) : string());
+        }
+    }
+
+    // ---- Miekki.cpp:426-483
+    void query_file(const string &path)
+    {
+        if (!mkhost::file_exists(path)) { cout << "File problem" << endl; return; }
+        vector<string> heads, seqs;
+        read_records(path, heads, seqs);
+        vector<size_t> kept;
+        for (size_t i = 0; i < seqs.size(); ++i)
+            if (seqs[i].size() >= k) kept.push_back(i);
+        const size_t super = 16384;
+        vector<mk_hit> hits;
+        vector<uint32_t> nhits;
+        for (size_t b = 0; b < kept.size(); b += super) {
+            const size_t e = min(kept.size(), b + super);
+            vector<const string *> q;
+            for (size_t i = b; i < e; ++i) q.push_back(&seqs[kept[i]]);
+            run_query(q, 10, 10, 0.5 * threshold, hits, nhits);
+            string text;
+            for (size_t i = b; i < e; ++i) {
+                text += heads[kept[i]] + ":" + hit_text(hits.data() + (i - b) * 10, nhits[i - b]) + "\n";
+                if ((i % 201) == 0) cout << "-" << flush_stream();      // one mark per reference batch (345)
+            }
+            out << text;
+        }
+        out << flush;
+    }
+
+    static string concat_sequence_lines(const string &text)
+    {
+        string ref;
+        for (const string &line : split_lines(text))
+            if (line.empty() || line[0] != '>') ref += line;
+        return ref;
+    }
+
+    // ---- Miekki.cpp:592-612, 487-514
+    void query_file_of_file(const string &list)
+    {
+        if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
+        string text;
+        mkhost::read_text(list, text);
+        for (const string &fn : split_lines(text)) {
+            if (fn.size() <= 3) continue;
+            if (!mkhost::file_exists(fn)) {
+                cout << "File problem" << endl;
+            } else {
+                string ftext;
+                mkhost::read_text(fn, ftext);
+                const string ref = concat_sequence_lines(ftext);
+                if (ref.size() >= k) {
+                    vector<mk_hit> hits;
+                    vector<uint32_t> nhits;
+                    run_query({&ref}, 10, 10, 0.5 * threshold, hits, nhits);
+                    if (nhits[0]) out << fn << ":" << hit_text(hits.data(), nhits[0]) << "\n";   // 506-511
+                    out << flush;
+                }
+            }
+            cout << "-" << flush_stream();
+        }
+    }
+
+    // ---- exact mode -------------------------------------------------------------
+    struct Pending { string seq, head; double jaccard, intersection; };
+
+    // ground_truth_batch (Miekki.cpp:792-859) for all pending queries of one genome file
+    void ground_truth(const string &file, const vector<Pending> &v)
+    {
+        if (!mkhost::file_exists(file)) { cout << "File problem: " << file << endl; return; }
+        string text;
+        mkhost::read_text(file, text);
+        vector<string> contigs;
+        string ref;
+        for (const string &line : split_lines(text)) {
+            if (!line.empty() && line[0] == '>') {
+                if (ref.size() >= k) { contigs.push_back(ref); ref.clear(); }    // short contigs leak (806-812)
+            } else {
+                ref += line;
+            }
+        }
+        if (ref.size() >= k) contigs.push_back(ref);
+        vector<const char *> cp, qp;
+        vector<uint64_t> cl, ql;
+        for (auto &c : contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
+        for (auto &q : v) { qp.push_back(q.seq.data()); ql.push_back(q.seq.size()); }
+        vector<uint64_t> inter(v.size()), uni(v.size());
+        if (mk_exact(ctx, cp.data(), cl.data(), (uint32_t)contigs.size(), qp.data(), ql.data(), (uint32_t)v.size(),
+                     inter.data(), uni.data()) != MK_OK)
+            die("exact mode failed");
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (!inter[i]) continue;                                             // 843
+            const double real_jax = (double)inter[i] / (double)uni[i];
+            out << real_jax << "\t" << v[i].jaccard << "\t" << (double)inter[i] << "\t" << v[i].intersection
+                << "\t" << v[i].head << "\t" << file << "\n";                    // 853
+        }
+    }
+
+    bool need_names()
+    {
+        if (file_names.size() == mk_index_size(ctx)) return true;
+        cout << "exact mode needs the genome files of the index: build it with -l in the same run "
+                "(file names are not stored in an index file)" << endl;
+        return false;
+    }
+
+    void exact_collect(const vector<string> &heads, const vector<const string *> &seqs, uint32_t nres,
+                       uint32_t min_score)
+    {
+        vector<mk_hit> hits;
+        vector<uint32_t> nhits;
+        run_query(seqs, nres, min_score, (double)threshold, hits, nhits);
+        map<uint32_t, vector<Pending>> per_genome;
+        for (size_t q = 0; q < seqs.size(); ++q)
+            for (uint32_t i = 0; i < nhits[q]; ++i) {
+                const mk_hit &h = hits[q * nres + i];
+                per_genome[h.genome].push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection});
+            }
+        for (auto &kv : per_genome) ground_truth(file_names[kv.first], kv.second);
+        out << flush;
+    }
+
+    // ---- Miekki.cpp:723-759
+    void query_file_exact(const string &path)
+    {
+        if (!mkhost::file_exists(path)) { cout << "File problem" << endl; return; }
+        if (!need_names()) return;
+        vector<string> heads, seqs, kh;
+        read_records(path, heads, seqs);
+        vector<const string *> kept;
+        for (size_t i = 0; i < seqs.size(); ++i)
+            if (seqs[i].size() >= k && nucleotide_start(seqs[i])) { kept.push_back(&seqs[i]); kh.push_back(heads[i]); }
+        exact_collect(kh, kept, 5, 10);
+    }
+
+    // ---- Miekki.cpp:616-645, 763-788
+    void query_file_of_file_exact(const string &list)
+    {
+        if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
+        if (!need_names()) return;
+        string text;
+        mkhost::read_text(list, text);
+        vector<string> heads, refs;
+        for (const string &fn : split_lines(text)) {
+            if (fn.size() <= 3) continue;
+            if (!mkhost::file_exists(fn)) {
+                cout << "File problem" << endl;
+            } else {
+                string ftext;
+                mkhost::read_text(fn, ftext);
+                vector<string> lines = split_lines(ftext);
+                string ref;
+                for (size_t i = 1; i < lines.size(); ++i)
+                    if (lines[i].size() >= k && nucleotide_start(lines[i])) ref += lines[i];   // 771-775
+                heads.push_back(lines.empty() ? string() : lines[0]);
+                refs.push_back(std::move(ref));
+            }
+            cout << "-" << flush_stream();
+        }
+        vector<const string *> ptrs;
+        for (auto &r : refs) ptrs.push_back(&r);
+        exact_collect(heads, ptrs, 5, 5);
+    }
+};
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { help(); return 0; }
+    string index_file, list_file, query_lines, query_list, output_file("out.txt"), index_dump;
+    uint64_t H = 17, core_number = 8, kmer_size = 31, bloom_size = 33, fingerprint_size = 3;   // main.cpp:131
+    double threshold = 200;
+    bool exact_mode = false;
+    int device = 0;
+    if (const char *d = getenv("MIEKKI_DEVICE")) device = atoi(d);
+    int c;
+    while ((c = getopt(argc, argv, "i:l:a:h:t:f:k:s:b:o:ed:A:")) != -1) {
+        switch (c) {
+        case 'i': index_file = optarg; break;
+        case 'l': list_file = optarg; break;
+        case 'a': query_lines = optarg; break;
+        case 'A': query_list = optarg; break;
+        case 'o': output_file = optarg; break;
+        case 'h': H = stoi(optarg); break;
+        case 't': core_number = stoi(optarg); break;
+        case 'k': kmer_size = stoi(optarg); break;
+        case 's': threshold = stof(optarg); break;
+        case 'f': fingerprint_size = stoi(optarg); break;
+        case 'b': bloom_size = stoi(optarg); break;
+        case 'e': exact_mode = true; break;
+        case 'd': index_dump = optarg; break;
+        }
+    }
+    (void)core_number;
+    const uint32_t bit_per_min = (uint32_t)(5 + fingerprint_size);                              // main.cpp:184
+    cout << "Using " << bit_per_min << " bits per minimizer, " << int_to_string(1ull << H) << " minimizers so "
+         << int_to_string((uint32_t)(bit_per_min * (1u << H))) << " bits per sequences" << endl;
+    auto start = chrono::system_clock::now();
+    Driver drv;
+    if (!index_file.empty()) {
+        if (!mkhost::file_exists(index_file)) {
+            cout << "File problem" << endl;
+            return 1;
+        }
+        string err;
+        if (mkhost::load_index(index_file, device, &drv.ctx, err) != 0) { cout << "Index load failed: " << err << endl; return 1; }
+        mk_params p;
+        mk_get_params(drv.ctx, &p);
+        drv.k = p.k; drv.threshold = p.threshold;          // -k -h -f -b -s come from the file (main.cpp:189-194)
+        drv.out.open(output_file.c_str());
+        cout << "I output results in " << output_file << endl;
+        cout << "Load sucessful" << endl;
+    } else if (!list_file.empty()) {
+        mk_params p{(uint32_t)kmer_size, (uint32_t)H, bit_per_min, (uint32_t)bloom_size, (uint32_t)threshold, device, 0, 0};
+        drv.out.open(output_file.c_str());
+        cout << "I output results in " << output_file << endl;
+        const int st = mk_create(&p, &drv.ctx);
+        if (st == MK_ERR_UNSUPPORTED) { cout << "not implemented" << endl; return 0; }       // Miekki.cpp:235-237
+        if (st != MK_OK) die("cannot create the index");
+        drv.k = p.k; drv.threshold = p.threshold;
+        drv.index_file_of_file(list_file);
+    } else {
+        cout << "What am I supposed to index ? use either -i or -l options please" << endl;
+        help();
+        return 0;
+    }
+    if (!index_dump.empty()) {
+        cout << "I write this index on the disk for later" << endl;
+        string err;
+        if (mkhost::dump_index(drv.ctx, index_dump, err) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
+    }
+    auto end_index = chrono::system_clock::now();
+    cout << "elapsed time: " << chrono::duration<double>(end_index - start).count() << "s\n";
+    if (!query_lines.empty()) {
+        if (exact_mode) {
+            cout << "running in exact mode, actual intersection will be computed on hits found by the index" << endl;
+            drv.query_file_exact(query_lines);
+        } else {
+            cout << "running in approx mode, intersection is estimated by the index" << endl;
+            drv.query_file(query_lines);
+        }
+    } else if (!query_list.empty()) {
+        if (exact_mode) {
+            cout << "running in exact mode, actual intersection will be computed on hits found by the index" << endl;
+            drv.query_file_of_file_exact(query_list);
+        } else {
+            cout << "running in approx mode, intersection is estimated by the index" << endl;
+            drv.query_file_of_file(query_list);
+        }
+    } else {
+        cout << "No query file, No queries" << endl;
+    }
+    auto end_query = chrono::system_clock::now();
+    cout << "elapsed time: " << chrono::duration<double>(end_query - end_index).count() << "s\n";
+    cout << "The end" << endl;
+    drv.out.close();
+    mk_destroy(drv.ctx);
+    return 0;
+}

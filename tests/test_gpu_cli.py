@@ -1,0 +1,99 @@
+"""The `miekki` host binary as a drop-in for the reference CLI: same files in,
+same out.txt / index payload / stdout banners out (goldens from the real
+reference at -t 1)."""
+import gzip
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "miekki_amd", "miekki")
+
+
+def norm(out: bytes) -> bytes:
+    return re.sub(rb"elapsed time: [0-9.e+-]+s", b"elapsed time: Xs", out)
+
+
+def run(args, cwd):
+    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    return r.stdout
+
+
+@pytest.fixture(scope="module")
+def workdirs(tmp_path_factory):
+    dirs = {}
+
+    def get(name):
+        if name not in dirs:
+            case = synth.CASES[name]()
+            d = tmp_path_factory.mktemp(name)
+            for fn, data, gz in case.genome_files:
+                (d / fn).write_bytes(gzip.compress(data, 1) if gz else data)
+            (d / "genomes.lst").write_bytes(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files)
+                                            + b"missing_file.fa\nab\n")
+            (d / "queries.fa").write_bytes(b"".join(h + b"\n" + s + b"\n" for h, s in case.queries))
+            (d / "qfiles.lst").write_bytes(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files))
+            base = ["-k", str(case.k), "-h", str(case.h), "-f", str(case.f), "-b", str(case.b),
+                    "-s", str(case.threshold), "-t", "1"]
+            dirs[name] = (case, d, base)
+        return dirs[name]
+    return get
+
+
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "c1"])
+def test_build_query_dump_like_the_reference(workdirs, golden_dir, name):
+    case, d, base = workdirs(name)
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    so = run(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out.txt", "-d", "idx.gz", *base], d)
+    assert (d / "out.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    raw = bytearray(gzip.decompress((d / "idx.gz").read_bytes()))
+    assert len(raw) == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    assert hashlib.sha256(bytes(raw)).hexdigest() == str(gold["stream_sha_masked"])
+    assert norm(so) == open(os.path.join(golden_dir, f"{name}_stdout_l.txt"), "rb").read()
+    # -i path on our own dump: same output, reference's banners
+    so_i = run(["-i", "idx.gz", "-a", "queries.fa", "-o", "out_i.txt", "-t", "1"], d)
+    assert (d / "out_i.txt").read_bytes() == (d / "out.txt").read_bytes()
+    assert norm(so_i) == open(os.path.join(golden_dir, f"{name}_stdout_i.txt"), "rb").read()
+    # whole-file queries
+    run(["-i", "idx.gz", "-A", "qfiles.lst", "-o", "outA.txt", "-t", "1"], d)
+    assert (d / "outA.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["messy", "h20", "w16"])
+def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
+    case, d, base = workdirs(name)
+    run(["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact.txt", *base], d)
+    got = (d / "exact.txt").read_bytes().decode().splitlines()
+    want = open(os.path.join(golden_dir, f"{name}_exact.txt"), "rb").read().decode().splitlines()
+    assert sorted(got) == sorted(want)       # the reference's line order comes from an unordered_map
+
+
+def test_reference_written_index_loads(workdirs, golden_dir, tmp_path):
+    """An index file written by the REFERENCE itself would be the strongest check;
+    the reference cannot travel, so a stream assembled from golden data stands in:
+    our loader must accept the oracle-serialised stream of the messy case."""
+    from oracle import oracle as orc
+    case = synth.CASES["messy"]()
+    o = orc.OracleMiekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+    o.insert_sequences(case.genome_sequences())
+    p = tmp_path / "oracle_idx.gz"
+    with gzip.open(p, "wb", compresslevel=1) as f:
+        f.write(o.serialize().tobytes())
+    _, d, _ = workdirs("messy")
+    run(["-i", str(p), "-a", "queries.fa", "-o", str(tmp_path / "o.txt"), "-t", "1"], d)
+    assert (tmp_path / "o.txt").read_bytes() == open(os.path.join(golden_dir, "messy_out.txt"), "rb").read()
+
+
+def test_unsupported_fingerprint_size_message(workdirs):
+    case, d, base = workdirs("messy")
+    out = run(["-l", "genomes.lst", "-k", "21", "-h", "12", "-f", "16", "-b", "32"], d)   # BASELINE's literal "-f 16"
+    assert b"not implemented" in out
