@@ -109,7 +109,7 @@ int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint3
 int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
                          const uint32_t *d_valid, uint32_t n, uint64_t *d_tables);
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0);
-int launch_bloom_insert(mk_ctx *c, const uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
+int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);

@@ -1,0 +1,187 @@
+// K5 scan kernel template (see scan.hip for the design notes).  Kept in a header so
+// that tools/scan_tune.hip can instantiate tuning variants of exactly this code.
+#pragma once
+#include "mk_internal.hpp"
+
+namespace mk {
+
+template <int W>
+__device__ __forceinline__ uint32_t bcast_fp(uint32_t fp)
+{
+    return W == 1 ? fp * 0x01010101u : fp * 0x00010001u;
+}
+
+// 1 in the low bit of every byte (half-word) of d that DIFFERS from the query fingerprint
+template <int W>
+__device__ __forceinline__ uint32_t ne_lanes(uint32_t d, uint32_t b)
+{
+    const uint32_t x = d ^ b;
+    if (W == 1) {
+        const uint32_t y = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+        return ((y | x) >> 7) & 0x01010101u;
+    } else {
+        const uint32_t y = (x & 0x7fff7fffu) + 0x7fff7fffu;
+        return ((y | x) >> 15) & 0x00010001u;
+    }
+}
+
+// Address of the wave's tile of row p as a SCALAR base (SALU multiply-add, kept in
+// SGPRs through readfirstlane) so that the load is the saddr form
+// `global_load_dwordx4 v, v_off, s[base]` with one 32-bit per-lane offset.
+template <bool NT>
+__device__ __forceinline__ uint4 load_row16(const uint8_t *p)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (NT) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+__device__ __forceinline__ const uint8_t *row_base(const uint8_t *base, uint32_t p, uint64_t ld)
+{
+    const uint64_t roff = (uint64_t)p * ld;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)roff);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(roff >> 32));
+    return base + (((uint64_t)hi << 32) | lo);
+}
+
+// ORDER 0: consecutive waves take adjacent tiles of one query (query-major);
+// ORDER 1: consecutive waves take the same tile of consecutive queries (tile-major).
+// NT: non-temporal row loads.
+template <int W, int UNROLL, bool FILTER, int ORDER = 0, bool NT = false>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+{
+    constexpr uint32_t NCNT = 16 / W;                    // genomes per lane
+    constexpr uint32_t CHUNK = W == 1 ? 255u : 65535u;   // entries before packed counters overflow
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    if (work >= a.nq * a.ntiles) return;                 // wave-uniform exit
+    uint32_t ql, tile;
+    if (ORDER == 0) { ql = work / a.ntiles; tile = work - ql * a.ntiles; }
+    else            { tile = work / a.nq;   ql = work - tile * a.nq; }
+    // lanes past the end of the row have nothing to compare: retire them now so the
+    // last tile of every row only fetches what it needs
+    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
+    const uint32_t q = a.q_begin + ql;
+    const uint64_t *__restrict__ ent = a.entries + a.ent_off[q];
+    const uint32_t n = a.nent[q];
+    // scalar row base + 32-bit per-lane offset -> global_load_dwordx4 v, v_off, s[base]
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint32_t voff = lane * 16u;
+    const uint64_t ld = a.ld;
+
+    uint32_t ne32[NCNT];
+#pragma unroll
+    for (uint32_t j = 0; j < NCNT; ++j) ne32[j] = 0;
+
+    for (uint32_t i0 = 0; i0 < n; i0 += CHUNK) {
+        const uint32_t m = min(n - i0, CHUNK);
+        const uint64_t *__restrict__ e = ent + i0;
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        uint32_t j = 0;
+        for (; j + UNROLL <= m; j += UNROLL) {
+            uint64_t ev[UNROLL];
+            uint4 d[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                d[u] = load_row16<NT>(row_base(base, (uint32_t)ev[u], ld) + voff);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
+                acc0 += ne_lanes<W>(d[u].x, b);
+                acc1 += ne_lanes<W>(d[u].y, b);
+                acc2 += ne_lanes<W>(d[u].z, b);
+                acc3 += ne_lanes<W>(d[u].w, b);
+            }
+        }
+        for (; j < m; ++j) {
+            const uint64_t ev = e[j];
+            const uint4 d = load_row16<NT>(row_base(base, (uint32_t)ev, ld) + voff);
+            const uint32_t b = bcast_fp<W>((uint32_t)(ev >> 32));
+            acc0 += ne_lanes<W>(d.x, b);
+            acc1 += ne_lanes<W>(d.y, b);
+            acc2 += ne_lanes<W>(d.z, b);
+            acc3 += ne_lanes<W>(d.w, b);
+        }
+        const uint32_t acc[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (W == 1) {
+                ne32[4 * w + 0] += acc[w] & 0xffu;
+                ne32[4 * w + 1] += (acc[w] >> 8) & 0xffu;
+                ne32[4 * w + 2] += (acc[w] >> 16) & 0xffu;
+                ne32[4 * w + 3] += acc[w] >> 24;
+            } else {
+                ne32[2 * w + 0] += acc[w] & 0xffffu;
+                ne32[2 * w + 1] += acc[w] >> 16;
+            }
+        }
+    }
+
+    // shared fingerprints = active entries - differing ones
+    const uint32_t g0 = tile * (kTileBytes / W) + lane * NCNT;
+    uint32_t score[NCNT];
+#pragma unroll
+    for (uint32_t j = 0; j < NCNT; ++j) score[j] = n - ne32[j];
+
+    if (a.scores) {
+        uint32_t *__restrict__ row = a.scores + (uint64_t)ql * a.G;
+        const bool vec = ((a.G & 3u) == 0) && ((reinterpret_cast<uintptr_t>(a.scores) & 15u) == 0);
+        if (vec && g0 + NCNT <= a.G) {
+#pragma unroll
+            for (uint32_t j = 0; j < NCNT; j += 4)
+                *reinterpret_cast<uint4 *>(row + g0 + j) =
+                    make_uint4(score[j], score[j + 1], score[j + 2], score[j + 3]);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < NCNT; ++j)
+                if (g0 + j < a.G) row[g0 + j] = score[j];
+        }
+    }
+
+    if (FILTER) {
+        const float mi_f = 0.999f * (float)a.min_inter;
+#pragma unroll
+        for (uint32_t j = 0; j < NCNT; ++j) {
+            const uint32_t g = g0 + j;
+            bool pass = false;
+            double jac = 0, inter = 0;
+            if (g < a.G && score[j] >= a.min_score) {           // Miekki.cpp:381
+                const uint32_t ss = a.sketch_size[g];
+                const uint64_t gs = a.genome_size[g];
+                // cheap single-precision screen; the decision itself is made in
+                // the reference's own double arithmetic (Miekki.cpp:382-384)
+                const float est = (float)score[j] * (float)gs / (float)ss;
+                if (!(est < mi_f)) {
+                    jac = (double)score[j] / (double)ss;
+                    inter = jac * (double)gs;
+                    pass = !(inter < a.min_inter);
+                }
+            }
+            const uint64_t mask = __ballot(pass);
+            if (mask) {                                          // wave-uniform
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+                uint32_t slot0 = 0;
+                if (lane == leader) slot0 = atomicAdd(a.count + ql, cnt);
+                slot0 = __shfl(slot0, (int)leader);
+                const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && slot < a.cap) {
+                    mk_hit hh;
+                    hh.genome = g + a.genome_id_base;
+                    hh.matches = score[j];
+                    hh.jaccard = jac;
+                    hh.intersection = inter;
+                    a.cand[(uint64_t)ql * a.cap + slot] = hh;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mk

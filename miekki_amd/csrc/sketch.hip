@@ -34,14 +34,44 @@ static SketchParams make_sp(const mk_ctx *c)
 }
 
 // canonical k-mer starting at sequence position i, read straight from the characters
-__device__ __forceinline__ uint64_t canon_at(const char *__restrict__ seq, uint64_t i, uint32_t k,
-                                             bool seed_valid)
+__device__ __forceinline__ uint64_t canon_at_bytes(const char *__restrict__ seq, uint64_t i, uint32_t k,
+                                                   bool seed_valid)
 {
     uint64_t S = 0, RC = 0;
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t cd = pos_codes((uint8_t)seq[i + j], i + j, k, seed_valid);
         S = (S << 2) | (cd & 3u);
         RC |= (uint64_t)(cd >> 2) << (2 * j);
+    }
+    return S < RC ? S : RC;
+}
+
+// Same value for k-mers clear of the k-1 seed, fetched as five aligned 64-bit words
+// (k <= 31 characters span at most 38 bytes) instead of k byte loads: the callers
+// read winners at random positions, so the load count is what they pay for.  The
+// sequence buffers carry 64 bytes of slack, and start 256-byte aligned, so the
+// aligned window never leaves the allocation.
+__device__ __forceinline__ uint64_t canon_at(const char *__restrict__ seq, uint64_t i, uint32_t k,
+                                             bool seed_valid)
+{
+    if (i + 1 < k) return canon_at_bytes(seq, i, k, seed_valid);      // touches the seed (Miekki.cpp:158)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(seq) + i;
+    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
+    const uint32_t sh = (uint32_t)(addr & 7u) * 8u;
+    const uint64_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+    uint64_t t[4];
+    t[0] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    t[1] = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+    t[2] = sh ? (w2 >> sh) | (w3 << (64 - sh)) : w2;
+    t[3] = sh ? (w3 >> sh) | (w4 << (64 - sh)) : w3;
+    uint64_t S = 0, RC = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 31; ++j) {
+        if (j < k) {
+            const uint8_t c = (uint8_t)(t[j >> 3] >> ((j & 7u) * 8u));
+            S = (S << 2) | fwd_code(c);
+            RC |= (uint64_t)rc_code(c) << (2 * j);
+        }
     }
     return S < RC ? S : RC;
 }
@@ -227,8 +257,9 @@ int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0
 // inserter in (genome, partition, hash index) order.  Pass A posts that order as a
 // 64-bit key per still-zero cell with an atomic minimum; pass B lets the winner
 // write the byte and reset the key.  Cells already non-zero are never touched.
+// The table is consumed: after pass A it holds canonical k-mers, not keys.
 template <bool WRITE>
-__global__ __launch_bounds__(256) void bloom_kernel(const uint64_t *__restrict__ tables,
+__global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ tables,
                                                     const char *__restrict__ seq,
                                                     const uint64_t *__restrict__ off,
                                                     const uint32_t *__restrict__ valid, uint8_t *bloom,
@@ -238,10 +269,18 @@ __global__ __launch_bounds__(256) void bloom_kernel(const uint64_t *__restrict__
     const uint32_t g = blockIdx.y;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= sp.P) return;
-    const uint64_t key = tables[(uint64_t)g * sp.P + p];
+    uint64_t *slot = tables + (uint64_t)g * sp.P + p;
+    const uint64_t key = *slot;
     if (key == kEmptyKey) return;
-    const uint64_t pos = key & ((1ULL << kPosBits) - 1);
-    const uint64_t canon = canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
+    uint64_t canon;
+    if (!WRITE) {
+        // pass A: the (fingerprint, position) key has served finalize; replace it by
+        // the winner's canonical k-mer so that pass B need not touch the sequence again
+        canon = canon_at(seq + off[g], key & ((1ULL << kPosBits) - 1), sp.k, valid[g] != 0);
+        *slot = canon;
+    } else {
+        canon = key;
+    }
     const uint64_t anc = revhash64(canon);
     for (uint32_t i = 0; i < kNumHash; ++i) {
         const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
@@ -259,7 +298,7 @@ __global__ __launch_bounds__(256) void bloom_kernel(const uint64_t *__restrict__
     }
 }
 
-int launch_bloom_insert(mk_ctx *c, const uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
+int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n)
 {
     if (!n || !c->d_bloom) return MK_OK;

@@ -1,0 +1,72 @@
+"""Multi-GPU layer: genome-sharded index, one gather of per-query candidates.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in CPU tests).  Rank r owns the contiguous genome range
+shard_range(G, r, world); every rank scans all queries against its shard and
+emits, per query, the candidates that passed filter_results' two thresholds
+(Miekki.cpp:381-384) in ascending genome id.  Because shards are contiguous and
+ordered by rank, concatenating the gathered rows in rank order reproduces exactly
+the sequence in which the reference's filter_results meets the genomes
+(Miekki.cpp:379), so the heap on rank 0 (mk_filter_candidates) is the reference's.
+There is no other data-path collective.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+HIT_BYTES = 24        # sizeof(mk_hit)
+HIT_DTYPE = np.dtype([("genome", "<u4"), ("matches", "<u4"), ("jaccard", "<f8"), ("intersection", "<f8")])
+assert HIT_DTYPE.itemsize == HIT_BYTES
+
+
+def shard_range(n_genomes: int, rank: int, world: int):
+    """Contiguous, ordered genome-id range of a rank (sizes differ by at most one)."""
+    base, rem = divmod(n_genomes, world)
+    g0 = rank * base + min(rank, rem)
+    return g0, g0 + base + (1 if rank < rem else 0)
+
+
+def gather_candidates(count: torch.Tensor, cand: torch.Tensor, dst: int = 0, group=None):
+    """The single exchange step.  count: int32 [nq]; cand: uint8 [nq*cap*24].
+    Returns (counts [world, nq], cands [world, nq*cap*24]) on dst, (None, None) elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        gc = [torch.empty_like(count) for _ in range(world)]
+        gd = [torch.empty_like(cand) for _ in range(world)]
+    else:
+        gc = gd = None
+    dist.gather(count, gc, dst=dst, group=group)
+    dist.gather(cand, gd, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    return torch.stack(gc).cpu().numpy(), torch.stack(gd).cpu().numpy()
+
+
+def merge_candidates(counts: np.ndarray, cands: np.ndarray, cap: int, nresults: int):
+    """Rank-0 merge: per query concatenate the shards' rows in rank order and run
+    the reference heap.  Returns (hits per query as structured arrays, overflow mask:
+    queries for which some shard had more candidates than `cap`)."""
+    lib = L.load_library()
+    world, nq = counts.shape
+    rows = np.ascontiguousarray(cands).view(np.uint8).reshape(world, nq, cap * HIT_BYTES)
+    overflow = (counts > cap).any(axis=0)
+    out = []
+    buf = np.empty(world * cap, HIT_DTYPE)
+    res = np.empty(max(nresults, 1), HIT_DTYPE)
+    for q in range(nq):
+        n = 0
+        for r in range(world):
+            m = int(min(counts[r, q], cap))
+            if m:
+                buf[n:n + m] = rows[r, q, :m * HIT_BYTES].view(HIT_DTYPE)
+                n += m
+        k = lib.mk_filter_candidates(buf.ctypes.data_as(C.c_void_p), n, nresults, res.ctypes.data_as(C.c_void_p))
+        out.append(res[:k].copy())
+    return out, overflow

@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the genome-sharded merge.
+
+Each rank holds an ORACLE index of its genome shard (the HIP path needs a GPU;
+what is under test here is the sharding rule, the single gather and the rank-0
+merge, which are device independent).  The merged hits must equal the
+unsharded oracle's filter_results, including heap tie behaviour."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from miekki_amd import distributed as mkd
+
+K, H, THR = 21, 10, 0
+CAP, NRES = 8, 5
+
+
+def make_inputs():
+    base = synth.genome_bases(777, 0, 6000)
+    genomes = [synth.genome_bases(500 + g, 0, 4000) for g in range(9)]
+    genomes[3] = base[:4000]; genomes[7] = base[:4000]        # identical genomes -> equal intersections (ties)
+    genomes[5] = base[1000:5000]
+    queries = [base[200:1800], genomes[0][100:900], genomes[8][:3000], synth.genome_bases(9, 0, 500), base[:K]]
+    return genomes, queries
+
+
+def shard_candidates(genomes, queries, g0, g1, min_score, min_inter):
+    from oracle import oracle as orc
+    o = orc.OracleMiekki(K, H, 8, 32, THR)
+    o.insert_sequences(genomes[g0:g1])
+    scores = o.query_sequences(queries)
+    ss, gs = o.sketch_size.astype(np.float64), o.genome_size.astype(np.float64)
+    count = np.zeros(len(queries), np.int32)
+    cand = np.zeros((len(queries), CAP), mkd.HIT_DTYPE)
+    for q in range(len(queries)):
+        n = 0
+        for g in range(g1 - g0):                               # ascending genome id
+            s = scores[q, g]
+            jac = float(s) / ss[g]; inter = jac * gs[g]
+            if s < min_score or inter < min_inter:
+                continue
+            if n < CAP:
+                cand[q, n] = (g + g0, s, jac, inter)
+            n += 1
+        count[q] = n
+    return count, cand
+
+
+def worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    genomes, queries = make_inputs()
+    g0, g1 = mkd.shard_range(len(genomes), rank, world)
+    count, cand = shard_candidates(genomes, queries, g0, g1, 1, 0.0)
+    counts, cands = mkd.gather_candidates(torch.from_numpy(count),
+                                          torch.from_numpy(cand.view(np.uint8).reshape(-1).copy()))
+    if rank == 0:
+        hits, overflow = mkd.merge_candidates(counts, cands, CAP, NRES)
+        ret["hits"] = [[(int(h["genome"]), int(h["matches"]), float(h["intersection"])) for h in row] for row in hits]
+        ret["overflow"] = overflow.tolist()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_ranges_are_contiguous_and_ordered():
+    for n, w in ((100_000, 8), (9, 2), (7, 8), (0, 4)):
+        r = [mkd.shard_range(n, i, w) for i in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_two_rank_gloo_merge_equals_unsharded_reference():
+    from oracle import oracle as orc
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    genomes, queries = make_inputs()
+    o = orc.OracleMiekki(K, H, 8, 32, THR)
+    o.insert_sequences(genomes)
+    scores = o.query_sequences(queries)
+    assert not any(ret["overflow"])
+    for q in range(len(queries)):
+        want = o.filter_results(scores[q], NRES, 1, 0.0)
+        got = ret["hits"][q]
+        assert [(g, m) for g, m, _ in got] == [(w[0], w[1]) for w in want], q
+        np.testing.assert_allclose([x for _, _, x in got], [w[3] for w in want], rtol=1e-12)

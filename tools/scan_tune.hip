@@ -1,0 +1,104 @@
+// scan_tune -- A/B timing of scan_kernel variants, interleaved rounds in ONE process
+// (cdna_hip_programming.md rule 24).  Synthetic matrix (random bytes) and random
+// sorted entry lists of realistic shape; timing only, plus a cross-variant checksum
+// of the candidate counts.  Build: make -C miekki_amd/csrc tune
+//   scan_tune <G> <h> <Q> <entries_per_query> <rounds>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../miekki_amd/csrc/scan_kernel.hpp"
+
+namespace mk { void set_error(const char *, ...) {} }
+using namespace mk;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ void fill_kernel(uint4 *p, uint64_t n16, uint64_t seed)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = splitmix64(seed ^ (2 * i)), b = splitmix64(seed ^ (2 * i + 1));
+        // skew towards a few values like real fingerprints: keep the high nibble in 0xC..0xF
+        const uint64_t m = 0x3f3f3f3f3f3f3f3fULL, o = 0xc0c0c0c0c0c0c0c0ULL;
+        const uint64_t x = (a & m) | o, y = (b & m) | o;
+        p[i] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+    }
+}
+
+struct Variant { const char *name; void (*fn)(const ScanArgs); };
+
+#define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, true, O, N>}
+
+int main(int argc, char **argv)
+{
+    const uint32_t G = argc > 1 ? atoi(argv[1]) : 12500;
+    const uint32_t h = argc > 2 ? atoi(argv[2]) : 20;
+    const uint32_t Q = argc > 3 ? atoi(argv[3]) : 20000;
+    const uint32_t NE = argc > 4 ? atoi(argv[4]) : 908;
+    const int rounds = argc > 5 ? atoi(argv[5]) : 5;
+    const uint32_t P = 1u << h;
+    const uint64_t ld = ((uint64_t)G + kTileBytes - 1) / kTileBytes * kTileBytes;
+    uint8_t *M; CK(hipMalloc((void **)&M, (uint64_t)P * ld));
+    hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, (uint4 *)M, (uint64_t)P * ld / 16, 0x1234567ULL);
+    std::vector<uint64_t> ent((size_t)Q * NE), off(Q + 1);
+    std::vector<uint32_t> nent(Q, NE);
+    std::mt19937_64 rng(42);
+    for (uint32_t q = 0; q < Q; ++q) {
+        off[q] = (uint64_t)q * NE;
+        std::vector<uint32_t> ps(NE);
+        for (auto &p : ps) p = (uint32_t)(rng() % P);
+        std::sort(ps.begin(), ps.end());
+        for (uint32_t i = 0; i < NE; ++i) ent[(size_t)q * NE + i] = make_entry(ps[i], 0xC0u | (uint32_t)(rng() & 0x3f));
+    }
+    off[Q] = (uint64_t)Q * NE;
+    uint64_t *d_ent, *d_off; uint32_t *d_nent, *d_ss, *d_count; uint64_t *d_gs; mk_hit *d_cand;
+    const uint32_t cap = 16;
+    CK(hipMalloc((void **)&d_ent, ent.size() * 8)); CK(hipMalloc((void **)&d_off, off.size() * 8));
+    CK(hipMalloc((void **)&d_nent, Q * 4)); CK(hipMalloc((void **)&d_ss, G * 4)); CK(hipMalloc((void **)&d_gs, G * 8));
+    CK(hipMalloc((void **)&d_count, Q * 4)); CK(hipMalloc((void **)&d_cand, (uint64_t)Q * cap * sizeof(mk_hit)));
+    CK(hipMemcpy(d_ent, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_nent, nent.data(), Q * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> ss(G, 1000000); std::vector<uint64_t> gs(G, 5000000);
+    CK(hipMemcpy(d_ss, ss.data(), G * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_gs, gs.data(), G * 8, hipMemcpyHostToDevice));
+    ScanArgs a;
+    a.M = M; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
+    a.ntiles = (G + kTileBytes - 1) / kTileBytes;
+    a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = nullptr; a.min_score = 10; a.min_inter = 100.0;
+    a.sketch_size = d_ss; a.genome_size = d_gs; a.genome_id_base = 0; a.cap = cap; a.count = d_count; a.cand = d_cand;
+    const Variant vars[] = {V(8, 0, false), V(4, 0, false), V(16, 0, false), V(8, 0, true), V(8, 1, false), V(8, 1, true),
+                            V(16, 1, false), V(4, 1, false)};
+    const int nv = sizeof vars / sizeof vars[0];
+    const uint64_t work = (uint64_t)Q * a.ntiles;
+    const uint32_t blocks = (uint32_t)((work + 3) / 4);
+    const double algo = (double)Q * NE * G + 4.0 * Q * G;
+    std::vector<std::vector<float>> ms(nv);
+    std::vector<uint64_t> chk(nv, 0);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds + 1; ++r)
+        for (int v = 0; v < nv; ++v) {
+            CK(hipMemsetAsync(d_count, 0, Q * 4, 0));
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(vars[v].fn, dim3(blocks), dim3(256), 0, 0, a);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            if (r) ms[v].push_back(t);                     // round 0 = warm-up
+            else {
+                std::vector<uint32_t> c(Q); CK(hipMemcpy(c.data(), d_count, Q * 4, hipMemcpyDeviceToHost));
+                for (uint32_t x : c) chk[v] += x;
+            }
+        }
+    printf("G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
+    for (int v = 0; v < nv; ++v) {
+        std::sort(ms[v].begin(), ms[v].end());
+        const float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
+        printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  %7.1f (min)  chk %llu\n", vars[v].name, med, mn,
+               algo / med / 1e6, algo / mn / 1e6, (unsigned long long)chk[v]);
+    }
+    return 0;
+}
