@@ -118,6 +118,9 @@ def main():
     L.check(lib.mk_sync(ix._h))
     build_s = time.time() - t0
     bst = ix.stats()
+    if world > 1:                                      # one global Bloom gate, as in a single-process build
+        from miekki_amd import distributed as mkd
+        mkd.sync_bloom(ix, device=torch.device("cuda", local_rank))
 
     qs = C.c_void_p()
     L.check(lib.mk_qset_synthetic(ix._h, 0, Q, G_total, GENOME_LEN, QUERY_LEN, C.byref(qs)))

@@ -70,3 +70,35 @@ def merge_candidates(counts: np.ndarray, cands: np.ndarray, cap: int, nresults: 
         k = lib.mk_filter_candidates(buf.ctypes.data_as(C.c_void_p), n, nresults, res.ctypes.data_as(C.c_void_p))
         out.append(res[:k].copy())
     return out, overflow
+
+
+def merge_bloom_first_writer(local: np.ndarray, device=None, group=None) -> np.ndarray:
+    """Global Bloom filter of a genome-sharded build, byte-exact.
+
+    The reference has ONE filter for the whole collection and a cell keeps the bit
+    of its FIRST inserter in genome order (Miekki.cpp:125-129).  With contiguous
+    shards ordered by rank the first inserter lives on the lowest rank whose cell is
+    non-zero, so a MIN all-reduce over (rank << 8 | byte), with 0xFFFF for empty
+    cells, reproduces the single-process bytes.  One collective, once per build."""
+    rank = dist.get_rank(group)
+    t = torch.from_numpy(local.astype(np.int32))
+    t = torch.where(t == 0, torch.full_like(t, 0xFFFF), t | (rank << 8))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    t = t.cpu()
+    return torch.where(t == 0xFFFF, torch.zeros_like(t), t & 0xFF).to(torch.uint8).numpy()
+
+
+def sync_bloom(ix, device=None, group=None):
+    """Make every rank's Bloom gate the global one (call once after the build)."""
+    lib = L.load_library()
+    nb = ix.bloom_size // 8
+    if nb == 0:
+        return
+    # only the cells a 2k-bit k-mer can reach are ever non-zero (see DESIGN.md section 3)
+    reach = min(nb, (((1 << (2 * ix.kmer_size)) - 1 + 1023) >> (ix.bloom_size_log2 + 3)) + 1)
+    local = np.empty(reach, np.uint8)
+    L.check(lib.mk_index_export_bloom(ix._h, 0, reach, local.ctypes.data))
+    merged = merge_bloom_first_writer(local, device, group)
+    L.check(lib.mk_index_import_bloom(ix._h, 0, reach, merged.ctypes.data))

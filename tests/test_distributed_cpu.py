@@ -29,10 +29,7 @@ def make_inputs():
     return genomes, queries
 
 
-def shard_candidates(genomes, queries, g0, g1, min_score, min_inter):
-    from oracle import oracle as orc
-    o = orc.OracleMiekki(K, H, 8, 32, THR)
-    o.insert_sequences(genomes[g0:g1])
+def shard_candidates(o, queries, g0, g1, min_score, min_inter):
     scores = o.query_sequences(queries)
     ss, gs = o.sketch_size.astype(np.float64), o.genome_size.astype(np.float64)
     count = np.zeros(len(queries), np.int32)
@@ -56,10 +53,17 @@ def worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     genomes, queries = make_inputs()
     g0, g1 = mkd.shard_range(len(genomes), rank, world)
-    count, cand = shard_candidates(genomes, queries, g0, g1, 1, 0.0)
+    from oracle import oracle as orc
+    o = orc.OracleMiekki(K, H, 8, 32, THR)
+    o.insert_sequences(genomes[g0:g1])
+    # global Bloom gate from the shards' filters, byte-exact (first writer = lowest rank)
+    merged = mkd.merge_bloom_first_writer(o.bloom[:1 << 20].copy())
+    o.bloom[:1 << 20] = merged
+    count, cand = shard_candidates(o, queries, g0, g1, 1, 0.0)
     counts, cands = mkd.gather_candidates(torch.from_numpy(count),
                                           torch.from_numpy(cand.view(np.uint8).reshape(-1).copy()))
     if rank == 0:
+        ret["bloom"] = merged.tobytes()
         hits, overflow = mkd.merge_candidates(counts, cands, CAP, NRES)
         ret["hits"] = [[(int(h["genome"]), int(h["matches"]), float(h["intersection"])) for h in row] for row in hits]
         ret["overflow"] = overflow.tolist()
@@ -91,6 +95,9 @@ def test_two_rank_gloo_merge_equals_unsharded_reference():
     o.insert_sequences(genomes)
     scores = o.query_sequences(queries)
     assert not any(ret["overflow"])
+    # k=21, b=32: reachable cells < 2^(42-35) -- the first 2^20 bytes cover them all
+    assert o.bloom[1 << 20:].max() == 0
+    assert ret["bloom"] == o.bloom[:1 << 20].tobytes()
     for q in range(len(queries)):
         want = o.filter_results(scores[q], NRES, 1, 0.0)
         got = ret["hits"][q]
