@@ -73,12 +73,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes-per-gpu", type=int, default=12_500)
+    ap.add_argument("--genomes-per-gpu", type=int, default=100_000,
+                    help="default = BASELINE config 3 (100,000 genomes, 105 GB matrix) on every GPU")
     ap.add_argument("--queries", type=int, default=100_000)
     ap.add_argument("--h", type=int, default=20)
     ap.add_argument("--fp-bits", type=int, default=8)
     ap.add_argument("--cap", type=int, default=16, help="candidate slots per query per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on ONE GPU: gloo collectives on host copies, every rank on device 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,9 +96,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmiekki_hip has no CPU path")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = torch.device("cpu") if args.rehearse else torch.device("cuda", local_rank)
 
     import miekki_amd
     from miekki_amd import lib as L
@@ -120,7 +129,7 @@ def main():
     bst = ix.stats()
     if world > 1:                                      # one global Bloom gate, as in a single-process build
         from miekki_amd import distributed as mkd
-        mkd.sync_bloom(ix, device=torch.device("cuda", local_rank))
+        mkd.sync_bloom(ix, device=coll_dev)
 
     qs = C.c_void_p()
     L.check(lib.mk_qset_synthetic(ix._h, 0, Q, G_total, GENOME_LEN, QUERY_LEN, C.byref(qs)))
@@ -128,16 +137,16 @@ def main():
     d_count = torch.zeros(Q, dtype=torch.int32, device="cuda")
     d_cand = torch.zeros(Q * cap * 24, dtype=torch.uint8, device="cuda")
     if world > 1 and rank == 0:
-        g_count = [torch.zeros_like(d_count) for _ in range(world)]
-        g_cand = [torch.zeros_like(d_cand) for _ in range(world)]
+        g_count = [torch.zeros_like(d_count, device=coll_dev) for _ in range(world)]
+        g_cand = [torch.zeros_like(d_cand, device=coll_dev) for _ in range(world)]
     min_score, min_inter = 10, 100.0                  # query_file's filter_results(.., 10, 10, 0.5*threshold)
 
     def step():
         L.check(lib.mk_qset_run(ix._h, qs, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
         L.check(lib.mk_sync(ix._h))
         if world > 1:                                 # the one exchange step: top candidates -> rank 0
-            dist.gather(d_count, g_count if rank == 0 else None, dst=0)
-            dist.gather(d_cand, g_cand if rank == 0 else None, dst=0)
+            dist.gather(d_count.to(coll_dev), g_count if rank == 0 else None, dst=0)
+            dist.gather(d_cand.to(coll_dev), g_cand if rank == 0 else None, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -153,10 +162,18 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    merged_ok = None
+    if world > 1 and rank == 0:                       # rank-0 merge with the reference heap, checked on a sample
+        from miekki_amd import distributed as mkd
+        counts = torch.stack(g_count).cpu().numpy()[:, :2000]
+        cands = torch.stack([c.view(Q, cap * 24)[:2000] for c in g_cand]).cpu().numpy()
+        hits, overflow = mkd.merge_candidates(counts, cands.reshape(world, -1), cap, 10)
+        # query q was cut from genome q mod G_total: it must come out on top
+        merged_ok = sum(1 for q, hrow in enumerate(hits) if len(hrow) and int(hrow[0]["genome"]) == q % G_total)
     st = ix.stats()
     active = np.zeros(Q, np.uint32)
     L.check(lib.mk_qset_active(ix._h, qs, active.ctypes.data))
@@ -175,6 +192,14 @@ def main():
         algo_per_launch = algo_bytes_step * args.steps / launches
         avg_launch_s = st["scan_ms"] / 1e3 / launches
         achieved = algo_per_launch / avg_launch_s / 1e9
+        traffic = None
+        try:                                           # PMC pass of this exact config, if one is committed
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            for e in pm["entries"]:
+                if (e["genomes_per_gpu"], e["queries"], e["h"], e["fp_bits"]) == (G, Q, args.h, args.fp_bits):
+                    traffic = e["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "query x genome fingerprint comparisons/sec at -h %d" % args.h,
             "value": value, "unit": "comparisons/s", "n_gpus": world, "steps": args.steps,
@@ -185,14 +210,14 @@ def main():
                        "genomes_per_gpu": G, "genomes_total": G_total, "queries": Q, "h": args.h,
                        "active_partitions_per_query": a_sum / max(Q, 1), "parallelism": "genome-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch},
             "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
                        "index_build_s": build_s, "index_sketches_per_s": G / build_s,
                        "index_kmers_per_s": bst["build_kmers"] / build_s,
                        "build_sketch_ms": bst["build_sketch_ms"], "build_finalize_ms": bst["build_finalize_ms"]},
-            "check": {"queries_with_candidates_on_rank0": n_hit},
+            "check": {"queries_with_candidates_on_rank0": n_hit, "merged_top_hit_correct_of_2000": merged_ok},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.h, os.cpu_count() or 1)
