@@ -2,8 +2,8 @@
 """bench.py -- query x genome fingerprint comparisons/s on MI355X.
 
 One "step" = one pass of the hot path (query sketch + Bloom gate + fingerprint
-scan + fused threshold filter, then -- for N > 1 -- the single RCCL gather of the
-per-query top candidates) over a batch of synthetic 1 kb queries that is already
+scan + top-hit selection, then -- for N > 1 -- the single RCCL gather of the
+per-query heap entrants) over a batch of synthetic 1 kb queries that is already
 resident in HBM, against an index of synthetic 5 Mb genomes that was built on the
 device by the sketch kernels before the timed region.
 
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100_000)
     ap.add_argument("--h", type=int, default=20)
     ap.add_argument("--fp-bits", type=int, default=8)
-    ap.add_argument("--cap", type=int, default=16, help="candidate slots per query per rank")
+    ap.add_argument("--cap", type=int, default=128, help="heap-entrant slots per query per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo collectives on host copies, every rank on device 0")
@@ -139,10 +139,10 @@ def main():
     if world > 1 and rank == 0:
         g_count = [torch.zeros_like(d_count, device=coll_dev) for _ in range(world)]
         g_cand = [torch.zeros_like(d_cand, device=coll_dev) for _ in range(world)]
-    min_score, min_inter = 10, 100.0                  # query_file's filter_results(.., 10, 10, 0.5*threshold)
+    nres, min_score, min_inter = 10, 10, 100.0        # query_file's filter_results(.., 10, 10, 0.5*threshold)
 
     def step():
-        L.check(lib.mk_qset_run(ix._h, qs, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
+        L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
         L.check(lib.mk_sync(ix._h))
         if world > 1:                                 # the one exchange step: top candidates -> rank 0
             dist.gather(d_count.to(coll_dev), g_count if rank == 0 else None, dst=0)

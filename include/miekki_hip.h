@@ -61,7 +61,7 @@ typedef struct {
 typedef struct {
     double sketch_ms;         /* query sketch + Bloom gate */
     double scan_ms;           /* fingerprint scan launches */
-    double filter_ms;         /* candidate ordering on device (0 when fused) */
+    double filter_ms;         /* top-hit selection over the score rows */
     uint64_t scan_launches;
     uint64_t comparisons;     /* G * sum of active partitions */
     uint64_t active_partitions;
@@ -129,9 +129,10 @@ int mk_query(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_
              uint32_t nresults, uint32_t min_score, double min_intersection,
              mk_hit *hits, uint32_t *nhits, uint32_t *active);
 
-/* Pure host function: Miekki::filter_results (Miekki.cpp:376-397) over
+/* Pure host function: the heap of Miekki::filter_results (Miekki.cpp:386-396) over
  * candidates that already passed both thresholds, given in ascending genome
- * order.  Used by mk_query and by the multi-GPU merge on rank 0. */
+ * order (all of them, or just the heap entrants mk_qset_run emits).  Used by
+ * mk_query and by the multi-GPU merge on rank 0. */
 uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresults, mk_hit *out);
 
 /* ---- device-resident query sets (bench / multi-GPU path) ------------------- */
@@ -147,13 +148,18 @@ int mk_qset_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t nq, uint64_t n_ge
                       uint64_t genome_len, uint64_t query_len, mk_qset **out);
 void mk_qset_free(mk_ctx *ctx, mk_qset *qs);
 
-/* One pass of the hot path over the set: sketch + Bloom gate + scan + threshold
- * filter.  Candidates (both thresholds passed) go to device memory owned by the
- * caller: d_count[nq] (u32, may exceed cap when a row overflows) and
- * d_cand[nq][cap] (mk_hit, ascending genome id per row).  Asynchronous on the
- * context's stream; mk_sync waits. */
-int mk_qset_run(mk_ctx *ctx, mk_qset *qs, uint32_t min_score, double min_intersection,
-                uint32_t cap, uint32_t *d_count, mk_hit *d_cand);
+/* One pass of the hot path over the set: sketch + Bloom gate + scan + top-hit
+ * selection.  For every query the device emits, in ascending genome id, the
+ * ENTRANTS of filter_results' heap (Miekki.cpp:376-397): the genomes that pass
+ * min_score / min_intersection and are not skipped by the heap-minimum test
+ * (Miekki.cpp:387) for a heap of `nresults` (<= 64).  Only entrants shape the
+ * reference's result, so mk_filter_candidates over a row reproduces it exactly;
+ * rows of several genome shards concatenated in shard order do too (multi-GPU
+ * merge).  Output goes to device memory owned by the caller: d_count[nq] (u32; a
+ * value above `cap` marks a row that overflowed) and d_cand[nq][cap] (mk_hit).
+ * Asynchronous on the context's stream; mk_sync waits. */
+int mk_qset_run(mk_ctx *ctx, mk_qset *qs, uint32_t nresults, uint32_t min_score,
+                double min_intersection, uint32_t cap, uint32_t *d_count, mk_hit *d_cand);
 /* Raw scores of queries [q_begin, q_end) of the set into d_scores[(q_end-q_begin)][G]. */
 int mk_qset_scores(mk_ctx *ctx, mk_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t *d_scores);
 /* active partitions per query after the last run/scores call */

@@ -240,9 +240,28 @@ static uint32_t ntiles_of(const mk_ctx *c)
     return (uint32_t)(((uint64_t)c->G * c->W + kTileBytes - 1) / kTileBytes);
 }
 
-// scan queries [q0, q1) of the set; scores and/or filtered candidates
-static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, bool filter,
-                     uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count, mk_hit *d_cand)
+static uint32_t score_pitch(const mk_ctx *c) { return (c->G + 15u) / 16u * 16u; }
+
+// queries per chunk so that the chunk's score matrix stays within ~4 GiB
+static uint32_t chunk_queries(const mk_ctx *c, uint32_t nq)
+{
+    const uint64_t per = std::max<uint64_t>(1, (1ull << 30) / std::max<uint32_t>(score_pitch(c), 1));
+    return (uint32_t)std::min<uint64_t>(per, std::max<uint32_t>(nq, 1));
+}
+
+static int ensure_scores(mk_ctx *c, uint64_t rows)
+{
+    const uint64_t need = rows * score_pitch(c);
+    if (need > c->scores_cap) {
+        dev_free(c->d_scores);
+        MK_TRY(dev_alloc(&c->d_scores, need));
+        c->scores_cap = need;
+    }
+    return MK_OK;
+}
+
+// scan queries [q0, q1) of the set into d_scores[(q1-q0)][score_ld]
+static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, uint32_t score_ld)
 {
     if (q1 <= q0 || c->G == 0) return MK_OK;
     const uint32_t nt = ntiles_of(c);
@@ -252,16 +271,24 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         ScanArgs a;
         a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
         a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_nent;
-        a.scores = d_scores ? d_scores + (uint64_t)(q - q0) * c->G : nullptr;
-        a.min_score = min_score; a.min_inter = min_inter;
-        a.sketch_size = c->d_sketch_size; a.genome_size = c->d_genome_size;
-        a.genome_id_base = c->p.genome_id_base; a.cap = cap;
-        a.count = d_count ? d_count + (q - q0) : nullptr;
-        a.cand = d_cand ? d_cand + (uint64_t)(q - q0) * cap : nullptr;
+        a.scores = d_scores + (uint64_t)(q - q0) * score_ld; a.score_ld = score_ld;
         ScopedTimer t(c, 1);
-        MK_TRY(launch_scan(c, a, filter));
+        MK_TRY(launch_scan(c, a));
     }
     return MK_OK;
+}
+
+// entrants of filter_results' heap for the rows in d_scores (see select.hip)
+static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, uint32_t score_ld, uint32_t nresults,
+                       uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count, mk_hit *d_cand)
+{
+    SelectArgs a;
+    a.scores = d_scores; a.score_ld = score_ld; a.G = c->G; a.nq = n; a.nresults = nresults;
+    a.min_score = min_score; a.min_inter = min_inter; a.sketch_size = c->d_sketch_size;
+    a.genome_size = c->d_genome_size; a.genome_id_base = c->p.genome_id_base; a.cap = cap;
+    a.count = d_count; a.cand = d_cand;
+    ScopedTimer t(c, 2);
+    return launch_select(c, a);
 }
 
 }  // namespace mk
@@ -552,17 +579,21 @@ void mk_qset_free(mk_ctx *c, mk_qset *qs)
     qset_release(qs);
 }
 
-int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count,
-                mk_hit *d_cand)
+int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
+                uint32_t *d_count, mk_hit *d_cand)
 {
     if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
+    if (nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     MK_TRY(qset_sketch(c, qs));
-    MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream));
-    MK_TRY(qset_scan(c, qs, 0, qs->nq, nullptr, true, min_score, min_inter, cap, d_count, d_cand));
-    {
-        ScopedTimer t(c, 2);
-        MK_TRY(launch_sort_candidates(c, qs->nq, cap, d_count, d_cand));
+    if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
+    const uint32_t per = chunk_queries(c, qs->nq), ld = score_pitch(c);
+    MK_TRY(ensure_scores(c, per));
+    for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
+        const uint32_t q1 = std::min(qs->nq, q0 + per);
+        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
+        MK_TRY(qset_select(c, q1 - q0, c->d_scores, ld, nresults, min_score, min_inter, cap, d_count + q0,
+                           d_cand + (uint64_t)q0 * cap));
     }
     return MK_OK;
 }
@@ -573,7 +604,7 @@ int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d
     if (q0 > q1 || q1 > qs->nq) { set_error("query range out of bounds"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
-    return qset_scan(c, qs, q0, q1, d_scores, false, 0, 0.0, 0, nullptr, nullptr);
+    return qset_scan(c, qs, q0, q1, d_scores, c->G);          // dense rows for the caller
 }
 
 int mk_qset_active(mk_ctx *c, mk_qset *qs, uint32_t *active)
@@ -607,23 +638,17 @@ int mk_query_scores(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
     MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
     MK_TRY(qset_sketch(c, qs));
-    const uint64_t per = std::max<uint64_t>(1, (1ull << 28) / c->G);       // <= 1 GiB of scores in flight
-    const uint64_t need = std::min<uint64_t>(per, nq) * c->G;
-    if (need > c->scores_cap) {
-        dev_free(c->d_scores);
-        MK_TRY(dev_alloc(&c->d_scores, need));
-        c->scores_cap = need;
-    }
-    for (uint64_t q0 = 0; q0 < nq; q0 += per) {
-        const uint32_t q1 = (uint32_t)std::min<uint64_t>(nq, q0 + per);
-        MK_TRY(qset_scan(c, qs, (uint32_t)q0, q1, c->d_scores, false, 0, 0.0, 0, nullptr, nullptr));
-        MK_HIP(hipMemcpyAsync(scores + q0 * c->G, c->d_scores, (size_t)(q1 - q0) * c->G * 4,
-                              hipMemcpyDeviceToHost, c->stream));
+    const uint32_t per = chunk_queries(c, nq), ld = score_pitch(c);
+    MK_TRY(ensure_scores(c, per));
+    for (uint32_t q0 = 0; q0 < nq; q0 += per) {
+        const uint32_t q1 = std::min(nq, q0 + per);
+        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
+        MK_HIP(hipMemcpy2DAsync(scores + (uint64_t)q0 * c->G, (size_t)c->G * 4, c->d_scores, (size_t)ld * 4,
+                                (size_t)c->G * 4, q1 - q0, hipMemcpyDeviceToHost, c->stream));
         MK_HIP(hipStreamSynchronize(c->stream));
     }
     std::vector<uint32_t> act;
     MK_TRY(account(c, qs, act));
-    MK_HIP(hipStreamSynchronize(c->stream));
     return MK_OK;
 }
 
@@ -663,50 +688,52 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     mk_qset *qs = nullptr;
     MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
+    MK_TRY(qset_sketch(c, qs));
     const uint32_t cap = 256;
-    if ((uint64_t)nq > c->cand_cap_q) {
+    const bool on_device = nresults <= kSelectMaxResults;
+    const uint32_t per = chunk_queries(c, nq), ld = score_pitch(c);
+    MK_TRY(ensure_scores(c, per));
+    if (on_device && (uint64_t)per > c->cand_cap_q) {
         dev_free(c->d_count); dev_free(c->d_cand);
-        MK_TRY(dev_alloc(&c->d_count, (uint64_t)nq));
-        MK_TRY(dev_alloc(&c->d_cand, (uint64_t)nq * cap));
-        c->cand_cap_q = nq;
+        MK_TRY(dev_alloc(&c->d_count, (uint64_t)per));
+        MK_TRY(dev_alloc(&c->d_cand, (uint64_t)per * cap));
+        c->cand_cap_q = per;
     }
-    MK_TRY(mk_qset_run(c, qs, min_score, min_inter, cap, c->d_count, c->d_cand));
-    std::vector<uint32_t> cnt(nq);
-    std::vector<mk_hit> cand((size_t)nq * cap);
-    MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)nq * cap * sizeof(mk_hit), hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> cnt(per), row(c->G);
+    std::vector<mk_hit> cand((size_t)per * cap), full;
+    for (uint32_t q0 = 0; q0 < nq; q0 += per) {
+        const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
+        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
+        if (on_device) {
+            MK_TRY(qset_select(c, n, c->d_scores, ld, nresults, min_score, min_inter, cap, c->d_count, c->d_cand));
+            MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)n * cap * sizeof(mk_hit), hipMemcpyDeviceToHost,
+                                  c->stream));
+        }
+        MK_HIP(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < n; ++i) {
+            mk_hit *out = hits + (size_t)(q0 + i) * nresults;
+            if (on_device && cnt[i] <= cap) {
+                nhits[q0 + i] = mk_filter_candidates(cand.data() + (size_t)i * cap, cnt[i], nresults, out);
+                continue;
+            }
+            // more heap entrants than the device row holds (or a top-N beyond the device
+            // selection): replay this query over its full score row, which is still in HBM
+            MK_HIP(hipMemcpy(row.data(), c->d_scores + (uint64_t)i * ld, (size_t)c->G * 4, hipMemcpyDeviceToHost));
+            full.clear();
+            for (uint32_t g = 0; g < c->G; ++g) {
+                if (row[g] < min_score) continue;
+                const double jac = (double)row[g] / c->h_sketch_size[g];
+                const double inter = jac * c->h_genome_size[g];
+                if (inter < min_inter) continue;
+                full.push_back(mk_hit{g + c->p.genome_id_base, row[g], jac, inter});
+            }
+            nhits[q0 + i] = mk_filter_candidates(full.data(), (uint32_t)full.size(), nresults, out);
+        }
+    }
     std::vector<uint32_t> act;
     MK_TRY(account(c, qs, act));
     if (active) memcpy(active, act.data(), (size_t)nq * 4);
-    std::vector<uint32_t> row;
-    std::vector<mk_hit> full;
-    for (uint32_t q = 0; q < nq; ++q) {
-        if (cnt[q] <= cap) {
-            nhits[q] = mk_filter_candidates(cand.data() + (size_t)q * cap, cnt[q], nresults, hits + (size_t)q * nresults);
-            continue;
-        }
-        // more candidates than the device row holds: replay this query over its
-        // full score row with the reference's own arithmetic
-        if (c->scores_cap < c->G) {
-            dev_free(c->d_scores);
-            MK_TRY(dev_alloc(&c->d_scores, (uint64_t)c->G));
-            c->scores_cap = c->G;
-        }
-        row.resize(c->G);
-        MK_TRY(qset_scan(c, qs, q, q + 1, c->d_scores, false, 0, 0.0, 0, nullptr, nullptr));
-        MK_HIP(hipMemcpyAsync(row.data(), c->d_scores, (size_t)c->G * 4, hipMemcpyDeviceToHost, c->stream));
-        MK_HIP(hipStreamSynchronize(c->stream));
-        full.clear();
-        for (uint32_t g = 0; g < c->G; ++g) {
-            if (row[g] < min_score) continue;
-            const double jac = (double)row[g] / c->h_sketch_size[g];
-            const double inter = jac * c->h_genome_size[g];
-            if (inter < min_inter) continue;
-            full.push_back(mk_hit{g + c->p.genome_id_base, row[g], jac, inter});
-        }
-        nhits[q] = mk_filter_candidates(full.data(), (uint32_t)full.size(), nresults, hits + (size_t)q * nresults);
-    }
     return MK_OK;
 }
 

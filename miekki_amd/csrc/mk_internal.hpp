@@ -68,7 +68,7 @@ struct mk_ctx {
     uint64_t seq_cap;
     uint64_t *d_seq_off;           // kBuildBatch + 1
     // query scratch
-    uint32_t *d_scores;
+    uint32_t *d_scores;            // score matrix of the query chunk in flight
     uint64_t scores_cap;
     uint32_t *d_count;
     mk_hit *d_cand;
@@ -126,18 +126,25 @@ struct ScanArgs {
     const uint64_t *entries;
     const uint64_t *ent_off;
     const uint32_t *nent;
-    uint32_t *scores;              // [nq][G] or null
-    // fused threshold filter
-    uint32_t min_score;
+    uint32_t *scores;              // [nq][score_ld]
+    uint32_t score_ld;             // row pitch in entries (>= G)
+};
+int launch_scan(mk_ctx *c, const ScanArgs &a);
+
+// ---- select.hip
+struct SelectArgs {
+    const uint32_t *scores;        // [nq][score_ld]
+    uint32_t score_ld, G, nq;
+    uint32_t nresults, min_score;
     double min_inter;
     const uint32_t *sketch_size;
     const uint64_t *genome_size;
     uint32_t genome_id_base, cap;
-    uint32_t *count;
-    mk_hit *cand;
+    uint32_t *count;               // [nq]
+    mk_hit *cand;                  // [nq][cap]
 };
-int launch_scan(mk_ctx *c, const ScanArgs &a, bool filter);
-int launch_sort_candidates(mk_ctx *c, uint32_t nq, uint32_t cap, const uint32_t *d_count, mk_hit *d_cand);
+constexpr uint32_t kSelectMaxResults = 64;   // top-N sizes the device selection supports
+int launch_select(mk_ctx *c, const SelectArgs &a);
 
 // ---- exact.hip
 int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,

@@ -50,7 +50,7 @@ __device__ __forceinline__ const uint8_t *row_base(const uint8_t *base, uint32_t
 // ORDER 0: consecutive waves take adjacent tiles of one query (query-major);
 // ORDER 1: consecutive waves take the same tile of consecutive queries (tile-major).
 // NT: non-temporal row loads.
-template <int W, int UNROLL, bool FILTER, int ORDER = 0, bool NT = false>
+template <int W, int UNROLL, int ORDER = 1, bool NT = false>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 {
     constexpr uint32_t NCNT = 16 / W;                    // genomes per lane
@@ -129,58 +129,17 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
     for (uint32_t j = 0; j < NCNT; ++j) score[j] = n - ne32[j];
 
-    if (a.scores) {
-        uint32_t *__restrict__ row = a.scores + (uint64_t)ql * a.G;
-        const bool vec = ((a.G & 3u) == 0) && ((reinterpret_cast<uintptr_t>(a.scores) & 15u) == 0);
-        if (vec && g0 + NCNT <= a.G) {
+    // score row pitch is a multiple of 16 entries, so the 64-byte lane pieces of the
+    // last tile stay inside the row's padding
+    uint32_t *__restrict__ row = a.scores + (uint64_t)ql * a.score_ld;
+    if ((a.score_ld & 3u) == 0 && g0 + NCNT <= a.score_ld) {
 #pragma unroll
-            for (uint32_t j = 0; j < NCNT; j += 4)
-                *reinterpret_cast<uint4 *>(row + g0 + j) =
-                    make_uint4(score[j], score[j + 1], score[j + 2], score[j + 3]);
-        } else {
+        for (uint32_t j = 0; j < NCNT; j += 4)
+            *reinterpret_cast<uint4 *>(row + g0 + j) = make_uint4(score[j], score[j + 1], score[j + 2], score[j + 3]);
+    } else {
 #pragma unroll
-            for (uint32_t j = 0; j < NCNT; ++j)
-                if (g0 + j < a.G) row[g0 + j] = score[j];
-        }
-    }
-
-    if (FILTER) {
-        const float mi_f = 0.999f * (float)a.min_inter;
-#pragma unroll
-        for (uint32_t j = 0; j < NCNT; ++j) {
-            const uint32_t g = g0 + j;
-            bool pass = false;
-            double jac = 0, inter = 0;
-            if (g < a.G && score[j] >= a.min_score) {           // Miekki.cpp:381
-                const uint32_t ss = a.sketch_size[g];
-                const uint64_t gs = a.genome_size[g];
-                // cheap single-precision screen; the decision itself is made in
-                // the reference's own double arithmetic (Miekki.cpp:382-384)
-                const float est = (float)score[j] * (float)gs / (float)ss;
-                if (!(est < mi_f)) {
-                    jac = (double)score[j] / (double)ss;
-                    inter = jac * (double)gs;
-                    pass = !(inter < a.min_inter);
-                }
-            }
-            const uint64_t mask = __ballot(pass);
-            if (mask) {                                          // wave-uniform
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-                uint32_t slot0 = 0;
-                if (lane == leader) slot0 = atomicAdd(a.count + ql, cnt);
-                slot0 = __shfl(slot0, (int)leader);
-                const uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                if (pass && slot < a.cap) {
-                    mk_hit hh;
-                    hh.genome = g + a.genome_id_base;
-                    hh.matches = score[j];
-                    hh.jaccard = jac;
-                    hh.intersection = inter;
-                    a.cand[(uint64_t)ql * a.cap + slot] = hh;
-                }
-            }
-        }
+        for (uint32_t j = 0; j < NCNT; ++j)
+            if (g0 + j < a.G) row[g0 + j] = score[j];
     }
 }
 

@@ -1,0 +1,120 @@
+// K6: top-hit selection over a score row -- the device half of
+// Miekki::filter_results (Miekki.cpp:376-397).
+//
+// The reference walks genomes in ascending id, skips those below min_score or
+// min_intersection (381-384) and, once its heap holds nresults entries, skips every
+// genome whose intersection is below the heap minimum (387) WITHOUT touching the
+// heap.  Only the genomes that are not skipped ("entrants") shape the heap and so
+// the result, ties included.  With chance matches most genomes pass the two
+// thresholds at scale (≈7 % of 100,000 at -h 20), but only ≈ N·ln(m/N) of them are
+// entrants.  This kernel emits exactly the entrants of each query, in genome order;
+// the heap itself (pop/push with ties replacing, sort_heap) is then replayed over
+// those few dozen records by mk_filter_candidates with the reference's own
+// libstdc++ calls -- on the host, or on rank 0 after the multi-GPU gather: a
+// shard's entrants are a superset of what the global heap can admit from that
+// shard, because the global minimum is never below the shard's own.
+//
+// One wave per query.  64 genomes per step: coalesced score / size loads, an f32
+// screen against max(min_intersection, current heap minimum), the decision in the
+// reference's double operations, `__ballot` to find candidate entrants, and a short
+// serial loop over the ballot that re-tests each against the evolving minimum.  The
+// current top-N multiset lives one value per lane; its minimum is a wave reduction.
+#include <cfloat>
+
+#include "mk_internal.hpp"
+
+namespace mk {
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, uint32_t l)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, (int)l);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (q >= a.nq) return;
+    const uint32_t *__restrict__ row = a.scores + (uint64_t)q * a.score_ld;
+    const uint32_t N = a.nresults;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double topv = inf;               // lane i < cnt: i-th value of the current top-N multiset
+    uint32_t cnt = 0, emitted = 0;   // wave-uniform
+    double minval = 0.0;             // minimum of the multiset, valid when cnt == N
+    float screen = 0.999f * (float)a.min_inter;
+    mk_hit *__restrict__ out = a.cand + (uint64_t)q * a.cap;
+
+    for (uint32_t g0 = 0; g0 < a.G; g0 += 64) {
+        const uint32_t g = g0 + lane;
+        bool pot = false;
+        uint32_t s = 0;
+        double jac = 0, inter = 0;
+        if (g < a.G) {
+            s = row[g];
+            if (s >= a.min_score) {                                        // Miekki.cpp:381
+                const uint32_t ss = a.sketch_size[g];
+                const uint64_t gs = a.genome_size[g];
+                const float est = (float)s * (float)gs / (float)ss;
+                if (!(est < screen)) {
+                    jac = (double)s / (double)ss;                          // Miekki.cpp:382-383
+                    inter = jac * (double)gs;
+                    pot = !(inter < a.min_inter) && (cnt < N || !(minval > inter));
+                }
+            }
+        }
+        uint64_t mask = __ballot(pot);
+        while (mask) {                                                      // ascending genome order
+            const uint32_t l = (uint32_t)__ffsll((long long)mask) - 1u;
+            mask &= mask - 1;
+            const double x = readlane_f64(inter, l);
+            if (cnt >= N && minval > x) continue;                           // Miekki.cpp:387: skipped, heap untouched
+            if (N == 0) continue;
+            if (lane == l && emitted < a.cap) {
+                mk_hit h;
+                h.genome = g + a.genome_id_base;
+                h.matches = s;
+                h.jaccard = jac;
+                h.intersection = inter;
+                out[emitted] = h;
+            }
+            ++emitted;
+            if (cnt < N) {
+                if (lane == cnt) topv = x;
+                ++cnt;
+            } else {                                                        // evict one holder of the minimum
+                const uint64_t holders = __ballot(lane < N && topv == minval);
+                const uint32_t victim = holders ? (uint32_t)__ffsll((long long)holders) - 1u : 0u;
+                if (lane == victim) topv = x;
+            }
+            if (cnt == N) {
+                minval = wave_min_f64(lane < N ? topv : inf);
+                const double bar = minval > a.min_inter ? minval : a.min_inter;
+                screen = 0.999f * (float)bar;
+            }
+        }
+    }
+    if (lane == 0) a.count[q] = emitted;
+}
+
+int launch_select(mk_ctx *c, const SelectArgs &a)
+{
+    if (!a.nq) return MK_OK;
+    if (a.nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
+    hipLaunchKernelGGL(select_kernel, dim3((a.nq + 3) / 4), dim3(256), 0, c->stream, a);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+}  // namespace mk

@@ -61,7 +61,7 @@ SIGNATURES = {
     "mk_qset_upload": (i32, [vp, vp, vp, u32, PP(vp)]),
     "mk_qset_synthetic": (i32, [vp, u64, u32, u64, u64, u64, PP(vp)]),
     "mk_qset_free": (None, [vp, vp]),
-    "mk_qset_run": (i32, [vp, vp, u32, C.c_double, u32, vp, vp]),
+    "mk_qset_run": (i32, [vp, vp, u32, u32, C.c_double, u32, vp, vp]),
     "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
     "mk_qset_active": (i32, [vp, vp, vp]),
     "mk_sync": (i32, [vp]),

@@ -80,3 +80,47 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(L.MiekkiHipError):
         miekki_amd.Miekki(31, 14, 8, 33, 200)
+
+
+def _entrants(vals, nres):
+    """Python statement of select.hip: indices that filter_results does not skip
+    (Miekki.cpp:386-387), tracking only the multiset of the current top-N."""
+    top, out = [], []
+    for i, x in enumerate(vals):
+        if len(top) >= nres:
+            if nres == 0 or min(top) > x:
+                continue
+            top.remove(min(top))
+        top.append(x)
+        out.append(i)
+    return out
+
+
+def test_heap_entrants_reproduce_the_full_replay_and_shard_merges():
+    """The claim select.hip and the multi-GPU merge rest on: replaying the reference
+    heap over the entrants only -- of the whole row, or of contiguous shards
+    concatenated in order -- gives the reference's result, ties included."""
+    import numpy as np
+    lib = L.load_library()
+    rng = np.random.default_rng(7)
+
+    def heap(cands, nres):
+        buf = (L.Hit * max(len(cands), 1))(*[L.Hit(g, 1, 0.0, float(v)) for g, v in cands])
+        out = (L.Hit * max(nres, 1))()
+        n = lib.mk_filter_candidates(buf, len(cands), nres, out)
+        return [(out[i].genome, out[i].intersection) for i in range(n)]
+
+    for trial in range(300):
+        m = int(rng.integers(0, 400))
+        nres = int(rng.choice([1, 2, 5, 10, 64]))
+        vals = rng.integers(0, int(rng.choice([3, 8, 50, 1000])), m).astype(float).tolist()   # few distinct values: many ties
+        full = heap(list(enumerate(vals)), nres)
+        ent = _entrants(vals, nres)
+        assert heap([(i, vals[i]) for i in ent], nres) == full, trial
+        # contiguous shards, each emitting only its own entrants
+        cuts = sorted(rng.integers(0, m + 1, int(rng.integers(1, 8))).tolist())
+        bounds = [0] + cuts + [m]
+        merged = []
+        for a, b in zip(bounds, bounds[1:]):
+            merged += [(a + i, vals[a + i]) for i in _entrants(vals[a:b], nres)]
+        assert heap(merged, nres) == full, trial

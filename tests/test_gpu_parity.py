@@ -220,3 +220,31 @@ def test_candidate_overflow_falls_back_to_full_row(hip):
         assert [(h_.genome, h_.matches) for h_ in hits[0]] == [(w[0], w[1]) for w in want]
     finally:
         ix.close()
+
+
+def test_heap_entrants_with_duplicate_genomes(hip):
+    """Thousands of genomes pass the thresholds and many tie exactly (duplicate
+    genomes: equal score, sketch_size and genome_size): the device must emit the
+    reference heap's entrants so that ties resolve as in the reference."""
+    from oracle import oracle as orc
+    k, h = 21, 9
+    rng = np.random.default_rng(3)
+    distinct = [synth.genome_bases(7000 + i, 0, 2500 + 13 * i) for i in range(40)]
+    order = rng.permutation(np.repeat(np.arange(40), 60))           # 2400 genomes, duplicates interleaved
+    seqs = [distinct[i] for i in order]
+    o = orc.OracleMiekki(k, h, 8, 32, 0)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 32, 0)
+    try:
+        ix.insert_sequences(seqs)
+        qs = [distinct[3][100:1400], distinct[17], distinct[39][500:900], synth.genome_bases(1, 0, 900)]
+        scores = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), scores)
+        for nres, ms, mi in ((10, 1, 0.0), (5, 2, 1.0), (64, 1, 0.0), (1, 0, 0.0), (100, 1, 0.0)):
+            hits, _ = ix.query(qs, nres, ms, mi)
+            for q in range(len(qs)):
+                want = o.filter_results(scores[q], nres, ms, mi)
+                assert [(h_.genome, h_.matches) for h_ in hits[q]] == [(w[0], w[1]) for w in want], (q, nres)
+                np.testing.assert_allclose([h_.intersection for h_ in hits[q]], [w[3] for w in want], rtol=RTOL)
+    finally:
+        ix.close()

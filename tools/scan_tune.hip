@@ -1,7 +1,7 @@
 // scan_tune -- A/B timing of scan_kernel variants, interleaved rounds in ONE process
 // (cdna_hip_programming.md rule 24).  Synthetic matrix (random bytes) and random
 // sorted entry lists of realistic shape; timing only, plus a cross-variant checksum
-// of the candidate counts.  Build: make -C miekki_amd/csrc tune
+// of the first score rows.  Build: make -C miekki_amd/csrc tune
 //   scan_tune <G> <h> <Q> <entries_per_query> <rounds>
 #include <algorithm>
 #include <cstdio>
@@ -30,7 +30,7 @@ __global__ void fill_kernel(uint4 *p, uint64_t n16, uint64_t seed)
 
 struct Variant { const char *name; void (*fn)(const ScanArgs); };
 
-#define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, true, O, N>}
+#define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>}
 
 int main(int argc, char **argv)
 {
@@ -54,21 +54,17 @@ int main(int argc, char **argv)
         for (uint32_t i = 0; i < NE; ++i) ent[(size_t)q * NE + i] = make_entry(ps[i], 0xC0u | (uint32_t)(rng() & 0x3f));
     }
     off[Q] = (uint64_t)Q * NE;
-    uint64_t *d_ent, *d_off; uint32_t *d_nent, *d_ss, *d_count; uint64_t *d_gs; mk_hit *d_cand;
-    const uint32_t cap = 16;
+    uint64_t *d_ent, *d_off; uint32_t *d_nent, *d_scores;
+    const uint32_t sld = (G + 15) / 16 * 16;
     CK(hipMalloc((void **)&d_ent, ent.size() * 8)); CK(hipMalloc((void **)&d_off, off.size() * 8));
-    CK(hipMalloc((void **)&d_nent, Q * 4)); CK(hipMalloc((void **)&d_ss, G * 4)); CK(hipMalloc((void **)&d_gs, G * 8));
-    CK(hipMalloc((void **)&d_count, Q * 4)); CK(hipMalloc((void **)&d_cand, (uint64_t)Q * cap * sizeof(mk_hit)));
+    CK(hipMalloc((void **)&d_nent, Q * 4)); CK(hipMalloc((void **)&d_scores, (uint64_t)Q * sld * 4));
     CK(hipMemcpy(d_ent, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nent, nent.data(), Q * 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t> ss(G, 1000000); std::vector<uint64_t> gs(G, 5000000);
-    CK(hipMemcpy(d_ss, ss.data(), G * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_gs, gs.data(), G * 8, hipMemcpyHostToDevice));
     ScanArgs a;
     a.M = M; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
     a.ntiles = (G + kTileBytes - 1) / kTileBytes;
-    a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = nullptr; a.min_score = 10; a.min_inter = 100.0;
-    a.sketch_size = d_ss; a.genome_size = d_gs; a.genome_id_base = 0; a.cap = cap; a.count = d_count; a.cand = d_cand;
+    a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores; a.score_ld = sld;
     const Variant vars[] = {V(8, 0, false), V(4, 0, false), V(16, 0, false), V(8, 0, true), V(8, 1, false), V(8, 1, true),
                             V(16, 1, false), V(4, 1, false)};
     const int nv = sizeof vars / sizeof vars[0];
@@ -81,7 +77,6 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     for (int r = 0; r < rounds + 1; ++r)
         for (int v = 0; v < nv; ++v) {
-            CK(hipMemsetAsync(d_count, 0, Q * 4, 0));
             CK(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(vars[v].fn, dim3(blocks), dim3(256), 0, 0, a);
             CK(hipEventRecord(e1, 0));
@@ -89,8 +84,10 @@ int main(int argc, char **argv)
             float t; CK(hipEventElapsedTime(&t, e0, e1));
             if (r) ms[v].push_back(t);                     // round 0 = warm-up
             else {
-                std::vector<uint32_t> c(Q); CK(hipMemcpy(c.data(), d_count, Q * 4, hipMemcpyDeviceToHost));
-                for (uint32_t x : c) chk[v] += x;
+                std::vector<uint32_t> c((size_t)std::min<uint32_t>(Q, 64) * sld);   // checksum of the first score rows
+                CK(hipMemcpy(c.data(), d_scores, c.size() * 4, hipMemcpyDeviceToHost));
+                for (uint32_t r = 0; r < std::min<uint32_t>(Q, 64); ++r)
+                    for (uint32_t g = 0; g < G; ++g) chk[v] += c[(size_t)r * sld + g];
             }
         }
     printf("G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
