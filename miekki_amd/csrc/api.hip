@@ -240,18 +240,20 @@ static uint32_t ntiles_of(const mk_ctx *c)
     return (uint32_t)(((uint64_t)c->G * c->W + kTileBytes - 1) / kTileBytes);
 }
 
-static uint32_t score_pitch(const mk_ctx *c) { return (c->G + 15u) / 16u * 16u; }
+static uint32_t tile_genomes(const mk_ctx *c) { return kTileBytes / c->W; }
+// entries of one query's scores in the tile-major matrix (whole tiles)
+static uint64_t score_row_entries(const mk_ctx *c) { return (uint64_t)ntiles_of(c) * tile_genomes(c); }
 
 // queries per chunk so that the chunk's score matrix stays within ~4 GiB
 static uint32_t chunk_queries(const mk_ctx *c, uint32_t nq)
 {
-    const uint64_t per = std::max<uint64_t>(1, (1ull << 30) / std::max<uint32_t>(score_pitch(c), 1));
+    const uint64_t per = std::max<uint64_t>(1, (1ull << 30) / std::max<uint64_t>(score_row_entries(c), 1));
     return (uint32_t)std::min<uint64_t>(per, std::max<uint32_t>(nq, 1));
 }
 
 static int ensure_scores(mk_ctx *c, uint64_t rows)
 {
-    const uint64_t need = rows * score_pitch(c);
+    const uint64_t need = rows * score_row_entries(c);
     if (need > c->scores_cap) {
         dev_free(c->d_scores);
         MK_TRY(dev_alloc(&c->d_scores, need));
@@ -260,8 +262,9 @@ static int ensure_scores(mk_ctx *c, uint64_t rows)
     return MK_OK;
 }
 
-// scan queries [q0, q1) of the set into d_scores[(q1-q0)][score_ld]
-static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, uint32_t score_ld)
+// scan queries [q0, q1) of the set into d_scores laid out as `lay` describes (the
+// tile-major layout is per call: its tile stride is (q1 - q0) * genomes per tile)
+static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, const ScoreLayout &lay)
 {
     if (q1 <= q0 || c->G == 0) return MK_OK;
     const uint32_t nt = ntiles_of(c);
@@ -271,7 +274,8 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         ScanArgs a;
         a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
         a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_nent;
-        a.scores = d_scores + (uint64_t)(q - q0) * score_ld; a.score_ld = score_ld;
+        a.scores = d_scores + (uint64_t)(q - q0) * lay.q_stride;
+        a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
         ScopedTimer t(c, 1);
         MK_TRY(launch_scan(c, a));
     }
@@ -279,11 +283,11 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
 }
 
 // entrants of filter_results' heap for the rows in d_scores (see select.hip)
-static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, uint32_t score_ld, uint32_t nresults,
+static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, uint32_t nresults,
                        uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count, mk_hit *d_cand)
 {
     SelectArgs a;
-    a.scores = d_scores; a.score_ld = score_ld; a.G = c->G; a.nq = n; a.nresults = nresults;
+    a.scores = d_scores; a.tile_genomes = tile_genomes(c); a.G = c->G; a.nq = n; a.nresults = nresults;
     a.min_score = min_score; a.min_inter = min_inter; a.sketch_size = c->d_sketch_size;
     a.genome_size = c->d_genome_size; a.genome_id_base = c->p.genome_id_base; a.cap = cap;
     a.count = d_count; a.cand = d_cand;
@@ -587,12 +591,12 @@ int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, d
     MK_TRY(use_device(c));
     MK_TRY(qset_sketch(c, qs));
     if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
-    const uint32_t per = chunk_queries(c, qs->nq), ld = score_pitch(c);
+    const uint32_t per = chunk_queries(c, qs->nq);
     MK_TRY(ensure_scores(c, per));
     for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
         const uint32_t q1 = std::min(qs->nq, q0 + per);
-        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
-        MK_TRY(qset_select(c, q1 - q0, c->d_scores, ld, nresults, min_score, min_inter, cap, d_count + q0,
+        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, q1 - q0)));
+        MK_TRY(qset_select(c, q1 - q0, c->d_scores, nresults, min_score, min_inter, cap, d_count + q0,
                            d_cand + (uint64_t)q0 * cap));
     }
     return MK_OK;
@@ -604,7 +608,7 @@ int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d
     if (q0 > q1 || q1 > qs->nq) { set_error("query range out of bounds"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
-    return qset_scan(c, qs, q0, q1, d_scores, c->G);          // dense rows for the caller
+    return qset_scan(c, qs, q0, q1, d_scores, score_layout_rows(c->W, c->G, c->G));   // dense rows for the caller
 }
 
 int mk_qset_active(mk_ctx *c, mk_qset *qs, uint32_t *active)
@@ -638,11 +642,12 @@ int mk_query_scores(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
     MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
     MK_TRY(qset_sketch(c, qs));
-    const uint32_t per = chunk_queries(c, nq), ld = score_pitch(c);
+    const uint32_t per = chunk_queries(c, nq);
+    const uint64_t ld = score_row_entries(c);                 // whole tiles per row: 16-byte stores everywhere
     MK_TRY(ensure_scores(c, per));
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t q1 = std::min(nq, q0 + per);
-        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
+        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_rows(c->W, ld, c->G)));
         MK_HIP(hipMemcpy2DAsync(scores + (uint64_t)q0 * c->G, (size_t)c->G * 4, c->d_scores, (size_t)ld * 4,
                                 (size_t)c->G * 4, q1 - q0, hipMemcpyDeviceToHost, c->stream));
         MK_HIP(hipStreamSynchronize(c->stream));
@@ -691,8 +696,8 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     MK_TRY(qset_sketch(c, qs));
     const uint32_t cap = 256;
     const bool on_device = nresults <= kSelectMaxResults;
-    const uint32_t per = chunk_queries(c, nq), ld = score_pitch(c);
-    MK_TRY(ensure_scores(c, per));
+    const uint32_t per = chunk_queries(c, nq);
+    MK_TRY(ensure_scores(c, per + 1));                        // + one row-major row for replays
     if (on_device && (uint64_t)per > c->cand_cap_q) {
         dev_free(c->d_count); dev_free(c->d_cand);
         MK_TRY(dev_alloc(&c->d_count, (uint64_t)per));
@@ -703,9 +708,9 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     std::vector<mk_hit> cand((size_t)per * cap), full;
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
-        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, ld));
         if (on_device) {
-            MK_TRY(qset_select(c, n, c->d_scores, ld, nresults, min_score, min_inter, cap, c->d_count, c->d_cand));
+            MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, n)));
+            MK_TRY(qset_select(c, n, c->d_scores, nresults, min_score, min_inter, cap, c->d_count, c->d_cand));
             MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
             MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)n * cap * sizeof(mk_hit), hipMemcpyDeviceToHost,
                                   c->stream));
@@ -718,8 +723,11 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
                 continue;
             }
             // more heap entrants than the device row holds (or a top-N beyond the device
-            // selection): replay this query over its full score row, which is still in HBM
-            MK_HIP(hipMemcpy(row.data(), c->d_scores + (uint64_t)i * ld, (size_t)c->G * 4, hipMemcpyDeviceToHost));
+            // selection): replay this query over a dense score row of its own
+            uint32_t *d_row = c->d_scores + (uint64_t)per * score_row_entries(c);
+            MK_TRY(qset_scan(c, qs, q0 + i, q0 + i + 1, d_row, score_layout_rows(c->W, score_row_entries(c), c->G)));
+            MK_HIP(hipMemcpyAsync(row.data(), d_row, (size_t)c->G * 4, hipMemcpyDeviceToHost, c->stream));
+            MK_HIP(hipStreamSynchronize(c->stream));
             full.clear();
             for (uint32_t g = 0; g < c->G; ++g) {
                 if (row[g] < min_score) continue;

@@ -126,15 +126,28 @@ struct ScanArgs {
     const uint64_t *entries;
     const uint64_t *ent_off;
     const uint32_t *nent;
-    uint32_t *scores;              // [nq][score_ld]
-    uint32_t score_ld;             // row pitch in entries (>= G)
+    uint32_t *scores;              // see scan_kernel.hpp: two-stride addressing
+    uint64_t score_tile_stride, score_q_stride;
+    uint32_t score_vec;            // 16-byte stores allowed (strides and padding permit it)
 };
 int launch_scan(mk_ctx *c, const ScanArgs &a);
+// the two layouts the pipeline uses
+struct ScoreLayout { uint64_t tile_stride, q_stride; uint32_t vec; };
+inline ScoreLayout score_layout_rows(uint32_t W, uint64_t pitch, uint32_t G)      // [query][pitch]
+{
+    const uint64_t tg = kTileBytes / W;
+    return {tg, pitch, (uint32_t)((pitch % 4 == 0) && ((uint64_t)((G + tg - 1) / tg) * tg <= pitch))};
+}
+inline ScoreLayout score_layout_tiles(uint32_t W, uint32_t nq)                     // [tile][query][genomes per tile]
+{
+    const uint64_t tg = kTileBytes / W;
+    return {(uint64_t)nq * tg, tg, 1u};
+}
 
 // ---- select.hip
 struct SelectArgs {
-    const uint32_t *scores;        // [nq][score_ld]
-    uint32_t score_ld, G, nq;
+    const uint32_t *scores;        // tile-major [tile][nq][tile_genomes]
+    uint32_t tile_genomes, G, nq;
     uint32_t nresults, min_score;
     double min_inter;
     const uint32_t *sketch_size;

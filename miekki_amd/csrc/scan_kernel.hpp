@@ -129,17 +129,20 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
     for (uint32_t j = 0; j < NCNT; ++j) score[j] = n - ne32[j];
 
-    // score row pitch is a multiple of 16 entries, so the 64-byte lane pieces of the
-    // last tile stay inside the row's padding
-    uint32_t *__restrict__ row = a.scores + (uint64_t)ql * a.score_ld;
-    if ((a.score_ld & 3u) == 0 && g0 + NCNT <= a.score_ld) {
+    // scores[tile * score_tile_stride + ql * score_q_stride + genome-in-tile]: row-major
+    // ([query][genome], q_stride = row pitch, tile_stride = genomes per tile) for callers
+    // that want dense rows, tile-major ([tile][query][genomes per tile]) for the
+    // pipeline -- there consecutive waves store consecutive 4 KiB pieces, a pure stream
+    uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)ql * a.score_q_stride;
+    const uint32_t i0 = lane * NCNT;                                   // genome index inside the tile
+    if (a.score_vec) {
 #pragma unroll
         for (uint32_t j = 0; j < NCNT; j += 4)
-            *reinterpret_cast<uint4 *>(row + g0 + j) = make_uint4(score[j], score[j + 1], score[j + 2], score[j + 3]);
+            *reinterpret_cast<uint4 *>(row + i0 + j) = make_uint4(score[j], score[j + 1], score[j + 2], score[j + 3]);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < NCNT; ++j)
-            if (g0 + j < a.G) row[g0 + j] = score[j];
+            if (g0 + j < a.G) row[i0 + j] = score[j];
     }
 }
 

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (q >= a.nq) return;
-    const uint32_t *__restrict__ row = a.scores + (uint64_t)q * a.score_ld;
+    // tile-major score matrix: this query's piece of tile t starts at (t * nq + q) * tile_genomes
+    const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;
+    const uint32_t *__restrict__ qbase = a.scores + (uint64_t)q * a.tile_genomes;
     const uint32_t N = a.nresults;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double topv = inf;               // lane i < cnt: i-th value of the current top-N multiset
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
         uint32_t s = 0;
         double jac = 0, inter = 0;
         if (g < a.G) {
-            s = row[g];
+            const uint32_t t = g / a.tile_genomes;                         // 64 | tile_genomes: wave-uniform
+            s = qbase[(uint64_t)t * tile_stride + (g - t * a.tile_genomes)];
             if (s >= a.min_score) {                                        // Miekki.cpp:381
                 const uint32_t ss = a.sketch_size[g];
                 const uint64_t gs = a.genome_size[g];

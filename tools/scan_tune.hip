@@ -55,7 +55,7 @@ int main(int argc, char **argv)
     }
     off[Q] = (uint64_t)Q * NE;
     uint64_t *d_ent, *d_off; uint32_t *d_nent, *d_scores;
-    const uint32_t sld = (G + 15) / 16 * 16;
+    const uint32_t sld = (G + kTileBytes - 1) / kTileBytes * kTileBytes;
     CK(hipMalloc((void **)&d_ent, ent.size() * 8)); CK(hipMalloc((void **)&d_off, off.size() * 8));
     CK(hipMalloc((void **)&d_nent, Q * 4)); CK(hipMalloc((void **)&d_scores, (uint64_t)Q * sld * 4));
     CK(hipMemcpy(d_ent, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
@@ -64,7 +64,10 @@ int main(int argc, char **argv)
     ScanArgs a;
     a.M = M; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
     a.ntiles = (G + kTileBytes - 1) / kTileBytes;
-    a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores; a.score_ld = sld;
+    a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores;
+    const bool tile_major_scores = getenv("SCORES_ROWS") == nullptr;
+    const ScoreLayout lay = tile_major_scores ? score_layout_tiles(1, Q) : score_layout_rows(1, sld, G);
+    a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
     const Variant vars[] = {V(8, 0, false), V(4, 0, false), V(16, 0, false), V(8, 0, true), V(8, 1, false), V(8, 1, true),
                             V(16, 1, false), V(4, 1, false)};
     const int nv = sizeof vars / sizeof vars[0];
@@ -84,13 +87,16 @@ int main(int argc, char **argv)
             float t; CK(hipEventElapsedTime(&t, e0, e1));
             if (r) ms[v].push_back(t);                     // round 0 = warm-up
             else {
-                std::vector<uint32_t> c((size_t)std::min<uint32_t>(Q, 64) * sld);   // checksum of the first score rows
+                std::vector<uint32_t> c((size_t)Q * sld);                 // checksum of all scores
                 CK(hipMemcpy(c.data(), d_scores, c.size() * 4, hipMemcpyDeviceToHost));
-                for (uint32_t r = 0; r < std::min<uint32_t>(Q, 64); ++r)
-                    for (uint32_t g = 0; g < G; ++g) chk[v] += c[(size_t)r * sld + g];
+                for (uint32_t r = 0; r < Q; ++r)
+                    for (uint32_t g = 0; g < G; ++g) {
+                        const uint32_t t = g / kTileBytes, w = g % kTileBytes;
+                        chk[v] += c[(size_t)t * lay.tile_stride + (size_t)r * lay.q_stride + w];
+                    }
             }
         }
-    printf("G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
+    printf("scores %s  G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", tile_major_scores ? "tile-major" : "row-major", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
     for (int v = 0; v < nv; ++v) {
         std::sort(ms[v].begin(), ms[v].end());
         const float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
