@@ -133,6 +133,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
     // ([query][genome], q_stride = row pitch, tile_stride = genomes per tile) for callers
     // that want dense rows, tile-major ([tile][query][genomes per tile]) for the
     // pipeline -- there consecutive waves store consecutive 4 KiB pieces, a pure stream
+    if (!a.scores) {                                                   // store-less timing runs (tools/scan_tune)
+#pragma unroll
+        for (uint32_t j = 0; j < NCNT; ++j) asm volatile("" ::"v"(score[j]));   // keep the compare loop live
+        return;
+    }
     uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)ql * a.score_q_stride;
     const uint32_t i0 = lane * NCNT;                                   // genome index inside the tile
     if (a.score_vec) {

@@ -66,6 +66,7 @@ int main(int argc, char **argv)
     a.ntiles = (G + kTileBytes - 1) / kTileBytes;
     a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores;
     const bool tile_major_scores = getenv("SCORES_ROWS") == nullptr;
+    if (getenv("NO_STORE")) a.scores = nullptr;
     const ScoreLayout lay = tile_major_scores ? score_layout_tiles(1, Q) : score_layout_rows(1, sld, G);
     a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
     const Variant vars[] = {V(8, 0, false), V(4, 0, false), V(16, 0, false), V(8, 0, true), V(8, 1, false), V(8, 1, true),
@@ -87,6 +88,7 @@ int main(int argc, char **argv)
             float t; CK(hipEventElapsedTime(&t, e0, e1));
             if (r) ms[v].push_back(t);                     // round 0 = warm-up
             else {
+                if (!a.scores) continue;
                 std::vector<uint32_t> c((size_t)Q * sld);                 // checksum of all scores
                 CK(hipMemcpy(c.data(), d_scores, c.size() * 4, hipMemcpyDeviceToHost));
                 for (uint32_t r = 0; r < Q; ++r)
