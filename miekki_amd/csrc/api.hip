@@ -158,7 +158,10 @@ static int build_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n)
     MK_TRY(launch_seed_valid(c, c->d_seq, c->d_seq_off, n, c->d_seed_valid));
     {
         ScopedTimer t(c, 3);
-        MK_TRY(launch_genome_sketch(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables));
+        bool binned = false;
+        MK_TRY(launch_genome_sketch_binned(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables, &binned));
+        if (!binned)
+            MK_TRY(launch_genome_sketch(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables));
     }
     {
         ScopedTimer t(c, 4);
@@ -329,8 +332,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
-    c->cand_cap_q = 0; c->cand_cap = 0; c->d_long_table = nullptr; c->d_long_flags = nullptr;
-    c->d_long_counts = nullptr;
+    c->cand_cap_q = 0; c->cand_cap = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
+    c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
@@ -359,8 +362,8 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq); dev_free(c->d_seq_off); dev_free(c->d_scores);
-    dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_long_flags);
-    dev_free(c->d_long_counts);
+    dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
+    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

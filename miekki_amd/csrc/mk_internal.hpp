@@ -74,8 +74,13 @@ struct mk_ctx {
     mk_hit *d_cand;
     uint64_t cand_cap_q, cand_cap;
     uint64_t *d_long_table;        // P keys, long-query path
-    uint8_t *d_long_flags;         // P
-    uint32_t *d_long_counts;
+    // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
+    uint64_t *d_slots;
+    uint64_t slots_cap;            // entries
+    uint16_t *d_slot_counts;
+    uint64_t slot_counts_cap;
+    uint64_t *d_ovf;               // (genome << 32 | bucket, key) pairs that missed their slot
+    uint32_t *d_ovf_count;
     // stats
     mk_stats stats;
     std::vector<mk::Timer> pending;
@@ -108,6 +113,10 @@ int drain_timers(mk_ctx *c);
 int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint32_t n, uint32_t *d_valid);
 int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
                          const uint32_t *d_valid, uint32_t n, uint64_t *d_tables);
+// same result through LDS-binned partitioning; *used = false when the shape does
+// not fit the binned path (the caller then takes the atomic kernel above)
+int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
+                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used);
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0);
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n);

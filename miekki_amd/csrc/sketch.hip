@@ -11,6 +11,8 @@
 // minimum of the key (fingerprint, position), which is what both paths compute:
 // genomes by 64-bit atomic minimum into a per-genome table in HBM, short queries
 // by an in-LDS sort of (partition, fingerprint, position) keys.
+#include <cmath>
+
 #include "mk_internal.hpp"
 
 namespace mk {
@@ -164,6 +166,196 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
     hipLaunchKernelGGL(genome_sketch_kernel, dim3((uint32_t)segs, n), dim3(256), 0, c->stream, d_seq, d_off,
                        d_valid, d_tables, make_sp(c));
     MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------- K1 (binned)
+// The atomic kernel above is bound by the chip's scattered 64-bit atomic rate
+// (~4e10/s), two orders of magnitude below what the hashing itself costs.  The
+// binned form trades the atomics for two streaming passes:
+//   A  every workgroup hashes its 4096 k-mers and drops each (fingerprint,
+//      position, partition) item into the slot of its BIN -- the partition's high
+//      bits -- in a fixed-capacity (genome, bin, workgroup) slot array; the rank
+//      inside the slot comes from an LDS counter, no global atomics;
+//   B  one workgroup per (genome, bin) reads its slots, takes the minimum per
+//      partition with LDS atomics in a 2^13-entry table and streams the table out.
+// Items that find their slot full (possible only for very repetitive sequence) go
+// to an overflow list that pass C folds in with global atomics.  Result: exactly
+// the per-partition minimum of (fingerprint, position), as before.
+constexpr uint32_t kBinBits = 13;                 // partitions per bin = LDS table entries
+constexpr uint32_t kMaxBins = 1024;
+constexpr uint32_t kItemPosBits = 35;
+constexpr uint32_t kOvfCap = 1u << 20;
+
+struct BinParams {
+    uint32_t nbins, low_bits, cap, nwg;           // low_bits = min(h, 13); nwg = workgroups per genome
+    uint64_t slots_per_genome;                    // nbins * nwg * cap
+};
+
+// item = fingerprint << 48 | position << 13 | partition-within-bin
+__device__ __forceinline__ uint64_t item_to_key(uint64_t item)
+{
+    return ((item >> 48) << kPosBits) | ((item >> kBinBits) & ((1ULL << kItemPosBits) - 1));
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict__ seq,
+                                                          const uint64_t *__restrict__ off,
+                                                          const uint32_t *__restrict__ valid,
+                                                          uint64_t *__restrict__ slots,
+                                                          uint16_t *__restrict__ slot_counts,
+                                                          uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count,
+                                                          SketchParams sp, BinParams bp)
+{
+    __shared__ uint8_t codes[kSegKmers + 64];
+    __shared__ uint32_t bin_count[kMaxBins];
+    const uint32_t g = blockIdx.y, wg = blockIdx.x;
+    const uint64_t len = off[g + 1] - off[g];
+    const uint64_t nk = len > sp.k ? len - sp.k : 0;
+    const uint64_t seg0 = (uint64_t)wg * kSegKmers;
+    for (uint32_t b = threadIdx.x; b < bp.nbins; b += 256) bin_count[b] = 0;
+    uint32_t cnt = 0;
+    if (seg0 < nk) {
+        cnt = (uint32_t)min((uint64_t)kSegKmers, nk - seg0);
+        const char *__restrict__ s = seq + off[g];
+        const bool sv = valid[g] != 0;
+        const uint32_t nchar = cnt + sp.k - 1;
+        for (uint32_t j = threadIdx.x; j < nchar; j += 256)
+            codes[j] = (uint8_t)pos_codes((uint8_t)s[seg0 + j], seg0 + j, sp.k, sv);
+    }
+    __syncthreads();
+    const uint32_t i0 = threadIdx.x * kPerThread;
+    if (i0 < cnt) {
+        const uint32_t i1 = min(i0 + kPerThread, cnt);
+        uint64_t S = 0, RC = 0;
+        for (uint32_t j = 0; j + 1 < sp.k; ++j) {
+            const uint32_t cd = codes[i0 + j];
+            S = (S << 2) | (cd & 3u);
+            RC |= (uint64_t)(cd >> 2) << (2 * (j + 1));
+        }
+        const uint32_t topshift = 2 * sp.k - 2;
+        uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const uint32_t cd = codes[i + sp.k - 1];
+            S = ((S << 2) | (cd & 3u)) & sp.kmask;
+            RC = (RC >> 2) | ((uint64_t)(cd >> 2) << topshift);
+            const uint64_t anc = revhash64(S < RC ? S : RC);
+            uint32_t bucket, fp;
+            bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+            if (fp == sp.empty) continue;
+            const uint32_t bin = bucket >> bp.low_bits;
+            const uint64_t item = ((uint64_t)fp << 48) | ((seg0 + i) << kBinBits) | (bucket & ((1u << bp.low_bits) - 1u));
+            const uint32_t rank = atomicAdd(&bin_count[bin], 1u);
+            if (rank < bp.cap) {
+                gslots[((uint64_t)bin * bp.nwg + wg) * bp.cap + rank] = item;
+            } else {
+                const uint32_t o = atomicAdd(ovf_count, 1u);
+                if (o < kOvfCap) {
+                    ovf[2 * (uint64_t)o] = ((uint64_t)g << 32) | bucket;
+                    ovf[2 * (uint64_t)o + 1] = item_to_key(item);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint16_t *__restrict__ gc = slot_counts + (uint64_t)g * bp.nbins * bp.nwg;
+    for (uint32_t b = threadIdx.x; b < bp.nbins; b += 256)
+        gc[(uint64_t)b * bp.nwg + wg] = (uint16_t)min(bin_count[b], bp.cap);
+}
+
+__global__ __launch_bounds__(256) void bin_reduce_kernel(const uint64_t *__restrict__ slots,
+                                                         const uint16_t *__restrict__ slot_counts,
+                                                         uint64_t *__restrict__ tables, SketchParams sp, BinParams bp)
+{
+    __shared__ unsigned long long table[1u << kBinBits];
+    const uint32_t bin = blockIdx.x, g = blockIdx.y;
+    const uint32_t R = 1u << bp.low_bits;
+    for (uint32_t i = threadIdx.x; i < R; i += 256) table[i] = kEmptyKey;
+    __syncthreads();
+    const uint64_t *__restrict__ base = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)bin * bp.nwg * bp.cap;
+    const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
+    // one wave per slot at a time: the used prefix of a slot is a short contiguous run
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t w = wave; w < bp.nwg; w += 4) {
+        const uint32_t cw = cnts[w];
+        const uint64_t *__restrict__ run = base + (uint64_t)w * bp.cap;
+        for (uint32_t i = lane; i < cw; i += 64) {
+            const uint64_t item = run[i];
+            atomicMin(&table[item & (R - 1u)], (unsigned long long)item);
+        }
+    }
+    __syncthreads();
+    uint64_t *__restrict__ out = tables + (uint64_t)g * sp.P + (uint64_t)bin * R;
+    for (uint32_t i = threadIdx.x; i < R; i += 256) {
+        const uint64_t item = table[i];
+        out[i] = item == kEmptyKey ? kEmptyKey : item_to_key(item);
+    }
+}
+
+__global__ void bin_overflow_kernel(const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_count,
+                                    uint64_t *__restrict__ tables, uint32_t P)
+{
+    const uint32_t n = min(*ovf_count, kOvfCap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t where = ovf[2 * (uint64_t)i], key = ovf[2 * (uint64_t)i + 1];
+        atomicMin((unsigned long long *)&tables[(where >> 32) * P + (uint32_t)where], (unsigned long long)key);
+    }
+}
+
+int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
+                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used)
+{
+    *used = false;
+    if (!n) return MK_OK;
+    uint64_t max_nk = 0, max_len = 0;
+    for (uint32_t g = 0; g < n; ++g) {
+        const uint64_t len = h_off[g + 1] - h_off[g];
+        max_len = std::max(max_len, len);
+        if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
+    }
+    BinParams bp;
+    bp.low_bits = std::min<uint32_t>(c->p.h, kBinBits);
+    bp.nbins = c->P >> bp.low_bits;
+    if (bp.nbins > kMaxBins || max_len >= (1ULL << kItemPosBits) || max_nk == 0) return MK_OK;
+    bp.nwg = (uint32_t)((max_nk + kSegKmers - 1) / kSegKmers);
+    // per (workgroup, bin) the count is ~Poisson(mean): size the slot for mean + 6 sigma
+    const double mean = (double)kSegKmers / bp.nbins;
+    bp.cap = bp.nbins == 1 ? kSegKmers
+                           : std::min<uint32_t>(kSegKmers, (uint32_t)((mean + 6.0 * std::sqrt(mean) + 8.0 + 7.0) / 8.0) * 8u);
+    bp.slots_per_genome = (uint64_t)bp.nbins * bp.nwg * bp.cap;
+    const uint64_t need = bp.slots_per_genome * n;
+    if (need * 8 > (12ull << 30)) return MK_OK;                    // slot memory budget
+    if (need > c->slots_cap) {
+        if (c->d_slots) (void)hipFree(c->d_slots);
+        c->d_slots = nullptr; c->slots_cap = 0;
+        MK_HIP(hipMalloc((void **)&c->d_slots, need * 8));
+        c->slots_cap = need;
+    }
+    const uint64_t ncnt = (uint64_t)n * bp.nbins * bp.nwg;
+    if (ncnt > c->slot_counts_cap) {
+        if (c->d_slot_counts) (void)hipFree(c->d_slot_counts);
+        c->d_slot_counts = nullptr; c->slot_counts_cap = 0;
+        MK_HIP(hipMalloc((void **)&c->d_slot_counts, ncnt * 2));
+        c->slot_counts_cap = ncnt;
+    }
+    if (!c->d_ovf) {
+        MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfCap * 16));
+        MK_HIP(hipMalloc((void **)&c->d_ovf_count, 4));
+    }
+    MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
+    const SketchParams sp = make_sp(c);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
+                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, sp, bp);
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(256), 0, c->stream, c->d_slots,
+                       c->d_slot_counts, d_tables, sp, bp);
+    hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
+                       c->P);
+    MK_HIP(hipGetLastError());
+    // a full overflow list would lose items: detect it and let the caller redo the batch
+    uint32_t novf = 0;
+    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    if (novf > kOvfCap) return MK_OK;                              // *used stays false
+    *used = true;
     return MK_OK;
 }
 
