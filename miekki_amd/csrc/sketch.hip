@@ -262,32 +262,47 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
         gc[(uint64_t)b * bp.nwg + wg] = (uint16_t)min(bin_count[b], bp.cap);
 }
 
-__global__ __launch_bounds__(256) void bin_reduce_kernel(const uint64_t *__restrict__ slots,
-                                                         const uint16_t *__restrict__ slot_counts,
-                                                         uint64_t *__restrict__ tables, SketchParams sp, BinParams bp)
+__global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint64_t *__restrict__ slots,
+                                                          const uint16_t *__restrict__ slot_counts,
+                                                          uint64_t *__restrict__ tables, SketchParams sp, BinParams bp)
 {
     __shared__ unsigned long long table[1u << kBinBits];
     const uint32_t bin = blockIdx.x, g = blockIdx.y;
     const uint32_t R = 1u << bp.low_bits;
-    for (uint32_t i = threadIdx.x; i < R; i += 256) table[i] = kEmptyKey;
+    for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kEmptyKey;
     __syncthreads();
     const uint64_t *__restrict__ base = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)bin * bp.nwg * bp.cap;
     const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
-    // one wave per slot at a time: the used prefix of a slot is a short contiguous run
+    // one wave per slot, four slots in flight per wave: the used prefix of a slot is a
+    // short contiguous run, and independent loads are what hides the HBM latency here
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t w = wave; w < bp.nwg; w += 4) {
-        const uint32_t cw = cnts[w];
-        const uint64_t *__restrict__ run = base + (uint64_t)w * bp.cap;
-        for (uint32_t i = lane; i < cw; i += 64) {
-            const uint64_t item = run[i];
-            atomicMin(&table[item & (R - 1u)], (unsigned long long)item);
+    constexpr uint32_t NW = 16, UN = 4;
+    for (uint32_t w0 = wave; w0 < bp.nwg; w0 += NW * UN) {
+        uint32_t cw[UN];
+        uint64_t item[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+            const uint32_t w = w0 + u * NW;
+            cw[u] = w < bp.nwg ? cnts[w] : 0u;
         }
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u)
+            item[u] = lane < cw[u] ? base[(uint64_t)(w0 + u * NW) * bp.cap + lane] : kEmptyKey;
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u)
+            if (item[u] != kEmptyKey) atomicMin(&table[item[u] & (R - 1u)], (unsigned long long)item[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u)                           // slots longer than a wave (small h)
+            for (uint32_t i = lane + 64; i < cw[u]; i += 64) {
+                const uint64_t it = base[(uint64_t)(w0 + u * NW) * bp.cap + i];
+                atomicMin(&table[it & (R - 1u)], (unsigned long long)it);
+            }
     }
     __syncthreads();
     uint64_t *__restrict__ out = tables + (uint64_t)g * sp.P + (uint64_t)bin * R;
-    for (uint32_t i = threadIdx.x; i < R; i += 256) {
-        const uint64_t item = table[i];
-        out[i] = item == kEmptyKey ? kEmptyKey : item_to_key(item);
+    for (uint32_t i = threadIdx.x; i < R; i += 1024) {
+        const uint64_t it = table[i];
+        out[i] = it == kEmptyKey ? kEmptyKey : item_to_key(it);
     }
 }
 
@@ -345,7 +360,7 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
                        c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, sp, bp);
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(256), 0, c->stream, c->d_slots,
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
                        c->d_slot_counts, d_tables, sp, bp);
     hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
                        c->P);
@@ -469,18 +484,21 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
         // pass A: the (fingerprint, position) key has served finalize; replace it by
         // the winner's canonical k-mer so that pass B need not touch the sequence again
         canon = canon_at(seq + off[g], key & ((1ULL << kPosBits) - 1), sp.k, valid[g] != 0);
-        *slot = canon;
     } else {
         canon = key;
     }
     const uint64_t anc = revhash64(canon);
+    bool posted = false;
     for (uint32_t i = 0; i < kNumHash; ++i) {
         const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
         const uint64_t cell = hsh >> 3;
         if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
         const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (i << 4) | (uint32_t)(hsh & 7);
         if (!WRITE) {
-            if (bloom[cell] == 0) atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+            if (bloom[cell] == 0) {
+                atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+                posted = true;
+            }
         } else {
             if (order[cell] == okey) {
                 bloom[cell] = (uint8_t)(1u << (hsh & 7));
@@ -488,6 +506,10 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
             }
         }
     }
+    // a k-mer whose five cells were all set already (the common case once the filter
+    // has filled up) has nothing to do in pass B: blank its slot so that pass B stops
+    // at the first test
+    if (!WRITE) *slot = posted ? canon : kEmptyKey;
 }
 
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
