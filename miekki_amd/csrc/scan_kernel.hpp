@@ -47,21 +47,12 @@ __device__ __forceinline__ const uint8_t *row_base(const uint8_t *base, uint32_t
     return base + (((uint64_t)hi << 32) | lo);
 }
 
-// ORDER 0: consecutive waves take adjacent tiles of one query (query-major);
-// ORDER 1: consecutive waves take the same tile of consecutive queries (tile-major).
-// NT: non-temporal row loads.
-template <int W, int UNROLL, int ORDER = 1, bool NT = false>
-__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+// One work item: query `ql` of the launch against row tile `tile`.
+template <int W, int UNROLL, bool NT>
+__device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32_t tile, uint32_t lane)
 {
     constexpr uint32_t NCNT = 16 / W;                    // genomes per lane
     constexpr uint32_t CHUNK = W == 1 ? 255u : 65535u;   // entries before packed counters overflow
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t work = blockIdx.x * 4u + wave;
-    if (work >= a.nq * a.ntiles) return;                 // wave-uniform exit
-    uint32_t ql, tile;
-    if (ORDER == 0) { ql = work / a.ntiles; tile = work - ql * a.ntiles; }
-    else            { tile = work / a.nq;   ql = work - tile * a.nq; }
     // lanes past the end of the row have nothing to compare: retire them now so the
     // last tile of every row only fetches what it needs
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
@@ -148,6 +139,39 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for (uint32_t j = 0; j < NCNT; ++j)
             if (g0 + j < a.G) row[i0 + j] = score[j];
+    }
+}
+
+// ORDER 0: consecutive waves take adjacent tiles of one query (query-major);
+// ORDER 1: consecutive waves take the same tile of consecutive queries (tile-major).
+// NT: non-temporal row loads.
+template <int W, int UNROLL, int ORDER = 1, bool NT = false>
+__global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    if (work >= a.nq * a.ntiles) return;                 // wave-uniform exit
+    uint32_t ql, tile;
+    if (ORDER == 0) { ql = work / a.ntiles; tile = work - ql * a.ntiles; }
+    else            { tile = work / a.nq;   ql = work - tile * a.nq; }
+    scan_item<W, UNROLL, NT>(a, ql, tile, lane);
+}
+
+// Phase-locked sweep: the grid holds only as many waves as the chip keeps resident
+// and every wave walks the tile-major work list with the grid's stride.  All items
+// cost the same (one query's sorted entry list), so the resident waves start item k
+// together and sweep the partitions 0 -> 2^h side by side: the rows they touch at any
+// moment lie in a narrow band of the column slab, which the Infinity Cache holds.
+template <int W, int UNROLL, bool NT = false>
+__global__ __launch_bounds__(256) void scan_sweep_kernel(const ScanArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total = a.nq * a.ntiles, stride = gridDim.x * 4u;
+    for (uint32_t work = blockIdx.x * 4u + wave; work < total; work += stride) {
+        const uint32_t tile = work / a.nq, ql = work - tile * a.nq;
+        scan_item<W, UNROLL, NT>(a, ql, tile, lane);
     }
 }
 

@@ -28,9 +28,67 @@ __global__ void fill_kernel(uint4 *p, uint64_t n16, uint64_t seed)
     }
 }
 
-struct Variant { const char *name; void (*fn)(const ScanArgs); };
 
-#define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>}
+// ---- experiment: narrower row tiles (LB bytes per lane instead of 16) so that the
+// tile-major column slab (2^h x 64*LB bytes) fits the Infinity Cache; store-less.
+template <int LB, int UNROLL>
+__global__ __launch_bounds__(256) void narrow_kernel(const ScanArgs a)
+{
+    constexpr uint32_t ND = LB / 4, TB = 64 * LB;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t ntiles = (a.G + TB - 1) / TB;
+    const uint32_t work = blockIdx.x * 4u + wave;
+    if (work >= a.nq * ntiles) return;
+    const uint32_t tile = work / a.nq, ql = work - tile * a.nq;
+    if ((uint64_t)tile * TB + lane * LB >= a.G) return;
+    const uint64_t *__restrict__ ent = a.entries + a.ent_off[ql];
+    const uint32_t n = a.nent[ql];
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * TB;
+    const uint32_t voff = lane * LB;
+    uint32_t tot[ND];
+    for (uint32_t k = 0; k < ND; ++k) tot[k] = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 255) {
+        const uint32_t m = min(n - i0, 255u);
+        const uint64_t *__restrict__ e = ent + i0;
+        uint32_t acc[ND];
+        for (uint32_t k = 0; k < ND; ++k) acc[k] = 0;
+        uint32_t j = 0;
+        for (; j + UNROLL <= m; j += UNROLL) {
+            uint64_t ev[UNROLL];
+            uint32_t d[UNROLL][ND];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint8_t *p = row_base(base, (uint32_t)ev[u], a.ld) + voff;
+                if (ND == 1) d[u][0] = *reinterpret_cast<const uint32_t *>(p);
+                else if (ND == 2) { const uint2 t = *reinterpret_cast<const uint2 *>(p); d[u][0] = t.x; d[u][1] = t.y; }
+                else { const uint4 t = *reinterpret_cast<const uint4 *>(p); d[u][0] = t.x; d[u][1] = t.y; d[u][2 % ND] = t.z; d[u][3 % ND] = t.w; }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint32_t b = bcast_fp<1>((uint32_t)(ev[u] >> 32));
+#pragma unroll
+                for (uint32_t k = 0; k < ND; ++k) acc[k] += ne_lanes<1>(d[u][k], b);
+            }
+        }
+        for (; j < m; ++j) {
+            const uint64_t ev = e[j];
+            const uint8_t *p = row_base(base, (uint32_t)ev, a.ld) + voff;
+            const uint32_t b = bcast_fp<1>((uint32_t)(ev >> 32));
+            for (uint32_t k = 0; k < ND; ++k) acc[k] += ne_lanes<1>(reinterpret_cast<const uint32_t *>(p)[k], b);
+        }
+        for (uint32_t k = 0; k < ND; ++k) tot[k] += (acc[k] & 0xff) + ((acc[k] >> 8) & 0xff) + ((acc[k] >> 16) & 0xff) + (acc[k] >> 24);
+    }
+    for (uint32_t k = 0; k < ND; ++k) asm volatile("" ::"v"(tot[k]));
+}
+
+struct Variant { const char *name; void (*fn)(const ScanArgs); uint32_t blocks_per_cu; uint32_t lane_bytes; };   // blocks_per_cu > 0: sweep grid
+
+#define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>, 0, 16}
+#define S(B) {"sweep_" #B "perCU", scan_sweep_kernel<1, 8, false>, B, 16}
+#define N(LB, U) {"narrow_" #LB "B_u" #U, narrow_kernel<LB, U>, 0, LB}
 
 int main(int argc, char **argv)
 {
@@ -39,6 +97,7 @@ int main(int argc, char **argv)
     const uint32_t Q = argc > 3 ? atoi(argv[3]) : 20000;
     const uint32_t NE = argc > 4 ? atoi(argv[4]) : 908;
     const int rounds = argc > 5 ? atoi(argv[5]) : 5;
+    const uint32_t range_div = argc > 6 ? atoi(argv[6]) : 1;      // draw partitions from [0, P / range_div): slab experiment
     const uint32_t P = 1u << h;
     const uint64_t ld = ((uint64_t)G + kTileBytes - 1) / kTileBytes * kTileBytes;
     uint8_t *M; CK(hipMalloc((void **)&M, (uint64_t)P * ld));
@@ -49,7 +108,7 @@ int main(int argc, char **argv)
     for (uint32_t q = 0; q < Q; ++q) {
         off[q] = (uint64_t)q * NE;
         std::vector<uint32_t> ps(NE);
-        for (auto &p : ps) p = (uint32_t)(rng() % P);
+        for (auto &p : ps) p = (uint32_t)(rng() % (P / range_div));
         std::sort(ps.begin(), ps.end());
         for (uint32_t i = 0; i < NE; ++i) ent[(size_t)q * NE + i] = make_entry(ps[i], 0xC0u | (uint32_t)(rng() & 0x3f));
     }
@@ -69,8 +128,7 @@ int main(int argc, char **argv)
     if (getenv("NO_STORE")) a.scores = nullptr;
     const ScoreLayout lay = tile_major_scores ? score_layout_tiles(1, Q) : score_layout_rows(1, sld, G);
     a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
-    const Variant vars[] = {V(8, 0, false), V(4, 0, false), V(16, 0, false), V(8, 0, true), V(8, 1, false), V(8, 1, true),
-                            V(16, 1, false), V(4, 1, false)};
+    const Variant vars[] = {V(8, 0, false), V(8, 1, false), N(16, 8), N(8, 8), N(8, 16), N(4, 8), N(4, 16)};
     const int nv = sizeof vars / sizeof vars[0];
     const uint64_t work = (uint64_t)Q * a.ntiles;
     const uint32_t blocks = (uint32_t)((work + 3) / 4);
@@ -82,7 +140,12 @@ int main(int argc, char **argv)
     for (int r = 0; r < rounds + 1; ++r)
         for (int v = 0; v < nv; ++v) {
             CK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(vars[v].fn, dim3(blocks), dim3(256), 0, 0, a);
+            uint32_t grid = vars[v].blocks_per_cu ? std::min(blocks, 256u * vars[v].blocks_per_cu) : blocks;
+            if (vars[v].lane_bytes != 16 || vars[v].fn == (void (*)(const ScanArgs))narrow_kernel<16, 8>) {
+                const uint32_t tb = 64 * vars[v].lane_bytes;
+                grid = (uint32_t)(((uint64_t)Q * ((G + tb - 1) / tb) + 3) / 4);
+            }
+            hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), 0, 0, a);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float t; CK(hipEventElapsedTime(&t, e0, e1));
@@ -98,7 +161,7 @@ int main(int argc, char **argv)
                     }
             }
         }
-    printf("scores %s  G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", tile_major_scores ? "tile-major" : "row-major", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
+    printf("range 1/%u  scores %s  G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", range_div, tile_major_scores ? "tile-major" : "row-major", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
     for (int v = 0; v < nv; ++v) {
         std::sort(ms[v].begin(), ms[v].end());
         const float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
