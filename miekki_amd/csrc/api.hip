@@ -193,7 +193,7 @@ static void qset_release(mk_qset *qs)
 {
     if (!qs) return;
     dev_free(qs->d_seq); dev_free(qs->d_off); dev_free(qs->d_ent_off); dev_free(qs->d_entries);
-    dev_free(qs->d_nent);
+    dev_free(qs->d_nent); dev_free(qs->d_split);
     delete qs;
 }
 
@@ -202,6 +202,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> qs(new mk_qset(), qset_release);
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
     qs->d_nent = nullptr; qs->sketched = false; qs->total_active = 0; qs->short_max_nk = 0;
+    qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
@@ -225,7 +226,9 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     return MK_OK;
 }
 
-static int qset_sketch(mk_ctx *c, mk_qset *qs)
+static int qset_prepare_slab(mk_ctx *c, mk_qset *qs);
+
+static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
 {
     ScopedTimer t(c, 0);
     MK_TRY(launch_query_sketch_short(c, qs));
@@ -238,9 +241,48 @@ static int qset_sketch(mk_ctx *c, mk_qset *qs)
     return MK_OK;
 }
 
+static int qset_sketch(mk_ctx *c, mk_qset *qs)
+{
+    MK_TRY(qset_sketch_only(c, qs));
+    return qset_prepare_slab(c, qs);
+}
+
 static uint32_t ntiles_of(const mk_ctx *c)
 {
     return (uint32_t)(((uint64_t)c->G * c->W + kTileBytes - 1) / kTileBytes);
+}
+
+// Ranges of the slab schedule: the (2^h / S) x 1 KiB column slab the waves in flight
+// share should fit the 256 MiB Infinity Cache with room to spare (target 128 MiB).
+static uint32_t slab_ranges(const mk_ctx *c)
+{
+    const uint64_t slab = (uint64_t)c->P * kTileBytes, target = 128ull << 20;
+    uint32_t S = 1;
+    while (S < 32 && slab / S > target) S <<= 1;
+    return S;
+}
+
+// Prepare the slab schedule for a sketched set: range boundaries per query, and the
+// check that every (query, range) fits the packed 8/16-bit counters.  Sets with long
+// (unsorted) queries, or that fail the check, use the plain schedule.
+static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
+{
+    const uint32_t S = slab_ranges(c);
+    qs->slab_ok = false;
+    if (S < 2 || !qs->long_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
+    if (qs->S != S) {
+        dev_free(qs->d_split);
+        MK_TRY(dev_alloc(&qs->d_split, (uint64_t)qs->nq * (S + 1)));
+        qs->S = S;
+    }
+    if (!c->d_flag) MK_TRY(dev_alloc(&c->d_flag, 1));
+    MK_HIP(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+    MK_TRY(launch_query_split(c, qs, S, c->W == 1 ? 255u : 65535u, c->d_flag));
+    uint32_t flag = 1;
+    MK_HIP(hipMemcpyAsync(&flag, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    qs->slab_ok = flag == 0;
+    return MK_OK;
 }
 
 static uint32_t tile_genomes(const mk_ctx *c) { return kTileBytes / c->W; }
@@ -285,12 +327,44 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     return MK_OK;
 }
 
+// ---- slab schedule: per-range partial counts instead of a u32 score matrix
+static uint64_t partial_bytes_per_query(const mk_ctx *c, uint32_t S) { return (uint64_t)ntiles_of(c) * S * kTileBytes; }
+
+static uint32_t chunk_queries_slab(const mk_ctx *c, uint32_t nq, uint32_t S)
+{
+    const uint64_t budget = 16ull << 30;
+    uint64_t per = std::max<uint64_t>(1, budget / std::max<uint64_t>(partial_bytes_per_query(c, S), 1));
+    per = std::min<uint64_t>(per, 0x7ffffff0ull / std::max<uint64_t>((uint64_t)ntiles_of(c) * S, 1));   // one launch
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), std::max<uint32_t>(nq, 1));
+}
+
+static int ensure_partials(mk_ctx *c, uint64_t bytes)
+{
+    if (bytes > c->partials_cap) {
+        dev_free(c->d_partials);
+        MK_TRY(dev_alloc(&c->d_partials, bytes));
+        c->partials_cap = bytes;
+    }
+    return MK_OK;
+}
+
+static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
+{
+    SlabArgs a;
+    a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c); a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S;
+    a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
+    ScopedTimer t(c, 1);
+    return launch_scan_slab(c, a);
+}
+
 // entrants of filter_results' heap for the rows in d_scores (see select.hip)
-static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, uint32_t nresults,
-                       uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count, mk_hit *d_cand)
+static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, const uint8_t *d_partials, uint32_t S,
+                       const uint32_t *d_nent, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
+                       uint32_t *d_count, mk_hit *d_cand)
 {
     SelectArgs a;
-    a.scores = d_scores; a.tile_genomes = tile_genomes(c); a.G = c->G; a.nq = n; a.nresults = nresults;
+    a.scores = d_scores; a.partials = d_partials; a.nent = d_nent; a.S = S; a.W = c->W;
+    a.tile_genomes = tile_genomes(c); a.G = c->G; a.nq = n; a.nresults = nresults;
     a.min_score = min_score; a.min_inter = min_inter; a.sketch_size = c->d_sketch_size;
     a.genome_size = c->d_genome_size; a.genome_id_base = c->p.genome_id_base; a.cap = cap;
     a.count = d_count; a.cand = d_cand;
@@ -332,6 +406,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
+    c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
     c->cand_cap_q = 0; c->cand_cap = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -363,7 +438,8 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
-    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count);
+    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
+    dev_free(c->d_flag);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -594,13 +670,24 @@ int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, d
     MK_TRY(use_device(c));
     MK_TRY(qset_sketch(c, qs));
     if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
+    if (qs->slab_ok) {
+        const uint32_t per = chunk_queries_slab(c, qs->nq, qs->S);
+        MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
+        for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
+            const uint32_t q1 = std::min(qs->nq, q0 + per);
+            MK_TRY(qset_scan_slab(c, qs, q0, q1));
+            MK_TRY(qset_select(c, q1 - q0, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
+                               min_inter, cap, d_count + q0, d_cand + (uint64_t)q0 * cap));
+        }
+        return MK_OK;
+    }
     const uint32_t per = chunk_queries(c, qs->nq);
     MK_TRY(ensure_scores(c, per));
     for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
         const uint32_t q1 = std::min(qs->nq, q0 + per);
         MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, q1 - q0)));
-        MK_TRY(qset_select(c, q1 - q0, c->d_scores, nresults, min_score, min_inter, cap, d_count + q0,
-                           d_cand + (uint64_t)q0 * cap));
+        MK_TRY(qset_select(c, q1 - q0, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
+                           d_count + q0, d_cand + (uint64_t)q0 * cap));
     }
     return MK_OK;
 }
@@ -699,8 +786,15 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     MK_TRY(qset_sketch(c, qs));
     const uint32_t cap = 256;
     const bool on_device = nresults <= kSelectMaxResults;
-    const uint32_t per = chunk_queries(c, nq);
-    MK_TRY(ensure_scores(c, per + 1));                        // + one row-major row for replays
+    const bool slab = on_device && qs->slab_ok;
+    const uint32_t per = slab ? chunk_queries_slab(c, nq, qs->S) : chunk_queries(c, nq);
+    if (slab) {
+        MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
+        MK_TRY(ensure_scores(c, 1));
+    } else {
+        MK_TRY(ensure_scores(c, per + 1));                    // + one row-major row for replays
+    }
+    uint32_t *const d_replay_row = c->d_scores + (slab ? 0 : (uint64_t)per * score_row_entries(c));
     if (on_device && (uint64_t)per > c->cand_cap_q) {
         dev_free(c->d_count); dev_free(c->d_cand);
         MK_TRY(dev_alloc(&c->d_count, (uint64_t)per));
@@ -712,8 +806,15 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
         if (on_device) {
-            MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, n)));
-            MK_TRY(qset_select(c, n, c->d_scores, nresults, min_score, min_inter, cap, c->d_count, c->d_cand));
+            if (slab) {
+                MK_TRY(qset_scan_slab(c, qs, q0, q1));
+                MK_TRY(qset_select(c, n, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
+                                   min_inter, cap, c->d_count, c->d_cand));
+            } else {
+                MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, n)));
+                MK_TRY(qset_select(c, n, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
+                                   c->d_count, c->d_cand));
+            }
             MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
             MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)n * cap * sizeof(mk_hit), hipMemcpyDeviceToHost,
                                   c->stream));
@@ -727,7 +828,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
             }
             // more heap entrants than the device row holds (or a top-N beyond the device
             // selection): replay this query over a dense score row of its own
-            uint32_t *d_row = c->d_scores + (uint64_t)per * score_row_entries(c);
+            uint32_t *d_row = d_replay_row;
             MK_TRY(qset_scan(c, qs, q0 + i, q0 + i + 1, d_row, score_layout_rows(c->W, score_row_entries(c), c->G)));
             MK_HIP(hipMemcpyAsync(row.data(), d_row, (size_t)c->G * 4, hipMemcpyDeviceToHost, c->stream));
             MK_HIP(hipStreamSynchronize(c->stream));

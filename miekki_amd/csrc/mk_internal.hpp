@@ -70,6 +70,9 @@ struct mk_ctx {
     // query scratch
     uint32_t *d_scores;            // score matrix of the query chunk in flight
     uint64_t scores_cap;
+    uint8_t *d_partials;           // slab schedule: per-range mismatch counts of the chunk in flight
+    uint64_t partials_cap;         // bytes
+    uint32_t *d_flag;              // one word for device-side eligibility checks
     uint32_t *d_count;
     mk_hit *d_cand;
     uint64_t cand_cap_q, cand_cap;
@@ -98,6 +101,9 @@ struct mk_qset {
     std::vector<uint64_t> h_off, h_ent_off;
     std::vector<uint32_t> long_q;  // queries with more than kShortMax k-mers
     uint32_t short_max_nk;         // longest short query (k-mers)
+    uint32_t *d_split;             // [nq][S + 1] entry index of each partition-range boundary
+    uint32_t S;                    // ranges of the slab schedule (0 = not prepared)
+    bool slab_ok;                  // every (query, range) fits the packed counters
     bool sketched;
     uint64_t total_active;
 };
@@ -122,6 +128,9 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
+// range boundaries of every query's (sorted) entry list; *d_flag |= 1 when a
+// (query, range) holds more than `limit` entries
+int launch_query_split(mk_ctx *c, mk_qset *qs, uint32_t S, uint32_t limit, uint32_t *d_flag);
 int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, char *d_out);
 int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
                          char *d_out);
@@ -140,6 +149,17 @@ struct ScanArgs {
     uint32_t score_vec;            // 16-byte stores allowed (strides and padding permit it)
 };
 int launch_scan(mk_ctx *c, const ScanArgs &a);
+// slab schedule (scan_kernel.hpp: scan_slab_kernel)
+struct SlabArgs {
+    const uint8_t *M;
+    uint64_t ld;
+    uint32_t G, ntiles, nq, q_begin, S;
+    const uint64_t *entries;
+    const uint64_t *ent_off;
+    const uint32_t *split;         // [query][S + 1] entry indices of the range boundaries
+    uint8_t *partials;             // [tile][range][query][1 KiB]
+};
+int launch_scan_slab(mk_ctx *c, const SlabArgs &a);
 // the two layouts the pipeline uses
 struct ScoreLayout { uint64_t tile_stride, q_stride; uint32_t vec; };
 inline ScoreLayout score_layout_rows(uint32_t W, uint64_t pitch, uint32_t G)      // [query][pitch]
@@ -155,7 +175,10 @@ inline ScoreLayout score_layout_tiles(uint32_t W, uint32_t nq)                  
 
 // ---- select.hip
 struct SelectArgs {
-    const uint32_t *scores;        // tile-major [tile][nq][tile_genomes]
+    const uint32_t *scores;        // tile-major [tile][nq][tile_genomes] (plain schedule) or null
+    const uint8_t *partials;       // [tile][range][nq][1 KiB] mismatch counts (slab schedule) or null
+    const uint32_t *nent;          // active partitions per query, offset to this chunk (slab schedule)
+    uint32_t S, W;
     uint32_t tile_genomes, G, nq;
     uint32_t nresults, min_score;
     double min_inter;

@@ -39,4 +39,16 @@ int launch_scan(mk_ctx *c, const ScanArgs &a)
     return c->W == 1 ? launch_scan_t<1>(c, a) : launch_scan_t<2>(c, a);
 }
 
+int launch_scan_slab(mk_ctx *c, const SlabArgs &a)
+{
+    const uint64_t work = (uint64_t)a.ntiles * a.S * a.nq;
+    if (work == 0) return MK_OK;
+    if (work >= (1ull << 31)) { set_error("scan launch too large"); return MK_ERR_ARG; }
+    const uint32_t blocks = (uint32_t)((work + 3) / 4);
+    if (c->W == 1) hipLaunchKernelGGL((scan_slab_kernel<1, 8>), dim3(blocks), dim3(256), 0, c->stream, a);
+    else           hipLaunchKernelGGL((scan_slab_kernel<2, 8>), dim3(blocks), dim3(256), 0, c->stream, a);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 }  // namespace mk

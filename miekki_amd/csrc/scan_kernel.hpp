@@ -175,4 +175,62 @@ __global__ __launch_bounds__(256) void scan_sweep_kernel(const ScanArgs a)
     }
 }
 
+// ---------------------------------------------------------------- slab schedule
+// The partitions are cut into S equal ranges and a work item is (tile, range,
+// query), ordered tile-major then range-major: the waves in flight share one
+// (2^h / S) x 1 KiB slab of the matrix, sized by the host to fit the Infinity
+// Cache, so a row piece is fetched from HBM about once and then re-read on die by
+// the other queries that need it (measured: 6.65 -> 8.0 TB/s at 1/8 of 2^20 rows).
+// A (query, range) has at most 255 entries (65,535 at 2 bytes) -- the host checks --
+// so the packed per-genome mismatch counters never overflow and are simply stored,
+// 16 bytes per lane, as this range's PARTIAL: no read-modify-write, no ordering
+// between ranges.  select.hip sums the S partials of a genome.
+template <int W, int UNROLL>
+__global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    if (work >= a.ntiles * a.S * a.nq) return;           // wave-uniform exit
+    const uint32_t tr = work / a.nq, ql = work - tr * a.nq;
+    const uint32_t tile = tr / a.S, r = tr - tile * a.S;
+    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
+    const uint32_t q = a.q_begin + ql;
+    const uint32_t lo = a.split[(uint64_t)q * (a.S + 1) + r], hi = a.split[(uint64_t)q * (a.S + 1) + r + 1];
+    const uint64_t *__restrict__ e = a.entries + a.ent_off[q] + lo;
+    const uint32_t m = hi - lo;
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint32_t voff = lane * 16u;
+    const uint64_t ld = a.ld;
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    uint32_t j = 0;
+    for (; j + UNROLL <= m; j += UNROLL) {
+        uint64_t ev[UNROLL];
+        uint4 d[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, (uint32_t)ev[u], ld) + voff);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
+            acc0 += ne_lanes<W>(d[u].x, b);
+            acc1 += ne_lanes<W>(d[u].y, b);
+            acc2 += ne_lanes<W>(d[u].z, b);
+            acc3 += ne_lanes<W>(d[u].w, b);
+        }
+    }
+    for (; j < m; ++j) {
+        const uint64_t ev = e[j];
+        const uint4 d = load_row16<false>(row_base(base, (uint32_t)ev, ld) + voff);
+        const uint32_t b = bcast_fp<W>((uint32_t)(ev >> 32));
+        acc0 += ne_lanes<W>(d.x, b);
+        acc1 += ne_lanes<W>(d.y, b);
+        acc2 += ne_lanes<W>(d.z, b);
+        acc3 += ne_lanes<W>(d.w, b);
+    }
+    uint8_t *__restrict__ out = a.partials + ((uint64_t)tr * a.nq + ql) * kTileBytes + voff;
+    *reinterpret_cast<uint4 *>(out) = make_uint4(acc0, acc1, acc2, acc3);
+}
+
 }  // namespace mk

@@ -42,6 +42,8 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// SRC 0: u32 scores (plain schedule); 1 / 2: per-range mismatch counts, 1 / 2 bytes each
+template <int SRC>
 __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     if (q >= a.nq) return;
     // tile-major score matrix: this query's piece of tile t starts at (t * nq + q) * tile_genomes
     const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;
-    const uint32_t *__restrict__ qbase = a.scores + (uint64_t)q * a.tile_genomes;
+    const uint32_t *__restrict__ qbase = SRC == 0 ? a.scores + (uint64_t)q * a.tile_genomes : nullptr;
+    const uint32_t n_active = SRC == 0 ? 0u : a.nent[q];
     const uint32_t N = a.nresults;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double topv = inf;               // lane i < cnt: i-th value of the current top-N multiset
@@ -65,7 +68,16 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
         double jac = 0, inter = 0;
         if (g < a.G) {
             const uint32_t t = g / a.tile_genomes;                         // 64 | tile_genomes: wave-uniform
-            s = qbase[(uint64_t)t * tile_stride + (g - t * a.tile_genomes)];
+            if (SRC == 0) {
+                s = qbase[(uint64_t)t * tile_stride + (g - t * a.tile_genomes)];
+            } else {                                                       // shared = active - sum of mismatches
+                const uint8_t *__restrict__ p =
+                    a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + (uint64_t)(g - t * a.tile_genomes) * SRC;
+                uint32_t ne = 0;
+                for (uint32_t r = 0; r < a.S; ++r, p += (uint64_t)a.nq * kTileBytes)
+                    ne += SRC == 1 ? (uint32_t)*p : (uint32_t)*reinterpret_cast<const uint16_t *>(p);
+                s = n_active - ne;
+            }
             if (s >= a.min_score) {                                        // Miekki.cpp:381
                 const uint32_t ss = a.sketch_size[g];
                 const uint64_t gs = a.genome_size[g];
@@ -115,7 +127,10 @@ int launch_select(mk_ctx *c, const SelectArgs &a)
 {
     if (!a.nq) return MK_OK;
     if (a.nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
-    hipLaunchKernelGGL(select_kernel, dim3((a.nq + 3) / 4), dim3(256), 0, c->stream, a);
+    const dim3 grid((a.nq + 3) / 4), block(256);
+    if (!a.partials)     hipLaunchKernelGGL(select_kernel<0>, grid, block, 0, c->stream, a);
+    else if (a.W == 1)   hipLaunchKernelGGL(select_kernel<1>, grid, block, 0, c->stream, a);
+    else                 hipLaunchKernelGGL(select_kernel<2>, grid, block, 0, c->stream, a);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

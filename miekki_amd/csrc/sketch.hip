@@ -711,6 +711,43 @@ int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q)
     return MK_OK;
 }
 
+// ---------------------------------------------------------------- range boundaries (slab schedule)
+// entries of a short query are ascending by partition: split[q][r] = first entry
+// whose partition is >= r * P / S.
+__global__ void split_kernel(const uint64_t *__restrict__ entries, const uint64_t *__restrict__ ent_off,
+                             const uint32_t *__restrict__ nent, uint32_t nq, uint32_t S, uint32_t P, uint32_t limit,
+                             uint32_t *__restrict__ split, uint32_t *__restrict__ flag)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint64_t)nq * S) return;
+    const uint32_t q = (uint32_t)(id / S), r = (uint32_t)(id - (uint64_t)q * S);
+    const uint64_t *__restrict__ e = entries + ent_off[q];
+    const uint32_t n = nent[q];
+    uint32_t bound[2];
+    for (uint32_t k = 0; k < 2; ++k) {
+        const uint64_t target = (uint64_t)(r + k) * (P / S);
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)e[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        bound[k] = (r + k == S) ? n : lo;
+    }
+    split[(uint64_t)q * (S + 1) + r] = bound[0];
+    if (r + 1 == S) split[(uint64_t)q * (S + 1) + S] = n;
+    if (bound[1] - bound[0] > limit) atomicOr(flag, 1u);
+}
+
+int launch_query_split(mk_ctx *c, mk_qset *qs, uint32_t S, uint32_t limit, uint32_t *d_flag)
+{
+    if (!qs->nq) return MK_OK;
+    const uint64_t n = (uint64_t)qs->nq * S;
+    hipLaunchKernelGGL(split_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, qs->d_entries,
+                       qs->d_ent_off, qs->d_nent, qs->nq, S, c->P, limit, qs->d_split, d_flag);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 // ---------------------------------------------------------------- synthetic inputs
 __global__ void synth_genomes_kernel(uint64_t first_id, uint32_t n, uint64_t len, char *__restrict__ out)
 {

@@ -98,6 +98,7 @@ int main(int argc, char **argv)
     const uint32_t NE = argc > 4 ? atoi(argv[4]) : 908;
     const int rounds = argc > 5 ? atoi(argv[5]) : 5;
     const uint32_t range_div = argc > 6 ? atoi(argv[6]) : 1;      // draw partitions from [0, P / range_div): slab experiment
+    const uint32_t slabS = argc > 7 ? atoi(argv[7]) : 8;           // ranges of the slab schedule
     const uint32_t P = 1u << h;
     const uint64_t ld = ((uint64_t)G + kTileBytes - 1) / kTileBytes * kTileBytes;
     uint8_t *M; CK(hipMalloc((void **)&M, (uint64_t)P * ld));
@@ -135,6 +136,23 @@ int main(int argc, char **argv)
     const double algo = (double)Q * NE * G + 4.0 * Q * G;
     std::vector<std::vector<float>> ms(nv);
     std::vector<uint64_t> chk(nv, 0);
+    // slab schedule inputs: per query the entry index of every range boundary
+    std::vector<uint32_t> split((size_t)Q * (slabS + 1));
+    for (uint32_t q = 0; q < Q; ++q)
+        for (uint32_t r = 0; r <= slabS; ++r) {
+            const uint64_t bound = (uint64_t)r * (P / slabS);
+            uint32_t i = 0;
+            while (i < NE && (uint32_t)ent[(size_t)q * NE + i] < bound) ++i;
+            split[(size_t)q * (slabS + 1) + r] = r == slabS ? NE : i;
+        }
+    uint32_t *d_split; uint8_t *d_part;
+    CK(hipMalloc((void **)&d_split, split.size() * 4));
+    CK(hipMemcpy(d_split, split.data(), split.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&d_part, (uint64_t)a.ntiles * slabS * Q * kTileBytes));
+    SlabArgs sa;
+    sa.M = M; sa.ld = ld; sa.G = G; sa.ntiles = a.ntiles; sa.nq = Q; sa.q_begin = 0; sa.S = slabS;
+    sa.entries = d_ent; sa.ent_off = d_off; sa.split = d_split; sa.partials = d_part;
+    std::vector<float> slab_ms;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipDeviceSynchronize());
     for (int r = 0; r < rounds + 1; ++r)
@@ -161,6 +179,32 @@ int main(int argc, char **argv)
                     }
             }
         }
+    for (int r = 0; r < rounds + 1; ++r) {
+        const uint64_t sw = (uint64_t)a.ntiles * slabS * Q;
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((scan_slab_kernel<1, 8>), dim3((uint32_t)((sw + 3) / 4)), dim3(256), 0, 0, sa);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        if (r) slab_ms.push_back(t);
+    }
+    // check the slab partials against the plain kernel's scores for the first queries
+    if (a.scores) {
+        hipLaunchKernelGGL((scan_kernel<1, 8, 1, false>), dim3(blocks), dim3(256), 0, 0, a);
+        std::vector<uint32_t> sc((size_t)Q * sld);
+        CK(hipMemcpy(sc.data(), d_scores, sc.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> pt((size_t)a.ntiles * slabS * Q * kTileBytes);
+        CK(hipMemcpy(pt.data(), d_part, pt.size(), hipMemcpyDeviceToHost));
+        uint64_t bad = 0;
+        for (uint32_t q = 0; q < std::min<uint32_t>(Q, 50); ++q)
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t t = g / kTileBytes, w = g % kTileBytes;
+                uint32_t ne = 0;
+                for (uint32_t r = 0; r < slabS; ++r) ne += pt[(((size_t)t * slabS + r) * Q + q) * kTileBytes + w];
+                bad += (NE - ne) != sc[(size_t)t * lay.tile_stride + (size_t)q * lay.q_stride + w];
+            }
+        printf("slab vs plain mismatches (first 50 queries): %llu\n", (unsigned long long)bad);
+    }
     printf("range 1/%u  scores %s  G=%u h=%u Q=%u entries=%u  M=%.1f GB  algorithmic %.1f GB per launch\n", range_div, tile_major_scores ? "tile-major" : "row-major", G, h, Q, NE, P * (double)ld / 1e9, algo / 1e9);
     for (int v = 0; v < nv; ++v) {
         std::sort(ms[v].begin(), ms[v].end());
@@ -168,5 +212,8 @@ int main(int argc, char **argv)
         printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  %7.1f (min)  chk %llu\n", vars[v].name, med, mn,
                algo / med / 1e6, algo / mn / 1e6, (unsigned long long)chk[v]);
     }
+    std::sort(slab_ms.begin(), slab_ms.end());
+    printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  [S=%u, partials %.1f GB]\n", "slab", slab_ms[slab_ms.size() / 2],
+           slab_ms[0], algo / slab_ms[slab_ms.size() / 2] / 1e6, slabS, (double)a.ntiles * slabS * Q * kTileBytes / 1e9);
     return 0;
 }
