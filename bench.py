@@ -211,7 +211,7 @@ def main():
                        "active_partitions_per_query": a_sum / max(Q, 1), "parallelism": "genome-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": "scan_slab_kernel" if st["scan_slab_launches"] else "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch},
             "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
                        "index_build_s": build_s, "index_sketches_per_s": G / build_s,

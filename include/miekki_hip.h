@@ -70,6 +70,7 @@ typedef struct {
     double build_finalize_ms; /* transposed matrix write, sizes, Bloom insert */
     uint64_t build_kmers;
     uint64_t build_genomes;
+    uint64_t scan_slab_launches; /* of scan_launches: launches of the slab schedule (scan_slab_kernel) */
 } mk_stats;
 
 const char *mk_last_error(void);

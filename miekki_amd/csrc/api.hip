@@ -353,6 +353,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     SlabArgs a;
     a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c); a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S;
     a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
+    c->stats.scan_slab_launches++;
     ScopedTimer t(c, 1);
     return launch_scan_slab(c, a);
 }

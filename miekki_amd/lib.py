@@ -29,7 +29,8 @@ class Stats(C.Structure):
     _fields_ = [("sketch_ms", C.c_double), ("scan_ms", C.c_double), ("filter_ms", C.c_double),
                 ("scan_launches", C.c_uint64), ("comparisons", C.c_uint64), ("active_partitions", C.c_uint64),
                 ("scan_algo_bytes", C.c_uint64), ("build_sketch_ms", C.c_double),
-                ("build_finalize_ms", C.c_double), ("build_kmers", C.c_uint64), ("build_genomes", C.c_uint64)]
+                ("build_finalize_ms", C.c_double), ("build_kmers", C.c_uint64), ("build_genomes", C.c_uint64),
+                ("scan_slab_launches", C.c_uint64)]
 
 
 vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
