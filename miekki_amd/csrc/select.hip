@@ -1,4 +1,4 @@
-// K6: top-hit selection over a score row -- the device half of
+// K6: top-hit selection over a query's scores -- the device half of
 // Miekki::filter_results (Miekki.cpp:376-397).
 //
 // The reference walks genomes in ascending id, skips those below min_score or
@@ -14,13 +14,14 @@
 // shard's entrants are a superset of what the global heap can admit from that
 // shard, because the global minimum is never below the shard's own.
 //
-// One wave per query.  64 genomes per step: coalesced score / size loads, an f32
-// screen against max(min_intersection, current heap minimum), the decision in the
-// reference's double operations, `__ballot` to find candidate entrants, and a short
-// serial loop over the ballot that re-tests each against the evolving minimum.  The
-// current top-N multiset lives one value per lane; its minimum is a wave reduction.
-#include <cfloat>
-
+// One wave per query, 256 genomes per step (four per lane): 16-byte loads of the
+// scores -- or, after the slab schedule, of the S per-range mismatch counts, summed
+// SWAR-wise -- and of the genomes' sizes; an f32 screen against
+// max(min_intersection, current heap minimum); the decision in the reference's
+// double operations; `__ballot` over the lanes that hold candidate entrants and a
+// short serial loop, lane by lane and genome by genome, that re-tests each against
+// the evolving minimum.  The current top-N multiset lives one value per lane; its
+// minimum is a wave reduction.
 #include "mk_internal.hpp"
 
 namespace mk {
@@ -49,9 +50,8 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (q >= a.nq) return;
-    // tile-major score matrix: this query's piece of tile t starts at (t * nq + q) * tile_genomes
-    const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;
-    const uint32_t *__restrict__ qbase = SRC == 0 ? a.scores + (uint64_t)q * a.tile_genomes : nullptr;
+    const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;      // entries (SRC 0)
+    const uint64_t range_stride = (uint64_t)a.nq * kTileBytes;          // bytes (SRC 1, 2)
     const uint32_t n_active = SRC == 0 ? 0u : a.nent[q];
     const uint32_t N = a.nresults;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
@@ -61,62 +61,89 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     float screen = 0.999f * (float)a.min_inter;
     mk_hit *__restrict__ out = a.cand + (uint64_t)q * a.cap;
 
-    for (uint32_t g0 = 0; g0 < a.G; g0 += 64) {
-        const uint32_t g = g0 + lane;
-        bool pot = false;
-        uint32_t s = 0;
-        double jac = 0, inter = 0;
-        if (g < a.G) {
-            const uint32_t t = g / a.tile_genomes;                         // 64 | tile_genomes: wave-uniform
+    for (uint32_t g0 = 0; g0 < a.G; g0 += 256) {
+        const uint32_t gl = g0 + lane * 4u;                            // this lane's four genomes
+        uint32_t s[4] = {0, 0, 0, 0};
+        double jac[4] = {0, 0, 0, 0}, inter[4] = {0, 0, 0, 0};
+        uint32_t pot = 0;
+        if (gl < a.G) {
+            const uint32_t t = gl / a.tile_genomes, wi = gl - t * a.tile_genomes;   // 256 | tile_genomes
             if (SRC == 0) {
-                s = qbase[(uint64_t)t * tile_stride + (g - t * a.tile_genomes)];
-            } else {                                                       // shared = active - sum of mismatches
+                const uint4 v = *reinterpret_cast<const uint4 *>(a.scores + (uint64_t)t * tile_stride +
+                                                                 (uint64_t)q * a.tile_genomes + wi);
+                s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+            } else {                                                   // shared = active - sum of mismatches
                 const uint8_t *__restrict__ p =
-                    a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + (uint64_t)(g - t * a.tile_genomes) * SRC;
-                uint32_t ne = 0;
-                for (uint32_t r = 0; r < a.S; ++r, p += (uint64_t)a.nq * kTileBytes)
-                    ne += SRC == 1 ? (uint32_t)*p : (uint32_t)*reinterpret_cast<const uint16_t *>(p);
-                s = n_active - ne;
+                    a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + (uint64_t)wi * SRC;
+                uint32_t ne[4] = {0, 0, 0, 0};
+                for (uint32_t r = 0; r < a.S; ++r, p += range_stride) {
+                    if (SRC == 1) {
+                        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+                        ne[0] += w & 0xffu; ne[1] += (w >> 8) & 0xffu; ne[2] += (w >> 16) & 0xffu; ne[3] += w >> 24;
+                    } else {
+                        const uint2 w = *reinterpret_cast<const uint2 *>(p);
+                        ne[0] += w.x & 0xffffu; ne[1] += w.x >> 16; ne[2] += w.y & 0xffffu; ne[3] += w.y >> 16;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] = n_active - ne[j];
             }
-            if (s >= a.min_score) {                                        // Miekki.cpp:381
-                const uint32_t ss = a.sketch_size[g];
-                const uint64_t gs = a.genome_size[g];
-                const float est = (float)s * (float)gs / (float)ss;
-                if (!(est < screen)) {
-                    jac = (double)s / (double)ss;                          // Miekki.cpp:382-383
-                    inter = jac * (double)gs;
-                    pot = !(inter < a.min_inter) && (cnt < N || !(minval > inter));
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) any |= (gl + j < a.G) && s[j] >= a.min_score;     // Miekki.cpp:381
+            if (any) {
+                // the size arrays are padded to whole tiles: 16-byte loads stay in bounds
+                const uint4 ss4 = *reinterpret_cast<const uint4 *>(a.sketch_size + gl);
+                const ulonglong2 gsa = *reinterpret_cast<const ulonglong2 *>(a.genome_size + gl);
+                const ulonglong2 gsb = *reinterpret_cast<const ulonglong2 *>(a.genome_size + gl + 2);
+                const uint32_t ss[4] = {ss4.x, ss4.y, ss4.z, ss4.w};
+                const uint64_t gs[4] = {gsa.x, gsa.y, gsb.x, gsb.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (gl + j < a.G && s[j] >= a.min_score) {
+                        const float est = (float)s[j] * (float)gs[j] / (float)ss[j];
+                        if (!(est < screen)) {
+                            jac[j] = (double)s[j] / (double)ss[j];              // Miekki.cpp:382-383
+                            inter[j] = jac[j] * (double)gs[j];
+                            if (!(inter[j] < a.min_inter) && (cnt < N || !(minval > inter[j]))) pot |= 1u << j;
+                        }
+                    }
                 }
             }
         }
-        uint64_t mask = __ballot(pot);
-        while (mask) {                                                      // ascending genome order
-            const uint32_t l = (uint32_t)__ffsll((long long)mask) - 1u;
-            mask &= mask - 1;
-            const double x = readlane_f64(inter, l);
-            if (cnt >= N && minval > x) continue;                           // Miekki.cpp:387: skipped, heap untouched
-            if (N == 0) continue;
-            if (lane == l && emitted < a.cap) {
-                mk_hit h;
-                h.genome = g + a.genome_id_base;
-                h.matches = s;
-                h.jaccard = jac;
-                h.intersection = inter;
-                out[emitted] = h;
-            }
-            ++emitted;
-            if (cnt < N) {
-                if (lane == cnt) topv = x;
-                ++cnt;
-            } else {                                                        // evict one holder of the minimum
-                const uint64_t holders = __ballot(lane < N && topv == minval);
-                const uint32_t victim = holders ? (uint32_t)__ffsll((long long)holders) - 1u : 0u;
-                if (lane == victim) topv = x;
-            }
-            if (cnt == N) {
-                minval = wave_min_f64(lane < N ? topv : inf);
-                const double bar = minval > a.min_inter ? minval : a.min_inter;
-                screen = 0.999f * (float)bar;
+        uint64_t lanes = __ballot(pot != 0);
+        while (lanes) {                                                    // ascending genome order
+            const uint32_t l = (uint32_t)__ffsll((long long)lanes) - 1u;
+            lanes &= lanes - 1;
+            const uint32_t pm = (uint32_t)__builtin_amdgcn_readlane((int)pot, (int)l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((pm >> j) & 1u)) continue;
+                const double x = readlane_f64(inter[j], l);
+                if (cnt >= N && minval > x) continue;                       // Miekki.cpp:387: skipped, heap untouched
+                if (N == 0) continue;
+                if (lane == l && emitted < a.cap) {
+                    mk_hit h;
+                    h.genome = gl + j + a.genome_id_base;
+                    h.matches = s[j];
+                    h.jaccard = jac[j];
+                    h.intersection = inter[j];
+                    out[emitted] = h;
+                }
+                ++emitted;
+                if (cnt < N) {
+                    if (lane == cnt) topv = x;
+                    ++cnt;
+                } else {                                                    // evict one holder of the minimum
+                    const uint64_t holders = __ballot(lane < N && topv == minval);
+                    const uint32_t victim = holders ? (uint32_t)__ffsll((long long)holders) - 1u : 0u;
+                    if (lane == victim) topv = x;
+                }
+                if (cnt == N) {
+                    minval = wave_min_f64(lane < N ? topv : inf);
+                    const double bar = minval > a.min_inter ? minval : a.min_inter;
+                    screen = 0.999f * (float)bar;
+                }
             }
         }
     }
