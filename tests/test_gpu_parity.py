@@ -332,10 +332,9 @@ def test_config3_shard_scale_properties(hip):
         try:
             small.insert_synthetic(100, 3, L_)
             a = small.query_sequences(qs[:8])
-            np.testing.assert_array_equal(a, scores[:8, 100:103] if False else a)   # shape sanity
-            b = ix.query_sequences(qs[:8])[:, 100:103]
-            # the Bloom gates differ (3 vs 12,500 genomes), so compare on partitions both admit: b >= a
-            assert (b >= a).all()
+            b = scores[:8, 100:103]
+            # the Bloom gate of 3 genomes admits a subset of what the gate of 12,500 admits
+            assert a.shape == b.shape and (b >= a).all()
         finally:
             small.close()
     finally:
