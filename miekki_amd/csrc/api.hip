@@ -193,7 +193,8 @@ static void qset_release(mk_qset *qs)
 {
     if (!qs) return;
     dev_free(qs->d_seq); dev_free(qs->d_off); dev_free(qs->d_ent_off); dev_free(qs->d_entries);
-    dev_free(qs->d_nent); dev_free(qs->d_split);
+    dev_free(qs->d_nent); dev_free(qs->d_split); dev_free(qs->d_dense); dev_free(qs->d_dense_q);
+    dev_free(qs->d_scan_n);
     delete qs;
 }
 
@@ -203,13 +204,18 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
     qs->d_nent = nullptr; qs->sketched = false; qs->total_active = 0; qs->short_max_nk = 0;
     qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
+    qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
         if (lens[q] >= (1ull << 40)) { set_error("query too long"); return MK_ERR_ARG; }
         qs->h_off[q + 1] = qs->h_off[q] + lens[q];
-        qs->h_ent_off[q + 1] = qs->h_ent_off[q] + std::min<uint64_t>(nk, c->P);
-        if (nk > kShortMax) qs->long_q.push_back(q);
+        // long queries that activate a large share of the partitions (whole genomes, -A)
+        // keep a dense fingerprint vector instead of an entry list
+        const bool dense = nk > kShortMax && nk >= c->P / 4;
+        qs->h_ent_off[q + 1] = qs->h_ent_off[q] + (dense ? 0 : std::min<uint64_t>(nk, c->P));
+        if (dense) qs->dense_q.push_back(q);
+        else if (nk > kShortMax) qs->long_q.push_back(q);
         else qs->short_max_nk = std::max<uint32_t>(qs->short_max_nk, (uint32_t)nk);
     }
     qs->total_len = qs->h_off[nq];
@@ -218,6 +224,16 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     MK_TRY(dev_alloc(&qs->d_ent_off, (uint64_t)nq + 1));
     MK_TRY(dev_alloc(&qs->d_entries, qs->h_ent_off[nq] + 1));
     MK_TRY(dev_alloc(&qs->d_nent, (uint64_t)nq + 1));
+    MK_TRY(dev_alloc(&qs->d_scan_n, (uint64_t)nq + 1));
+    if (!qs->dense_q.empty()) {
+        while (qs->dense_q.size() % 4) qs->dense_q.push_back(0xffffffffu);          // pad the last group
+        const uint64_t bytes = (uint64_t)(qs->dense_q.size() / 4) * c->P * 4 * c->W;
+        MK_TRY(dev_alloc(&qs->d_dense, bytes));
+        MK_TRY(dev_alloc(&qs->d_dense_q, qs->dense_q.size()));
+        MK_HIP(hipMemsetAsync(qs->d_dense, 0xFF, bytes, c->stream));                 // every slot starts empty
+        MK_HIP(hipMemcpyAsync(qs->d_dense_q, qs->dense_q.data(), qs->dense_q.size() * 4, hipMemcpyHostToDevice,
+                              c->stream));
+    }
     MK_HIP(hipMemcpyAsync(qs->d_off, qs->h_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     MK_HIP(hipMemcpyAsync(qs->d_ent_off, qs->h_ent_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice,
                           c->stream));
@@ -237,6 +253,13 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
         for (uint32_t q : qs->long_q) MK_TRY(launch_query_sketch_long(c, qs, q));
     }
+    if (!qs->dense_q.empty()) {
+        if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
+        if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
+        for (uint32_t slot = 0; slot < qs->dense_q.size(); ++slot)
+            if (qs->dense_q[slot] != 0xffffffffu) MK_TRY(launch_query_sketch_dense(c, qs, slot));
+    }
+    MK_TRY(launch_scan_counts(c, qs));
     qs->sketched = true;
     return MK_OK;
 }
@@ -269,7 +292,7 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
 {
     const uint32_t S = slab_ranges(c);
     qs->slab_ok = false;
-    if (S < 2 || !qs->long_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
+    if (S < 2 || !qs->long_q.empty() || !qs->dense_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
     if (qs->S != S) {
         dev_free(qs->d_split);
         MK_TRY(dev_alloc(&qs->d_split, (uint64_t)qs->nq * (S + 1)));
@@ -318,11 +341,24 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         const uint32_t n = std::min(per_launch, q1 - q);
         ScanArgs a;
         a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
-        a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_nent;
+        a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_scan_n;
         a.scores = d_scores + (uint64_t)(q - q0) * lay.q_stride;
         a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
         ScopedTimer t(c, 1);
         MK_TRY(launch_scan(c, a));
+    }
+    if (!qs->dense_q.empty()) {
+        // the sparse kernel has just written zero rows for the dense queries (scan_n = 0);
+        // the dense kernel adds their scores, four queries per pass over the matrix
+        DenseArgs d;
+        d.M = c->d_M; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
+        d.rows_per_item = std::min<uint32_t>(c->P, 8192);
+        d.nchunks = (c->P + d.rows_per_item - 1) / d.rows_per_item;
+        d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
+        d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
+        d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
+        ScopedTimer t(c, 1);
+        MK_TRY(launch_scan_dense(c, d));
     }
     return MK_OK;
 }

@@ -99,7 +99,13 @@ struct mk_qset {
     uint64_t *d_entries;
     uint32_t *d_nent;              // active partitions per query
     std::vector<uint64_t> h_off, h_ent_off;
-    std::vector<uint32_t> long_q;  // queries with more than kShortMax k-mers
+    std::vector<uint32_t> long_q;  // queries with more than kShortMax k-mers (sparse long path)
+    // dense long path: queries with >= P/4 k-mers (whole genomes) keep their full 2^h
+    // fingerprint vector, four queries interleaved per group: dense[group][p][4] (W bytes each)
+    std::vector<uint32_t> dense_q; // set indices, group-major; 0xffffffff pads the last group
+    uint8_t *d_dense;
+    uint32_t *d_dense_q;
+    uint32_t *d_scan_n;            // entries the sparse scan walks: nent for sparse queries, 0 for dense ones
     uint32_t short_max_nk;         // longest short query (k-mers)
     uint32_t *d_split;             // [nq][S + 1] entry index of each partition-range boundary
     uint32_t S;                    // ranges of the slab schedule (0 = not prepared)
@@ -128,6 +134,8 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
+int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q
+int launch_scan_counts(mk_ctx *c, mk_qset *qs);                          // fills qs->d_scan_n
 // range boundaries of every query's (sorted) entry list; *d_flag |= 1 when a
 // (query, range) holds more than `limit` entries
 int launch_query_split(mk_ctx *c, mk_qset *qs, uint32_t S, uint32_t limit, uint32_t *d_flag);
@@ -172,6 +180,20 @@ inline ScoreLayout score_layout_tiles(uint32_t W, uint32_t nq)                  
     const uint64_t tg = kTileBytes / W;
     return {(uint64_t)nq * tg, tg, 1u};
 }
+
+// dense long queries (scan_kernel.hpp: scan_dense_kernel): adds into the score rows
+struct DenseArgs {
+    const uint8_t *M;
+    uint64_t ld;
+    uint32_t G, ntiles, P, rows_per_item, nchunks, ngroups;
+    const uint8_t *dense;          // [group][P][4] fingerprints (W bytes each), empty = inactive
+    const uint32_t *dense_q;       // [group][4] set index of each slot or 0xffffffff
+    uint32_t q0, q1;               // set range the score buffer covers
+    uint32_t *scores;
+    uint64_t score_tile_stride, score_q_stride;
+    uint32_t empty;
+};
+int launch_scan_dense(mk_ctx *c, const DenseArgs &a);
 
 // ---- select.hip
 struct SelectArgs {

@@ -1,6 +1,8 @@
 // K5 scan kernel template (see scan.hip for the design notes).  Kept in a header so
 // that tools/scan_tune.hip can instantiate tuning variants of exactly this code.
 #pragma once
+#include <type_traits>
+
 #include "mk_internal.hpp"
 
 namespace mk {
@@ -231,6 +233,104 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
     }
     uint8_t *__restrict__ out = a.partials + ((uint64_t)tr * a.nq + ql) * kTileBytes + voff;
     *reinterpret_cast<uint4 *>(out) = make_uint4(acc0, acc1, acc2, acc3);
+}
+
+// ---------------------------------------------------------------- dense queries
+// Whole-genome queries (-A) have nearly every partition active: walking a sparse
+// list buys nothing and every query would stream the whole matrix on its own.
+// Here a wave owns (group of four queries, row tile, chunk of rows): each row piece is
+// loaded ONCE and compared against the four queries' fingerprints of that partition
+// (one scalar dword), which quarters the bytes per comparison.  Mismatch counters are
+// packed per query as in the sparse kernel; the wave's share of each score is added
+// to the score row with integer atomics (order-independent, exact).
+template <int W>
+__global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
+{
+    constexpr uint32_t NCNT = 16 / W, FLUSH = W == 1 ? 248u : 65528u, QB = 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    if (work >= a.ngroups * a.ntiles * a.nchunks) return;
+    const uint32_t chunk = work % a.nchunks, gt = work / a.nchunks;
+    const uint32_t tile = gt % a.ntiles, group = gt / a.ntiles;
+    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
+    uint32_t qidx[QB];
+    bool any = false;
+#pragma unroll
+    for (uint32_t j = 0; j < QB; ++j) {
+        qidx[j] = a.dense_q[group * QB + j];
+        any |= qidx[j] >= a.q0 && qidx[j] < a.q1;
+    }
+    if (!any) return;
+    const uint32_t row0 = chunk * a.rows_per_item, row1 = min(a.P, row0 + a.rows_per_item);
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint32_t voff = lane * 16u;
+    using fp4_t = typename std::conditional<W == 1, uint32_t, uint2>::type;
+    const fp4_t *__restrict__ dv = reinterpret_cast<const fp4_t *>(a.dense) + (uint64_t)group * a.P;
+    uint32_t ne32[QB][NCNT], nact[QB];
+#pragma unroll
+    for (uint32_t j = 0; j < QB; ++j) {
+        nact[j] = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < NCNT; ++k) ne32[j][k] = 0;
+    }
+    for (uint32_t r0 = row0; r0 < row1; r0 += FLUSH) {
+        const uint32_t r1 = min(row1, r0 + FLUSH);
+        uint32_t acc[QB][4];
+#pragma unroll
+        for (uint32_t j = 0; j < QB; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0;
+        for (uint32_t r = r0; r < r1; r += 4) {
+            uint4 d[4];
+            fp4_t f[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t rr = min(r + u, r1 - 1);                   // tail rows repeat the last (masked below)
+                f[u] = dv[rr];
+                d[u] = load_row16<false>(row_base(base, rr, a.ld) + voff);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (r + u >= r1) break;
+#pragma unroll
+                for (uint32_t j = 0; j < QB; ++j) {
+                    uint32_t fp;
+                    if (W == 1) fp = (reinterpret_cast<const uint32_t &>(f[u]) >> (8 * j)) & 0xffu;
+                    else { const uint2 &ff = reinterpret_cast<const uint2 &>(f[u]); fp = ((j < 2 ? ff.x : ff.y) >> (16 * (j & 1))) & 0xffffu; }
+                    if (fp == a.empty) continue;                          // wave-uniform
+                    ++nact[j];
+                    const uint32_t b = bcast_fp<W>(fp);
+                    acc[j][0] += ne_lanes<W>(d[u].x, b);
+                    acc[j][1] += ne_lanes<W>(d[u].y, b);
+                    acc[j][2] += ne_lanes<W>(d[u].z, b);
+                    acc[j][3] += ne_lanes<W>(d[u].w, b);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < QB; ++j)
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (W == 1) {
+                    ne32[j][4 * w + 0] += acc[j][w] & 0xffu;
+                    ne32[j][4 * w + 1] += (acc[j][w] >> 8) & 0xffu;
+                    ne32[j][4 * w + 2] += (acc[j][w] >> 16) & 0xffu;
+                    ne32[j][4 * w + 3] += acc[j][w] >> 24;
+                } else {
+                    ne32[j][2 * w + 0] += acc[j][w] & 0xffffu;
+                    ne32[j][2 * w + 1] += acc[j][w] >> 16;
+                }
+            }
+    }
+    const uint32_t g0 = tile * (kTileBytes / W) + lane * NCNT;
+#pragma unroll
+    for (uint32_t j = 0; j < QB; ++j) {
+        if (qidx[j] < a.q0 || qidx[j] >= a.q1 || nact[j] == 0) continue;
+        uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride +
+                                     (uint64_t)(qidx[j] - a.q0) * a.score_q_stride + lane * NCNT;
+#pragma unroll
+        for (uint32_t k = 0; k < NCNT; ++k)
+            if (g0 + k < a.G && nact[j] != ne32[j][k]) atomicAdd(row + k, nact[j] - ne32[j][k]);
+    }
 }
 
 }  // namespace mk

@@ -711,6 +711,76 @@ int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q)
     return MK_OK;
 }
 
+// ---------------------------------------------------------------- K4'' query sketch (dense)
+// table -> this query's lane of the group's interleaved fingerprint vector
+template <int W>
+__global__ __launch_bounds__(256) void long_dense_kernel(const uint64_t *__restrict__ table,
+                                                         const char *__restrict__ s,
+                                                         const uint32_t *__restrict__ seed_valid,
+                                                         const uint8_t *__restrict__ bloom,
+                                                         uint64_t bloom_dev_bytes, uint8_t *__restrict__ dense_group,
+                                                         uint32_t slot_in_group, uint32_t *__restrict__ count,
+                                                         SketchParams sp)
+{
+    using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    uint32_t fp = sp.empty;
+    if (p < sp.P) {
+        const uint64_t key = table[p];
+        if (key != kEmptyKey) {
+            const uint64_t canon = canon_at(s, key & ((1ULL << kPosBits) - 1), sp.k, seed_valid[0] != 0);
+            keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2);
+            if (keep) fp = (uint32_t)(key >> kPosBits);
+        }
+        reinterpret_cast<fp_t *>(dense_group)[(uint64_t)p * 4 + slot_in_group] = (fp_t)fp;
+    }
+    const uint64_t mask = __ballot(keep);
+    if (mask && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)mask) - 1u) atomicAdd(count, (uint32_t)__popcll(mask));
+}
+
+int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot)
+{
+    const uint32_t q = qs->dense_q[slot];
+    const uint64_t one_off[2] = {qs->h_off[q], qs->h_off[q + 1]};
+    uint32_t *d_valid = c->d_seed_valid;
+    hipLaunchKernelGGL(seed_valid_kernel, dim3(1), dim3(64), 0, c->stream, qs->d_seq, qs->d_off + q, 1u,
+                       c->p.k, d_valid);
+    MK_TRY(launch_genome_sketch(c, qs->d_seq, qs->d_off + q, one_off, d_valid, 1, c->d_long_table));
+    uint8_t *group = qs->d_dense + (uint64_t)(slot / 4) * c->P * 4 * c->W;
+    if (c->W == 1)
+        hipLaunchKernelGGL(long_dense_kernel<1>, dim3((c->P + 255) / 256), dim3(256), 0, c->stream, c->d_long_table,
+                           qs->d_seq + qs->h_off[q], d_valid, c->d_bloom, c->bloom_dev_bytes, group, slot % 4,
+                           qs->d_nent + q, make_sp(c));
+    else
+        hipLaunchKernelGGL(long_dense_kernel<2>, dim3((c->P + 255) / 256), dim3(256), 0, c->stream, c->d_long_table,
+                           qs->d_seq + qs->h_off[q], d_valid, c->d_bloom, c->bloom_dev_bytes, group, slot % 4,
+                           qs->d_nent + q, make_sp(c));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// scan_n = nent, except 0 for the queries the dense kernel handles
+__global__ void scan_counts_kernel(const uint32_t *__restrict__ nent, uint32_t nq, const uint32_t *__restrict__ dense_q,
+                                   uint32_t ndense, uint32_t *__restrict__ scan_n, int pass)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pass == 0) { if (i < nq) scan_n[i] = nent[i]; }
+    else if (i < ndense && dense_q[i] != 0xffffffffu) scan_n[dense_q[i]] = 0;
+}
+
+int launch_scan_counts(mk_ctx *c, mk_qset *qs)
+{
+    if (!qs->nq) return MK_OK;
+    hipLaunchKernelGGL(scan_counts_kernel, dim3((qs->nq + 255) / 256), dim3(256), 0, c->stream, qs->d_nent, qs->nq,
+                       qs->d_dense_q, (uint32_t)qs->dense_q.size(), qs->d_scan_n, 0);
+    if (!qs->dense_q.empty())
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(((uint32_t)qs->dense_q.size() + 255) / 256), dim3(256), 0, c->stream,
+                           qs->d_nent, qs->nq, qs->d_dense_q, (uint32_t)qs->dense_q.size(), qs->d_scan_n, 1);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 // ---------------------------------------------------------------- range boundaries (slab schedule)
 // entries of a short query are ascending by partition: split[q][r] = first entry
 // whose partition is >= r * P / S.
