@@ -682,7 +682,7 @@ int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uin
                       mk_qset **out)
 {
     if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
-    if (!G || qlen == 0 || L <= qlen) { set_error("bad synthetic query shape"); return MK_ERR_ARG; }
+    if (!G || qlen == 0 || L <= qlen) { set_error("bad synthetic query shape (need genome_len > query_len)"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     std::vector<uint64_t> lens(nq, qlen);
     mk_qset *qs = nullptr;
