@@ -7,7 +7,8 @@
 // sketch / scan / filter / exact-intersection computation is a call into the HIP
 // layer.  Differences from the reference, all deliberate:
 //   * genome ids follow list order and output follows query order (what the
-//     reference does at -t 1); -t is accepted and ignored,
+//     reference does at -t 1) for every -t; -t sets the number of host threads that
+//     read and parse input files ahead of the device,
 //   * `-i ... -e` reports that genome file names are not stored in an index
 //     instead of crashing,
 //   * no zlib re-compression of the in-memory columns (main.cpp:198): they live
@@ -15,14 +16,18 @@
 #include <getopt.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "index_io.hpp"
@@ -57,7 +62,7 @@ void help()
             "  -h <int>   use 2^h minimizers per sequence (17)\n"
             "  -k <int>   k-mer size (31)\n"
             "  -s <num>   minimal estimated intersection to be reported (200)\n"
-            "  -t <int>   thread number of the CPU version; accepted and ignored\n"
+            "  -t <int>   host threads that read and parse the input files (8)\n"
             "Advanced usage\n"
             "  -f <int>   fingerprint size: 3 (1-byte) or 11 (2-byte)\n"
             "  -b <int>   2^b bits used for the Bloom filter (33)\n"
@@ -88,8 +93,79 @@ bool nucleotide_start(const string &s)           // Miekki.cpp:736, 771
     return !s.empty() && (s[0] == 'A' || s[0] == 'C' || s[0] == 'G' || s[0] == 'T' || s[0] == 'N');
 }
 
+// Ingest pipeline: `threads` readers (the reference's -t) decompress and parse the
+// listed FASTA files ahead of the consumer, which still receives them strictly in
+// list order -- so genome ids and output order stay those of the reference at -t 1
+// while the host side keeps up with the device.
+class OrderedFastaReader {
+public:
+    struct Item { bool exists = false; string seq; };   // seq: all non-'>' lines concatenated (Miekki.cpp:563-566)
+    OrderedFastaReader(vector<string> files, unsigned threads)
+        : files_(std::move(files)), items_(files_.size()), ready_(files_.size())
+    {
+        for (auto &r : ready_) r.store(0);
+        const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
+        window_ = 2 * n + 8;
+        for (unsigned t = 0; t < n; ++t) workers_.emplace_back([this] { work(); });
+    }
+    ~OrderedFastaReader()
+    {
+        { std::lock_guard<std::mutex> g(m_); consumed_ = files_.size() + window_; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    // blocks until file i (called with i = 0, 1, 2, ...) has been read; the item is moved out
+    Item take(size_t i)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return ready_[i].load() != 0; });
+        Item it = std::move(items_[i]);
+        consumed_ = i + 1;
+        lk.unlock();
+        cv_.notify_all();
+        return it;
+    }
+private:
+    void work()
+    {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= files_.size()) return;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return i < consumed_ + window_; });      // bounded read-ahead
+            }
+            Item it;
+            it.exists = mkhost::file_exists(files_[i]);
+            if (it.exists) {
+                string text;
+                mkhost::read_text(files_[i], text);
+                it.seq.reserve(text.size());
+                size_t pos = 0;
+                while (pos <= text.size()) {                                // getline semantics
+                    size_t e = text.find('\n', pos);
+                    if (e == string::npos) e = text.size();
+                    if (e == pos || text[pos] != '>') it.seq.append(text, pos, e - pos);
+                    pos = e + 1;
+                }
+            }
+            { std::lock_guard<std::mutex> g(m_); items_[i] = std::move(it); ready_[i].store(1); }
+            cv_.notify_all();
+        }
+    }
+    vector<string> files_;
+    vector<Item> items_;
+    vector<std::atomic<int>> ready_;
+    vector<std::thread> workers_;
+    std::atomic<size_t> next_{0};
+    size_t consumed_ = 0, window_ = 8;
+    std::mutex m_;
+    std::condition_variable cv_;
+};
+
 struct Driver {
     mk_ctx *ctx = nullptr;
+    unsigned threads = 8;                        // -t: host reader threads
     uint32_t k = 31, threshold = 200;
     vector<string> file_names;                   // Miekki.h:59, never persisted
     ofstream out;
@@ -111,13 +187,15 @@ struct Driver {
             file_names.insert(file_names.end(), names.begin(), names.end());
             seqs.clear(); names.clear(); bytes = 0;
         };
-        for (const string &fn : split_lines(text)) {
-            if (fn.size() <= 3) continue;
-            if (!mkhost::file_exists(fn)) { cout << "Missed file: " << fn << endl; continue; }
-            string ftext, ref;
-            mkhost::read_text(fn, ftext);
-            for (const string &line : split_lines(ftext))
-                if (line.empty() || line[0] != '>') ref += line;       // contigs concatenated (563-566)
+        vector<string> files;
+        for (const string &fn : split_lines(text))
+            if (fn.size() > 3) files.push_back(fn);
+        OrderedFastaReader reader(files, threads);
+        for (size_t i = 0; i < files.size(); ++i) {
+            const string &fn = files[i];
+            OrderedFastaReader::Item item = reader.take(i);
+            if (!item.exists) { cout << "Missed file: " << fn << endl; continue; }
+            string ref = std::move(item.seq);
             if (ref.size() >= k) {
                 bytes += ref.size();
                 seqs.push_back(std::move(ref)); names.push_back(fn);
@@ -198,38 +276,47 @@ struct Driver {
         out << flush;
     }
 
-    static string concat_sequence_lines(const string &text)
-    {
-        string ref;
-        for (const string &line : split_lines(text))
-            if (line.empty() || line[0] != '>') ref += line;
-        return ref;
-    }
-
     // ---- Miekki.cpp:592-612, 487-514
     void query_file_of_file(const string &list)
     {
         if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
         string text;
         mkhost::read_text(list, text);
-        for (const string &fn : split_lines(text)) {
-            if (fn.size() <= 3) continue;
-            if (!mkhost::file_exists(fn)) {
+        vector<string> files;
+        for (const string &fn : split_lines(text))
+            if (fn.size() > 3) files.push_back(fn);
+        OrderedFastaReader reader(files, threads);
+        // whole files are queried in batches so that the dense kernel can take four per
+        // pass over the matrix; output stays in list order
+        vector<string> names, refs;
+        uint64_t bytes = 0;
+        auto flush = [&]() {
+            if (refs.empty()) return;
+            vector<const string *> q;
+            for (auto &r : refs) q.push_back(&r);
+            vector<mk_hit> hits;
+            vector<uint32_t> nhits;
+            run_query(q, 10, 10, 0.5 * threshold, hits, nhits);
+            for (size_t i = 0; i < refs.size(); ++i)
+                if (nhits[i]) out << names[i] << ":" << hit_text(hits.data() + i * 10, nhits[i]) << "\n";   // 506-511
+            out << std::flush;
+            names.clear(); refs.clear(); bytes = 0;
+        };
+        for (size_t i = 0; i < files.size(); ++i) {
+            OrderedFastaReader::Item item = reader.take(i);
+            if (!item.exists) {
                 cout << "File problem" << endl;
             } else {
-                string ftext;
-                mkhost::read_text(fn, ftext);
-                const string ref = concat_sequence_lines(ftext);
+                string ref = std::move(item.seq);
                 if (ref.size() >= k) {
-                    vector<mk_hit> hits;
-                    vector<uint32_t> nhits;
-                    run_query({&ref}, 10, 10, 0.5 * threshold, hits, nhits);
-                    if (nhits[0]) out << fn << ":" << hit_text(hits.data(), nhits[0]) << "\n";   // 506-511
-                    out << flush;
+                    bytes += ref.size();
+                    names.push_back(files[i]); refs.push_back(std::move(ref));
+                    if (refs.size() >= 32 || bytes > (1ull << 30)) flush();
                 }
             }
             cout << "-" << flush_stream();
         }
+        flush();
     }
 
     // ---- exact mode -------------------------------------------------------------
@@ -363,12 +450,13 @@ int main(int argc, char **argv)
         case 'd': index_dump = optarg; break;
         }
     }
-    (void)core_number;
+    const unsigned reader_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(core_number, 64));
     const uint32_t bit_per_min = (uint32_t)(5 + fingerprint_size);                              // main.cpp:184
     cout << "Using " << bit_per_min << " bits per minimizer, " << int_to_string(1ull << H) << " minimizers so "
          << int_to_string((uint32_t)(bit_per_min * (1u << H))) << " bits per sequences" << endl;
     auto start = chrono::system_clock::now();
     Driver drv;
+    drv.threads = reader_threads;
     if (!index_file.empty()) {
         if (!mkhost::file_exists(index_file)) {
             cout << "File problem" << endl;
