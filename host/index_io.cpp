@@ -3,8 +3,14 @@
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace mkhost {
@@ -65,39 +71,105 @@ bool gz_read_all(gzFile f, void *p, size_t n)
 
 constexpr uint64_t kChunk = 64ull << 20;
 
+// Ordered multi-threaded gzip writer: blocks are deflated concurrently, each into its
+// own gzip member (level 1, like zstr), and written to the file in submission order.
+class ParallelGzipWriter {
+public:
+    ParallelGzipWriter(const std::string &path, unsigned threads)
+        : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads)) {}
+    ~ParallelGzipWriter() { if (f_) fclose(f_); }
+    bool ok() const { return f_ && !failed_; }
+    void write(const void *p, size_t n)
+    {
+        const uint8_t *c = (const uint8_t *)p;
+        while (n) {
+            const size_t take = std::min(n, kBlock - cur_.size());
+            cur_.insert(cur_.end(), c, c + take);
+            c += take; n -= take;
+            if (cur_.size() == kBlock) submit();
+        }
+    }
+    bool finish()
+    {
+        if (!cur_.empty() || !wrote_any_) submit();            // an empty stream is still one (empty) member
+        while (!jobs_.empty()) drain_one();
+        if (f_) { if (fclose(f_) != 0) failed_ = true; f_ = nullptr; }
+        return !failed_;
+    }
+private:
+    static constexpr size_t kBlock = 32u << 20;
+    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; };
+    static void deflate_block(Job *j)
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->bad = true; return; }
+        j->out.resize(deflateBound(&zs, j->in.size()) + 64);
+        zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
+        zs.next_out = j->out.data(); zs.avail_out = (uInt)j->out.size();
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
+        j->out.resize(zs.total_out);
+        deflateEnd(&zs);
+        std::vector<uint8_t>().swap(j->in);
+    }
+    void submit()
+    {
+        wrote_any_ = true;
+        std::unique_ptr<Job> j(new Job());
+        j->in.swap(cur_);
+        cur_.reserve(kBlock);
+        Job *raw = j.get();
+        j->th = std::thread(deflate_block, raw);
+        jobs_.push_back(std::move(j));
+        while (jobs_.size() >= nthreads_) drain_one();
+    }
+    void drain_one()
+    {
+        std::unique_ptr<Job> j = std::move(jobs_.front());
+        jobs_.pop_front();
+        j->th.join();
+        if (j->bad || !f_ || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
+    }
+    FILE *f_;
+    unsigned nthreads_;
+    std::vector<uint8_t> cur_;
+    std::deque<std::unique_ptr<Job>> jobs_;
+    bool failed_ = false, wrote_any_ = false;
+};
+
 }  // namespace
 
-int dump_index(mk_ctx *ctx, const std::string &path, std::string &err)
+int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned threads)
 {
     mk_params p;
     if (mk_get_params(ctx, &p) != MK_OK) { err = mk_last_error(); return -1; }
     const uint32_t G = mk_index_size(ctx), W = p.fp_bits / 8, P = 1u << p.h;
-    gzFile f = gzopen(path.c_str(), "wb1");
-    if (!f) { err = "cannot open " + path; return -1; }
-    gzbuffer(f, 1 << 20);
+    ParallelGzipWriter w(path, threads);
+    if (!w.ok()) { err = "cannot open " + path; return -1; }
     Header hd{p.k, p.h, p.fp_bits, 5, G, p.bloom_log2, p.bloom_log2 ? 1ull << p.bloom_log2 : 0, 0, 0, p.threshold, 1};
-    bool ok = gz_write_all(f, &hd, sizeof hd);
+    w.write(&hd, sizeof hd);
+    bool ok = true;
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
     std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1));
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
         if (G && mk_index_export_columns(ctx, pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
-        ok = gz_write_all(f, buf.data(), (size_t)(pe - pb) * row);
+        w.write(buf.data(), (size_t)(pe - pb) * row);
     }
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
     if (ok && mk_index_export_sizes(ctx, gs.data(), ss.data()) != MK_OK) { err = mk_last_error(); ok = false; }
-    if (ok) ok = gz_write_all(f, gs.data(), (size_t)G * 8);
+    if (ok) w.write(gs.data(), (size_t)G * 8);
     const uint64_t nb = hd.bloom_bits / 8;
     buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(nb, 1)));
     for (uint64_t o = 0; ok && o < nb; o += kChunk) {
         const uint64_t e = std::min(nb, o + kChunk);
         if (mk_index_export_bloom(ctx, o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
-        ok = gz_write_all(f, buf.data(), (size_t)(e - o));
+        w.write(buf.data(), (size_t)(e - o));
     }
-    if (ok) ok = gz_write_all(f, ss.data(), (size_t)G * 4);
-    if (gzclose(f) != Z_OK) ok = false;
+    if (ok) w.write(ss.data(), (size_t)G * 4);
+    if (!w.finish()) ok = false;
     if (!ok && err.empty()) err = "write error on " + path;
     return ok ? 0 : -1;
 }

@@ -11,8 +11,11 @@ namespace mkhost {
 bool file_exists(const std::string &path);
 // whole file; gunzipped when it carries the gzip magic (zstr.hpp:157-167 semantics)
 bool read_text(const std::string &path, std::string &out);
-// dump_disk: gzip level 1 like zstr::ofstream (zstr.hpp:82)
-int dump_index(mk_ctx *ctx, const std::string &path, std::string &err);
+// dump_disk: gzip level 1 like zstr::ofstream (zstr.hpp:82).  With threads > 1 the
+// stream is cut into 32 MiB blocks compressed concurrently into consecutive gzip
+// members -- the reference's reader restarts its inflator at every member end
+// (zstr.hpp:186-190), as does zlib's gzread, so the file stays loadable by both.
+int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned threads = 1);
 // Miekki(const string&): builds a context from the file's own header
 int load_index(const std::string &path, int device, mk_ctx **out, std::string &err);
 

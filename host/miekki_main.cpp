@@ -487,7 +487,7 @@ int main(int argc, char **argv)
     if (!index_dump.empty()) {
         cout << "I write this index on the disk for later" << endl;
         string err;
-        if (mkhost::dump_index(drv.ctx, index_dump, err) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
+        if (mkhost::dump_index(drv.ctx, index_dump, err, reader_threads) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
     }
     auto end_index = chrono::system_clock::now();
     cout << "elapsed time: " << chrono::duration<double>(end_index - start).count() << "s\n";
