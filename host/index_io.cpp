@@ -47,17 +47,6 @@ struct Header {                  // 39 bytes, little-endian, unpadded (Miekki.cp
 #pragma pack(pop)
 static_assert(sizeof(Header) == 39, "index header layout");
 
-bool gz_write_all(gzFile f, const void *p, size_t n)
-{
-    const char *c = (const char *)p;
-    while (n) {
-        const unsigned chunk = (unsigned)std::min<size_t>(n, 1u << 30);
-        if (gzwrite(f, c, chunk) != (int)chunk) return false;
-        c += chunk; n -= chunk;
-    }
-    return true;
-}
-
 bool gz_read_all(gzFile f, void *p, size_t n)
 {
     char *c = (char *)p;
