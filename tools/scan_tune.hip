@@ -84,6 +84,56 @@ __global__ __launch_bounds__(256) void narrow_kernel(const ScanArgs a)
     for (uint32_t k = 0; k < ND; ++k) asm volatile("" ::"v"(tot[k]));
 }
 
+// ---- experiment: the query's entry list staged in LDS (the north-star's suggestion)
+// instead of SGPRs.  A workgroup = one query x four adjacent tiles (query-major), the
+// list is loaded cooperatively (coalesced) into LDS once per workgroup, every wave
+// then reads entry i as a broadcast ds_read_b64 and lifts it to SGPRs.
+__global__ __launch_bounds__(256) void lds_kernel(const ScanArgs a)
+{
+    extern __shared__ uint64_t s_ent[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tiles4 = (a.ntiles + 3) / 4;
+    const uint32_t ql = blockIdx.x / tiles4, tile = (blockIdx.x - ql * tiles4) * 4 + wave;
+    const uint64_t *__restrict__ ent = a.entries + a.ent_off[ql];
+    const uint32_t n = a.nent[ql];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s_ent[i] = ent[i];
+    __syncthreads();
+    if (tile >= a.ntiles || (uint64_t)tile * kTileBytes + lane * 16u >= a.G) return;
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint32_t voff = lane * 16u;
+    uint32_t tot[4] = {0, 0, 0, 0};
+    for (uint32_t i0 = 0; i0 < n; i0 += 248) {
+        const uint32_t m = min(n - i0, 248u);
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, j = 0;
+        for (; j + 8 <= m; j += 8) {
+            uint64_t ev[8]; uint4 d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t v = s_ent[i0 + j + u];                      // same address in every lane: broadcast
+                ev[u] = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = load_row16<false>(row_base(base, (uint32_t)ev[u], a.ld) + voff);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t b = bcast_fp<1>((uint32_t)(ev[u] >> 32));
+                acc0 += ne_lanes<1>(d[u].x, b); acc1 += ne_lanes<1>(d[u].y, b);
+                acc2 += ne_lanes<1>(d[u].z, b); acc3 += ne_lanes<1>(d[u].w, b);
+            }
+        }
+        for (; j < m; ++j) {
+            const uint64_t v = s_ent[i0 + j];
+            const uint64_t ev = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+            const uint4 d = load_row16<false>(row_base(base, (uint32_t)ev, a.ld) + voff);
+            const uint32_t b = bcast_fp<1>((uint32_t)(ev >> 32));
+            acc0 += ne_lanes<1>(d.x, b); acc1 += ne_lanes<1>(d.y, b); acc2 += ne_lanes<1>(d.z, b); acc3 += ne_lanes<1>(d.w, b);
+        }
+        tot[0] += acc0; tot[1] += acc1; tot[2] += acc2; tot[3] += acc3;   // timing build: no widening
+    }
+    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(tot[k]));
+}
+
 struct Variant { const char *name; void (*fn)(const ScanArgs); uint32_t blocks_per_cu; uint32_t lane_bytes; };   // blocks_per_cu > 0: sweep grid
 
 #define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>, 0, 16}
@@ -129,7 +179,7 @@ int main(int argc, char **argv)
     if (getenv("NO_STORE")) a.scores = nullptr;
     const ScoreLayout lay = tile_major_scores ? score_layout_tiles(1, Q) : score_layout_rows(1, sld, G);
     a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
-    const Variant vars[] = {V(8, 0, false), V(8, 1, false), N(16, 8), N(8, 8), N(8, 16), N(4, 8), N(4, 16)};
+    const Variant vars[] = {V(8, 0, false), V(8, 1, false), {"lds_staged_o0", lds_kernel, 0, 16}, N(8, 8), N(4, 8)};
     const int nv = sizeof vars / sizeof vars[0];
     const uint64_t work = (uint64_t)Q * a.ntiles;
     const uint32_t blocks = (uint32_t)((work + 3) / 4);
@@ -163,7 +213,9 @@ int main(int argc, char **argv)
                 const uint32_t tb = 64 * vars[v].lane_bytes;
                 grid = (uint32_t)(((uint64_t)Q * ((G + tb - 1) / tb) + 3) / 4);
             }
-            hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), 0, 0, a);
+            size_t lds = 0;
+            if (vars[v].fn == lds_kernel) { grid = Q * ((a.ntiles + 3) / 4); lds = (size_t)NE * 8; }
+            hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), lds, 0, a);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float t; CK(hipEventElapsedTime(&t, e0, e1));
