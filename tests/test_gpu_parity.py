@@ -339,3 +339,35 @@ def test_config3_shard_scale_properties(hip):
             small.close()
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("k,h,fpb,b", [(11, 6, 8, 32), (21, 13, 16, 33), (31, 15, 8, 40), (27, 22, 8, 33), (5, 3, 16, 32)])
+def test_parameter_sweep_against_oracle(hip, k, h, fpb, b):
+    """Odd corners of the parameter space (tiny and large h, small k, both widths,
+    large b): index stream, scores and hits equal the oracle's."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(k * 100 + h)
+    lens = [int(x) for x in rng.integers(k, 9000, 23)] + [40_000, 70_001]
+    seqs = [synth.genome_bases(4000 + i, int(rng.integers(0, 1000)), n) for i, n in enumerate(lens)]
+    seqs[3] = seqs[3][:200].lower() + seqs[3][200:]                 # lower case inside the seed region and after
+    o = orc.OracleMiekki(k, h, fpb, b, 7)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, fpb, b, 7)
+    try:
+        ix.insert_sequences(seqs[:10]); ix.insert_sequences(seqs[10:])
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+        raw = np.frombuffer(stream_of(ix), np.uint8).copy()
+        want = o.serialize()
+        raw[32] = want[32] = 0
+        assert raw.size == want.size and sha(raw.tobytes()) == sha(want.tobytes())
+        qs = [seqs[24][100:1400], seqs[25], seqs[0], seqs[7][:k + 3], synth.genome_bases(9, 0, 3000), seqs[24][5000:25_000]]
+        scores = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), scores)
+        hits, act = ix.query(qs, 7, 1, 0.0)
+        for q, s in enumerate(qs):
+            assert int(act[q]) == o.query_sequence(s)[1]
+            want_h = o.filter_results(scores[q], 7, 1, 0.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want_h], q
+    finally:
+        ix.close()
