@@ -361,7 +361,7 @@ def test_parameter_sweep_against_oracle(hip, k, h, fpb, b):
         want = o.serialize()
         raw[32] = want[32] = 0
         assert raw.size == want.size and sha(raw.tobytes()) == sha(want.tobytes())
-        qs = [seqs[24][100:1400], seqs[25], seqs[0], seqs[7][:k + 3], synth.genome_bases(9, 0, 3000), seqs[24][5000:25_000]]
+        qs = [seqs[23][100:1400], seqs[24], seqs[0], seqs[7][:k + 3], synth.genome_bases(9, 0, 3000), seqs[23][5000:25_000]]
         scores = o.query_sequences(qs)
         np.testing.assert_array_equal(ix.query_sequences(qs), scores)
         hits, act = ix.query(qs, 7, 1, 0.0)
