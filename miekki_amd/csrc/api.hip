@@ -817,6 +817,32 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         if (active) memset(active, 0, (size_t)nq * 4);     // no column is ever compared
         return MK_OK;
     }
+    // A batch that mixes short queries with long ones is answered as two batches, so
+    // that the short ones keep the slab schedule (long ones need the plain / dense kernels)
+    {
+        std::vector<uint32_t> idx_short, idx_long;
+        for (uint32_t q = 0; q < nq; ++q)
+            (lens[q] > (uint64_t)c->p.k + kShortMax ? idx_long : idx_short).push_back(q);
+        if (!idx_short.empty() && !idx_long.empty() && nresults > 0) {
+            for (const std::vector<uint32_t> *part : {&idx_short, &idx_long}) {
+                const uint32_t n = (uint32_t)part->size();
+                std::vector<const char *> s(n);
+                std::vector<uint64_t> l(n);
+                std::vector<mk_hit> h((size_t)n * nresults);
+                std::vector<uint32_t> nh(n), act(n);
+                for (uint32_t i = 0; i < n; ++i) { s[i] = seqs[(*part)[i]]; l[i] = lens[(*part)[i]]; }
+                MK_TRY(mk_query(c, s.data(), l.data(), n, nresults, min_score, min_inter, h.data(), nh.data(), act.data()));
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t q = (*part)[i];
+                    nhits[q] = nh[i];
+                    if (active) active[q] = act[i];
+                    std::copy(h.begin() + (size_t)i * nresults, h.begin() + (size_t)i * nresults + nh[i],
+                              hits + (size_t)q * nresults);
+                }
+            }
+            return MK_OK;
+        }
+    }
     mk_qset *qs = nullptr;
     MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
