@@ -1,0 +1,156 @@
+"""Multi-GPU `miekki -l … -a … -o …`: genome-sharded index, one gather of top hits.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        -m miekki_amd.mgpu -l genomes.txt -a queries.fa -o out.txt -h 20
+
+One process per GPU (backend "nccl" = RCCL over xGMI).  Rank r indexes the r-th
+contiguous slice of the genome list on its own GPU -- genome ids are those of a
+single-process run because the slices are contiguous and every rank learns how many
+genomes the ranks before it kept (one tiny all-gather at build time).  The Bloom
+filters are merged byte-exactly (distributed.sync_bloom), every rank scans all
+queries against its shard, and the per-query heap entrants are gathered on rank 0,
+which replays the reference heap and writes the reference's out.txt
+(Miekki.cpp:440-444).  `--rehearse` runs the same program with gloo collectives and
+every rank on GPU 0 (single-GPU boxes, tests).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import distributed as mkd
+from . import lib as L
+from .index import Miekki, SimilarityScore, _read_text
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("-l", required=True); ap.add_argument("-a", required=True)
+    ap.add_argument("-o", default="out.txt")
+    ap.add_argument("-h", type=int, default=17); ap.add_argument("-k", type=int, default=31)
+    ap.add_argument("-f", type=int, default=3); ap.add_argument("-b", type=int, default=33)
+    ap.add_argument("-s", type=float, default=200.0); ap.add_argument("-t", type=int, default=8)
+    ap.add_argument("--cap", type=int, default=128)
+    ap.add_argument("--rehearse", action="store_true")
+    ap.add_argument("--help", action="help")
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    coll = torch.device("cpu") if args.rehearse else torch.device("cuda", local)
+    lib = L.load_library()
+
+    # ---- build: contiguous slice of the list per rank (Miekki.cpp:540-588 semantics per file)
+    files = [f.decode() for f in _read_text(args.l).split(b"\n") if len(f) > 3]
+    f0, f1 = mkd.shard_range(len(files), rank, world)
+    seqs = []
+    for fn in files[f0:f1]:
+        if not os.path.exists(fn):
+            print(f"Missed file: {fn}", flush=True)
+            continue
+        ref = b"".join(l for l in _read_text(fn).split(b"\n") if not l.startswith(b">"))
+        if len(ref) >= args.k:
+            seqs.append(ref)
+    kept = torch.tensor([len(seqs)], dtype=torch.int64, device=coll)
+    if world > 1:
+        all_kept = [torch.zeros_like(kept) for _ in range(world)]
+        dist.all_gather(all_kept, kept)
+        base = int(sum(int(t.item()) for t in all_kept[:rank]))
+        total = int(sum(int(t.item()) for t in all_kept))
+    else:
+        base, total = 0, len(seqs)
+    ix = Miekki(args.k, args.h, 5 + args.f, args.b, int(args.s), device=local, genome_id_base=base)
+    for i in range(0, len(seqs), 64):
+        ix.insert_sequences(seqs[i:i + 64])
+    del seqs
+    if world > 1:
+        mkd.sync_bloom(ix, device=coll)
+    if rank == 0:
+        print(f"Reference indexed: {total}", flush=True)
+
+    # ---- query: every rank scans all records against its shard (Miekki.cpp:426-483)
+    lines = _read_text(args.a).split(b"\n")
+    recs = [(lines[i], lines[i + 1] if i + 1 < len(lines) else b"") for i in range(0, len(lines), 2)]
+    recs = [(h, s) for h, s in recs if len(s) >= args.k]
+    nres, min_score, min_inter, cap = 10, 10, 0.5 * int(args.s), args.cap
+    out = open(args.o, "wb") if rank == 0 else None
+    for b0 in range(0, len(recs), 16384):
+        chunk = recs[b0:b0 + 16384]
+        nq = len(chunk)
+        ptrs, lens = L.seq_arrays([s for _, s in chunk])
+        qs = C.c_void_p()
+        L.check(lib.mk_qset_upload(ix._h, ptrs, lens, nq, C.byref(qs)))
+        d_count = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        d_cand = torch.zeros(nq * cap * mkd.HIT_BYTES, dtype=torch.uint8, device="cuda")
+        L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, float(min_inter), cap, d_count.data_ptr(), d_cand.data_ptr()))
+        L.check(lib.mk_sync(ix._h))
+        lib.mk_qset_free(ix._h, qs)
+        if world > 1:                                            # the one exchange step
+            counts, cands = mkd.gather_candidates(d_count.to(coll), d_cand.to(coll))
+        else:
+            counts, cands = d_count.cpu().numpy()[None], d_cand.cpu().numpy()[None]
+        # rows that overflowed on some shard: every rank answers them again with its
+        # complete (not just entrant) candidate list, gathered as objects
+        over = None
+        if rank == 0:
+            over = np.flatnonzero((counts > cap).any(axis=0)).tolist()
+        if world > 1:
+            box = [over]
+            dist.broadcast_object_list(box, src=0)
+            over = box[0]
+        full = {}
+        if over:
+            scores = ix.query_sequences([chunk[q][1] for q in over])
+            ss, gs = ix.sketch_size.astype(np.float64), ix.genome_size.astype(np.float64)
+            mine = {}
+            for j, q in enumerate(over):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    jac = scores[j] / ss
+                    inter = jac * gs
+                keep = np.flatnonzero((scores[j] >= min_score) & ~(inter < min_inter))
+                mine[q] = [(int(g) + base, int(scores[j][g]), float(jac[g]), float(inter[g])) for g in keep]
+            gathered = [None] * world
+            if world > 1:
+                dist.gather_object(mine, gathered if rank == 0 else None, dst=0)
+            else:
+                gathered = [mine]
+            if rank == 0:
+                for q in over:
+                    full[q] = [c for part in gathered for c in part[q]]
+        if rank == 0:
+            hits, _ = mkd.merge_candidates(counts, cands.reshape(world, -1), cap, nres)
+            text = []
+            for q, (head, _) in enumerate(chunk):
+                if q in full:
+                    buf = (L.Hit * max(len(full[q]), 1))(*[L.Hit(*c) for c in full[q]])
+                    res = (L.Hit * nres)()
+                    n = lib.mk_filter_candidates(buf, len(full[q]), nres, res)
+                    row = [SimilarityScore(res[i].genome, res[i].matches, res[i].jaccard, res[i].intersection) for i in range(n)]
+                else:
+                    row = [SimilarityScore(int(h["genome"]), int(h["matches"]), float(h["jaccard"]), float(h["intersection"]))
+                           for h in hits[q]]
+                text.append(Miekki.format_hits(head, row))
+            out.write(b"".join(text))
+    if out:
+        out.close()
+    ix.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

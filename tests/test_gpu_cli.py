@@ -97,3 +97,23 @@ def test_unsupported_fingerprint_size_message(workdirs):
     case, d, base = workdirs("messy")
     out = run(["-l", "genomes.lst", "-k", "21", "-h", "12", "-f", "16", "-b", "32"], d)   # BASELINE's literal "-f 16"
     assert b"not implemented" in out
+
+
+@pytest.mark.parametrize("name,ranks", [("messy", 3), ("h20", 2)])
+def test_multi_rank_driver_equals_reference(workdirs, golden_dir, name, ranks):
+    """miekki_amd.mgpu: genome-sharded ranks (rehearsal: gloo, every rank on GPU 0),
+    Bloom merge, gather of heap entrants, rank-0 merge -> the reference's out.txt."""
+    import socket
+    import sys
+    case, d, base = workdirs(name)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "miekki_amd.mgpu",
+           "-l", "genomes.lst", "-a", "queries.fa", "-o", "out_mgpu.txt", "-k", str(case.k), "-h", str(case.h),
+           "-f", str(case.f), "-b", str(case.b), "-s", str(case.threshold), "--rehearse"]
+    r = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    assert (d / "out_mgpu.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
