@@ -1,0 +1,124 @@
+"""Edge cases of the C ABI on the GPU: empty and degenerate inputs, error returns,
+matrix re-layout on growth, append after import."""
+import ctypes as C
+import gzip
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import miekki_amd
+    return miekki_amd
+
+
+def stream_of(ix):
+    return b"".join(ix.serialize())
+
+
+def test_empty_index_and_empty_batches(hip, tmp_path):
+    from oracle import oracle as orc
+    ix = hip.Miekki(31, 10, 8, 32, 50)
+    try:
+        assert ix.index_size == 0
+        ix.insert_sequences([])
+        hits, act = ix.query([synth.genome_bases(0, 0, 500)], 10, 10, 1.0)
+        assert hits == [[]] and int(act[0]) == 0
+        assert ix.query_sequences([synth.genome_bases(0, 0, 500)]).shape == (1, 0)
+        hits, act = ix.query([], 10, 10, 1.0)
+        assert hits == []
+        # an empty index dumps and loads like the reference's would (header + Bloom only)
+        o = orc.OracleMiekki(31, 10, 8, 32, 50)
+        raw = bytearray(stream_of(ix)); want = bytearray(o.serialize().tobytes())
+        raw[32] = want[32] = 0
+        assert bytes(raw) == bytes(want)
+        ix.dump_disk(str(tmp_path / "empty.gz"))
+        back = hip.Miekki.load(str(tmp_path / "empty.gz"))
+        try:
+            assert back.index_size == 0 and back.threshold == 50
+            back.insert_sequences([synth.genome_bases(1, 0, 4000)])      # append after load
+            assert back.index_size == 1
+        finally:
+            back.close()
+    finally:
+        ix.close()
+
+
+def test_queries_without_kmers(hip):
+    ix = hip.Miekki(31, 10, 8, 32, 0)
+    try:
+        g = synth.genome_bases(3, 0, 5000)
+        ix.insert_sequences([g])
+        qs = [g[:10], g[:31], b"", g[:32], g[100:400]]               # < k, = k (no k-mer processed), empty, one k-mer
+        scores = ix.query_sequences(qs)
+        assert scores[:3].sum() == 0
+        hits, act = ix.query(qs, 10, 0, 0.0)
+        assert [int(a) for a in act[:3]] == [0, 0, 0] and int(act[4]) > 0
+        assert hits[4] and hits[4][0].genome == 0
+    finally:
+        ix.close()
+
+
+def test_error_returns(hip):
+    from miekki_amd import lib as L
+    lib = L.load_library()
+    ix = hip.Miekki(31, 10, 8, 32, 0)
+    try:
+        with pytest.raises(L.MiekkiHipError) as e:
+            ix.insert_sequences([b"ACGT"])                              # shorter than k: the driver's job (Miekki.cpp:569)
+        assert e.value.status == -1 and "shorter than k" in str(e.value)
+        buf = np.zeros(16, np.uint8)
+        assert lib.mk_index_export_columns(ix._h, 5, 2000, buf.ctypes.data) == -1     # partition range out of bounds
+        assert lib.mk_index_export_bloom(ix._h, 0, (1 << 29) + 1, buf.ctypes.data) == -1
+        assert lib.mk_qset_run(ix._h, None, 10, 10, 1.0, 16, None, None) == -1
+    finally:
+        ix.close()
+    for bad in (dict(k=40), dict(k=1), dict(h=0), dict(h=29), dict(b=31), dict(b=41)):
+        p = L.Params(bad.get("k", 31), bad.get("h", 14), 8, bad.get("b", 33), 200, 0, 0, 0)
+        h = C.c_void_p()
+        assert lib.mk_create(C.byref(p), C.byref(h)) == -1, bad
+
+
+def test_growth_past_the_reservation_relays_the_matrix(hip):
+    """1,100 one-byte genomes exceed the first 1 KiB row pitch: the matrix is re-laid
+    out mid-build and must still equal the oracle's."""
+    from oracle import oracle as orc
+    k, h = 21, 8
+    seqs = [synth.genome_bases(8000 + g, 0, 600 + (g % 50)) for g in range(1100)]
+    o = orc.OracleMiekki(k, h, 8, 32, 0)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 32, 0)
+    try:
+        for i in range(0, len(seqs), 257):
+            ix.insert_sequences(seqs[i:i + 257])
+        raw = bytearray(stream_of(ix)); want = bytearray(o.serialize().tobytes())
+        raw[32] = want[32] = 0
+        assert bytes(raw) == bytes(want)
+        q = [seqs[1050][50:500], seqs[3]]
+        np.testing.assert_array_equal(ix.query_sequences(q), o.query_sequences(q))
+    finally:
+        ix.close()
+
+
+def test_append_after_import_equals_one_build(hip, tmp_path):
+    k, h = 31, 12
+    seqs = [synth.genome_bases(8500 + g, 0, 20_000) for g in range(20)]
+    a = hip.Miekki(k, h, 16, 33, 10)
+    b = hip.Miekki(k, h, 16, 33, 10)
+    try:
+        a.insert_sequences(seqs)
+        b.insert_sequences(seqs[:9])
+        b.dump_disk(str(tmp_path / "part.gz"))
+        c = hip.Miekki.load(str(tmp_path / "part.gz"))
+        try:
+            c.insert_sequences(seqs[9:])
+            assert stream_of(c) == stream_of(a)
+        finally:
+            c.close()
+    finally:
+        a.close(); b.close()
