@@ -202,7 +202,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
 {
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> qs(new mk_qset(), qset_release);
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
-    qs->d_nent = nullptr; qs->sketched = false; qs->total_active = 0; qs->short_max_nk = 0;
+    qs->d_nent = nullptr; qs->sketched = false; qs->short_max_nk = 0;
     qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
     qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
@@ -444,7 +444,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
-    c->cand_cap_q = 0; c->cand_cap = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
+    c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));

@@ -75,7 +75,7 @@ struct mk_ctx {
     uint32_t *d_flag;              // one word for device-side eligibility checks
     uint32_t *d_count;
     mk_hit *d_cand;
-    uint64_t cand_cap_q, cand_cap;
+    uint64_t cand_cap_q;           // queries d_count / d_cand are sized for
     uint64_t *d_long_table;        // P keys, long-query path
     // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
     uint64_t *d_slots;
@@ -111,7 +111,6 @@ struct mk_qset {
     uint32_t S;                    // ranges of the slab schedule (0 = not prepared)
     bool slab_ok;                  // every (query, range) fits the packed counters
     bool sketched;
-    uint64_t total_active;
 };
 
 namespace mk {

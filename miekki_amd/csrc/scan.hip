@@ -1,23 +1,24 @@
-// K5: query-vs-all-genomes fingerprint scan.
+// K5: query-vs-all-genomes fingerprint scan -- launchers.  The kernels are in
+// scan_kernel.hpp (shared with tools/scan_tune.hip); DESIGN.md section 4.1 has the
+// measurements behind each choice.
 //
 // Replaces the loop nest of Miekki::query_sequences (Miekki.cpp:355-369); the
-// filter of Miekki::filter_results runs over its score rows in select.hip (K6).
+// filter of Miekki::filter_results runs over the scores in select.hip (K6).
 //
-// Work decomposition (gfx950): one WAVE owns one (query, 1 KiB row tile) pair --
-// 1024 genomes at 1-byte fingerprints, 512 at 2-byte -- so that tiny collections
-// (G = 1000 is one tile) and huge ones (G = 100,000 is 98 tiles) both fill the
-// 256 CUs.  The query's sparse sketch (partition, fingerprint) list is wave-uniform:
-// it is staged in SGPRs through the scalar cache, the per-row base address is
-// scalar arithmetic, and every lane issues one 16-byte load per entry from
-// M[p][tile*1024 + lane*16] -- 1 KiB contiguous per wave-instruction.  Work items
-// are ordered TILE-major (all queries of tile 0, then tile 1, ...): the waves in
-// flight at any moment then share one 2^h x 1 KiB column slab of the matrix, a
-// quarter of which stays resident in the 256 MiB Infinity Cache at h = 20, which
-// measured +16 % over query-major order (tools/scan_tune, profiles/).  Fingerprints are compared
-// four (two) at a time with SWAR zero-byte detection on the XOR against the
-// broadcast query fingerprint; per-genome counters live in packed 8-bit (16-bit)
-// register lanes and are widened every 255 (65535) entries.  No atomics in the
-// main loop, no LDS: the kernel is a pure HBM row-stream.
+// One WAVE owns one (query, 1 KiB row tile) pair -- 1024 genomes at 1-byte
+// fingerprints, 512 at 2-byte -- so that tiny collections (G = 1000 is one tile) and
+// huge ones (G = 100,000 is 98 tiles) both fill the 256 CUs.  The query's sparse
+// sketch is wave-uniform: it is staged in SGPRs through the scalar cache, the row base
+// is scalar arithmetic, and every lane issues one 16-byte load per entry from
+// M[p][tile*1024 + lane*16].  Fingerprints are compared four (two) at a time with
+// SWAR zero-byte detection on the XOR against the broadcast query fingerprint, into
+// packed 8-bit (16-bit) per-genome counters.  No atomics, no LDS: a pure row stream
+// whose speed is decided by the ORDER of the work items:
+//   scan_slab_kernel   (tile, partition range, query): the waves in flight share a
+//                      128 MiB slab that the Infinity Cache holds -- default pipeline;
+//   scan_kernel        tile-major over whole entry lists, u32 scores -- long queries,
+//                      score export;
+//   scan_dense_kernel  four whole-genome queries per pass over the matrix (-A).
 #include "scan_kernel.hpp"
 
 namespace mk {
