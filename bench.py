@@ -127,8 +127,12 @@ def main():
     L.check(lib.mk_sync(ix._h))
     build_s = time.time() - t0
     bst = ix.stats()
+    build_s_max = build_s
     if world > 1:                                      # one global Bloom gate, as in a single-process build
         from miekki_amd import distributed as mkd
+        tb = torch.tensor([build_s], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        build_s_max = float(tb.item())
         mkd.sync_bloom(ix, device=coll_dev)
 
     qs = C.c_void_p()
@@ -214,8 +218,9 @@ def main():
                          "kernel": "scan_slab_kernel" if st["scan_slab_launches"] else "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch},
             "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
-                       "index_build_s": build_s, "index_sketches_per_s": G / build_s,
-                       "index_kmers_per_s": bst["build_kmers"] / build_s,
+                       "index_build_s": build_s_max, "index_sketches_per_s": G_total / build_s_max,
+                       "index_sketches_per_s_per_gpu": G / build_s,
+                       "index_kmers_per_s": world * bst["build_kmers"] / build_s_max,
                        "build_sketch_ms": bst["build_sketch_ms"], "build_finalize_ms": bst["build_finalize_ms"]},
             "check": {"queries_with_candidates_on_rank0": n_hit, "merged_top_hit_correct_of_2000": merged_ok},
         }
