@@ -1,0 +1,200 @@
+#include "gzpar.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mkhost {
+
+namespace {
+
+constexpr size_t kHeader = 24;     // fixed gzip header (10) + XLEN (2) + "MK" subfield (4 + 8)
+
+void put_le(uint8_t *p, uint64_t v, int n) { for (int i = 0; i < n; ++i) p[i] = (uint8_t)(v >> (8 * i)); }
+uint64_t get_le(const uint8_t *p, int n) { uint64_t v = 0; for (int i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i); return v; }
+
+bool is_mk_header(const uint8_t *h)
+{
+    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && get_le(h + 10, 2) == 12 && h[12] == 'M' &&
+           h[13] == 'K' && get_le(h + 14, 2) == 8;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ writer
+ParallelGzipWriter::ParallelGzipWriter(const std::string &path, unsigned threads)
+    : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads)) {}
+
+ParallelGzipWriter::~ParallelGzipWriter()
+{
+    for (auto &j : jobs_) if (j->th.joinable()) j->th.join();
+    if (f_) fclose(f_);
+}
+
+void ParallelGzipWriter::write(const void *p, size_t n)
+{
+    const uint8_t *c = (const uint8_t *)p;
+    while (n) {
+        const size_t take = std::min(n, kBlock - cur_.size());
+        cur_.insert(cur_.end(), c, c + take);
+        c += take; n -= take;
+        if (cur_.size() == kBlock) submit();
+    }
+}
+
+bool ParallelGzipWriter::finish()
+{
+    if (!cur_.empty() || !wrote_any_) submit();                  // an empty stream is still one (empty) member
+    while (!jobs_.empty()) drain_one();
+    if (f_) { if (fclose(f_) != 0) failed_ = true; f_ = nullptr; }
+    return !failed_;
+}
+
+void ParallelGzipWriter::deflate_block(Job *j)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->bad = true; return; }   // raw deflate
+    const size_t bound = deflateBound(&zs, (uLong)j->in.size()) + 64;
+    j->out.resize(kHeader + bound + 8);
+    zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
+    zs.next_out = j->out.data() + kHeader; zs.avail_out = (uInt)bound;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
+    const uint64_t payload = zs.total_out;
+    deflateEnd(&zs);
+    uint8_t *h = j->out.data();
+    h[0] = 0x1f; h[1] = 0x8b; h[2] = 8; h[3] = 4;                // FLG.FEXTRA
+    put_le(h + 4, 0, 4); h[8] = 4; h[9] = 3;                     // mtime 0, XFL = fastest, OS = unix
+    put_le(h + 10, 12, 2); h[12] = 'M'; h[13] = 'K'; put_le(h + 14, 8, 2);
+    put_le(h + 16, payload, 8);
+    uint8_t *t = h + kHeader + payload;
+    put_le(t, crc32(crc32(0L, Z_NULL, 0), j->in.data(), (uInt)j->in.size()), 4);
+    put_le(t + 4, j->in.size() & 0xffffffffu, 4);
+    j->out.resize(kHeader + payload + 8);
+    std::vector<uint8_t>().swap(j->in);
+}
+
+void ParallelGzipWriter::submit()
+{
+    wrote_any_ = true;
+    std::unique_ptr<Job> j(new Job());
+    j->in.swap(cur_);
+    cur_.reserve(kBlock);
+    Job *raw = j.get();
+    j->th = std::thread(deflate_block, raw);
+    jobs_.push_back(std::move(j));
+    while (jobs_.size() >= nthreads_) drain_one();
+}
+
+void ParallelGzipWriter::drain_one()
+{
+    std::unique_ptr<Job> j = std::move(jobs_.front());
+    jobs_.pop_front();
+    j->th.join();
+    if (j->bad || !f_ || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
+}
+
+// ------------------------------------------------------------------ reader
+ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads) : nthreads_(std::max(1u, threads))
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { failed_ = true; return; }
+    uint8_t h[kHeader];
+    const size_t got = fread(h, 1, kHeader, f);
+    if (got == kHeader && is_mk_header(h)) {
+        fseek(f, 0, SEEK_SET);
+        f_ = f;
+        prefetch();
+    } else {
+        fclose(f);
+        gz_ = gzopen(path.c_str(), "rb");                        // gzip of any make, or plain bytes
+        if (!gz_) failed_ = true; else gzbuffer(gz_, 1 << 20);
+    }
+}
+
+ParallelGzipReader::~ParallelGzipReader()
+{
+    for (auto &j : jobs_) if (j->th.joinable()) j->th.join();
+    if (f_) fclose(f_);
+    if (gz_) gzclose(gz_);
+}
+
+bool ParallelGzipReader::read_member_header(uint64_t &payload)
+{
+    uint8_t h[kHeader];
+    const size_t got = fread(h, 1, kHeader, f_);
+    if (got == 0) { eof_ = true; return false; }
+    if (got != kHeader || !is_mk_header(h)) { failed_ = true; return false; }
+    payload = get_le(h + 16, 8);
+    return true;
+}
+
+void ParallelGzipReader::inflate_block(Job *j)
+{
+    const size_t payload = j->in.size() - 8;
+    const uint32_t crc = (uint32_t)get_le(j->in.data() + payload, 4), isize = (uint32_t)get_le(j->in.data() + payload + 4, 4);
+    j->out.resize((size_t)isize + 1);                            // one spare byte: an empty member still needs room to finish
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { j->bad = true; return; }
+    zs.next_in = j->in.data(); zs.avail_in = (uInt)payload;
+    zs.next_out = j->out.data(); zs.avail_out = isize + 1;
+    const int rc = inflate(&zs, Z_FINISH);
+    if (rc != Z_STREAM_END || zs.total_out != isize) j->bad = true;
+    inflateEnd(&zs);
+    j->out.resize(isize);
+    if (!j->bad && (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->out.data(), isize) != crc) j->bad = true;
+    std::vector<uint8_t>().swap(j->in);
+}
+
+void ParallelGzipReader::prefetch()
+{
+    while (!eof_ && !failed_ && jobs_.size() < nthreads_ + 1) {
+        uint64_t payload = 0;
+        if (!read_member_header(payload)) break;
+        if (payload > (1ull << 31)) { failed_ = true; break; }
+        std::unique_ptr<Job> j(new Job());
+        j->in.resize((size_t)payload + 8);
+        if (fread(j->in.data(), 1, j->in.size(), f_) != j->in.size()) { failed_ = true; break; }
+        Job *raw = j.get();
+        j->th = std::thread(inflate_block, raw);
+        jobs_.push_back(std::move(j));
+    }
+}
+
+size_t ParallelGzipReader::read_some(void *dst, size_t n)
+{
+    size_t done = 0;
+    if (gz_) {
+        char *c = (char *)dst;
+        while (done < n) {
+            const unsigned chunk = (unsigned)std::min<size_t>(n - done, 1u << 30);
+            const int got = gzread(gz_, c + done, chunk);
+            if (got < 0) { failed_ = true; break; }
+            done += (size_t)got;
+            if ((unsigned)got < chunk) break;
+        }
+        return done;
+    }
+    if (!f_) return 0;
+    uint8_t *c = (uint8_t *)dst;
+    while (done < n) {
+        if (cur_pos_ == cur_.size()) {
+            if (jobs_.empty()) prefetch();
+            if (jobs_.empty()) break;                              // end of stream
+            std::unique_ptr<Job> j = std::move(jobs_.front());
+            jobs_.pop_front();
+            j->th.join();
+            if (j->bad) { failed_ = true; break; }
+            cur_.swap(j->out);
+            cur_pos_ = 0;
+            prefetch();
+            continue;
+        }
+        const size_t take = std::min(n - done, cur_.size() - cur_pos_);
+        memcpy(c + done, cur_.data() + cur_pos_, take);
+        cur_pos_ += take; done += take;
+    }
+    return done;
+}
+
+}  // namespace mkhost

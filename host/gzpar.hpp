@@ -1,0 +1,70 @@
+// Parallel gzip for the index file (host only, plain zlib + std::thread).
+//
+// Writer: the byte stream is cut into 32 MiB blocks, each deflated (level 1, like
+// zstr::ofstream, zstr.hpp:82) by its own thread into its own gzip MEMBER, written
+// in order.  Every member's header carries an FEXTRA subfield "MK" with the
+// compressed payload size, the way BGZF does, so that a reader can find member
+// boundaries without inflating.  Any gzip reader -- zlib's gzread, the reference's
+// zstr::ifstream (which restarts its inflator at each member end, zstr.hpp:186-190),
+// gunzip -- reads such a file as one stream.
+//
+// Reader: members with the "MK" subfield are inflated concurrently and delivered in
+// order; anything else (the reference's own dumps, plain files) goes through gzread.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <deque>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mkhost {
+
+class ParallelGzipWriter {
+public:
+    ParallelGzipWriter(const std::string &path, unsigned threads);
+    ~ParallelGzipWriter();
+    bool ok() const { return f_ && !failed_; }
+    void write(const void *p, size_t n);
+    bool finish();                       // flushes, closes; false on any error
+    static constexpr size_t kBlock = 32u << 20;
+private:
+    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; };
+    static void deflate_block(Job *j);
+    void submit();
+    void drain_one();
+    FILE *f_;
+    unsigned nthreads_;
+    std::vector<uint8_t> cur_;
+    std::deque<std::unique_ptr<Job>> jobs_;
+    bool failed_ = false, wrote_any_ = false;
+};
+
+class ParallelGzipReader {
+public:
+    ParallelGzipReader(const std::string &path, unsigned threads);
+    ~ParallelGzipReader();
+    bool ok() const { return (f_ || gz_) && !failed_; }
+    // up to n bytes; 0 at the end of the stream (or on error: check ok())
+    size_t read_some(void *dst, size_t n);
+    // exactly n bytes or false (truncated / corrupt)
+    bool read(void *dst, size_t n) { return read_some(dst, n) == n; }
+    bool parallel() const { return f_ != nullptr; }
+private:
+    struct Job { std::vector<uint8_t> in, out; uint32_t crc = 0, isize = 0; std::thread th; bool bad = false; };
+    static void inflate_block(Job *j);
+    bool read_member_header(uint64_t &payload);   // positions f_ at the payload; false at clean EOF or on error
+    void prefetch();
+    FILE *f_ = nullptr;                  // "MK" member mode
+    gzFile gz_ = nullptr;                // generic mode
+    unsigned nthreads_;
+    std::deque<std::unique_ptr<Job>> jobs_;
+    std::vector<uint8_t> cur_;
+    size_t cur_pos_ = 0;
+    bool eof_ = false, failed_ = false;
+};
+
+}  // namespace mkhost

@@ -1,5 +1,7 @@
 #include "index_io.hpp"
 
+#include "gzpar.hpp"
+
 #include <sys/stat.h>
 #include <zlib.h>
 
@@ -47,84 +49,7 @@ struct Header {                  // 39 bytes, little-endian, unpadded (Miekki.cp
 #pragma pack(pop)
 static_assert(sizeof(Header) == 39, "index header layout");
 
-bool gz_read_all(gzFile f, void *p, size_t n)
-{
-    char *c = (char *)p;
-    while (n) {
-        const unsigned chunk = (unsigned)std::min<size_t>(n, 1u << 30);
-        if (gzread(f, c, chunk) != (int)chunk) return false;
-        c += chunk; n -= chunk;
-    }
-    return true;
-}
-
 constexpr uint64_t kChunk = 64ull << 20;
-
-// Ordered multi-threaded gzip writer: blocks are deflated concurrently, each into its
-// own gzip member (level 1, like zstr), and written to the file in submission order.
-class ParallelGzipWriter {
-public:
-    ParallelGzipWriter(const std::string &path, unsigned threads)
-        : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads)) {}
-    ~ParallelGzipWriter() { if (f_) fclose(f_); }
-    bool ok() const { return f_ && !failed_; }
-    void write(const void *p, size_t n)
-    {
-        const uint8_t *c = (const uint8_t *)p;
-        while (n) {
-            const size_t take = std::min(n, kBlock - cur_.size());
-            cur_.insert(cur_.end(), c, c + take);
-            c += take; n -= take;
-            if (cur_.size() == kBlock) submit();
-        }
-    }
-    bool finish()
-    {
-        if (!cur_.empty() || !wrote_any_) submit();            // an empty stream is still one (empty) member
-        while (!jobs_.empty()) drain_one();
-        if (f_) { if (fclose(f_) != 0) failed_ = true; f_ = nullptr; }
-        return !failed_;
-    }
-private:
-    static constexpr size_t kBlock = 32u << 20;
-    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; };
-    static void deflate_block(Job *j)
-    {
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->bad = true; return; }
-        j->out.resize(deflateBound(&zs, j->in.size()) + 64);
-        zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
-        zs.next_out = j->out.data(); zs.avail_out = (uInt)j->out.size();
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
-        j->out.resize(zs.total_out);
-        deflateEnd(&zs);
-        std::vector<uint8_t>().swap(j->in);
-    }
-    void submit()
-    {
-        wrote_any_ = true;
-        std::unique_ptr<Job> j(new Job());
-        j->in.swap(cur_);
-        cur_.reserve(kBlock);
-        Job *raw = j.get();
-        j->th = std::thread(deflate_block, raw);
-        jobs_.push_back(std::move(j));
-        while (jobs_.size() >= nthreads_) drain_one();
-    }
-    void drain_one()
-    {
-        std::unique_ptr<Job> j = std::move(jobs_.front());
-        jobs_.pop_front();
-        j->th.join();
-        if (j->bad || !f_ || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
-    }
-    FILE *f_;
-    unsigned nthreads_;
-    std::vector<uint8_t> cur_;
-    std::deque<std::unique_ptr<Job>> jobs_;
-    bool failed_ = false, wrote_any_ = false;
-};
 
 }  // namespace
 
@@ -163,15 +88,14 @@ int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned 
     return ok ? 0 : -1;
 }
 
-int load_index(const std::string &path, int device, mk_ctx **out, std::string &err)
+int load_index(const std::string &path, int device, mk_ctx **out, std::string &err, unsigned threads)
 {
     *out = nullptr;
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) { err = "cannot open " + path; return -1; }
-    gzbuffer(f, 1 << 20);
+    ParallelGzipReader f(path, threads);
+    if (!f.ok()) { err = "cannot open " + path; return -1; }
     Header hd;
     mk_ctx *ctx = nullptr;
-    bool ok = gz_read_all(f, &hd, sizeof hd);
+    bool ok = f.read(&hd, sizeof hd);
     if (!ok) err = "truncated index header";
     if (ok) {
         mk_params p{hd.kmer_size, hd.h, hd.fp_bits, hd.bloom_log2, hd.threshold, device, 0, 0};
@@ -184,24 +108,23 @@ int load_index(const std::string &path, int device, mk_ctx **out, std::string &e
     std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1));
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
-        ok = gz_read_all(f, buf.data(), (size_t)(pe - pb) * row);
+        ok = f.read(buf.data(), (size_t)(pe - pb) * row);
         if (!ok) { err = "truncated index columns"; break; }
         if (G && mk_index_import_columns(ctx, pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
     }
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
-    if (ok && !(ok = gz_read_all(f, gs.data(), (size_t)G * 8))) err = "truncated genome sizes";
+    if (ok && !(ok = f.read(gs.data(), (size_t)G * 8))) err = "truncated genome sizes";
     const uint64_t nb = ok ? hd.bloom_bits / 8 : 0;
     buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(nb, 1)));
     for (uint64_t o = 0; ok && o < nb; o += kChunk) {
         const uint64_t e = std::min(nb, o + kChunk);
-        ok = gz_read_all(f, buf.data(), (size_t)(e - o));
+        ok = f.read(buf.data(), (size_t)(e - o));
         if (!ok) { err = "truncated Bloom filter"; break; }
         if (mk_index_import_bloom(ctx, o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
     }
-    if (ok && !(ok = gz_read_all(f, ss.data(), (size_t)G * 4))) err = "truncated sketch sizes";
+    if (ok && !(ok = f.read(ss.data(), (size_t)G * 4))) err = "truncated sketch sizes";
     if (ok && G && mk_index_import_sizes(ctx, gs.data(), ss.data()) != MK_OK) { err = mk_last_error(); ok = false; }
-    gzclose(f);
     if (!ok) { mk_destroy(ctx); return -1; }
     *out = ctx;
     return 0;

@@ -11,12 +11,13 @@ namespace mkhost {
 bool file_exists(const std::string &path);
 // whole file; gunzipped when it carries the gzip magic (zstr.hpp:157-167 semantics)
 bool read_text(const std::string &path, std::string &out);
-// dump_disk: gzip level 1 like zstr::ofstream (zstr.hpp:82).  With threads > 1 the
-// stream is cut into 32 MiB blocks compressed concurrently into consecutive gzip
-// members -- the reference's reader restarts its inflator at every member end
-// (zstr.hpp:186-190), as does zlib's gzread, so the file stays loadable by both.
+// dump_disk: gzip level 1 like zstr::ofstream (zstr.hpp:82), as consecutive 32 MiB
+// gzip members compressed by `threads` threads (gzpar.hpp) -- loadable by the
+// reference's reader and by zlib's gzread alike.
 int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned threads = 1);
-// Miekki(const string&): builds a context from the file's own header
-int load_index(const std::string &path, int device, mk_ctx **out, std::string &err);
+// Miekki(const string&): builds a context from the file's own header.  Files written
+// by dump_index are inflated by `threads` threads; the reference's own dumps (and
+// plain, uncompressed streams) load through gzread.
+int load_index(const std::string &path, int device, mk_ctx **out, std::string &err, unsigned threads = 1);
 
 }  // namespace mkhost

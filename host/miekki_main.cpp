@@ -463,7 +463,7 @@ int main(int argc, char **argv)
             return 1;
         }
         string err;
-        if (mkhost::load_index(index_file, device, &drv.ctx, err) != 0) { cout << "Index load failed: " << err << endl; return 1; }
+        if (mkhost::load_index(index_file, device, &drv.ctx, err, reader_threads) != 0) { cout << "Index load failed: " << err << endl; return 1; }
         mk_params p;
         mk_get_params(drv.ctx, &p);
         drv.k = p.k; drv.threshold = p.threshold;          // -k -h -f -b -s come from the file (main.cpp:189-194)

@@ -1,15 +1,17 @@
 """Drop-in check in the other direction: the REAL reference binary loads an index
-file laid out the way our writer lays it out -- the row-P stream cut into 32 MiB
-blocks, each its own gzip member (host/index_io.cpp ParallelGzipWriter) -- and
-answers queries from it exactly as from its own dump.
+file written by OUR writer -- host/gzpar.cpp, the parallel gzip layer of the
+`miekki` binary, exercised here through the stand-alone `mkgz` filter (no GPU
+needed) -- and answers queries from it exactly as from its own dump.
 
-Needs oracle/_ref/Miekki (built from /root/reference by `make -C oracle ref`), so it
-runs in the authoring container and skips elsewhere.  The stream itself comes from
-the oracle, which test_oracle_golden.py pins byte-for-byte to the reference's dump."""
+The reference part needs oracle/_ref/Miekki (built from /root/reference by
+`make -C oracle ref`), so it runs in the authoring container and skips elsewhere.
+The stream itself comes from the oracle, which test_oracle_golden.py pins
+byte-for-byte to the reference's dump."""
 import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import synth
@@ -17,18 +19,51 @@ from oracle import oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "Miekki")
+MKGZ = os.path.join(ROOT, "miekki_amd", "mkgz")
+
+
+def mkgz(args, data=None):
+    r = subprocess.run([MKGZ, *args], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+    return r.stdout
+
+
+@pytest.mark.parametrize("size", [0, 1, 70_000, (32 << 20) - 1, 32 << 20, (96 << 20) + 12345])
+def test_parallel_gzip_round_trips_and_is_plain_gzip(tmp_path, size):
+    rng = np.random.default_rng(size % 1000)
+    data = (rng.integers(0, 4, size, dtype=np.uint8) + 200).tobytes()          # fingerprint-like bytes
+    path = str(tmp_path / "x.gz")
+    mkgz(["c", path, "6"], data)
+    assert mkgz(["d", path, "5"]) == data                                      # our parallel reader
+    assert gzip.decompress(open(path, "rb").read()) == data                    # any gzip reader
+    members = open(path, "rb").read().count(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x04\x03\x0c\x00MK\x08\x00")
+    assert members == max(1, -(-size // (32 << 20)))
+    # and files that are NOT ours go through the generic path: one-member gzip, plain bytes
+    other = str(tmp_path / "y.gz")
+    open(other, "wb").write(gzip.compress(data, 1))
+    assert mkgz(["d", other, "4"]) == data
+    open(other, "wb").write(data)
+    if size >= 2 and data[:2] != b"\x1f\x8b":
+        assert mkgz(["d", other, "4"]) == data
+
+
+def test_corrupt_member_is_detected(tmp_path):
+    data = bytes(range(256)) * 4000
+    path = str(tmp_path / "x.gz")
+    mkgz(["c", path, "2"], data)
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(path, "wb").write(bytes(raw))
+    r = subprocess.run([MKGZ, "d", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="reference build (oracle/_ref) not present")
-def test_reference_loads_multi_member_gzip_index(tmp_path, golden_dir):
+def test_reference_loads_an_index_written_by_our_writer(tmp_path, golden_dir):
     case = synth.CASES["messy"]()
     o = orc.OracleMiekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
     o.insert_sequences(case.genome_sequences())
-    raw = o.serialize().tobytes()
-    block = 32 << 20
-    with open(tmp_path / "idx.gz", "wb") as f:
-        for i in range(0, len(raw), block):
-            f.write(gzip.compress(raw[i:i + block], 1))            # one member per block
+    mkgz(["c", str(tmp_path / "idx.gz"), "8"], o.serialize().tobytes())        # 17 members of 32 MiB
     (tmp_path / "queries.fa").write_bytes(b"".join(h + b"\n" + s + b"\n" for h, s in case.queries))
     r = subprocess.run([REF, "-i", "idx.gz", "-a", "queries.fa", "-o", "out.txt", "-t", "1"], cwd=tmp_path,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
