@@ -372,3 +372,26 @@ def test_parameter_sweep_against_oracle(hip, k, h, fpb, b):
             assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want_h], q
     finally:
         ix.close()
+
+
+def test_slab_schedule_two_byte_fingerprints(hip):
+    """-h 20 with 2-byte fingerprints: the slab schedule's 16-bit partial counters
+    and the selection kernel's u16 path against the oracle."""
+    from oracle import oracle as orc
+    k, h, G = 31, 20, 24
+    seqs = [synth.genome_bases(6000 + g, 0, 150_000) for g in range(G)]
+    o = orc.OracleMiekki(k, h, 16, 33, 30)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 16, 33, 30)
+    try:
+        ix.insert_sequences(seqs)
+        qs = [seqs[q % G][1000 * q:1000 * q + 1000] for q in range(60)] + [synth.genome_bases(77, 0, 1000)]
+        scores = o.query_sequences(qs)
+        hits, act = ix.query(qs, 10, 5, 15.0)                        # short queries only: slab schedule
+        for q, s in enumerate(qs):
+            want = o.filter_results(scores[q], 10, 5, 15.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want], q
+            np.testing.assert_allclose([x.intersection for x in hits[q]], [w[3] for w in want], rtol=RTOL)
+        np.testing.assert_array_equal(ix.query_sequences(qs), scores)  # plain kernel, same scores
+    finally:
+        ix.close()
