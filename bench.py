@@ -144,6 +144,7 @@ def main():
         g_count = [torch.zeros_like(d_count, device=coll_dev) for _ in range(world)]
         g_cand = [torch.zeros_like(d_cand, device=coll_dev) for _ in range(world)]
     nres, min_score, min_inter = 10, 10, 100.0        # query_file's filter_results(.., 10, 10, 0.5*threshold)
+    torch.cuda.synchronize()                          # torch's fills are on its own stream, the library has another
 
     def step():
         L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
