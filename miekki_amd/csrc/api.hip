@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -279,7 +280,12 @@ static uint32_t ntiles_of(const mk_ctx *c)
 // share should fit the 256 MiB Infinity Cache with room to spare (target 128 MiB).
 static uint32_t slab_ranges(const mk_ctx *c)
 {
-    const uint64_t slab = (uint64_t)c->P * kTileBytes, target = 128ull << 20;
+    uint64_t target = 128ull << 20;
+    if (const char *e = getenv("MIEKKI_SLAB_MIB")) {             // tuning knob
+        const long v = atol(e);
+        if (v >= 1 && v <= 4096) target = (uint64_t)v << 20;
+    }
+    const uint64_t slab = (uint64_t)c->P * kTileBytes;
     uint32_t S = 1;
     while (S < 32 && slab / S > target) S <<= 1;
     return S;
