@@ -296,9 +296,14 @@ static uint32_t slab_ranges(const mk_ctx *c)
 // (unsorted) queries, or that fail the check, use the plain schedule.
 static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
 {
-    const uint32_t S = slab_ranges(c);
+    uint32_t S = slab_ranges(c);
     qs->slab_ok = false;
     if (S < 2 || !qs->long_q.empty() || !qs->dense_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
+    // longer queries need more (smaller) ranges to keep every (query, range) within the
+    // packed counters: aim at <= 180 entries per range on average, the device check
+    // below still decides
+    const uint32_t limit = c->W == 1 ? 255u : 65535u;
+    while (S < 64 && (uint64_t)qs->short_max_nk > (uint64_t)S * (limit * 7 / 10)) S <<= 1;
     if (qs->S != S) {
         dev_free(qs->d_split);
         MK_TRY(dev_alloc(&qs->d_split, (uint64_t)qs->nq * (S + 1)));
@@ -306,7 +311,7 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
     }
     if (!c->d_flag) MK_TRY(dev_alloc(&c->d_flag, 1));
     MK_HIP(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
-    MK_TRY(launch_query_split(c, qs, S, c->W == 1 ? 255u : 65535u, c->d_flag));
+    MK_TRY(launch_query_split(c, qs, S, limit, c->d_flag));
     uint32_t flag = 1;
     MK_HIP(hipMemcpyAsync(&flag, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
     MK_HIP(hipStreamSynchronize(c->stream));
