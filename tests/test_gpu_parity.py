@@ -395,3 +395,25 @@ def test_slab_schedule_two_byte_fingerprints(hip):
         np.testing.assert_array_equal(ix.query_sequences(qs), scores)  # plain kernel, same scores
     finally:
         ix.close()
+
+
+def test_slab_schedule_longer_queries(hip):
+    """Queries of 2-4 kb at -h 20: more, smaller partition ranges keep every
+    (query, range) within the 8-bit counters; mixed with 1 kb queries."""
+    from oracle import oracle as orc
+    k, h, G = 31, 20, 16
+    seqs = [synth.genome_bases(6100 + g, 0, 120_000) for g in range(G)]
+    o = orc.OracleMiekki(k, h, 8, 33, 30)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 33, 30)
+    try:
+        ix.insert_sequences(seqs)
+        qs = [seqs[q % G][2000 * q:2000 * q + 2000 + 137 * q] for q in range(15)] + [seqs[3][:4100], seqs[5][500:1500]]
+        scores = o.query_sequences(qs)
+        hits, act = ix.query(qs, 10, 5, 15.0)
+        for q, s in enumerate(qs):
+            assert int(act[q]) == o.query_sequence(s)[1]
+            want = o.filter_results(scores[q], 10, 5, 15.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want], q
+    finally:
+        ix.close()
