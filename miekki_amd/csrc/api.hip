@@ -541,15 +541,20 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
     for (uint32_t g = 0; g < n; ++g)
         if (lens[g] < c->p.k) { set_error("sequence %u shorter than k", g); return MK_ERR_ARG; }
     MK_TRY(ensure_build_scratch(c, 0));
-    for (uint32_t g0 = 0; g0 < n; g0 += c->build_batch) {
-        const uint32_t nb = std::min(c->build_batch, n - g0);
+    for (uint32_t g0 = 0; g0 < n;) {
+        // a batch = up to build_batch genomes and (beyond the first) at most 2 GiB of sequence
         uint64_t off[kBuildBatch + 1];
         off[0] = 0;
-        for (uint32_t g = 0; g < nb; ++g) off[g + 1] = off[g] + lens[g0 + g];
+        uint32_t nb = 0;
+        while (nb < c->build_batch && g0 + nb < n && (nb == 0 || off[nb] + lens[g0 + nb] <= (2ull << 30))) {
+            off[nb + 1] = off[nb] + lens[g0 + nb];
+            ++nb;
+        }
         MK_TRY(ensure_build_scratch(c, off[nb]));
         for (uint32_t g = 0; g < nb; ++g)
             MK_HIP(hipMemcpyAsync(c->d_seq + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice, c->stream));
         MK_TRY(build_batch(c, off, nb));
+        g0 += nb;
     }
     return MK_OK;
 }
@@ -560,8 +565,9 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
     if (length < c->p.k) { set_error("sequence shorter than k"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     MK_TRY(ensure_build_scratch(c, 0));
-    for (uint32_t g0 = 0; g0 < n; g0 += c->build_batch) {
-        const uint32_t nb = std::min(c->build_batch, n - g0);
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->build_batch, (2ull << 30) / length));
+    for (uint32_t g0 = 0; g0 < n; g0 += per) {
+        const uint32_t nb = std::min(per, n - g0);
         uint64_t off[kBuildBatch + 1];
         for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
         MK_TRY(ensure_build_scratch(c, off[nb]));
