@@ -92,14 +92,23 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
                 acc3 += ne_lanes<W>(d[u].w, b);
             }
         }
-        for (; j < m; ++j) {
-            const uint64_t ev = e[j];
-            const uint4 d = load_row16<NT>(row_base(base, (uint32_t)ev, ld) + voff);
-            const uint32_t b = bcast_fp<W>((uint32_t)(ev >> 32));
-            acc0 += ne_lanes<W>(d.x, b);
-            acc1 += ne_lanes<W>(d.y, b);
-            acc2 += ne_lanes<W>(d.z, b);
-            acc3 += ne_lanes<W>(d.w, b);
+        if (j < m) {                                                     // ragged last step: see scan_slab_kernel
+            uint64_t ev[UNROLL];
+            uint4 d[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                d[u] = load_row16<NT>(row_base(base, (uint32_t)ev[u], ld) + voff);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint32_t keep = j + u < m ? 0xffffffffu : 0u;
+                const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
+                acc0 += ne_lanes<W>(d[u].x, b) & keep;
+                acc1 += ne_lanes<W>(d[u].y, b) & keep;
+                acc2 += ne_lanes<W>(d[u].z, b) & keep;
+                acc3 += ne_lanes<W>(d[u].w, b) & keep;
+            }
         }
         const uint32_t acc[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
@@ -222,14 +231,25 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
             acc3 += ne_lanes<W>(d[u].w, b);
         }
     }
-    for (; j < m; ++j) {
-        const uint64_t ev = e[j];
-        const uint4 d = load_row16<false>(row_base(base, (uint32_t)ev, ld) + voff);
-        const uint32_t b = bcast_fp<W>((uint32_t)(ev >> 32));
-        acc0 += ne_lanes<W>(d.x, b);
-        acc1 += ne_lanes<W>(d.y, b);
-        acc2 += ne_lanes<W>(d.z, b);
-        acc3 += ne_lanes<W>(d.w, b);
+    if (j < m) {
+        // ragged last step, still UNROLL loads in flight: the spare slots re-read the
+        // last entry (cached) and are masked out of the sums -- branch-free, so the
+        // tail costs one memory latency instead of one per entry
+        uint64_t ev[UNROLL];
+        uint4 d[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, (uint32_t)ev[u], ld) + voff);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t keep = j + u < m ? 0xffffffffu : 0u;           // wave-uniform
+            const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
+            acc0 += ne_lanes<W>(d[u].x, b) & keep;
+            acc1 += ne_lanes<W>(d[u].y, b) & keep;
+            acc2 += ne_lanes<W>(d[u].z, b) & keep;
+            acc3 += ne_lanes<W>(d[u].w, b) & keep;
+        }
     }
     uint8_t *__restrict__ out = a.partials + ((uint64_t)tr * a.nq + ql) * kTileBytes + voff;
     *reinterpret_cast<uint4 *>(out) = make_uint4(acc0, acc1, acc2, acc3);
