@@ -76,6 +76,28 @@ def library_path() -> str:
     return _LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """Keep ONE HIP runtime in the process.  The PyTorch wheel bundles its own
+    libamdhip64.so (SONAME libamdhip64.so.7) which its libraries request by FILE name,
+    so a system runtime loaded first for us is not reused by a later `import torch`:
+    the process would then hold two runtimes and the second one finds no GPU.  Loading
+    torch's copy first (when torch is installed) makes our library bind to it by
+    SONAME, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                     # fall back to the system runtime
+
+
 def load_library():
     """Load libmiekki_hip.so.  Fails loudly when it has not been built."""
     global _lib
@@ -83,6 +105,7 @@ def load_library():
         if not os.path.exists(_LIB_PATH):
             raise MiekkiHipError(-3, f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                      "or `make -C miekki_amd/csrc lib` (there is no CPU fallback)")
+        _share_torch_hip_runtime()
         lib = C.CDLL(_LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
