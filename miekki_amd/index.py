@@ -10,7 +10,6 @@ import ctypes as C
 import gzip
 import os
 import struct
-import zlib
 from collections import namedtuple
 
 import numpy as np
@@ -281,5 +280,5 @@ def _read_text(path) -> bytes:
     with open(path, "rb") as f:
         data = f.read()
     if data[:2] == b"\x1f\x8b":
-        data = zlib.decompress(data, 15 + 32)
+        data = gzip.decompress(data)          # every member, like zstr (zstr.hpp:186-190)
     return data

@@ -124,3 +124,33 @@ def test_heap_entrants_reproduce_the_full_replay_and_shard_merges():
         for a, b in zip(bounds, bounds[1:]):
             merged += [(a + i, vals[a + i]) for i in _entrants(vals[a:b], nres)]
         assert heap(merged, nres) == full, trial
+
+
+def test_python_host_formatting_reproduces_reference_out_txt(golden_dir):
+    """Host logic without a GPU: Miekki.format_hits (Miekki.cpp:440-444) over the golden
+    hit tuples gives the reference's out.txt byte for byte; _read_text sniffs gzip."""
+    import gzip
+    import numpy as np
+    import synth
+    from miekki_amd.index import Miekki, SimilarityScore, _read_text
+    for name in ("messy", "h20", "w16", "c1"):
+        gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+        case = synth.CASES[name]()
+        off = gold["hits_approx_off"]
+        text = b""
+        for q, (head, _) in enumerate(case.query_sequences()):
+            lo, hi = int(off[q]), int(off[q + 1])
+            hits = [SimilarityScore(int(gold["hits_approx_genome"][i]), int(gold["hits_approx_matches"][i]),
+                                    float(gold["hits_approx_jaccard"][i]), float(gold["hits_approx_inter"][i]))
+                    for i in range(lo, hi)]
+            text += Miekki.format_hits(head, hits)
+        assert text == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read(), name
+
+
+def test_read_text_sniffs_gzip(tmp_path):
+    import gzip
+    from miekki_amd.index import _read_text
+    (tmp_path / "a.fa").write_bytes(b">x\nACGT\n")
+    (tmp_path / "b.fa").write_bytes(gzip.compress(b">x\nACGT\n") + gzip.compress(b"TTTT\n"))   # two members
+    assert _read_text(str(tmp_path / "a.fa")) == b">x\nACGT\n"
+    assert _read_text(str(tmp_path / "b.fa")) == b">x\nACGT\nTTTT\n"
