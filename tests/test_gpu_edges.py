@@ -122,3 +122,30 @@ def test_append_after_import_equals_one_build(hip, tmp_path):
             c.close()
     finally:
         a.close(); b.close()
+
+
+def test_repetitive_sequences_overflow_the_bins_gracefully(hip):
+    """Low-complexity genomes put thousands of identical k-mers into one partition:
+    the binned sketch's fixed slots overflow (overflow list, then the atomic-kernel
+    fallback when even that is full) and the result must not change."""
+    from oracle import oracle as orc
+    k, h = 31, 16
+    seqs = [b"A" * 300_000,                                             # one k-mer, 300k times
+            b"ACGT" * 400_000,                                           # 4 distinct k-mers, 1.6 M positions (> overflow list)
+            (synth.genome_bases(1, 0, 977) * 300)[:250_000],             # period-977 repeat
+            synth.genome_bases(2, 0, 100_000),                           # a normal one in the same batch
+            b"N" * 5000 + synth.genome_bases(3, 0, 50_000) + b"n" * 4000]
+    o = orc.OracleMiekki(k, h, 8, 33, 5)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 33, 5)
+    try:
+        ix.insert_sequences(seqs)
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+        raw = bytearray(stream_of(ix)); want = bytearray(o.serialize().tobytes())
+        raw[32] = want[32] = 0
+        assert bytes(raw) == bytes(want)
+        qs = [b"A" * 500, b"ACGT" * 300, seqs[2][100:1500], seqs[3][5:1005], seqs[4][4990:6000]]
+        np.testing.assert_array_equal(ix.query_sequences(qs), o.query_sequences(qs))
+    finally:
+        ix.close()
