@@ -395,11 +395,11 @@ static int ensure_partials(mk_ctx *c, uint64_t bytes)
     return MK_OK;
 }
 
-static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint8_t *d_partials)
+static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
 {
     SlabArgs a;
     a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c); a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S;
-    a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = d_partials;
+    a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
     c->stats.scan_slab_launches++;
     ScopedTimer t(c, 1);
     return launch_scan_slab(c, a);
@@ -460,11 +460,6 @@ int mk_create(const mk_params *p, mk_ctx **out)
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
-    MK_HIP(hipStreamCreate(&c->stream2));
-    for (int i = 0; i < 2; ++i) {
-        MK_HIP(hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
-        MK_HIP(hipEventCreateWithFlags(&c->ev_sel[i], hipEventDisableTiming));
-    }
     c->bloom_bytes = p->bloom_log2 ? (1ull << p->bloom_log2) / 8 : 0;
     c->bloom_dev_bytes = 0;
     if (p->bloom_log2) {
@@ -493,8 +488,6 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
     dev_free(c->d_flag);
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(c->ev_scan[i]); (void)hipEventDestroy(c->ev_sel[i]); }
-    (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -732,31 +725,14 @@ int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, d
     MK_TRY(qset_sketch(c, qs));
     if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
     if (qs->slab_ok) {
-        // two partial buffers: K6 of chunk i runs on the second stream while the first
-        // one already scans chunk i+1 (K6 is light on bandwidth; serialised it is 2.4 %
-        // of a step)
         const uint32_t per = chunk_queries_slab(c, qs->nq, qs->S);
-        const uint64_t half = (uint64_t)per * partial_bytes_per_query(c, qs->S);
-        const bool two = qs->nq > per;
-        MK_TRY(ensure_partials(c, two ? 2 * half : half));
-        hipStream_t sa = c->stream, sb = c->stream2;
-        uint32_t i = 0;
-        for (uint32_t q0 = 0; q0 < qs->nq; q0 += per, ++i) {
-            const uint32_t q1 = std::min(qs->nq, q0 + per), b = two ? (i & 1u) : 0u;
-            uint8_t *buf = c->d_partials + (uint64_t)b * half;
-            if (i >= 2) MK_HIP(hipStreamWaitEvent(sa, c->ev_sel[b], 0));        // K6 of chunk i-2 is done with this buffer
-            MK_TRY(qset_scan_slab(c, qs, q0, q1, buf));
-            MK_HIP(hipEventRecord(c->ev_scan[b], sa));
-            MK_HIP(hipStreamWaitEvent(sb, c->ev_scan[b], 0));
-            c->stream = sb;                                                     // launchers and timers follow c->stream
-            const int rc = qset_select(c, q1 - q0, nullptr, buf, qs->S, qs->d_nent + q0, nresults, min_score, min_inter,
-                                       cap, d_count + q0, d_cand + (uint64_t)q0 * cap);
-            c->stream = sa;
-            MK_TRY(rc);
-            MK_HIP(hipEventRecord(c->ev_sel[b], sb));
+        MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
+        for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
+            const uint32_t q1 = std::min(qs->nq, q0 + per);
+            MK_TRY(qset_scan_slab(c, qs, q0, q1));
+            MK_TRY(qset_select(c, q1 - q0, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
+                               min_inter, cap, d_count + q0, d_cand + (uint64_t)q0 * cap));
         }
-        for (uint32_t b = 0; b < std::min<uint32_t>(i, 2); ++b)                 // the call completes on the main stream
-            MK_HIP(hipStreamWaitEvent(sa, c->ev_sel[b], 0));
         return MK_OK;
     }
     const uint32_t per = chunk_queries(c, qs->nq);
@@ -911,7 +887,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
         if (on_device) {
             if (slab) {
-                MK_TRY(qset_scan_slab(c, qs, q0, q1, c->d_partials));
+                MK_TRY(qset_scan_slab(c, qs, q0, q1));
                 MK_TRY(qset_select(c, n, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
                                    min_inter, cap, c->d_count, c->d_cand));
             } else {

@@ -46,8 +46,6 @@ struct mk_ctx {
     mk_params p;
     uint32_t P, W, f, empty;
     hipStream_t stream;
-    hipStream_t stream2;           // K6 of chunk i runs here while `stream` scans chunk i+1
-    hipEvent_t ev_scan[2], ev_sel[2];
     // fingerprint matrix, partition-major: row p at d_M + p * ld (bytes); 16-bit values native LE
     uint8_t *d_M;
     uint64_t ld;
