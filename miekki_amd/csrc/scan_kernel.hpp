@@ -169,23 +169,6 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
     scan_item<W, UNROLL, NT>(a, ql, tile, lane);
 }
 
-// Phase-locked sweep: the grid holds only as many waves as the chip keeps resident
-// and every wave walks the tile-major work list with the grid's stride.  All items
-// cost the same (one query's sorted entry list), so the resident waves start item k
-// together and sweep the partitions 0 -> 2^h side by side: the rows they touch at any
-// moment lie in a narrow band of the column slab, which the Infinity Cache holds.
-template <int W, int UNROLL, bool NT = false>
-__global__ __launch_bounds__(256) void scan_sweep_kernel(const ScanArgs a)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t total = a.nq * a.ntiles, stride = gridDim.x * 4u;
-    for (uint32_t work = blockIdx.x * 4u + wave; work < total; work += stride) {
-        const uint32_t tile = work / a.nq, ql = work - tile * a.nq;
-        scan_item<W, UNROLL, NT>(a, ql, tile, lane);
-    }
-}
-
 // ---------------------------------------------------------------- slab schedule
 // The partitions are cut into S equal ranges and a work item is (tile, range,
 // query), ordered tile-major then range-major: the waves in flight share one
