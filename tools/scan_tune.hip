@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256) void lds_kernel(const ScanArgs a)
     for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(tot[k]));
 }
 
+// ---- the box's read-only stream ceiling (SURVEY.md 8d asks for it): every lane sums
+// 16-byte loads over the whole matrix buffer, grid-stride, 8 loads in flight
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16, uint32_t *sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) *sink = acc;                       // keeps the loads live
+}
+
 struct Variant { const char *name; void (*fn)(const ScanArgs); uint32_t blocks_per_cu; uint32_t lane_bytes; };   // blocks_per_cu > 0: sweep grid
 
 #define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>, 0, 16}
@@ -282,6 +300,22 @@ int main(int argc, char **argv)
         const float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
         printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  %7.1f (min)  chk %llu\n", vars[v].name, med, mn,
                algo / med / 1e6, algo / mn / 1e6, (unsigned long long)chk[v]);
+    }
+    {   // read-only stream over the same buffer
+        uint32_t *d_sink; CK(hipMalloc((void **)&d_sink, 4));
+        const uint64_t n16 = (uint64_t)P * ld / 16;
+        std::vector<float> t;
+        for (int r = 0; r < rounds + 1; ++r) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, 0, (const uint4 *)M, n16, d_sink);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  [read-only stream of the %.1f GB matrix]\n", "stream_read",
+               t[t.size() / 2], t[0], (double)P * ld / t[t.size() / 2] / 1e6, (double)P * ld / 1e9);
     }
     std::sort(slab_ms.begin(), slab_ms.end());
     printf("%-14s median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  [S=%u, partials %.1f GB]\n", "slab", slab_ms[slab_ms.size() / 2],
