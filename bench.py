@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+STREAM_READ_GBS = 6249.0     # read-only stream ceiling measured on the box (tools/scan_tune)
 GENOME_LEN = 5_000_000
 QUERY_LEN = 1000
 
@@ -215,7 +216,7 @@ def main():
                        "genomes_per_gpu": G, "genomes_total": G_total, "queries": Q, "h": args.h,
                        "active_partitions_per_query": a_sum / max(Q, 1), "parallelism": "genome-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_stream_read_ceiling": STREAM_READ_GBS,
                          "kernel": "scan_slab_kernel" if st["scan_slab_launches"] else "scan_kernel", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch},
             "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
