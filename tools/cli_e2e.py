@@ -28,7 +28,8 @@ with tempfile.TemporaryDirectory(prefix="mk_e2e_", dir="/tmp") as d:
     for args, tag in ((["-l", "genomes.lst", "-a", "queries.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], "build+query"),
                       (["-l", "genomes.lst", "-d", "idx.gz", "-o", "o2.txt", "-h", "20", "-t", str(T)], "build+dump"),
                       (["-i", "idx.gz", "-a", "queries.fa", "-o", "out_i.txt", "-t", str(T)], "load+query"),
-                      (["-i", "idx.gz", "-A", "genomes.lst", "-o", "outA.txt", "-t", str(T)], "load+whole-genome queries")):
+                      (["-i", "idx.gz", "-A", "genomes.lst", "-o", "outA.txt", "-t", str(T)], "load+whole-genome queries"),
+                      (["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact.txt", "-h", "20", "-t", str(T)], "build+exact mode")):
         t0 = time.time()
         out = subprocess.run([cli, *args], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
         el = re.findall(r"elapsed time: ([0-9.e+-]+)s", out)
@@ -38,3 +39,6 @@ with tempfile.TemporaryDirectory(prefix="mk_e2e_", dir="/tmp") as d:
     print(f"-l and -i outputs identical: {a == b}; top hit = source genome for {ok}/{Q} queries; idx.gz = {os.path.getsize(os.path.join(d, 'idx.gz')) / 1e6:.0f} MB")
     nA = len(open(os.path.join(d, "outA.txt"), "rb").read().splitlines())
     print(f"-A lines: {nA}")
+    ex = open(os.path.join(d, "exact.txt"), "rb").read().splitlines()
+    good = sum(1 for l in ex if float(l.split(b"\t")[2]) >= 900)
+    print(f"exact-mode lines: {len(ex)}; with >= 900 shared k-mers (the source genome): {good}")
