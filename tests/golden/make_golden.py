@@ -159,6 +159,27 @@ def make_case(name):
     print(f"{name}: G={G} nq={nq} stream={len(raw)}B out.txt={len(out_txt)}B exact={len(exact_txt)}B")
 
 
+def make_exact_whole_file(name):
+    """`-l … -A … -e` (query_file_of_file_exact, Miekki.cpp:616-645, 763-788): every
+    genome file of the case as one whole-file query in exact mode."""
+    case = synth.CASES[name]()
+    sfx = "16" if case.fp_bits == 16 else ""
+    cli = os.path.join(REFDIR, "Miekki" + sfx)
+    with tempfile.TemporaryDirectory(prefix="mkgold_") as d:
+        for fn, data, gz in case.genome_files:
+            with open(os.path.join(d, fn), "wb") as f:
+                f.write(gzip.compress(data, 1) if gz else data)
+        with open(os.path.join(d, "genomes.lst"), "wb") as f:
+            f.write(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files))
+        base = ["-k", str(case.k), "-h", str(case.h), "-f", str(case.f), "-b", str(case.b),
+                "-s", str(case.threshold), "-t", "1"]
+        run([cli, "-l", "genomes.lst", "-A", "genomes.lst", "-e", "-o", "exactA.txt", *base], d)
+        txt = open(os.path.join(d, "exactA.txt"), "rb").read()
+    with open(os.path.join(HERE, f"{name}_exactA.txt"), "wb") as f:
+        f.write(txt)
+    print(f"{name}: -A -e output {len(txt)}B, {len(txt.splitlines())} lines")
+
+
 def make_filter_cases():
     """Synthetic filter_results inputs built to hit heap ties and replacement."""
     rng = np.random.default_rng(20261003)
@@ -189,6 +210,11 @@ def make_filter_cases():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(synth.CASES) + ["filter"])
+    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16"])
     for n in names:
-        make_filter_cases() if n == "filter" else make_case(n)
+        if n == "filter":
+            make_filter_cases()
+        elif n.startswith("exactA:"):
+            make_exact_whole_file(n.split(":", 1)[1])
+        else:
+            make_case(n)

@@ -117,3 +117,13 @@ def test_multi_rank_driver_equals_reference(workdirs, golden_dir, name, ranks):
     r = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     assert (d / "out_mgpu.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["messy", "h20", "w16"])
+def test_whole_file_exact_mode_like_the_reference(workdirs, golden_dir, name):
+    """`-l … -A … -e`: query_file_of_file_exact / query_whole_file_exact (Miekki.cpp:616-645, 763-788)."""
+    case, d, base = workdirs(name)
+    run(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA.txt", *base], d)
+    got = (d / "exactA.txt").read_bytes().decode().splitlines()
+    want = open(os.path.join(golden_dir, f"{name}_exactA.txt"), "rb").read().decode().splitlines()
+    assert sorted(got) == sorted(want)
