@@ -36,6 +36,7 @@ def main(argv=None):
     ap.add_argument("-h", type=int, default=17); ap.add_argument("-k", type=int, default=31)
     ap.add_argument("-f", type=int, default=3); ap.add_argument("-b", type=int, default=33)
     ap.add_argument("-s", type=float, default=200.0); ap.add_argument("-t", type=int, default=8)
+    ap.add_argument("-e", action="store_true", help="exact mode: real intersection computed on hits (Miekki.cpp:723-759)")
     ap.add_argument("--cap", type=int, default=128)
     ap.add_argument("--rehearse", action="store_true")
     ap.add_argument("--help", action="help")
@@ -56,7 +57,7 @@ def main(argv=None):
     # ---- build: contiguous slice of the list per rank (Miekki.cpp:540-588 semantics per file)
     files = [f.decode() for f in _read_text(args.l).split(b"\n") if len(f) > 3]
     f0, f1 = mkd.shard_range(len(files), rank, world)
-    seqs = []
+    seqs, my_files = [], []
     for fn in files[f0:f1]:
         if not os.path.exists(fn):
             print(f"Missed file: {fn}", flush=True)
@@ -64,6 +65,7 @@ def main(argv=None):
         ref = b"".join(l for l in _read_text(fn).split(b"\n") if not l.startswith(b">"))
         if len(ref) >= args.k:
             seqs.append(ref)
+            my_files.append(fn)
     kept = torch.tensor([len(seqs)], dtype=torch.int64, device=coll)
     if world > 1:
         all_kept = [torch.zeros_like(kept) for _ in range(world)]
@@ -86,6 +88,9 @@ def main(argv=None):
     recs = [(lines[i], lines[i + 1] if i + 1 < len(lines) else b"") for i in range(0, len(lines), 2)]
     recs = [(h, s) for h, s in recs if len(s) >= args.k]
     nres, min_score, min_inter, cap = 10, 10, 0.5 * int(args.s), args.cap
+    if args.e:                                                   # query_file_exact: filter_results(.., 5, 10, threshold)
+        recs = [(h, s) for h, s in recs if s[:1] in (b"A", b"C", b"G", b"T", b"N")]
+        nres, min_inter = 5, float(int(args.s))
     out = open(args.o, "wb") if rank == 0 else None
     for b0 in range(0, len(recs), 16384):
         chunk = recs[b0:b0 + 16384]
@@ -142,8 +147,46 @@ def main(argv=None):
                 else:
                     row = [SimilarityScore(int(h["genome"]), int(h["matches"]), float(h["jaccard"]), float(h["intersection"]))
                            for h in hits[q]]
-                text.append(Miekki.format_hits(head, row))
-            out.write(b"".join(text))
+                if args.e:
+                    text.append(row)
+                else:
+                    text.append(Miekki.format_hits(head, row))
+            if not args.e:
+                out.write(b"".join(text))
+        if args.e:
+            # K7 on the rank that owns the genome: rank 0 hands every owner its (genome, queries)
+            # work list, the owners answer with (inter, union) per query, rank 0 prints
+            # ground_truth_batch's lines (Miekki.cpp:843-855)
+            work = [dict() for _ in range(world)]
+            if rank == 0:
+                bases = [0]
+                for t in (all_kept if world > 1 else [kept]):
+                    bases.append(bases[-1] + int(t.item()))
+                for q, row in enumerate(text):
+                    for h in row:
+                        owner = max(r for r in range(world) if bases[r] <= h.genome)
+                        work[owner].setdefault(h.genome - bases[owner], []).append((q, h.jaccard, h.intersection))
+            if world > 1:
+                mine = [None]
+                dist.scatter_object_list(mine, work if rank == 0 else None, src=0)
+                mine = mine[0]
+            else:
+                mine = work[0]
+            answers = []
+            for g_local, items in sorted(mine.items()):
+                inter, uni = ix.ground_truth_batch([chunk[q][1] for q, _, _ in items], _read_text(my_files[g_local]))
+                for (q, jac, est), ni, nu in zip(items, inter, uni):
+                    if ni > 0:
+                        answers.append((q, int(ni) / int(nu), jac, int(ni), est, my_files[g_local]))
+            gathered = [None] * world
+            if world > 1:
+                dist.gather_object(answers, gathered if rank == 0 else None, dst=0)
+            else:
+                gathered = [answers]
+            if rank == 0:
+                for part in gathered:
+                    for q, real, jac, ni, est, fn in part:
+                        out.write(("%g\t%g\t%g\t%g\t%s\t%s\n" % (real, jac, ni, est, chunk[q][0].decode(), fn)).encode())
     if out:
         out.close()
     ix.close()
