@@ -31,7 +31,7 @@ from .index import Miekki, SimilarityScore, _read_text
 
 def main(argv=None):
     ap = argparse.ArgumentParser(add_help=False)
-    ap.add_argument("-l", required=True); ap.add_argument("-a", required=True)
+    ap.add_argument("-l", required=True); ap.add_argument("-a"); ap.add_argument("-A")
     ap.add_argument("-o", default="out.txt")
     ap.add_argument("-h", type=int, default=17); ap.add_argument("-k", type=int, default=31)
     ap.add_argument("-f", type=int, default=3); ap.add_argument("-b", type=int, default=33)
@@ -84,16 +84,32 @@ def main(argv=None):
         print(f"Reference indexed: {total}", flush=True)
 
     # ---- query: every rank scans all records against its shard (Miekki.cpp:426-483)
-    lines = _read_text(args.a).split(b"\n")
-    recs = [(lines[i], lines[i + 1] if i + 1 < len(lines) else b"") for i in range(0, len(lines), 2)]
-    recs = [(h, s) for h, s in recs if len(s) >= args.k]
+    if args.a:
+        lines = _read_text(args.a).split(b"\n")
+        recs = [(lines[i], lines[i + 1] if i + 1 < len(lines) else b"") for i in range(0, len(lines), 2)]
+        recs = [(h, s) for h, s in recs if len(s) >= args.k]
+    elif args.A:                                                 # whole files as queries (Miekki.cpp:592-612, 487-514)
+        recs = []
+        for fn in [f.decode() for f in _read_text(args.A).split(b"\n") if len(f) > 3]:
+            if not os.path.exists(fn):
+                if rank == 0:
+                    print("File problem", flush=True)
+                continue
+            ref = b"".join(l for l in _read_text(fn).split(b"\n") if not l.startswith(b">"))
+            if len(ref) >= args.k:
+                recs.append((fn.encode(), ref))
+    else:
+        raise SystemExit("No query file, No queries")
     nres, min_score, min_inter, cap = 10, 10, 0.5 * int(args.s), args.cap
+    if args.e and args.A:
+        raise SystemExit("-A -e is not implemented in the multi-GPU driver")
     if args.e:                                                   # query_file_exact: filter_results(.., 5, 10, threshold)
         recs = [(h, s) for h, s in recs if s[:1] in (b"A", b"C", b"G", b"T", b"N")]
         nres, min_inter = 5, float(int(args.s))
     out = open(args.o, "wb") if rank == 0 else None
-    for b0 in range(0, len(recs), 16384):
-        chunk = recs[b0:b0 + 16384]
+    step = 64 if args.A else 16384
+    for b0 in range(0, len(recs), step):
+        chunk = recs[b0:b0 + step]
         nq = len(chunk)
         ptrs, lens = L.seq_arrays([s for _, s in chunk])
         qs = C.c_void_p()
@@ -149,6 +165,8 @@ def main(argv=None):
                            for h in hits[q]]
                 if args.e:
                     text.append(row)
+                elif args.A:                                     # a line only when there are hits (Miekki.cpp:506-511)
+                    text.append(Miekki.format_hits(head, row) if row else b"")
                 else:
                     text.append(Miekki.format_hits(head, row))
             if not args.e:

@@ -148,3 +148,22 @@ def test_multi_rank_driver_exact_mode(workdirs, golden_dir):
     got = (d / "exact_mgpu.txt").read_bytes().decode().splitlines()
     want = open(os.path.join(golden_dir, f"{name}_exact.txt"), "rb").read().decode().splitlines()
     assert sorted(got) == sorted(want)
+
+
+def test_multi_rank_driver_whole_file_queries(workdirs, golden_dir):
+    """miekki_amd.mgpu -A: whole genome files as (dense) queries against genome shards."""
+    import socket
+    import sys
+    name, ranks = "w16", 2
+    case, d, base = workdirs(name)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "miekki_amd.mgpu",
+           "-l", "genomes.lst", "-A", "qfiles.lst", "-o", "outA_mgpu.txt", "-k", str(case.k), "-h", str(case.h),
+           "-f", str(case.f), "-b", str(case.b), "-s", str(case.threshold), "--rehearse"]
+    r = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    assert (d / "outA_mgpu.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
