@@ -1,4 +1,4 @@
-"""Multi-GPU `miekki -l … -a … -o …`: genome-sharded index, one gather of top hits.
+"""Multi-GPU `miekki -l … (-a | -A) … [-e] -o …`: genome-sharded index, one gather of top hits.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         -m miekki_amd.mgpu -l genomes.txt -a queries.fa -o out.txt -h 20
