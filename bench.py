@@ -141,22 +141,37 @@ def main():
     cap = args.cap
     d_count = torch.zeros(Q, dtype=torch.int32, device="cuda")
     d_cand = torch.zeros(Q * cap * 24, dtype=torch.uint8, device="cuda")
+    from miekki_amd import distributed as mkd
+    g_rows = None
     if world > 1 and rank == 0:
-        g_count = [torch.zeros_like(d_count, device=coll_dev) for _ in range(world)]
-        g_cand = [torch.zeros_like(d_cand, device=coll_dev) for _ in range(world)]
+        g_rows = (torch.zeros((world, Q), dtype=torch.int32, device=coll_dev),
+                  torch.zeros((world, Q * cap * 24), dtype=torch.uint8, device=coll_dev))
     nres, min_score, min_inter = 10, 10, 100.0        # query_file's filter_results(.., 10, 10, 0.5*threshold)
+    d_hits = torch.zeros((Q, nres * 24), dtype=torch.uint8, device="cuda")      # the step's product, on rank 0
+    d_nhits = torch.zeros(Q, dtype=torch.int32, device="cuda")
+    merge_s = [0.0]
     torch.cuda.synchronize()                          # torch's fills are on its own stream, the library has another
 
     def step():
         L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, min_inter, cap, d_count.data_ptr(), d_cand.data_ptr()))
         L.check(lib.mk_sync(ix._h))
-        if world > 1:                                 # the one exchange step: top candidates -> rank 0
-            dist.gather(d_count.to(coll_dev), g_count if rank == 0 else None, dst=0)
-            dist.gather(d_cand.to(coll_dev), g_cand if rank == 0 else None, dst=0)
+        rows_c, rows_d = d_count, d_cand
+        if world > 1:                                 # the one exchange step: heap entrants -> rank 0
+            rows_c, rows_d = mkd.gather_rows(d_count.to(coll_dev), d_cand.to(coll_dev), out=g_rows)
+        if rank == 0:                                 # filter_results' heap over the rows in shard order (K6b)
+            t_m = time.perf_counter()
+            if args.rehearse and world > 1:
+                rows_c, rows_d = rows_c.cuda(), rows_d.cuda()
+            torch.cuda.current_stream().synchronize() # the gather ran on torch's streams, the merge on the library's
+            L.check(lib.mk_merge_entrants(ix._h, rows_c.data_ptr(), rows_d.data_ptr(), world, Q, cap, nres,
+                                          d_hits.data_ptr(), d_nhits.data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            merge_s[0] += time.perf_counter() - t_m
 
     for _ in range(args.warmup):
         step()
     ix.reset_stats()
+    merge_s[0] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -172,17 +187,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    merged_ok = None
-    if rank == 0:                                     # rank-0 merge with the reference heap, checked on a sample
-        from miekki_amd import distributed as mkd
+    merged_ok = host_heap_ok = n_over = None
+    if rank == 0:                                     # the step's hits, checked on a sample
         ns = min(Q, 2000)
-        src_count = g_count if world > 1 else [d_count]
-        src_cand = g_cand if world > 1 else [d_cand]
-        counts = torch.stack(src_count).cpu().numpy()[:, :ns]
-        cands = torch.stack([c.view(Q, cap * 24)[:ns] for c in src_cand]).cpu().numpy()
-        hits, overflow = mkd.merge_candidates(counts, cands.reshape(world, -1), cap, 10)
-        # query q was cut from genome q mod G_total: it must come out on top (when rank 0..N-1 hold it)
-        merged_ok = sum(1 for q, hrow in enumerate(hits) if len(hrow) and int(hrow[0]["genome"]) == q % G_total)
+        nh = d_nhits.cpu().numpy().view(np.uint32)
+        n_over = int((nh == mkd.MERGE_OVERFLOW).sum())
+        hits_dev = d_hits[:ns].cpu().numpy().view(mkd.HIT_DTYPE).reshape(ns, nres)
+        # query q was cut from genome q mod G_total: it must come out on top
+        merged_ok = sum(1 for q in range(ns) if 0 < nh[q] <= nres and int(hits_dev[q, 0]["genome"]) == q % G_total)
+        # and the device heap must be the host's std:: heap over the same rows
+        src_count = g_rows[0] if world > 1 else d_count.view(1, Q)
+        src_cand = g_rows[1] if world > 1 else d_cand.view(1, -1)
+        counts = src_count.cpu().numpy()[:, :ns]
+        cands = src_cand.view(world, Q, cap * 24)[:, :ns].cpu().numpy()
+        hits, overflow = mkd.merge_candidates(counts, cands.reshape(world, -1), cap, nres)
+        host_heap_ok = sum(1 for q in range(ns) if overflow[q] or
+                           (nh[q] == len(hits[q]) and hits_dev[q, :nh[q]].tobytes() == hits[q].tobytes()))
     st = ix.stats()
     active = np.zeros(Q, np.uint32)
     L.check(lib.mk_qset_active(ix._h, qs, active.ctypes.data))
@@ -227,7 +247,10 @@ def main():
                        "index_sketches_per_s_per_gpu": G / build_s,
                        "index_kmers_per_s": world * bst["build_kmers"] / build_s_max,
                        "build_sketch_ms": bst["build_sketch_ms"], "build_finalize_ms": bst["build_finalize_ms"]},
-            "check": {"queries_with_candidates_on_rank0": n_hit, "top_hit_is_source_genome_of_first_2000": merged_ok},
+            "merge": {"kernel": "merge_kernel", "ms_per_step": merge_s[0] / args.steps * 1e3, "overflowed_queries": n_over,
+                      "note": "rank 0: stream hand-over + filter_results heap over the (gathered) entrant rows, inside the timed step"},
+            "check": {"queries_with_candidates_on_rank0": n_hit, "top_hit_is_source_genome_of_first_2000": merged_ok,
+                      "device_heap_equals_host_heap_of_first_2000": host_heap_ok},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.h, os.cpu_count() or 1)

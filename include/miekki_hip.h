@@ -136,6 +136,17 @@ int mk_query(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_
  * mk_query and by the multi-GPU merge on rank 0. */
 uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresults, mk_hit *out);
 
+/* The same heap on the device, for whole batches: d_count[world][nq] and
+ * d_cand[world][nq][cap] are the entrant rows of `world` genome shards in shard
+ * order (world = 1: what mk_qset_run wrote; world > 1: the gathered rows on rank
+ * 0).  Writes d_hits[nq][nresults] and d_nhits[nq]; a query for which some shard's
+ * count exceeds `cap` gets d_nhits = MK_MERGE_OVERFLOW and no hits (answer it
+ * again from a dense score row).  nresults <= 64.  All pointers are device
+ * memory; asynchronous on the context's stream. */
+#define MK_MERGE_OVERFLOW 0xffffffffu
+int mk_merge_entrants(mk_ctx *ctx, const uint32_t *d_count, const mk_hit *d_cand, uint32_t world,
+                      uint32_t nq, uint32_t cap, uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits);
+
 /* ---- device-resident query sets (bench / multi-GPU path) ------------------- */
 
 typedef struct mk_qset mk_qset;

@@ -455,6 +455,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
+    c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -483,6 +484,7 @@ void mk_destroy(mk_ctx *c)
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
+    dev_free(c->d_hits); dev_free(c->d_nhits);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
@@ -823,6 +825,16 @@ uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresu
     return (uint32_t)heap.size();
 }
 
+int mk_merge_entrants(mk_ctx *c, const uint32_t *d_count, const mk_hit *d_cand, uint32_t world, uint32_t nq,
+                      uint32_t cap, uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits)
+{
+    if (!c || (nq && (!d_count || !d_cand || !d_nhits || (nresults && !d_hits)))) { set_error("null argument"); return MK_ERR_ARG; }
+    if (!world || !cap) { set_error("world and cap must be positive"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MergeArgs ma{d_count, d_cand, world, nq, cap, nresults, d_hits, d_nhits};
+    return launch_merge(c, ma);
+}
+
 int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t nresults,
              uint32_t min_score, double min_inter, mk_hit *hits, uint32_t *nhits, uint32_t *active)
 {
@@ -881,8 +893,15 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         MK_TRY(dev_alloc(&c->d_cand, (uint64_t)per * cap));
         c->cand_cap_q = per;
     }
-    std::vector<uint32_t> cnt(per), row(c->G);
-    std::vector<mk_hit> cand((size_t)per * cap), full;
+    if (on_device && (uint64_t)per * std::max(nresults, 1u) > c->hits_cap) {
+        dev_free(c->d_hits); dev_free(c->d_nhits);
+        c->hits_cap = 0;
+        MK_TRY(dev_alloc(&c->d_hits, (uint64_t)per * std::max(nresults, 1u)));
+        MK_TRY(dev_alloc(&c->d_nhits, (uint64_t)per));
+        c->hits_cap = (uint64_t)per * std::max(nresults, 1u);
+    }
+    std::vector<uint32_t> row(c->G);
+    std::vector<mk_hit> full;
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
         if (on_device) {
@@ -895,17 +914,18 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
                 MK_TRY(qset_select(c, n, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
                                    c->d_count, c->d_cand));
             }
-            MK_HIP(hipMemcpyAsync(cnt.data(), c->d_count, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            MK_HIP(hipMemcpyAsync(cand.data(), c->d_cand, (size_t)n * cap * sizeof(mk_hit), hipMemcpyDeviceToHost,
-                                  c->stream));
+            // the heap over the entrants runs on the device too (K6b): only the hits come back
+            MergeArgs ma{c->d_count, c->d_cand, 1, n, cap, nresults, c->d_hits, c->d_nhits};
+            MK_TRY(launch_merge(c, ma));
+            MK_HIP(hipMemcpyAsync(nhits + q0, c->d_nhits, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (nresults)
+                MK_HIP(hipMemcpyAsync(hits + (size_t)q0 * nresults, c->d_hits, (size_t)n * nresults * sizeof(mk_hit),
+                                      hipMemcpyDeviceToHost, c->stream));
         }
         MK_HIP(hipStreamSynchronize(c->stream));
         for (uint32_t i = 0; i < n; ++i) {
             mk_hit *out = hits + (size_t)(q0 + i) * nresults;
-            if (on_device && cnt[i] <= cap) {
-                nhits[q0 + i] = mk_filter_candidates(cand.data() + (size_t)i * cap, cnt[i], nresults, out);
-                continue;
-            }
+            if (on_device && nhits[q0 + i] != kMergeOverflow) continue;
             // more heap entrants than the device row holds (or a top-N beyond the device
             // selection): replay this query over a dense score row of its own
             uint32_t *d_row = d_replay_row;

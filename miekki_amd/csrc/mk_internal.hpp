@@ -76,6 +76,9 @@ struct mk_ctx {
     uint32_t *d_count;
     mk_hit *d_cand;
     uint64_t cand_cap_q;           // queries d_count / d_cand are sized for
+    mk_hit *d_hits;                // [queries per chunk][nresults]: K6b output of mk_query
+    uint32_t *d_nhits;
+    uint64_t hits_cap;             // records d_hits is sized for
     uint64_t *d_long_table;        // P keys, long-query path
     // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
     uint64_t *d_slots;
@@ -211,6 +214,17 @@ struct SelectArgs {
 };
 constexpr uint32_t kSelectMaxResults = 64;   // top-N sizes the device selection supports
 int launch_select(mk_ctx *c, const SelectArgs &a);
+
+// ---- merge.hip (K6b): filter_results' heap over the entrant rows of `world` shards
+constexpr uint32_t kMergeOverflow = 0xffffffffu;   // nhits value of a query some shard's row overflowed for
+struct MergeArgs {
+    const uint32_t *count;         // [world][nq]
+    const mk_hit *cand;            // [world][nq][cap]
+    uint32_t world, nq, cap, nresults;
+    mk_hit *hits;                  // [nq][nresults]
+    uint32_t *nhits;               // [nq]
+};
+int launch_merge(mk_ctx *c, const MergeArgs &a);
 
 // ---- exact.hip
 int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,

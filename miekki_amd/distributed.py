@@ -32,21 +32,31 @@ def shard_range(n_genomes: int, rank: int, world: int):
     return g0, g0 + base + (1 if rank < rem else 0)
 
 
-def gather_candidates(count: torch.Tensor, cand: torch.Tensor, dst: int = 0, group=None):
+def gather_rows(count: torch.Tensor, cand: torch.Tensor, dst: int = 0, group=None, out=None):
     """The single exchange step.  count: int32 [nq]; cand: uint8 [nq*cap*24].
-    Returns (counts [world, nq], cands [world, nq*cap*24]) on dst, (None, None) elsewhere."""
+    Returns tensors (counts [world, nq], cands [world, nq*cap*24]) on dst -- on the device
+    the inputs live on, rank-major, i.e. the layout mk_merge_entrants takes -- and
+    (None, None) elsewhere.  `out` = a (counts, cands) pair to receive into (reused by
+    bench.py from step to step)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    gc = gd = big_c = big_d = None
     if rank == dst:
-        gc = [torch.empty_like(count) for _ in range(world)]
-        gd = [torch.empty_like(cand) for _ in range(world)]
-    else:
-        gc = gd = None
+        big_c, big_d = out if out is not None else (count.new_empty((world, count.numel())),
+                                                    cand.new_empty((world, cand.numel())))
+        gc = [big_c[r] for r in range(world)]
+        gd = [big_d[r] for r in range(world)]
     dist.gather(count, gc, dst=dst, group=group)
     dist.gather(cand, gd, dst=dst, group=group)
-    if rank != dst:
+    return big_c, big_d
+
+
+def gather_candidates(count: torch.Tensor, cand: torch.Tensor, dst: int = 0, group=None):
+    """gather_rows, as numpy arrays on the host (the CPU-side merge and the tests)."""
+    gc, gd = gather_rows(count, cand, dst, group)
+    if gc is None:
         return None, None
-    return torch.stack(gc).cpu().numpy(), torch.stack(gd).cpu().numpy()
+    return gc.cpu().numpy(), gd.cpu().numpy()
 
 
 def merge_candidates(counts: np.ndarray, cands: np.ndarray, cap: int, nresults: int):
@@ -70,6 +80,26 @@ def merge_candidates(counts: np.ndarray, cands: np.ndarray, cap: int, nresults: 
         k = lib.mk_filter_candidates(buf.ctypes.data_as(C.c_void_p), n, nresults, res.ctypes.data_as(C.c_void_p))
         out.append(res[:k].copy())
     return out, overflow
+
+
+MERGE_OVERFLOW = 0xFFFFFFFF
+
+
+def merge_on_device(ix, counts: torch.Tensor, cands: torch.Tensor, cap: int, nresults: int):
+    """Rank-0 merge on the GPU (K6b, mk_merge_entrants): counts int32 [world, nq] and cands
+    uint8 [world, nq*cap*24] are the gathered rows, resident on this rank's GPU.  Returns
+    device tensors (hits uint8 [nq, nresults*24], nhits int32 [nq]); nhits == -1
+    (MK_MERGE_OVERFLOW) marks a query some shard overflowed for.  The caller must have
+    ordered the producers of counts/cands before the library's stream (e.g.
+    torch.cuda.current_stream().synchronize())."""
+    lib = L.load_library()
+    world, nq = counts.shape
+    assert counts.is_cuda and cands.is_cuda and counts.is_contiguous() and cands.is_contiguous()
+    hits = torch.empty((nq, max(nresults, 1) * HIT_BYTES), dtype=torch.uint8, device=counts.device)
+    nhits = torch.empty(nq, dtype=torch.int32, device=counts.device)
+    L.check(lib.mk_merge_entrants(ix._h, counts.data_ptr(), cands.data_ptr(), world, nq, cap, nresults,
+                                  hits.data_ptr(), nhits.data_ptr()))
+    return hits, nhits
 
 
 def merge_bloom_first_writer(local: np.ndarray, device=None, group=None) -> np.ndarray:

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mk_query_scores": (i32, [vp, vp, vp, u32, vp]),
     "mk_query": (i32, [vp, vp, vp, u32, u32, u32, C.c_double, vp, vp, vp]),
     "mk_filter_candidates": (u32, [vp, u32, u32, vp]),
+    "mk_merge_entrants": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
     "mk_qset_upload": (i32, [vp, vp, vp, u32, PP(vp)]),
     "mk_qset_synthetic": (i32, [vp, u64, u32, u64, u64, u64, PP(vp)]),
     "mk_qset_free": (None, [vp, vp]),

@@ -120,14 +120,22 @@ def main(argv=None):
         L.check(lib.mk_sync(ix._h))
         lib.mk_qset_free(ix._h, qs)
         if world > 1:                                            # the one exchange step
-            counts, cands = mkd.gather_candidates(d_count.to(coll), d_cand.to(coll))
+            counts, cands = mkd.gather_rows(d_count.to(coll), d_cand.to(coll))
         else:
-            counts, cands = d_count.cpu().numpy()[None], d_cand.cpu().numpy()[None]
-        # rows that overflowed on some shard: every rank answers them again with its
+            counts, cands = d_count.view(1, -1), d_cand.view(1, -1)
+        # rank 0: filter_results' heap over the rows in shard order, on the GPU (K6b).
+        # Rows that overflowed on some shard: every rank answers them again with its
         # complete (not just entrant) candidate list, gathered as objects
         over = None
         if rank == 0:
-            over = np.flatnonzero((counts > cap).any(axis=0)).tolist()
+            if not counts.is_cuda:
+                counts, cands = counts.cuda(), cands.cuda()
+            torch.cuda.current_stream().synchronize()
+            d_hits, d_nh = mkd.merge_on_device(ix, counts.contiguous(), cands.contiguous(), cap, nres)
+            L.check(lib.mk_sync(ix._h))
+            nh = d_nh.cpu().numpy().view(np.uint32)
+            hits = d_hits.cpu().numpy().view(mkd.HIT_DTYPE).reshape(nq, max(nres, 1))
+            over = np.flatnonzero(nh == mkd.MERGE_OVERFLOW).tolist()
         if world > 1:
             box = [over]
             dist.broadcast_object_list(box, src=0)
@@ -152,7 +160,6 @@ def main(argv=None):
                 for q in over:
                     full[q] = [c for part in gathered for c in part[q]]
         if rank == 0:
-            hits, _ = mkd.merge_candidates(counts, cands.reshape(world, -1), cap, nres)
             text = []
             for q, (head, _) in enumerate(chunk):
                 if q in full:
@@ -162,7 +169,7 @@ def main(argv=None):
                     row = [SimilarityScore(res[i].genome, res[i].matches, res[i].jaccard, res[i].intersection) for i in range(n)]
                 else:
                     row = [SimilarityScore(int(h["genome"]), int(h["matches"]), float(h["jaccard"]), float(h["intersection"]))
-                           for h in hits[q]]
+                           for h in hits[q, :nh[q]]]
                 if args.e:
                     text.append(row)
                 elif args.A:                                     # a line only when there are hits (Miekki.cpp:506-511)

@@ -417,3 +417,47 @@ def test_slab_schedule_longer_queries(hip):
             assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want], q
     finally:
         ix.close()
+
+
+def test_device_heap_merge_is_the_host_heap(hip):
+    """K6b (mk_merge_entrants) against the host's own std::push_heap/pop_heap/sort_heap
+    (mk_filter_candidates) on rows full of ties: random shard counts, few distinct
+    intersection values, several nresults incl. 0, 1 and 64, infinities, overflowed rows."""
+    import ctypes as C
+    import torch
+    from miekki_amd import distributed as mkd
+    from miekki_amd import lib as L
+    lib = L.load_library()
+    ix = hip.Miekki(21, 9, 8, 32, 0)
+    rng = np.random.default_rng(11)
+    try:
+        for world, nq, cap, nres in ((1, 700, 32, 10), (3, 500, 16, 5), (8, 300, 24, 64), (2, 200, 8, 1),
+                                     (4, 100, 8, 0), (5, 400, 40, 2), (2, 300, 12, 33)):
+            counts = rng.integers(0, cap + 1, (world, nq)).astype(np.int32)
+            over = rng.random(nq) < 0.03
+            counts[rng.integers(0, world, nq)[over], np.flatnonzero(over)] = cap + 1 + rng.integers(0, 5)
+            cands = np.zeros((world, nq, cap), mkd.HIT_DTYPE)
+            span = rng.choice([2, 4, 30, 1000], nq)
+            cands["intersection"] = rng.integers(0, span[None, :, None], (world, nq, cap)).astype(np.float64)
+            cands["intersection"][rng.random((world, nq, cap)) < 0.01] = np.inf
+            cands["genome"] = (np.arange(world)[:, None, None] * cap + np.arange(cap)[None, None, :]) + 1000 * np.arange(nq)[None, :, None]
+            cands["matches"] = rng.integers(0, 500, (world, nq, cap))
+            cands["jaccard"] = rng.random((world, nq, cap))
+            d_counts = torch.from_numpy(counts).cuda()
+            d_cands = torch.from_numpy(cands.view(np.uint8).reshape(world, -1)).cuda()
+            torch.cuda.synchronize()
+            hits, nhits = mkd.merge_on_device(ix, d_counts, d_cands, cap, nres)
+            L.check(lib.mk_sync(ix._h))
+            nhits = nhits.cpu().numpy().view(np.uint32)
+            hits = hits.cpu().numpy().reshape(nq, -1).view(mkd.HIT_DTYPE)
+            for q in range(nq):
+                if (counts[:, q] > cap).any():
+                    assert nhits[q] == mkd.MERGE_OVERFLOW
+                    continue
+                row = np.concatenate([cands[r, q, :counts[r, q]] for r in range(world)])
+                want = np.zeros(max(nres, 1), mkd.HIT_DTYPE)
+                n = lib.mk_filter_candidates(row.ctypes.data_as(C.c_void_p), len(row), nres, want.ctypes.data_as(C.c_void_p))
+                assert nhits[q] == n, (world, nres, q)
+                assert hits[q, :n].tobytes() == want[:n].tobytes(), (world, nres, q)
+    finally:
+        ix.close()
