@@ -1,0 +1,64 @@
+// Ingest pipeline of the host driver: `threads` readers (the reference's -t) read,
+// gunzip and parse the listed FASTA files ahead of the consumer, which still receives
+// them strictly in list order -- so genome ids and output order stay those of the
+// reference at -t 1 (Miekki.cpp:546-581) while the host side keeps up with the device.
+//
+// A sequence is what Miekki.cpp:559-567 builds: every line that does not start with
+// '>' appended to one string.  It is written straight into a buffer from a pool whose
+// memory comes from the caller's allocator -- the driver passes mk_host_alloc, i.e.
+// pinned memory, so that mk_index_append's copy to the GPU is one DMA per genome with
+// no staging copy on the host.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mkhost {
+
+struct HostAllocator {
+    void *(*alloc)(void *user, size_t bytes);     // nullptr: malloc / free
+    void (*release)(void *user, void *p);
+    void *user;
+};
+
+// all non-'>' lines of text[0..n) concatenated into dst (room for n bytes); getline semantics
+size_t strip_fasta(const char *text, size_t n, char *dst);
+
+// whole file into `out`, gunzipped when it starts with the gzip magic (any number of members)
+bool read_file(const std::string &path, std::vector<char> &out, std::vector<char> &scratch);
+
+class OrderedFastaReader {
+public:
+    struct Item {
+        bool exists = false;
+        char *data = nullptr;      // pooled buffer: hand it back with recycle()
+        size_t len = 0, cap = 0;
+    };
+    // window = how many files may be parsed ahead of the consumer (each holds one buffer)
+    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window);
+    ~OrderedFastaReader();
+    // blocks until file i (called with i = 0, 1, 2, ...) has been read
+    Item take(size_t i);
+    void recycle(Item &it);
+private:
+    void work();
+    char *pool_get(size_t need, size_t &cap);
+    std::vector<std::string> files_;
+    std::vector<Item> items_;
+    std::vector<std::atomic<int>> ready_;
+    std::vector<std::thread> workers_;
+    std::atomic<size_t> next_{0};
+    size_t consumed_ = 0, window_ = 8, ahead_bytes_ = 0;
+    static constexpr size_t kAheadBytes = 4ull << 30;
+    std::mutex m_;
+    std::condition_variable cv_;
+    HostAllocator a_;
+    std::mutex pool_m_;
+    std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
+};
+
+}  // namespace mkhost

@@ -30,6 +30,7 @@
 #include <thread>
 #include <vector>
 
+#include "fasta_reader.hpp"
 #include "index_io.hpp"
 #include "miekki_hip.h"
 
@@ -93,75 +94,14 @@ bool nucleotide_start(const string &s)           // Miekki.cpp:736, 771
     return !s.empty() && (s[0] == 'A' || s[0] == 'C' || s[0] == 'G' || s[0] == 'T' || s[0] == 'N');
 }
 
-// Ingest pipeline: `threads` readers (the reference's -t) decompress and parse the
-// listed FASTA files ahead of the consumer, which still receives them strictly in
-// list order -- so genome ids and output order stay those of the reference at -t 1
-// while the host side keeps up with the device.
-class OrderedFastaReader {
-public:
-    struct Item { bool exists = false; string seq; };   // seq: all non-'>' lines concatenated (Miekki.cpp:563-566)
-    OrderedFastaReader(vector<string> files, unsigned threads)
-        : files_(std::move(files)), items_(files_.size()), ready_(files_.size())
-    {
-        for (auto &r : ready_) r.store(0);
-        const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
-        window_ = 2 * n + 8;
-        for (unsigned t = 0; t < n; ++t) workers_.emplace_back([this] { work(); });
-    }
-    ~OrderedFastaReader()
-    {
-        { std::lock_guard<std::mutex> g(m_); consumed_ = files_.size() + window_; }
-        cv_.notify_all();
-        for (auto &w : workers_) w.join();
-    }
-    // blocks until file i (called with i = 0, 1, 2, ...) has been read; the item is moved out
-    Item take(size_t i)
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return ready_[i].load() != 0; });
-        Item it = std::move(items_[i]);
-        consumed_ = i + 1;
-        lk.unlock();
-        cv_.notify_all();
-        return it;
-    }
-private:
-    void work()
-    {
-        for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= files_.size()) return;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return i < consumed_ + window_; });      // bounded read-ahead
-            }
-            Item it;
-            it.exists = mkhost::file_exists(files_[i]);
-            if (it.exists) {
-                string text;
-                mkhost::read_text(files_[i], text);
-                it.seq.reserve(text.size());
-                size_t pos = 0;
-                while (pos <= text.size()) {                                // getline semantics
-                    size_t e = text.find('\n', pos);
-                    if (e == string::npos) e = text.size();
-                    if (e == pos || text[pos] != '>') it.seq.append(text, pos, e - pos);
-                    pos = e + 1;
-                }
-            }
-            { std::lock_guard<std::mutex> g(m_); items_[i] = std::move(it); ready_[i].store(1); }
-            cv_.notify_all();
-        }
-    }
-    vector<string> files_;
-    vector<Item> items_;
-    vector<std::atomic<int>> ready_;
-    vector<std::thread> workers_;
-    std::atomic<size_t> next_{0};
-    size_t consumed_ = 0, window_ = 8;
-    std::mutex m_;
-    std::condition_variable cv_;
-};
+using mkhost::OrderedFastaReader;
+
+void *pinned_alloc(void *ctx, size_t bytes)
+{
+    void *p = nullptr;
+    return mk_host_alloc((mk_ctx *)ctx, bytes, &p) == MK_OK ? p : nullptr;
+}
+void pinned_free(void *ctx, void *p) { mk_host_free((mk_ctx *)ctx, p); }
 
 struct Driver {
     mk_ctx *ctx = nullptr;
@@ -176,35 +116,49 @@ struct Driver {
         if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
         string text;
         mkhost::read_text(list, text);
-        vector<string> seqs, names;
+        vector<OrderedFastaReader::Item> seqs;
+        vector<string> names;
         uint64_t bytes = 0;
+        vector<string> files;
+        for (const string &fn : split_lines(text))
+            if (fn.size() > 3) files.push_back(fn);
+        // readers parse into pinned buffers, three device batches ahead; the append of one
+        // batch returns as soon as its copy is done, so parsing, copying and sketching overlap
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64);
+        double t_append = 0, t_wait = 0;                           // where the host thread spends its time
+        auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto flush = [&]() {
             if (seqs.empty()) return;
             vector<const char *> p;
             vector<uint64_t> l;
-            for (auto &s : seqs) { p.push_back(s.data()); l.push_back(s.size()); }
+            for (auto &s : seqs) { p.push_back(s.data); l.push_back(s.len); }
+            const double t0 = now();
             if (mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size()) != MK_OK) die("index build failed");
+            t_append += now() - t0;
             file_names.insert(file_names.end(), names.begin(), names.end());
+            for (auto &s : seqs) reader.recycle(s);
             seqs.clear(); names.clear(); bytes = 0;
         };
-        vector<string> files;
-        for (const string &fn : split_lines(text))
-            if (fn.size() > 3) files.push_back(fn);
-        OrderedFastaReader reader(files, threads);
+        string marks;
         for (size_t i = 0; i < files.size(); ++i) {
             const string &fn = files[i];
+            const double t0 = now();
             OrderedFastaReader::Item item = reader.take(i);
-            if (!item.exists) { cout << "Missed file: " << fn << endl; continue; }
-            string ref = std::move(item.seq);
-            if (ref.size() >= k) {
-                bytes += ref.size();
-                seqs.push_back(std::move(ref)); names.push_back(fn);
-                if (seqs.size() >= 64 || bytes > (1ull << 30)) flush();
-                cout << "-" << flush_stream();
+            t_wait += now() - t0;
+            if (!item.exists) { cout << marks << "Missed file: " << fn << endl; marks.clear(); reader.recycle(item); continue; }
+            if (item.len >= k) {
+                bytes += item.len;
+                seqs.push_back(item); names.push_back(fn);
+                if (seqs.size() >= 64 || bytes > (1ull << 30)) { flush(); cout << marks << flush_stream(); marks.clear(); }
+                marks += '-';
+            } else {
+                reader.recycle(item);
             }
         }
         flush();
-        cout << endl;
+        cout << marks << endl;
+        if (getenv("MIEKKI_VERBOSE"))
+            cout << "[ingest] waited for the readers " << t_wait << "s, in mk_index_append " << t_append << "s" << endl;
         cout << "Reference indexed: " << mk_index_size(ctx) << endl;
         mk_params p;
         mk_get_params(ctx, &p);
@@ -285,7 +239,7 @@ struct Driver {
         vector<string> files;
         for (const string &fn : split_lines(text))
             if (fn.size() > 3) files.push_back(fn);
-        OrderedFastaReader reader(files, threads);
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{nullptr, nullptr, nullptr}, 2 * 32);
         // whole files are queried in batches so that the dense kernel can take four per
         // pass over the matrix; output stays in list order
         vector<string> names, refs;
@@ -307,7 +261,8 @@ struct Driver {
             if (!item.exists) {
                 cout << "File problem" << endl;
             } else {
-                string ref = std::move(item.seq);
+                string ref(item.data ? item.data : "", item.len);
+                reader.recycle(item);
                 if (ref.size() >= k) {
                     bytes += ref.size();
                     names.push_back(files[i]); refs.push_back(std::move(ref));

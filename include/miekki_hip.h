@@ -93,8 +93,19 @@ int mk_reset_stats(mk_ctx *ctx);
 
 /* Miekki::insert_sequences (Miekki.cpp:277-314; called from index_file_of_file,
  * Miekki.cpp:572,580).  Genome ids follow call order.  Sequences shorter than k
- * are rejected with MK_ERR_ARG (the driver filters them, Miekki.cpp:569). */
+ * are rejected with MK_ERR_ARG (the driver filters them, Miekki.cpp:569).
+ * Pipelined: the sequences are copied to the GPU while the kernels of the previous
+ * call still run; the call returns when the copy is done (seqs may be reused) and
+ * leaves this batch's kernels in flight.  Every other entry point first settles
+ * the batch in flight, so results are always those of a synchronous build. */
 int mk_index_append(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t n);
+
+/* Page-locked host memory for sequences handed to mk_index_append / mk_qset_upload:
+ * from such buffers the copy to the GPU is a direct DMA (no staging copy on the
+ * host) and runs beside the kernels.  Ordinary memory works too, only slower.
+ * Thread-safe. */
+int mk_host_alloc(mk_ctx *ctx, uint64_t bytes, void **out);
+void mk_host_free(mk_ctx *ctx, void *p);
 
 /* Same, for the synthetic genomes of SURVEY.md 8d generated on the device
  * (ids first_id .. first_id+n-1, `length` bases each): no PCIe traffic. */

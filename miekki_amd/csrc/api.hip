@@ -81,9 +81,15 @@ struct ScopedTimer {
     ~ScopedTimer() { if (on) (void)timer_end(c, t); }
 };
 
-static int use_device(const mk_ctx *c)
+static int settle_build(mk_ctx *c);
+
+// Every entry point starts here: bind the device and, unless the caller is an append
+// that wants to overlap with it, fold the build batch still in flight into the index.
+static int use_device(const mk_ctx *cc, bool settle = true)
 {
-    MK_HIP(hipSetDevice(c->p.device));
+    MK_HIP(hipSetDevice(cc->p.device));
+    mk_ctx *c = const_cast<mk_ctx *>(cc);
+    if (settle && c->build.on) MK_TRY(settle_build(c));
     return MK_OK;
 }
 
@@ -116,7 +122,7 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
 }
 
 // ---- index build ---------------------------------------------------------------
-static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes)
+static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
 {
     if (!c->d_tables) {
         const uint64_t budget = 1ull << 30;                       // table bytes per batch
@@ -131,11 +137,13 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes)
         }
     }
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-    if (seq_bytes > c->seq_cap) {
-        dev_free(c->d_seq);
-        const uint64_t cap = std::max<uint64_t>(seq_bytes, c->seq_cap * 2);
-        MK_TRY(dev_alloc(&c->d_seq, cap + 64));
-        c->seq_cap = cap;
+    if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
+    if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
+        dev_free(c->d_seq[buf]);
+        c->seq_cap[buf] = 0;
+        const uint64_t cap = std::max<uint64_t>(seq_bytes, std::max(c->seq_cap[buf ^ 1], c->seq_cap[buf] * 2));
+        MK_TRY(dev_alloc(&c->d_seq[buf], cap + 64));
+        c->seq_cap[buf] = cap;
     }
     return MK_OK;
 }
@@ -151,33 +159,67 @@ static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t
     return (uint64_t)est;
 }
 
-// sequences already in c->d_seq at offsets h_off[0..n]
-static int build_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n)
+// Kernels of one batch: sequences already on their way into c->d_seq[buf] at offsets
+// h_off[0..n] (the caller has ordered the stream behind that copy).  Nothing here waits
+// for the device; the results are read back into pinned memory and folded in by
+// settle_build.
+static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
 {
     MK_TRY(ensure_capacity(c, c->G + n));
-    MK_HIP(hipMemcpyAsync(c->d_seq_off, h_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    MK_TRY(launch_seed_valid(c, c->d_seq, c->d_seq_off, n, c->d_seed_valid));
+    mk_ctx::BuildInFlight &b = c->build;
+    b.n = n; b.buf = buf; b.binned = false;
+    memcpy(b.off, h_off, (size_t)(n + 1) * 8);
+    const char *d_seq = c->d_seq[buf];
+    MK_HIP(hipMemcpyAsync(c->d_seq_off, b.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MK_TRY(launch_seed_valid(c, d_seq, c->d_seq_off, n, c->d_seed_valid));
     {
         ScopedTimer t(c, 3);
-        bool binned = false;
-        MK_TRY(launch_genome_sketch_binned(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables, &binned));
-        if (!binned)
-            MK_TRY(launch_genome_sketch(c, c->d_seq, c->d_seq_off, h_off, c->d_seed_valid, n, c->d_tables));
+        MK_TRY(launch_genome_sketch_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables, &b.binned));
+        if (!b.binned)
+            MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables));
     }
+    const uint32_t *d_abort = b.binned ? c->d_ovf_count : nullptr;
     {
         ScopedTimer t(c, 4);
-        MK_TRY(launch_finalize(c, c->d_tables, n, c->G));
-        MK_TRY(launch_bloom_insert(c, c->d_tables, c->d_seq, c->d_seq_off, c->d_seed_valid, n));
+        MK_TRY(launch_finalize(c, c->d_tables, n, c->G, d_abort));
+        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, d_abort));
+    }
+    c->h_back->ovf = 0;
+    MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(c->h_back->card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (b.binned) MK_HIP(hipMemcpyAsync(&c->h_back->ovf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
+    b.on = true;
+    return MK_OK;
+}
+
+// Wait for the batch in flight and fold it into the index (Miekki.cpp:303-311).
+static int settle_build(mk_ctx *c)
+{
+    mk_ctx::BuildInFlight &b = c->build;
+    if (!b.on) return MK_OK;
+    b.on = false;
+    MK_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t n = b.n;
+    if (b.binned && binned_overflowed(c->h_back->ovf)) {
+        // the overflow list of the binned sketch ran over (very repetitive sequence): the
+        // batch's later kernels saw the same mark and did nothing; redo it with the atomic kernel
+        const char *d_seq = c->d_seq[b.buf];
+        { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
+        {
+            ScopedTimer t(c, 4);
+            MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
+            MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr));
+        }
+        MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipMemcpyAsync(c->h_back->card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
     }
     uint32_t act[kBuildBatch];
-    uint64_t card[kBuildBatch];
-    MK_HIP(hipMemcpyAsync(act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipMemcpyAsync(card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
     uint64_t gsz[kBuildBatch];
     for (uint32_t g = 0; g < n; ++g) {
-        const uint64_t len = h_off[g + 1] - h_off[g];
-        gsz[g] = estimate_genome_size(act[g], card[g], len);
+        const uint64_t len = b.off[g + 1] - b.off[g];
+        act[g] = c->h_back->act[g];
+        gsz[g] = estimate_genome_size(act[g], c->h_back->card[g], len);
         c->h_sketch_size.push_back(act[g]);
         c->h_genome_size.push_back(gsz[g]);
         c->stats.build_kmers += len > c->p.k ? len - c->p.k : 0;
@@ -452,7 +494,10 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
-    c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_seq = nullptr; c->seq_cap = 0;
+    c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr;
+    c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
+    c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
+    memset(&c->build, 0, sizeof c->build);
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
     c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0;
@@ -461,6 +506,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
+    MK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    MK_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     c->bloom_bytes = p->bloom_log2 ? (1ull << p->bloom_log2) / 8 : 0;
     c->bloom_dev_bytes = 0;
     if (p->bloom_log2) {
@@ -486,10 +533,13 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
-    dev_free(c->d_seed_valid); dev_free(c->d_seq); dev_free(c->d_seq_off); dev_free(c->d_scores);
+    dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
     dev_free(c->d_flag);
+    if (c->h_back) (void)hipHostFree(c->h_back);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -501,7 +551,12 @@ int mk_reserve(mk_ctx *c, uint32_t n)
     return ensure_capacity(c, n);
 }
 
-uint32_t mk_index_size(const mk_ctx *c) { return c ? c->G : 0; }
+uint32_t mk_index_size(const mk_ctx *c)
+{
+    if (!c) return 0;
+    if (c->build.on) (void)use_device(c);                        // count the batch still in flight
+    return c->G;
+}
 
 int mk_get_params(const mk_ctx *c, mk_params *out)
 {
@@ -539,10 +594,10 @@ int mk_reset_stats(mk_ctx *c)
 int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t n)
 {
     if (!c || (n && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
-    MK_TRY(use_device(c));
+    MK_TRY(use_device(c, false));
     for (uint32_t g = 0; g < n; ++g)
         if (lens[g] < c->p.k) { set_error("sequence %u shorter than k", g); return MK_ERR_ARG; }
-    MK_TRY(ensure_build_scratch(c, 0));
+    MK_TRY(ensure_build_scratch(c, 0, c->seq_cur ^ 1));
     for (uint32_t g0 = 0; g0 < n;) {
         // a batch = up to build_batch genomes and (beyond the first) at most 2 GiB of sequence
         uint64_t off[kBuildBatch + 1];
@@ -552,29 +607,59 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
             off[nb + 1] = off[nb] + lens[g0 + nb];
             ++nb;
         }
-        MK_TRY(ensure_build_scratch(c, off[nb]));
+        // The copy goes into the buffer the batch in flight does NOT use, on its own stream,
+        // so that it overlaps with that batch's kernels; then that batch is settled and this
+        // one's kernels are queued behind the copy.  The call returns once the copy has
+        // finished -- the caller's buffers are free again -- not when the kernels have.
+        const int buf = c->seq_cur ^ 1;
+        MK_TRY(ensure_build_scratch(c, off[nb], buf));
         for (uint32_t g = 0; g < nb; ++g)
-            MK_HIP(hipMemcpyAsync(c->d_seq + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice, c->stream));
-        MK_TRY(build_batch(c, off, nb));
+            MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice,
+                                  c->copy_stream));
+        MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
+        MK_TRY(settle_build(c));
+        MK_HIP(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        MK_TRY(enqueue_batch(c, off, nb, buf));
+        c->seq_cur = buf;
+        MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
     }
     return MK_OK;
+}
+
+int mk_host_alloc(mk_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = nullptr;
+    MK_TRY(use_device(c, false));
+    MK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MK_OK;
+}
+
+void mk_host_free(mk_ctx *c, void *p)
+{
+    if (!c || !p) return;
+    (void)hipSetDevice(c->p.device);
+    (void)hipHostFree(p);
 }
 
 int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
     if (length < c->p.k) { set_error("sequence shorter than k"); return MK_ERR_ARG; }
-    MK_TRY(use_device(c));
-    MK_TRY(ensure_build_scratch(c, 0));
+    MK_TRY(use_device(c, false));
+    MK_TRY(ensure_build_scratch(c, 0, c->seq_cur ^ 1));
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->build_batch, (2ull << 30) / length));
     for (uint32_t g0 = 0; g0 < n; g0 += per) {
         const uint32_t nb = std::min(per, n - g0);
         uint64_t off[kBuildBatch + 1];
         for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
-        MK_TRY(ensure_build_scratch(c, off[nb]));
-        MK_TRY(launch_synth_genomes(c, first_id + g0, nb, length, c->d_seq));
-        MK_TRY(build_batch(c, off, nb));
+        const int buf = c->seq_cur ^ 1;
+        MK_TRY(ensure_build_scratch(c, off[nb], buf));
+        MK_TRY(settle_build(c));
+        MK_TRY(launch_synth_genomes(c, first_id + g0, nb, length, c->d_seq[buf]));
+        MK_TRY(enqueue_batch(c, off, nb, buf));
+        c->seq_cur = buf;
     }
     return MK_OK;
 }

@@ -64,9 +64,28 @@ struct mk_ctx {
     uint32_t *d_active;            // per batch genome: non-empty partitions
     uint64_t *d_cardsum;           // per batch genome: sum of 2^(31-exp)
     uint32_t *d_seed_valid;
-    char *d_seq;                   // batch sequences, concatenated
-    uint64_t seq_cap;
+    // batch sequences, concatenated.  Two buffers: while the kernels of one batch run out
+    // of one, the next batch is copied into the other on copy_stream (mk_index_append)
+    char *d_seq[2];
+    uint64_t seq_cap[2];
+    int seq_cur;                   // buffer of the batch enqueued last
     uint64_t *d_seq_off;           // kBuildBatch + 1
+    hipStream_t copy_stream;
+    hipEvent_t ev_copy;
+    // The batch whose kernels are enqueued but whose results (active counts, cardinality
+    // sums, overflow mark) the host has not folded into the index yet.  Every entry point
+    // other than the appends settles it first (settle_build in api.hip).
+    struct BuildInFlight {
+        bool on, binned;
+        uint32_t n;
+        int buf;
+        uint64_t off[mk::kBuildBatch + 1];
+    } build;
+    struct BuildReadback {         // pinned, so that the copy back does not block the host
+        uint32_t act[mk::kBuildBatch];
+        uint64_t card[mk::kBuildBatch];
+        uint32_t ovf;
+    } *h_back;
     // query scratch
     uint32_t *d_scores;            // score matrix of the query chunk in flight
     uint64_t scores_cap;
@@ -131,9 +150,11 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
 // not fit the binned path (the caller then takes the atomic kernel above)
 int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
                                 const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used);
-int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0);
+// d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
+int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
+bool binned_overflowed(uint32_t ovf_count);
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n);
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
 int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q

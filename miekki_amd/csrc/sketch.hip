@@ -365,14 +365,15 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
                        c->P);
     MK_HIP(hipGetLastError());
-    // a full overflow list would lose items: detect it and let the caller redo the batch
-    uint32_t novf = 0;
-    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
-    if (novf > kOvfCap) return MK_OK;                              // *used stays false
+    // A full overflow list would lose items.  Nothing waits for that here: the later
+    // kernels of the batch look at *d_ovf_count themselves and do nothing if it ran over,
+    // and the host, which reads the count back with the batch's results, then redoes the
+    // batch with the atomic kernel (binned_overflowed).
     *used = true;
     return MK_OK;
 }
+
+bool binned_overflowed(uint32_t ovf_count) { return ovf_count > kOvfCap; }
 
 // ---------------------------------------------------------------- K2 finalize
 // tables[n][P] -> M[p][g0 .. g0+n) (transposed through LDS), plus per-genome
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t *__restric
                                                        uint32_t g0, uint8_t *__restrict__ M, uint64_t ld,
                                                        uint32_t *__restrict__ active,
                                                        unsigned long long *__restrict__ cardsum,
-                                                       SketchParams sp)
+                                                       const uint32_t *__restrict__ ovf_count, SketchParams sp)
 {
+    if (ovf_count && *ovf_count > kOvfCap) return;      // the binned sketch lost items: the host redoes the batch
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
     __shared__ fp_t tile[kFinRows][kBuildBatch + 2];
     __shared__ uint32_t s_act[kBuildBatch];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t *__restric
     }
 }
 
-int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0)
+int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort)
 {
     if (!n) return MK_OK;
     MK_HIP(hipMemsetAsync(c->d_active, 0, kBuildBatch * sizeof(uint32_t), c->stream));
@@ -451,10 +453,10 @@ int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0
     const uint32_t blocks = (c->P + per_block - 1) / per_block;
     if (c->W == 1)
         hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
-                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, make_sp(c));
+                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, d_abort, make_sp(c));
     else
         hipLaunchKernelGGL(finalize_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
-                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, make_sp(c));
+                           c->ld, c->d_active, (unsigned long long *)c->d_cardsum, d_abort, make_sp(c));
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
@@ -471,8 +473,9 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
                                                     const uint64_t *__restrict__ off,
                                                     const uint32_t *__restrict__ valid, uint8_t *bloom,
                                                     uint64_t bloom_dev_bytes, uint64_t *order,
-                                                    SketchParams sp)
+                                                    const uint32_t *__restrict__ ovf_count, SketchParams sp)
 {
+    if (ovf_count && *ovf_count > kOvfCap) return;      // see finalize_kernel
     const uint32_t g = blockIdx.y;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= sp.P) return;
@@ -513,14 +516,14 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
 }
 
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n)
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort)
 {
     if (!n || !c->d_bloom) return MK_OK;
     dim3 grid((c->P + 255) / 256, n);
     hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, make_sp(c));
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, make_sp(c));
     hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, make_sp(c));
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, make_sp(c));
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mk_get_stats": (i32, [vp, PP(Stats)]),
     "mk_reset_stats": (i32, [vp]),
     "mk_index_append": (i32, [vp, vp, vp, u32]),
+    "mk_host_alloc": (i32, [vp, u64, PP(vp)]),
+    "mk_host_free": (None, [vp, vp]),
     "mk_index_append_synthetic": (i32, [vp, u64, u32, u64]),
     "mk_index_export_columns": (i32, [vp, u32, u32, vp]),
     "mk_index_export_sizes": (i32, [vp, vp, vp]),

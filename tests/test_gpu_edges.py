@@ -149,3 +149,46 @@ def test_repetitive_sequences_overflow_the_bins_gracefully(hip):
         np.testing.assert_array_equal(ix.query_sequences(qs), o.query_sequences(qs))
     finally:
         ix.close()
+
+
+def test_pipelined_appends_from_pinned_buffers(hip):
+    """mk_index_append returns once its copy is done and leaves the kernels in flight: the
+    caller may overwrite its buffers at once, and back-to-back appends (two alternating
+    device buffers, batches of different sizes, a >64-genome call) must give the index of
+    one synchronous build.  Buffers come from mk_host_alloc (pinned: the copy is a DMA)."""
+    from miekki_amd import lib as L
+    lib = L.load_library()
+    k, h = 25, 12
+    seqs = [synth.genome_bases(900 + i, 0, 20_000 + 997 * (i % 7)) for i in range(150)]
+    ref = hip.Miekki(k, h, 8, 33, 20)
+    ix = hip.Miekki(k, h, 8, 33, 20)
+    try:
+        ref.insert_sequences(seqs)
+        want = stream_of(ref)
+        cap = max(len(s) for s in seqs)
+        slots = []
+        for _ in range(70):
+            p = C.c_void_p()
+            L.check(lib.mk_host_alloc(ix._h, cap, C.byref(p)))
+            slots.append(p)
+        pos = 0
+        for n in (3, 64, 1, 70, 12):                                       # 150 genomes; 70 > one device batch
+            ptrs = (C.c_char_p * n)()
+            lens = (C.c_uint64 * n)()
+            for j in range(n):
+                s = seqs[pos + j]
+                C.memmove(slots[j], s, len(s))
+                ptrs[j] = C.cast(slots[j], C.c_char_p)
+                lens[j] = len(s)
+            L.check(lib.mk_index_append(ix._h, ptrs, lens, n))
+            for j in range(n):                                             # the buffers are ours again
+                C.memset(slots[j], ord("T"), cap)
+            pos += n
+        assert ix.index_size == 150
+        assert stream_of(ix) == want
+        q = [seqs[5][100:1100], seqs[149][:900]]
+        np.testing.assert_array_equal(ix.query_sequences(q), ref.query_sequences(q))
+        for p in slots:
+            lib.mk_host_free(ix._h, p)
+    finally:
+        ref.close(); ix.close()

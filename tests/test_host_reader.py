@@ -1,0 +1,87 @@
+"""Host ingest (host/fasta_reader.cpp): ordered parallel FASTA reading with pooled buffers.
+
+The sequence of a file is what Miekki.cpp:559-567 builds with getline: every line not
+starting with '>' appended to one string.  Checked against a Python statement of that on
+plain, gzip, multi-member gzip, CRLF, unterminated, empty and missing files, for several
+thread counts and read-ahead windows (order must be list order for every -t).
+"""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for c in b:
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def reference_sequence(text: bytes) -> bytes:
+    return b"".join(l for l in text.split(b"\n") if not l.startswith(b">"))
+
+
+@pytest.fixture(scope="module")
+def dumper(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("rd") / "reader_dump")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "helpers", "reader_dump.cpp"),
+                    os.path.join(ROOT, "host", "fasta_reader.cpp"), "-lz", "-lpthread"], check=True)
+    return exe
+
+
+def test_reader_matches_getline_semantics(dumper, tmp_path):
+    rng = np.random.default_rng(5)
+
+    def bases(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), n))
+
+    texts = []
+    for i in range(40):
+        n = int(rng.integers(0, 30000))
+        body = bases(n)
+        w = int(rng.choice([60, 80, 1000000]))
+        lines = [b">seq%d some description" % i] + [body[j:j + w] for j in range(0, len(body), w)]
+        if i % 5 == 0:
+            lines.insert(len(lines) // 2, b">contig2")                  # multi-FASTA: concatenated
+        t = (b"\r\n" if i % 7 == 3 else b"\n").join(lines)
+        if i % 3:
+            t += b"\n"                                                  # else: unterminated last line
+        texts.append(t)
+    texts += [b"", b"\n\n", b">only a header\n", b"ACGT", b">h\n\n\nAC\n\nGT\n"]
+    names, want = [], []
+    for i, t in enumerate(texts):
+        fn = str(tmp_path / f"f{i}.fa")
+        if i % 4 == 1:
+            fn += ".gz"
+            with gzip.open(fn, "wb") as f:
+                f.write(t)
+        elif i % 4 == 2:                                                # two gzip members back to back
+            fn += ".gz"
+            cut = len(t) // 2
+            with open(fn, "wb") as f:
+                f.write(gzip.compress(t[:cut]) + gzip.compress(t[cut:]))
+        else:
+            with open(fn, "wb") as f:
+                f.write(t)
+        names.append(fn)
+        want.append(reference_sequence(t))
+        if i % 9 == 4:
+            names.append(str(tmp_path / f"missing{i}.fa"))
+            want.append(None)
+    lst = str(tmp_path / "list.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(names) + "\n")
+    for threads, window in ((1, 1), (3, 2), (8, 64)):
+        out = subprocess.run([dumper, lst, str(threads), str(window)], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
+        for i, w in enumerate(want):
+            ex, ln, h = out[i].split()
+            if w is None:
+                assert ex == "0", i
+            else:
+                assert (ex, int(ln), int(h, 16)) == ("1", len(w), fnv1a(w)), (i, names[i], threads)
