@@ -21,7 +21,9 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -31,6 +33,8 @@
 #include <vector>
 
 #include "fasta_reader.hpp"
+#include <zlib.h>
+
 #include "index_io.hpp"
 #include "miekki_hip.h"
 
@@ -203,29 +207,81 @@ struct Driver {
         }
     }
 
+    // 2-line records streamed from a (possibly gzipped) file: the reference reads a query
+    // file record by record too (Miekki.cpp:458-464), so its size never has to fit in memory
+    class RecordStream {
+    public:
+        explicit RecordStream(const string &path) : f_(gzopen(path.c_str(), "rb")), buf_(4u << 20)
+        {
+            if (f_) gzbuffer(f_, 1u << 20);
+        }
+        ~RecordStream() { if (f_) gzclose(f_); }
+        // up to `want` records with at least k bases (shorter ones are dropped, 465-468); false at the end
+        bool next(size_t want, uint32_t k, vector<string> &heads, vector<string> &seqs)
+        {
+            heads.clear(); seqs.clear();
+            string head, ref;
+            while (seqs.size() < want && !done_) {
+                const bool got_head = getline(head);
+                const bool got_ref = getline(ref);
+                if (!got_head && !got_ref) break;
+                if (ref.size() >= k) { heads.push_back(std::move(head)); seqs.push_back(std::move(ref)); }
+                head.clear(); ref.clear();
+            }
+            return !seqs.empty();
+        }
+    private:
+        bool getline(string &out)                  // std::getline: false only when nothing was left
+        {
+            out.clear();
+            bool any = false;
+            for (;;) {
+                if (pos_ == len_) {
+                    if (done_ || !f_) { done_ = true; return any; }
+                    const int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+                    if (n <= 0) { done_ = true; return any; }
+                    pos_ = 0; len_ = (size_t)n;
+                }
+                any = true;
+                const char *p = buf_.data() + pos_;
+                const char *e = (const char *)memchr(p, '\n', len_ - pos_);
+                if (e) { out.append(p, (size_t)(e - p)); pos_ += (size_t)(e - p) + 1; return true; }
+                out.append(p, len_ - pos_);
+                pos_ = len_;
+            }
+        }
+        gzFile f_;
+        vector<char> buf_;
+        size_t pos_ = 0, len_ = 0;
+        bool done_ = false;
+    };
+
     // ---- Miekki.cpp:426-483
     void query_file(const string &path)
     {
         if (!mkhost::file_exists(path)) { cout << "File problem" << endl; return; }
-        vector<string> heads, seqs;
-        read_records(path, heads, seqs);
-        vector<size_t> kept;
-        for (size_t i = 0; i < seqs.size(); ++i)
-            if (seqs[i].size() >= k) kept.push_back(i);
+        RecordStream in(path);
         const size_t super = 16384;
+        vector<string> heads, seqs, next_heads, next_seqs;
         vector<mk_hit> hits;
         vector<uint32_t> nhits;
-        for (size_t b = 0; b < kept.size(); b += super) {
-            const size_t e = min(kept.size(), b + super);
+        size_t done = 0;
+        bool more = in.next(super, k, heads, seqs);
+        while (more) {
+            // the next super-batch is read and split while the device works on this one
+            auto ahead = std::async(std::launch::async, [&] { return in.next(super, k, next_heads, next_seqs); });
             vector<const string *> q;
-            for (size_t i = b; i < e; ++i) q.push_back(&seqs[kept[i]]);
+            for (auto &r : seqs) q.push_back(&r);
             run_query(q, 10, 10, 0.5 * threshold, hits, nhits);
             string text;
-            for (size_t i = b; i < e; ++i) {
-                text += heads[kept[i]] + ":" + hit_text(hits.data() + (i - b) * 10, nhits[i - b]) + "\n";
-                if ((i % 201) == 0) cout << "-" << flush_stream();      // one mark per reference batch (345)
+            for (size_t i = 0; i < seqs.size(); ++i) {
+                text += heads[i] + ":" + hit_text(hits.data() + i * 10, nhits[i]) + "\n";
+                if (((done + i) % 201) == 0) cout << "-" << flush_stream();   // one mark per reference batch (345)
             }
             out << text;
+            done += seqs.size();
+            more = ahead.get();
+            heads.swap(next_heads); seqs.swap(next_seqs);
         }
         out << flush;
     }
