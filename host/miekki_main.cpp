@@ -30,6 +30,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "fasta_reader.hpp"
@@ -379,13 +380,20 @@ struct Driver {
         vector<mk_hit> hits;
         vector<uint32_t> nhits;
         run_query(seqs, nres, min_score, (double)threshold, hits, nhits);
-        map<uint32_t, vector<Pending>> per_genome;
+        // Same container, same insertion sequence and the same flush-at-100 rule as the
+        // reference (Miekki.cpp:728-754, 779-785): with the same libstdc++ the lines of the
+        // output file then come out in the reference's order, not just as the same set.
+        unordered_map<string, vector<Pending>> batch;
         for (size_t q = 0; q < seqs.size(); ++q)
             for (uint32_t i = 0; i < nhits[q]; ++i) {
                 const mk_hit &h = hits[q * nres + i];
-                per_genome[h.genome].push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection});
+                const string &file_name = file_names[h.genome];
+                vector<Pending> &v = batch[file_name];
+                v.push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection});
+                if (v.size() >= 100) { ground_truth(file_name, v); v.clear(); }
             }
-        for (auto &kv : per_genome) ground_truth(file_names[kv.first], kv.second);
+        for (auto itr = batch.begin(); itr != batch.end(); ++itr)
+            if (!itr->second.empty()) ground_truth(itr->first, itr->second);
         out << flush;
     }
 

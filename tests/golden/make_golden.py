@@ -180,6 +180,27 @@ def make_exact_whole_file(name):
     print(f"{name}: -A -e output {len(txt)}B, {len(txt.splitlines())} lines")
 
 
+def make_exact_only(name):
+    """`-l … -a … -e` of an EXTRA_CASES entry: only the exact-mode output file is kept."""
+    case = synth.EXTRA_CASES[name]()
+    cli = os.path.join(REFDIR, "Miekki" + ("16" if case.fp_bits == 16 else ""))
+    with tempfile.TemporaryDirectory(prefix="mkgold_") as d:
+        for fn, data, gz in case.genome_files:
+            with open(os.path.join(d, fn), "wb") as f:
+                f.write(gzip.compress(data, 1) if gz else data)
+        with open(os.path.join(d, "genomes.lst"), "wb") as f:
+            f.write(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files))
+        with open(os.path.join(d, "queries.fa"), "wb") as f:
+            f.write(b"".join(h + b"\n" + s + b"\n" for h, s in case.queries))
+        base = ["-k", str(case.k), "-h", str(case.h), "-f", str(case.f), "-b", str(case.b),
+                "-s", str(case.threshold), "-t", "1"]
+        run([cli, "-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact.txt", *base], d)
+        txt = open(os.path.join(d, "exact.txt"), "rb").read()
+    with open(os.path.join(HERE, f"{name}_exact.txt"), "wb") as f:
+        f.write(txt)
+    print(f"{name}: -a -e output {len(txt)}B, {len(txt.splitlines())} lines")
+
+
 def make_filter_cases():
     """Synthetic filter_results inputs built to hit heap ties and replacement."""
     rng = np.random.default_rng(20261003)
@@ -210,10 +231,12 @@ def make_filter_cases():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16"])
+    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16", "exact:flush"])
     for n in names:
         if n == "filter":
             make_filter_cases()
+        elif n.startswith("exact:"):
+            make_exact_only(n.split(":", 1)[1])
         elif n.startswith("exactA:"):
             make_exact_whole_file(n.split(":", 1)[1])
         else:

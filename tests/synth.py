@@ -179,4 +179,20 @@ def case_messy() -> Case:
     return c
 
 
+def case_flush() -> Case:
+    """Exact mode with more than 100 pending queries per genome file: the reference verifies a
+    file's queries as soon as 100 have accumulated (Miekki.cpp:745-748) and the rest at the end in
+    unordered_map order (752-754), which fixes the line order of the output."""
+    c = Case("flush", 21, 12, 3, 32, 20)
+    L = 40_000
+    for g in range(4):
+        c.genome_files.append((f"fl{g}.fa", fasta(f"fl{g}", genome_bases(300 + g, 0, L), 60), g == 1))
+    for q in range(330):
+        g = 0 if q % 10 < 7 else 1 + q % 3                     # 231 queries on fl0: two flushes + a rest
+        off = splitmix64_int(SEED_Q ^ (9000 + q)) % (L - 700)
+        c.queries.append((f">f{q}_g{g}".encode(), genome_bases(300 + g, off, 400 + 3 * (q % 90))))
+    return c
+
+
 CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy}
+EXTRA_CASES = {"flush": case_flush}       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)
