@@ -131,13 +131,24 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
         MK_TRY(dev_alloc(&c->d_active, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_cardsum, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
+        MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
         if (c->d_bloom) {
             MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
             MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
+            MK_TRY(dev_alloc(&c->d_bloom_full, (c->bloom_dev_bytes / 8 + 31) / 32 + 1));
+            c->bloom_full_stale = true;
         }
     }
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
     if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
+    const uint64_t code_bytes = seq_bytes / 2 + 16ull * (kBuildBatch + 1) + 64;
+    if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
+        MK_HIP(hipStreamSynchronize(c->stream));
+        dev_free(c->d_codes);
+        c->codes_cap = 0;
+        MK_TRY(dev_alloc(&c->d_codes, code_bytes + code_bytes / 4));
+        c->codes_cap = code_bytes + code_bytes / 4;
+    }
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
         dev_free(c->d_seq[buf]);
         c->seq_cap[buf] = 0;
@@ -171,7 +182,16 @@ static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
     memcpy(b.off, h_off, (size_t)(n + 1) * 8);
     const char *d_seq = c->d_seq[buf];
     MK_HIP(hipMemcpyAsync(c->d_seq_off, b.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t code_off[kBuildBatch + 1];                          // 8-byte aligned, 8 bytes of slack each
+    code_off[0] = 0;
+    for (uint32_t g = 0; g < n; ++g)
+        code_off[g + 1] = (code_off[g] + (b.off[g + 1] - b.off[g] + 1) / 2 + 8 + 7) / 8 * 8;
+    MK_HIP(hipMemcpyAsync(c->d_code_off, code_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     MK_TRY(launch_seed_valid(c, d_seq, c->d_seq_off, n, c->d_seed_valid));
+    if (c->d_bloom && c->bloom_full_stale) {
+        MK_TRY(launch_bloom_summary(c));
+        c->bloom_full_stale = false;
+    }
     {
         ScopedTimer t(c, 3);
         MK_TRY(launch_genome_sketch_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables, &b.binned));
@@ -182,7 +202,8 @@ static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
     {
         ScopedTimer t(c, 4);
         MK_TRY(launch_finalize(c, c->d_tables, n, c->G, d_abort));
-        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, d_abort));
+        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, d_abort,
+                                   b.binned ? c->d_codes : nullptr, c->d_code_off));
     }
     c->h_back->ovf = 0;
     MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -208,7 +229,7 @@ static int settle_build(mk_ctx *c)
         {
             ScopedTimer t(c, 4);
             MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
-            MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr));
+            MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr));
         }
         MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
         MK_HIP(hipMemcpyAsync(c->h_back->card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -497,6 +518,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
     c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
+    c->d_codes = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
@@ -532,6 +554,7 @@ void mk_destroy(mk_ctx *c)
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     dev_free(c->d_hits); dev_free(c->d_nhits);
+    dev_free(c->d_codes); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
@@ -730,6 +753,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
     c->G = n;
     c->h_sketch_size.assign(n, 0); c->h_genome_size.assign(n, 0);
     if (c->d_bloom) MK_HIP(hipMemset(c->d_bloom, 0, c->bloom_dev_bytes));
+    c->bloom_full_stale = true;
     return MK_OK;
 }
 
@@ -760,6 +784,7 @@ int mk_index_import_bloom(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t
     MK_TRY(use_device(c));
     const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
     if (begin < dev_end) MK_HIP(hipMemcpy(c->d_bloom + begin, src, dev_end - begin, hipMemcpyHostToDevice));
+    c->bloom_full_stale = true;
     return MK_OK;
 }
 

@@ -70,6 +70,17 @@ struct mk_ctx {
     uint64_t seq_cap[2];
     int seq_cur;                   // buffer of the batch enqueued last
     uint64_t *d_seq_off;           // kBuildBatch + 1
+    // the batch's sequences once more as 4-bit (forward, reverse) code pairs, written by the
+    // binned sketch for the Bloom pass: 2.5 MB per 5 Mb genome, which stays in one XCD's L2
+    // while that genome's winners are looked up (the characters, 5 MB, do not)
+    uint8_t *d_codes;
+    uint64_t codes_cap;            // bytes
+    uint64_t *d_code_off;          // kBuildBatch + 1 byte offsets (8-byte aligned)
+    // one bit per 8 Bloom cells: all eight are non-zero (so none of them can change any more).
+    // 1 MiB for the 64 MiB of reachable cells at -b 33: L2-resident, and once the filter has
+    // filled up it answers almost every probe of the build without touching the cells
+    uint32_t *d_bloom_full;
+    bool bloom_full_stale;         // the cells were written behind the summary's back (import)
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
     // The batch whose kernels are enqueued but whose results (active counts, cardinality
@@ -153,8 +164,11 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
 // d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 bool binned_overflowed(uint32_t ovf_count);
+// d_codes != nullptr: the winners' k-mers are read from the packed code array of the batch
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort);
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
+                        const uint64_t *d_code_off);
+int launch_bloom_summary(mk_ctx *c);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
 int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q

@@ -78,6 +78,43 @@ __device__ __forceinline__ uint64_t canon_at(const char *__restrict__ seq, uint6
     return S < RC ? S : RC;
 }
 
+// The same canonical k-mer from the packed 4-bit code array of a sequence: 31 nibbles
+// = 124 bits out of three aligned 64-bit words.  Seed positions need no special case,
+// the codes already are what the rolling state saw.  The two 2-bit streams are pulled
+// out of the nibbles 16 codes at a time (the Bloom pass is ALU-bound once its lookups
+// hit L2): `pairs` squeezes the low two bits of every nibble of x together.
+__device__ __forceinline__ uint32_t pairs(uint64_t x)
+{
+    x &= 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    return (uint32_t)(x | (x >> 16));
+}
+
+__device__ __forceinline__ uint64_t canon_from_codes(const uint8_t *__restrict__ codes, uint64_t pos, uint32_t k)
+{
+    const uint64_t byte = pos >> 1;
+    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(codes) + (byte >> 3);
+    const uint32_t sh = (uint32_t)(byte & 7u) * 8u + (uint32_t)(pos & 1u) * 4u;        // 0..60
+    // two loads, not three: every load of every lane is a request of its own at the L2, and
+    // the request rate of the L2 is what bounds this pass
+    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
+    const u64x2_a8 x01 = *reinterpret_cast<const u64x2_a8 *>(w);
+    const uint64_t x0 = x01.x, x1 = x01.y, x2 = w[2];
+    const uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;                      // codes 0..15
+    const uint64_t hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;                      // codes 16..31
+    const uint64_t kmask = (1ULL << (2 * k)) - 1;                                      // k <= 31
+    // digit j of the k-mer at bits 2j: that is RC as update_kmer_RC leaves it ...
+    const uint64_t F = (((uint64_t)pairs(hi) << 32) | pairs(lo)) & kmask;
+    const uint64_t RC = (((uint64_t)pairs(hi >> 2) << 32) | pairs(lo >> 2)) & kmask;
+    // ... and S has digit 0 on top: reverse the order of the 2-bit digits
+    uint64_t r = __builtin_bitreverse64(F);
+    r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
+    const uint64_t S = r >> (64 - 2 * k);
+    return S < RC ? S : RC;
+}
+
 // ---------------------------------------------------------------- seed validity
 __global__ void seed_valid_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
                                   uint32_t n, uint32_t k, uint32_t *__restrict__ valid)
@@ -204,6 +241,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
                                                           uint64_t *__restrict__ slots,
                                                           uint16_t *__restrict__ slot_counts,
                                                           uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count,
+                                                          uint8_t *__restrict__ packed, const uint64_t *__restrict__ code_off,
                                                           SketchParams sp, BinParams bp)
 {
     __shared__ uint8_t codes[kSegKmers + 64];
@@ -224,6 +262,23 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
     }
     __syncthreads();
     const uint32_t i0 = threadIdx.x * kPerThread;
+    if (cnt) {
+        // this workgroup's own 4096 positions, 16 per thread, as 4-bit (forward, reverse)
+        // codes: what the Bloom pass reads back for the winners.  The k-1 characters past
+        // them belong to the next workgroup -- or to this one if it is the sequence's last.
+        static_assert(kPerThread == 16, "one 64-bit word of 4-bit codes per thread");
+        const uint32_t nchar = cnt + sp.k - 1;
+        uint64_t *__restrict__ dst = reinterpret_cast<uint64_t *>(packed + code_off[g] + seg0 / 2);
+        auto pack16 = [&](uint32_t c0) {
+            uint64_t w = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < kPerThread; ++e)
+                if (c0 + e < nchar) w |= (uint64_t)codes[c0 + e] << (4 * e);
+            dst[c0 / kPerThread] = w;
+        };
+        if (i0 < nchar) pack16(i0);
+        if (seg0 + cnt == nk && kSegKmers + i0 < nchar) pack16(kSegKmers + i0);
+    }
     if (i0 < cnt) {
         const uint32_t i1 = min(i0 + kPerThread, cnt);
         uint64_t S = 0, RC = 0;
@@ -359,7 +414,7 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
-                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, sp, bp);
+                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, sp, bp);
     hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
                        c->d_slot_counts, d_tables, sp, bp);
     hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
@@ -473,31 +528,44 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
                                                     const uint64_t *__restrict__ off,
                                                     const uint32_t *__restrict__ valid, uint8_t *bloom,
                                                     uint64_t bloom_dev_bytes, uint64_t *order,
-                                                    const uint32_t *__restrict__ ovf_count, SketchParams sp)
+                                                    const uint32_t *__restrict__ ovf_count,
+                                                    const uint8_t *__restrict__ codes,
+                                                    const uint64_t *__restrict__ code_off,
+                                                    const uint32_t *__restrict__ full, SketchParams sp)
 {
     if (ovf_count && *ovf_count > kOvfCap) return;      // see finalize_kernel
     const uint32_t g = blockIdx.y;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= sp.P) return;
     uint64_t *slot = tables + (uint64_t)g * sp.P + p;
-    const uint64_t key = *slot;
+    // the table streams through once: keep it from evicting the codes and the summary from L2
+    const uint64_t key = __builtin_nontemporal_load(slot);
     if (key == kEmptyKey) return;
     uint64_t canon;
     if (!WRITE) {
         // pass A: the (fingerprint, position) key has served finalize; replace it by
         // the winner's canonical k-mer so that pass B need not touch the sequence again
-        canon = canon_at(seq + off[g], key & ((1ULL << kPosBits) - 1), sp.k, valid[g] != 0);
+        const uint64_t pos = key & ((1ULL << kPosBits) - 1);
+        canon = codes ? canon_from_codes(codes + code_off[g], pos, sp.k)
+                      : canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
     } else {
         canon = key;
     }
     const uint64_t anc = revhash64(canon);
     bool posted = false;
+    uint64_t sum_idx = ~0ull;
+    uint32_t sum_word = 0;
     for (uint32_t i = 0; i < kNumHash; ++i) {
         const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
         const uint64_t cell = hsh >> 3;
         if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
         const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (i << 4) | (uint32_t)(hsh & 7);
         if (!WRITE) {
+            // the summary first (one bit per 8 cells, L2-resident): a full group has no zero cell.
+            // The five positions of a k-mer differ by less than 1024 >> b: nearly always one word
+            const uint64_t grp = cell >> 3;
+            if ((grp >> 5) != sum_idx) { sum_idx = grp >> 5; sum_word = full[sum_idx]; }
+            if ((sum_word >> (grp & 31u)) & 1u) continue;
             if (bloom[cell] == 0) {
                 atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
                 posted = true;
@@ -512,20 +580,67 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
     // a k-mer whose five cells were all set already (the common case once the filter
     // has filled up) has nothing to do in pass B: blank its slot so that pass B stops
     // at the first test
-    if (!WRITE) *slot = posted ? canon : kEmptyKey;
+    if (!WRITE) __builtin_nontemporal_store(posted ? canon : kEmptyKey, slot);
+}
+
+// full[grp] = all eight cells of group grp are non-zero.  Cells never go back to zero, so a
+// summary taken before a batch stays true during it; it is refreshed after every pass B.
+__global__ void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                     uint32_t *__restrict__ full, uint64_t nwords)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one summary word = 32 groups = 256 cells
+    if (w >= nwords) return;
+    uint32_t bits = 0;
+    const uint64_t base = w * 256;
+    if (base + 256 <= bloom_dev_bytes) {
+        const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(bloom + base);
+#pragma unroll 4
+        for (uint32_t i = 0; i < 16; ++i) {                                   // 16 bytes = 2 groups per load
+            const uint4 v = p[i];
+            const uint64_t a = ((uint64_t)v.y << 32) | v.x, b = ((uint64_t)v.w << 32) | v.z;
+            // exact zero-byte test: high bit of each byte set iff the byte is zero
+            const uint64_t za = ~(((a & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | a | 0x7f7f7f7f7f7f7f7fULL);
+            const uint64_t zb = ~(((b & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | b | 0x7f7f7f7f7f7f7f7fULL);
+            bits |= (za == 0 ? 1u : 0u) << (2 * i);
+            bits |= (zb == 0 ? 1u : 0u) << (2 * i + 1);
+        }
+    } else {                                                                  // ragged end of the reachable region
+        for (uint32_t gI = 0; gI < 32; ++gI) {
+            bool all = true;
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint64_t cell = base + gI * 8 + j;
+                all = all && cell < bloom_dev_bytes && bloom[cell] != 0;
+            }
+            bits |= (all ? 1u : 0u) << gI;
+        }
+    }
+    full[w] = bits;
+}
+
+int launch_bloom_summary(mk_ctx *c)
+{
+    if (!c->d_bloom) return MK_OK;
+    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1;
+    hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((nwords + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
+                       c->bloom_dev_bytes, c->d_bloom_full, nwords);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
 }
 
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort)
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
+                        const uint64_t *d_code_off)
 {
     if (!n || !c->d_bloom) return MK_OK;
     dim3 grid((c->P + 255) / 256, n);
     hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, make_sp(c));
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
+                       c->d_bloom_full, make_sp(c));
     hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, make_sp(c));
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
+                       c->d_bloom_full, make_sp(c));
     MK_HIP(hipGetLastError());
-    return MK_OK;
+    return launch_bloom_summary(c);
 }
 
 __device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
