@@ -328,10 +328,10 @@ __global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint64_t *__rest
     __syncthreads();
     const uint64_t *__restrict__ base = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)bin * bp.nwg * bp.cap;
     const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
-    // one wave per slot, four slots in flight per wave: the used prefix of a slot is a
+    // one wave per slot, eight slots in flight per wave: the used prefix of a slot is a
     // short contiguous run, and independent loads are what hides the HBM latency here
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    constexpr uint32_t NW = 16, UN = 4;
+    constexpr uint32_t NW = 16, UN = 8;
     for (uint32_t w0 = wave; w0 < bp.nwg; w0 += NW * UN) {
         uint32_t cw[UN];
         uint64_t item[UN];
