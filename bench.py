@@ -247,6 +247,7 @@ def main():
                        "index_sketches_per_s_per_gpu": G / build_s,
                        "index_kmers_per_s": world * bst["build_kmers"] / build_s_max,
                        "build_sketch_ms": bst["build_sketch_ms"], "build_finalize_ms": bst["build_finalize_ms"]},
+            "select": {"kernel": "select_kernel", "ms_per_step": st["filter_ms"] / args.steps},
             "merge": {"kernel": "merge_kernel", "ms_per_step": merge_s[0] / args.steps * 1e3, "overflowed_queries": n_over,
                       "note": "rank 0: stream hand-over + filter_results heap over the (gathered) entrant rows, inside the timed step"},
             "check": {"queries_with_candidates_on_rank0": n_hit, "top_hit_is_source_genome_of_first_2000": merged_ok,

@@ -61,14 +61,46 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     float screen = 0.999f * (float)a.min_inter;
     mk_hit *__restrict__ out = a.cand + (uint64_t)q * a.cap;
 
+    // A step is a dependent load -> test -> ballot chain, and the kernel spends three
+    // quarters of its wave cycles waiting for the loads (PMC).  With at most eight ranges of
+    // byte counters (the default slab shape) the RAW words of a step are therefore
+    // requested one step ahead and only summed when their turn comes.
+    constexpr uint32_t PF = 8;
+    const bool prefetch = SRC == 1 && a.S <= PF;
+    uint32_t raw[PF];
+    auto request = [&](uint32_t g0) {
+        const uint32_t gl = g0 + lane * 4u;
+#pragma unroll
+        for (uint32_t r = 0; r < PF; ++r) raw[r] = 0;
+        if (gl >= a.G) return;
+        const uint32_t t = gl / a.tile_genomes, wi = gl - t * a.tile_genomes;
+        const uint8_t *__restrict__ p = a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + wi;
+#pragma unroll
+        for (uint32_t r = 0; r < PF; ++r)
+            if (r < a.S) raw[r] = *reinterpret_cast<const uint32_t *>(p + (uint64_t)r * range_stride);
+    };
+    if (prefetch) request(0);
     for (uint32_t g0 = 0; g0 < a.G; g0 += 256) {
         const uint32_t gl = g0 + lane * 4u;                            // this lane's four genomes
         uint32_t s[4] = {0, 0, 0, 0};
         double jac[4] = {0, 0, 0, 0}, inter[4] = {0, 0, 0, 0};
         uint32_t pot = 0;
+        if (prefetch) {
+            // byte-wise sums of up to eight words, two bytes per 16-bit lane: no carry between counters
+            uint32_t even = 0, odd = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < PF; ++r) { even += raw[r] & 0x00ff00ffu; odd += (raw[r] >> 8) & 0x00ff00ffu; }
+            s[0] = n_active - (even & 0xffffu); s[1] = n_active - (odd & 0xffffu);
+            s[2] = n_active - (even >> 16);     s[3] = n_active - (odd >> 16);
+        }
+        uint32_t ss[4] = {1, 1, 1, 1};
+        uint64_t gs[4] = {0, 0, 0, 0};
+        bool any = false;
         if (gl < a.G) {
             const uint32_t t = gl / a.tile_genomes, wi = gl - t * a.tile_genomes;   // 256 | tile_genomes
-            if (SRC == 0) {
+            if (prefetch) {
+                // scores are in s already
+            } else if (SRC == 0) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(a.scores + (uint64_t)t * tile_stride +
                                                                  (uint64_t)q * a.tile_genomes + wi);
                 s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
@@ -88,7 +120,6 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[j] = n_active - ne[j];
             }
-            bool any = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) any |= (gl + j < a.G) && s[j] >= a.min_score;     // Miekki.cpp:381
             if (any) {
@@ -96,8 +127,17 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
                 const uint4 ss4 = *reinterpret_cast<const uint4 *>(a.sketch_size + gl);
                 const ulonglong2 gsa = *reinterpret_cast<const ulonglong2 *>(a.genome_size + gl);
                 const ulonglong2 gsb = *reinterpret_cast<const ulonglong2 *>(a.genome_size + gl + 2);
-                const uint32_t ss[4] = {ss4.x, ss4.y, ss4.z, ss4.w};
-                const uint64_t gs[4] = {gsa.x, gsa.y, gsb.x, gsb.y};
+                ss[0] = ss4.x; ss[1] = ss4.y; ss[2] = ss4.z; ss[3] = ss4.w;
+                gs[0] = gsa.x; gs[1] = gsa.y; gs[2] = gsb.x; gs[3] = gsb.y;
+            }
+        }
+        // the next step's words are requested AFTER this step's size loads: loads return in
+        // order, so waiting for the sizes must not mean waiting for the prefetch as well
+        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch && g0 + 256 < a.G) request(g0 + 256);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gl < a.G) {
+            if (any) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (gl + j < a.G && s[j] >= a.min_score) {
