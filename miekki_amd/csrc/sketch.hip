@@ -646,10 +646,15 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
 __device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
                                             uint64_t canon, uint64_t anc, uint32_t bloom_log2)
 {
-    // check_bloom, Miekki.cpp:135-146: `cell && mask[hit]` is a logical and -> byte != 0
+    // check_bloom, Miekki.cpp:135-146: `cell && mask[hit]` is a logical and -> byte != 0.
+    // The five positions differ by less than 1024 >> b, i.e. nearly always name ONE cell:
+    // it is loaded once (every lane-load is a request of its own at the L2).
+    uint64_t prev = ~0ull;
     for (uint32_t i = 0; i < kNumHash; ++i) {
         const uint64_t cell = bloom_pos(canon, anc, i, bloom_log2) >> 3;
+        if (cell == prev) continue;
         if (cell >= bloom_dev_bytes || bloom[cell] == 0) return false;
+        prev = cell;
     }
     return true;
 }
