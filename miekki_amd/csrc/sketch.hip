@@ -661,10 +661,13 @@ __device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, u
 
 // ---------------------------------------------------------------- K4 query sketch (short)
 // One workgroup per query of at most kShortMax k-mers.  Keys
-// (partition << 34 | fingerprint << 18 | position) are sorted in LDS; the first
-// key of every partition run is that partition's winner.  Winners that pass the
-// Bloom gate are compacted, in ascending partition order, into the query's slice
-// of the entry list -- the sparse form of the reference's dense 2^h vector.
+// (partition << 34 | fingerprint << 18 | position << 1 | Bloom gate) are sorted in
+// LDS -- grouped by the partition's top bits with one LDS atomic per key, then a few
+// keys per group sorted where they lie; a full bitonic sort (55 barriers for 1,024
+// keys) only when a group is crowded.  The first key of every partition run is that
+// partition's winner.  Winners that pass the Bloom gate are compacted, in ascending
+// partition order, into the query's slice of the entry list -- the sparse form of the
+// reference's dense 2^h vector.
 __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restrict__ seq,
                                                            const uint64_t *__restrict__ off,
                                                            const uint64_t *__restrict__ ent_off,
@@ -676,8 +679,10 @@ __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restric
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint8_t *codes = smem + (size_t)npad_max * sizeof(uint64_t);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + (size_t)npad_max * sizeof(uint64_t));   // npad + 1 entries
+    uint8_t *codes = smem + (size_t)npad_max * (sizeof(uint64_t) + sizeof(uint32_t)) + 16;
     __shared__ uint32_t s_seed_bad;
+    __shared__ uint32_t s_max_bucket;
     __shared__ uint32_t s_wave_tot[4];
     const uint32_t q = blockIdx.x;
     const uint64_t len = off[q + 1] - off[q];
@@ -698,39 +703,114 @@ __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restric
     for (uint32_t j = threadIdx.x; j < nchar; j += 256) codes[j] = (uint8_t)pos_codes((uint8_t)s[j], j, sp.k, sv);
     __syncthreads();
 
-    for (uint32_t i = threadIdx.x; i < npad; i += 256) {
-        uint64_t key = kEmptyKey;
-        if (i < nk) {
-            uint64_t S = 0, RC = 0;
-            for (uint32_t j = 0; j < sp.k; ++j) {
-                const uint32_t cd = codes[i + j];
-                S = (S << 2) | (cd & 3u);
-                RC |= (uint64_t)(cd >> 2) << (2 * j);
-            }
-            const uint64_t anc = revhash64(S < RC ? S : RC);
-            uint32_t bucket, fp;
-            bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
-            if (fp != sp.empty) key = ((uint64_t)bucket << 34) | ((uint64_t)fp << 18) | i;
-        }
-        keys[i] = key;
-    }
+    // ---- keys, grouped by bucket = the top log2(npad) bits of the partition -----------------
+    // Thread t rolls the k-mers [t * per, (t + 1) * per) and keeps their keys in registers;
+    // one LDS atomic per key gives both the bucket histogram and the key's rank in its bucket.
+    constexpr uint32_t kMaxPer = kShortMax / 256;
+    const uint32_t per = npad / 256;
+    uint32_t lg = 8;
+    while ((1u << lg) < npad) ++lg;
+    const uint32_t bshift = sp.h > lg ? sp.h - lg : 0;             // bucket = partition >> bshift  (< npad)
+    for (uint32_t i = threadIdx.x; i <= npad; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) s_max_bucket = 0;
     __syncthreads();
-
-    for (uint32_t kk = 2; kk <= npad; kk <<= 1)
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < npad; i += 256) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const uint64_t a = keys[i], b = keys[l];
-                    const bool up = (i & kk) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+    uint64_t kreg[kMaxPer];
+    uint32_t rreg[kMaxPer];
+    {
+        const uint32_t i0 = threadIdx.x * per;
+        uint64_t S = 0, RC = 0;
+        if (i0 < nk)
+            for (uint32_t j = 0; j + 1 < sp.k; ++j) {              // first k-1 digits of k-mer i0
+                const uint32_t cd = codes[i0 + j];
+                S = (S << 2) | (cd & 3u);
+                RC |= (uint64_t)(cd >> 2) << (2 * (j + 1));
+            }
+        const uint32_t topshift = 2 * sp.k - 2;
+#pragma unroll
+        for (uint32_t e = 0; e < kMaxPer; ++e) {
+            kreg[e] = kEmptyKey; rreg[e] = 0;
+            const uint32_t i = i0 + e;
+            if (e < per && i < nk) {
+                const uint32_t cd = codes[i + sp.k - 1];
+                S = ((S << 2) | (cd & 3u)) & sp.kmask;
+                RC = (RC >> 2) | ((uint64_t)(cd >> 2) << topshift);
+                const uint64_t canon = S < RC ? S : RC;
+                const uint64_t anc = revhash64(canon);
+                uint32_t bucket, fp;
+                bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+                if (fp != sp.empty) {
+                    // the Bloom gate is asked here, where the k-mer is at hand, and rides in the
+                    // key's lowest bit (below the position: it cannot change who wins a partition)
+                    const uint32_t pass = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, anc, sp.bloom_log2);
+                    kreg[e] = ((uint64_t)bucket << 34) | ((uint64_t)fp << 18) | (i << 1) | pass;
+                    rreg[e] = atomicAdd(&hist[bucket >> bshift], 1u);
                 }
             }
-            __syncthreads();
         }
+    }
+    __syncthreads();
+    // exclusive prefix of the histogram (per consecutive entries per thread), total in hist[npad]
+    {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        uint32_t c[kMaxPer], tsum = 0, cmax = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < kMaxPer; ++e) {
+            c[e] = e < per ? hist[threadIdx.x * per + e] : 0u;
+            tsum += c[e];
+            cmax = max(cmax, c[e]);
+        }
+        if (cmax > 16) atomicMax(&s_max_bucket, cmax);
+        uint32_t v = tsum;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(v, o);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) s_wave_tot[wave] = v;
+        __syncthreads();
+        uint32_t excl = v - tsum;
+        for (uint32_t w = 0; w < wave; ++w) excl += s_wave_tot[w];
+#pragma unroll
+        for (uint32_t e = 0; e < kMaxPer; ++e)
+            if (e < per) { hist[threadIdx.x * per + e] = excl; excl += c[e]; }
+        if (threadIdx.x == 255) hist[npad] = excl;
+    }
+    __syncthreads();
+    const uint32_t nvalid = hist[npad];
+#pragma unroll
+    for (uint32_t e = 0; e < kMaxPer; ++e)
+        if (kreg[e] != kEmptyKey) keys[hist[(uint32_t)(kreg[e] >> 34) >> bshift] + rreg[e]] = kreg[e];
+    for (uint32_t i = nvalid + threadIdx.x; i < npad; i += 256) keys[i] = kEmptyKey;
+    __syncthreads();
+    if (s_max_bucket == 0) {
+        // ---- the usual case: a handful of keys per bucket, sorted where they lie -----------------
+        for (uint32_t e = 0; e < per; ++e) {
+            const uint32_t bI = threadIdx.x * per + e;
+            const uint32_t lo = hist[bI], hi = hist[bI + 1];
+            for (uint32_t i = lo + 1; i < hi; ++i) {                // insertion sort, at most 16 keys
+                const uint64_t x = keys[i];
+                uint32_t j = i;
+                while (j > lo && keys[j - 1] > x) { keys[j] = keys[j - 1]; --j; }
+                keys[j] = x;
+            }
+        }
+        __syncthreads();
+    } else {
+        // ---- a crowded bucket (repetitive query): bitonic sort of everything -------------------
+        for (uint32_t kk = 2; kk <= npad; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < npad; i += 256) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const uint64_t a = keys[i], b = keys[l];
+                        const bool up = (i & kk) == 0;
+                        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
 
     // each thread owns a contiguous run so that the compaction keeps partition order
-    const uint32_t per = npad / 256;
     const uint32_t b0 = threadIdx.x * per;
     uint64_t out[kShortMax / 256];
     uint32_t cnt = 0;
@@ -740,16 +820,7 @@ __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restric
         if (key == kEmptyKey) continue;
         const uint32_t bucket = (uint32_t)(key >> 34);
         if (i > 0 && (uint32_t)(keys[i - 1] >> 34) == bucket) continue;   // not the run's first
-        const uint32_t pos = (uint32_t)(key & 0x3ffffu);
-        uint64_t S = 0, RC = 0;
-        for (uint32_t j = 0; j < sp.k; ++j) {
-            const uint32_t cd = codes[pos + j];
-            S = (S << 2) | (cd & 3u);
-            RC |= (uint64_t)(cd >> 2) << (2 * j);
-        }
-        const uint64_t canon = S < RC ? S : RC;
-        if (!bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2))
-            out[cnt++] = make_entry(bucket, (uint32_t)(key >> 18) & 0xffffu);
+        if (key & 1u) out[cnt++] = make_entry(bucket, (uint32_t)(key >> 18) & 0xffffu);
     }
     // exclusive scan of cnt over the workgroup
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -778,7 +849,7 @@ int launch_query_sketch_short(mk_ctx *c, mk_qset *qs)
     uint32_t npad = 256;
     while (npad < qs->short_max_nk) npad <<= 1;
     MK_HIP(hipMemsetAsync(qs->d_nent, 0, (size_t)qs->nq * sizeof(uint32_t), c->stream));
-    const size_t lds = (size_t)npad * sizeof(uint64_t) + npad + 64;
+    const size_t lds = (size_t)npad * (sizeof(uint64_t) + sizeof(uint32_t)) + 16 + npad + 64;   // keys, histogram, codes
     hipLaunchKernelGGL(query_sketch_kernel, dim3(qs->nq), dim3(256), lds, c->stream, qs->d_seq, qs->d_off,
                        qs->d_ent_off, qs->d_entries, qs->d_nent, c->d_bloom, c->bloom_dev_bytes, npad,
                        make_sp(c));
