@@ -122,6 +122,47 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
 }
 
 // ---- index build ---------------------------------------------------------------
+// packed 4-bit codes of up to a build batch of sequences totalling seq_bytes characters
+int ensure_codes(mk_ctx *c, uint64_t seq_bytes)
+{
+    if (!c->d_code_off) MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
+    const uint64_t code_bytes = seq_bytes / 2 + 16ull * (kBuildBatch + 1) + 64;
+    if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
+        MK_HIP(hipStreamSynchronize(c->stream));
+        dev_free(c->d_codes);
+        c->codes_cap = 0;
+        MK_TRY(dev_alloc(&c->d_codes, code_bytes + code_bytes / 4));
+        c->codes_cap = code_bytes + code_bytes / 4;
+    }
+    return MK_OK;
+}
+
+// offsets of the sequences' code arrays inside d_codes: 8-byte aligned, 8 bytes of slack each
+int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n)
+{
+    uint64_t code_off[kBuildBatch + 1];
+    code_off[0] = 0;
+    for (uint32_t g = 0; g < n; ++g)
+        code_off[g + 1] = (code_off[g] + (h_off[g + 1] - h_off[g] + 1) / 2 + 8 + 7) / 8 * 8;
+    MK_HIP(hipMemcpyAsync(c->d_code_off, code_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    return MK_OK;
+}
+
+// the "all eight cells set" summary of the Bloom filter, current
+int ensure_bloom_summary(mk_ctx *c)
+{
+    if (!c->d_bloom) return MK_OK;
+    if (!c->d_bloom_full) {
+        MK_TRY(dev_alloc(&c->d_bloom_full, (c->bloom_dev_bytes / 8 + 31) / 32 + 1));
+        c->bloom_full_stale = true;
+    }
+    if (c->bloom_full_stale) {
+        MK_TRY(launch_bloom_summary(c));
+        c->bloom_full_stale = false;
+    }
+    return MK_OK;
+}
+
 static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
 {
     if (!c->d_tables) {
@@ -131,24 +172,14 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
         MK_TRY(dev_alloc(&c->d_active, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_cardsum, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
-        MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
         if (c->d_bloom) {
             MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
             MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
-            MK_TRY(dev_alloc(&c->d_bloom_full, (c->bloom_dev_bytes / 8 + 31) / 32 + 1));
-            c->bloom_full_stale = true;
         }
     }
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
     if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
-    const uint64_t code_bytes = seq_bytes / 2 + 16ull * (kBuildBatch + 1) + 64;
-    if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
-        MK_HIP(hipStreamSynchronize(c->stream));
-        dev_free(c->d_codes);
-        c->codes_cap = 0;
-        MK_TRY(dev_alloc(&c->d_codes, code_bytes + code_bytes / 4));
-        c->codes_cap = code_bytes + code_bytes / 4;
-    }
+    MK_TRY(ensure_codes(c, seq_bytes));
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
         dev_free(c->d_seq[buf]);
         c->seq_cap[buf] = 0;
@@ -182,16 +213,9 @@ static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
     memcpy(b.off, h_off, (size_t)(n + 1) * 8);
     const char *d_seq = c->d_seq[buf];
     MK_HIP(hipMemcpyAsync(c->d_seq_off, b.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    uint64_t code_off[kBuildBatch + 1];                          // 8-byte aligned, 8 bytes of slack each
-    code_off[0] = 0;
-    for (uint32_t g = 0; g < n; ++g)
-        code_off[g + 1] = (code_off[g] + (b.off[g + 1] - b.off[g] + 1) / 2 + 8 + 7) / 8 * 8;
-    MK_HIP(hipMemcpyAsync(c->d_code_off, code_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MK_TRY(upload_code_offsets(c, b.off, n));
     MK_TRY(launch_seed_valid(c, d_seq, c->d_seq_off, n, c->d_seed_valid));
-    if (c->d_bloom && c->bloom_full_stale) {
-        MK_TRY(launch_bloom_summary(c));
-        c->bloom_full_stale = false;
-    }
+    MK_TRY(ensure_bloom_summary(c));
     {
         ScopedTimer t(c, 3);
         MK_TRY(launch_genome_sketch_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables, &b.binned));
@@ -310,6 +334,7 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs);
 
 static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
 {
+    MK_TRY(ensure_bloom_summary(c));
     ScopedTimer t(c, 0);
     MK_TRY(launch_query_sketch_short(c, qs));
     if (!qs->long_q.empty()) {
@@ -320,8 +345,19 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
     if (!qs->dense_q.empty()) {
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-        for (uint32_t slot = 0; slot < qs->dense_q.size(); ++slot)
-            if (qs->dense_q[slot] != 0xffffffffu) MK_TRY(launch_query_sketch_dense(c, qs, slot));
+        // neighbours in the set go through the binned genome sketch together (K1), up to a
+        // build batch at a time; loners and shapes the bins do not fit go one by one
+        MK_TRY(ensure_build_scratch(c, 0, 0));
+        for (uint32_t slot = 0; slot < qs->dense_q.size();) {
+            if (qs->dense_q[slot] == 0xffffffffu) { ++slot; continue; }
+            uint32_t n = 1;
+            while (slot + n < qs->dense_q.size() && n < c->build_batch && qs->dense_q[slot + n] == qs->dense_q[slot] + n) ++n;
+            bool done = false;
+            if (n > 1) MK_TRY(launch_query_sketch_dense_batch(c, qs, slot, n, &done));
+            if (!done)
+                for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_dense(c, qs, slot + j));
+            slot += n;
+        }
     }
     MK_TRY(launch_scan_counts(c, qs));
     qs->sketched = true;

@@ -160,7 +160,7 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
 // same result through LDS-binned partitioning; *used = false when the shape does
 // not fit the binned path (the caller then takes the atomic kernel above)
 int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used);
+                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used, bool write_codes = true);
 // d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 bool binned_overflowed(uint32_t ovf_count);
@@ -169,9 +169,14 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
                         const uint64_t *d_code_off);
 int launch_bloom_summary(mk_ctx *c);
+// api.hip: scratch shared by the build and the long-query sketches
+int ensure_codes(mk_ctx *c, uint64_t seq_bytes);
+int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);
+int ensure_bloom_summary(mk_ctx *c);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
 int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q
+int launch_query_sketch_dense_batch(mk_ctx *c, mk_qset *qs, uint32_t slot, uint32_t n, bool *done);
 int launch_scan_counts(mk_ctx *c, mk_qset *qs);                          // fills qs->d_scan_n
 // range boundaries of every query's (sorted) entry list; *d_flag |= 1 when a
 // (query, range) holds more than `limit` entries

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
     }
     __syncthreads();
     const uint32_t i0 = threadIdx.x * kPerThread;
-    if (cnt) {
+    if (cnt && packed) {
         // this workgroup's own 4096 positions, 16 per thread, as 4-bit (forward, reverse)
         // codes: what the Bloom pass reads back for the winners.  The k-1 characters past
         // them belong to the next workgroup -- or to this one if it is the sequence's last.
@@ -372,7 +372,7 @@ __global__ void bin_overflow_kernel(const uint64_t *__restrict__ ovf, const uint
 }
 
 int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used)
+                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used, bool write_codes)
 {
     *used = false;
     if (!n) return MK_OK;
@@ -414,7 +414,8 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
-                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, sp, bp);
+                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, write_codes ? c->d_codes : nullptr,
+                       c->d_code_off, sp, bp);
     hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
                        c->d_slot_counts, d_tables, sp, bp);
     hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
@@ -644,17 +645,21 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
 }
 
 __device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
-                                            uint64_t canon, uint64_t anc, uint32_t bloom_log2)
+                                            uint64_t canon, uint64_t anc, uint32_t bloom_log2,
+                                            const uint32_t *__restrict__ full = nullptr)
 {
     // check_bloom, Miekki.cpp:135-146: `cell && mask[hit]` is a logical and -> byte != 0.
     // The five positions differ by less than 1024 >> b, i.e. nearly always name ONE cell:
-    // it is loaded once (every lane-load is a request of its own at the L2).
+    // it is looked at once (every lane-load is a request of its own at the L2), and in the
+    // "all eight cells set" summary first when there is one (1 MiB, L2-resident).
     uint64_t prev = ~0ull;
     for (uint32_t i = 0; i < kNumHash; ++i) {
         const uint64_t cell = bloom_pos(canon, anc, i, bloom_log2) >> 3;
         if (cell == prev) continue;
-        if (cell >= bloom_dev_bytes || bloom[cell] == 0) return false;
         prev = cell;
+        if (cell >= bloom_dev_bytes) return false;
+        if (full && ((full[cell >> 8] >> ((cell >> 3) & 31u)) & 1u)) continue;
+        if (bloom[cell] == 0) return false;
     }
     return true;
 }
@@ -674,7 +679,8 @@ __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restric
                                                            uint64_t *__restrict__ entries,
                                                            uint32_t *__restrict__ nent,
                                                            const uint8_t *__restrict__ bloom,
-                                                           uint64_t bloom_dev_bytes, uint32_t npad_max,
+                                                           uint64_t bloom_dev_bytes,
+                                                           const uint32_t *__restrict__ bloom_full, uint32_t npad_max,
                                                            SketchParams sp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(256) void query_sketch_kernel(const char *__restric
                 if (fp != sp.empty) {
                     // the Bloom gate is asked here, where the k-mer is at hand, and rides in the
                     // key's lowest bit (below the position: it cannot change who wins a partition)
-                    const uint32_t pass = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, anc, sp.bloom_log2);
+                    const uint32_t pass = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, anc, sp.bloom_log2, bloom_full);
                     kreg[e] = ((uint64_t)bucket << 34) | ((uint64_t)fp << 18) | (i << 1) | pass;
                     rreg[e] = atomicAdd(&hist[bucket >> bshift], 1u);
                 }
@@ -851,7 +857,7 @@ int launch_query_sketch_short(mk_ctx *c, mk_qset *qs)
     MK_HIP(hipMemsetAsync(qs->d_nent, 0, (size_t)qs->nq * sizeof(uint32_t), c->stream));
     const size_t lds = (size_t)npad * (sizeof(uint64_t) + sizeof(uint32_t)) + 16 + npad + 64;   // keys, histogram, codes
     hipLaunchKernelGGL(query_sketch_kernel, dim3(qs->nq), dim3(256), lds, c->stream, qs->d_seq, qs->d_off,
-                       qs->d_ent_off, qs->d_entries, qs->d_nent, c->d_bloom, c->bloom_dev_bytes, npad,
+                       qs->d_ent_off, qs->d_entries, qs->d_nent, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, npad,
                        make_sp(c));
     MK_HIP(hipGetLastError());
     return MK_OK;
@@ -951,6 +957,89 @@ int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot)
                            qs->d_seq + qs->h_off[q], d_valid, c->d_bloom, c->bloom_dev_bytes, group, slot % 4,
                            qs->d_nent + q, make_sp(c));
     MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// The same for a batch: tables of n queries (one binned K1 run), k-mers read from the packed
+// codes that run wrote, Bloom gate through the summary -- the access pattern of the build's
+// Bloom pass A, and the same remedies.  grid = (P / 256, n).  The count of active partitions
+// goes through per-workgroup partial sums: one atomic per wave on the n adjacent counters
+// (two cache lines) serialises a million atomics on one L2 channel -- 10 ms per batch.
+template <int W>
+__global__ __launch_bounds__(256) void dense_batch_kernel(const uint64_t *__restrict__ tables,
+                                                          const uint8_t *__restrict__ codes,
+                                                          const uint64_t *__restrict__ code_off,
+                                                          const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                                          const uint32_t *__restrict__ full,
+                                                          uint8_t *__restrict__ dense, uint32_t slot0,
+                                                          uint32_t *__restrict__ partial, SketchParams sp)
+{
+    using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t g = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t slot = slot0 + g;
+    bool keep = false;
+    uint32_t fp = sp.empty;
+    if (p < sp.P) {
+        const uint64_t key = __builtin_nontemporal_load(tables + (uint64_t)g * sp.P + p);
+        if (key != kEmptyKey) {
+            const uint64_t canon = canon_from_codes(codes + code_off[g], key & ((1ULL << kPosBits) - 1), sp.k);
+            keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2, full);
+            if (keep) fp = (uint32_t)(key >> kPosBits);
+        }
+        fp_t *group = reinterpret_cast<fp_t *>(dense + (uint64_t)(slot / 4) * sp.P * 4 * W);
+        group[(uint64_t)p * 4 + (slot & 3u)] = (fp_t)fp;
+    }
+    const uint64_t mask = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(uint64_t)g * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void dense_count_kernel(const uint32_t *__restrict__ partial, uint32_t nblk,
+                                                          uint32_t *__restrict__ nent)
+{
+    __shared__ uint32_t s_sum[4];
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < nblk; i += 256) v += partial[(uint64_t)blockIdx.x * nblk + i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) nent[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// Dense queries dense_q[slot .. slot+n) that are neighbours in the set (q, q+1, ...): their
+// tables come from ONE run of the binned genome sketch (K1) instead of n runs of the atomic
+// kernel.  *done = false leaves the queries untouched (shape does not fit the bins, or the
+// overflow list ran over): the caller then sketches them one by one.
+int launch_query_sketch_dense_batch(mk_ctx *c, mk_qset *qs, uint32_t slot, uint32_t n, bool *done)
+{
+    *done = false;
+    const uint32_t q0 = qs->dense_q[slot];
+    MK_TRY(launch_seed_valid(c, qs->d_seq, qs->d_off + q0, n, c->d_seed_valid));
+    MK_TRY(ensure_codes(c, qs->h_off[q0 + n] - qs->h_off[q0]));
+    MK_TRY(upload_code_offsets(c, qs->h_off.data() + q0, n));
+    bool used = false;
+    MK_TRY(launch_genome_sketch_binned(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, c->d_seed_valid, n,
+                                       c->d_tables, &used, true));
+    if (!used) return MK_OK;
+    uint32_t novf = 0;
+    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    if (binned_overflowed(novf)) return MK_OK;
+    const dim3 grid((c->P + 255) / 256, n);
+    // the overflow list has been folded in (and found short enough): its buffer is free scratch
+    uint32_t *partial = reinterpret_cast<uint32_t *>(c->d_ovf);
+    if ((uint64_t)grid.x * n * 4 > (uint64_t)kOvfCap * 16) return MK_OK;
+    if (c->W == 1)
+        hipLaunchKernelGGL(dense_batch_kernel<1>, grid, dim3(256), 0, c->stream, c->d_tables, c->d_codes, c->d_code_off,
+                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
+    else
+        hipLaunchKernelGGL(dense_batch_kernel<2>, grid, dim3(256), 0, c->stream, c->d_tables, c->d_codes, c->d_code_off,
+                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
+    hipLaunchKernelGGL(dense_count_kernel, dim3(n), dim3(256), 0, c->stream, partial, grid.x, qs->d_nent + q0);
+    MK_HIP(hipGetLastError());
+    *done = true;
     return MK_OK;
 }
 
