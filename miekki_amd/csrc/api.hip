@@ -340,7 +340,17 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
     if (!qs->long_q.empty()) {
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-        for (uint32_t q : qs->long_q) MK_TRY(launch_query_sketch_long(c, qs, q));
+        // neighbours in the set share one binned K1 run and one gate-and-append launch
+        MK_TRY(ensure_build_scratch(c, 0, 0));
+        for (size_t i = 0; i < qs->long_q.size();) {
+            uint32_t n = 1;
+            while (i + n < qs->long_q.size() && n < c->build_batch && qs->long_q[i + n] == qs->long_q[i] + n) ++n;
+            bool done = false;
+            if (n > 1) MK_TRY(launch_query_sketch_long_batch(c, qs, qs->long_q[i], n, &done));
+            if (!done)
+                for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_long(c, qs, qs->long_q[i + j]));
+            i += n;
+        }
     }
     if (!qs->dense_q.empty()) {
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));

@@ -175,6 +175,7 @@ int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);
 int ensure_bloom_summary(mk_ctx *c);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
+int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t n, bool *done);
 int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q
 int launch_query_sketch_dense_batch(mk_ctx *c, mk_qset *qs, uint32_t slot, uint32_t n, bool *done);
 int launch_scan_counts(mk_ctx *c, mk_qset *qs);                          // fills qs->d_scan_n

@@ -911,6 +911,81 @@ int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q)
     return MK_OK;
 }
 
+// The same for a run of neighbouring long queries: one binned K1 run builds their tables,
+// one launch (grid = (P / 256, n)) gates and appends.  A workgroup adds its keepers up first
+// and reserves their places with ONE atomic, on a counter that has a cache line to itself:
+// per-wave atomics on the n adjacent d_nent words would all queue on one L2 channel.
+constexpr uint32_t kCountStride = 32;             // u32 words between two queries' counters
+__global__ __launch_bounds__(256) void long_compact_batch_kernel(const uint64_t *__restrict__ tables,
+                                                                 const uint8_t *__restrict__ codes,
+                                                                 const uint64_t *__restrict__ code_off,
+                                                                 const uint8_t *__restrict__ bloom,
+                                                                 uint64_t bloom_dev_bytes,
+                                                                 const uint32_t *__restrict__ full,
+                                                                 uint64_t *__restrict__ entries,
+                                                                 const uint64_t *__restrict__ ent_off,
+                                                                 uint32_t *__restrict__ counters, SketchParams sp)
+{
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_base;
+    const uint32_t g = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool keep = false;
+    uint32_t fp = 0;
+    if (p < sp.P) {
+        const uint64_t key = __builtin_nontemporal_load(tables + (uint64_t)g * sp.P + p);
+        if (key != kEmptyKey) {
+            fp = (uint32_t)(key >> kPosBits);
+            const uint64_t canon = canon_from_codes(codes + code_off[g], key & ((1ULL << kPosBits) - 1), sp.k);
+            keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2, full);
+        }
+    }
+    const uint64_t mask = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (total == 0) return;                                        // uniform over the workgroup
+    if (threadIdx.x == 0) s_base = atomicAdd(counters + (uint64_t)g * kCountStride, total);
+    __syncthreads();
+    if (!keep) return;
+    uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w];
+    entries[ent_off[g] + at] = make_entry(p, fp);
+}
+
+__global__ void spread_counts_kernel(const uint32_t *__restrict__ counters, uint32_t n, uint32_t *__restrict__ nent)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) nent[g] = counters[(uint64_t)g * kCountStride];
+}
+
+// long queries q0 .. q0+n-1 (neighbours in the set); *done = false: nothing was written, sketch them one by one
+int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t n, bool *done)
+{
+    *done = false;
+    MK_TRY(launch_seed_valid(c, qs->d_seq, qs->d_off + q0, n, c->d_seed_valid));
+    MK_TRY(ensure_codes(c, qs->h_off[q0 + n] - qs->h_off[q0]));
+    MK_TRY(upload_code_offsets(c, qs->h_off.data() + q0, n));
+    bool used = false;
+    MK_TRY(launch_genome_sketch_binned(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, c->d_seed_valid, n,
+                                       c->d_tables, &used, true));
+    if (!used) return MK_OK;
+    uint32_t novf = 0;
+    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    if (binned_overflowed(novf)) return MK_OK;
+    // the overflow list has been folded in (and found short enough): its buffer is free scratch
+    uint32_t *counters = reinterpret_cast<uint32_t *>(c->d_ovf);
+    MK_HIP(hipMemsetAsync(counters, 0, (size_t)n * kCountStride * 4, c->stream));
+    hipLaunchKernelGGL(long_compact_batch_kernel, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables,
+                       c->d_codes, c->d_code_off, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_entries,
+                       qs->d_ent_off + q0, counters, make_sp(c));
+    hipLaunchKernelGGL(spread_counts_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, counters, n, qs->d_nent + q0);
+    MK_HIP(hipGetLastError());
+    *done = true;
+    return MK_OK;
+}
+
 // ---------------------------------------------------------------- K4'' query sketch (dense)
 // table -> this query's lane of the group's interleaved fingerprint vector
 template <int W>

@@ -461,3 +461,35 @@ def test_device_heap_merge_is_the_host_heap(hip):
                 assert hits[q, :n].tobytes() == want[:n].tobytes(), (world, nres, q)
     finally:
         ix.close()
+
+
+def test_runs_of_long_queries_against_oracle(hip):
+    """Queries beyond the in-LDS sketch (more than 4,096 k-mers) that sit next to each other in a
+    batch are sketched together (binned K1 + one gate-and-append launch); loners go one by one.
+    Mixed with short queries, a too-long-for-sparse (dense) one and a repetitive one."""
+    from oracle import oracle as orc
+    k, h = 31, 15
+    seqs = [synth.genome_bases(400 + i, 0, 150_000) for i in range(12)]
+    o = orc.OracleMiekki(k, h, 8, 33, 10)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 33, 10)
+    try:
+        ix.insert_sequences(seqs)
+        qs = []
+        for j in range(70):                                             # one run of 70 long queries: two batches
+            g = j % 12
+            qs.append(seqs[g][1000 * j:1000 * j + 4200 + 731 * (j % 9)])
+        qs.append(seqs[3][500:1500])                                    # short
+        qs.append(seqs[5][:70_000])                                     # dense at h=15 (>= 2^h / 4 k-mers)
+        qs.append(seqs[7][100:9100])                                    # a loner
+        qs.append(seqs[1][200:900])
+        qs.append((b"ACGTTGCA" * 2000)[:12_000])                        # repetitive long query
+        qs += [seqs[2][3000:9000], seqs[9][10:8000]]                    # a run of two
+        want = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), want)
+        hits, _ = ix.query(qs, 10, 5, 1.0)
+        for q in range(len(qs)):
+            w = o.filter_results(want[q], 10, 5, 1.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(y[0], y[1]) for y in w], q
+    finally:
+        ix.close()
