@@ -182,18 +182,24 @@ struct Driver {
         return s;
     }
 
+    void run_query(const vector<const char *> &p, const vector<uint64_t> &l, uint32_t nres, uint32_t min_score,
+                   double min_inter, vector<mk_hit> &hits, vector<uint32_t> &nhits)
+    {
+        hits.assign((size_t)p.size() * nres + 1, mk_hit{});
+        nhits.assign(p.size() + 1, 0);
+        if (p.empty()) return;
+        if (mk_query(ctx, p.data(), l.data(), (uint32_t)p.size(), nres, min_score, min_inter, hits.data(),
+                     nhits.data(), nullptr) != MK_OK)
+            die("query failed");
+    }
+
     void run_query(const vector<const string *> &seqs, uint32_t nres, uint32_t min_score, double min_inter,
                    vector<mk_hit> &hits, vector<uint32_t> &nhits)
     {
         vector<const char *> p;
         vector<uint64_t> l;
         for (auto s : seqs) { p.push_back(s->data()); l.push_back(s->size()); }
-        hits.assign((size_t)seqs.size() * nres + 1, mk_hit{});
-        nhits.assign(seqs.size() + 1, 0);
-        if (seqs.empty()) return;
-        if (mk_query(ctx, p.data(), l.data(), (uint32_t)seqs.size(), nres, min_score, min_inter, hits.data(),
-                     nhits.data(), nullptr) != MK_OK)
-            die("query failed");
+        run_query(p, l, nres, min_score, min_inter, hits, nhits);
     }
 
     // strict 2-line records (Miekki.cpp:458-464)
@@ -296,35 +302,39 @@ struct Driver {
         vector<string> files;
         for (const string &fn : split_lines(text))
             if (fn.size() > 3) files.push_back(fn);
-        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{nullptr, nullptr, nullptr}, 2 * 32);
+        // readers parse into pinned buffers, two batches ahead: the upload of a batch is a DMA
+        // straight out of them
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 2 * 32);
         // whole files are queried in batches so that the dense kernel can take four per
         // pass over the matrix; output stays in list order
-        vector<string> names, refs;
+        vector<string> names;
+        vector<OrderedFastaReader::Item> refs;
         uint64_t bytes = 0;
         auto flush = [&]() {
             if (refs.empty()) return;
-            vector<const string *> q;
-            for (auto &r : refs) q.push_back(&r);
+            vector<const char *> p;
+            vector<uint64_t> l;
+            for (auto &r : refs) { p.push_back(r.data); l.push_back(r.len); }
             vector<mk_hit> hits;
             vector<uint32_t> nhits;
-            run_query(q, 10, 10, 0.5 * threshold, hits, nhits);
+            run_query(p, l, 10, 10, 0.5 * threshold, hits, nhits);
             for (size_t i = 0; i < refs.size(); ++i)
                 if (nhits[i]) out << names[i] << ":" << hit_text(hits.data() + i * 10, nhits[i]) << "\n";   // 506-511
             out << std::flush;
+            for (auto &r : refs) reader.recycle(r);
             names.clear(); refs.clear(); bytes = 0;
         };
         for (size_t i = 0; i < files.size(); ++i) {
             OrderedFastaReader::Item item = reader.take(i);
             if (!item.exists) {
                 cout << "File problem" << endl;
-            } else {
-                string ref(item.data ? item.data : "", item.len);
                 reader.recycle(item);
-                if (ref.size() >= k) {
-                    bytes += ref.size();
-                    names.push_back(files[i]); refs.push_back(std::move(ref));
-                    if (refs.size() >= 32 || bytes > (1ull << 30)) flush();
-                }
+            } else if (item.len >= k) {
+                bytes += item.len;
+                names.push_back(files[i]); refs.push_back(item);
+                if (refs.size() >= 32 || bytes > (1ull << 30)) flush();
+            } else {
+                reader.recycle(item);
             }
             cout << "-" << flush_stream();
         }

@@ -841,10 +841,30 @@ int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uin
     MK_TRY(use_device(c));
     mk_qset *qs = nullptr;
     MK_TRY(qset_alloc(c, lens, nq, &qs));
-    // one pinned staging pass keeps the upload a single large copy
-    std::vector<char> host(qs->total_len);
-    for (uint32_t q = 0; q < nq; ++q) memcpy(host.data() + qs->h_off[q], seqs[q], lens[q]);
-    if (qs->total_len && hipMemcpy(qs->d_seq, host.data(), qs->total_len, hipMemcpyHostToDevice) != hipSuccess) {
+    // Short sequences are gathered so that a run of them is ONE copy (100,000 reads must not be
+    // 100,000 copies); a long one (a contig, a whole genome) goes straight from the caller's
+    // buffer -- a DMA when that buffer is pinned (mk_host_alloc), and no extra pass over it.
+    constexpr uint64_t kDirect = 256u << 10;
+    std::vector<char> host;
+    bool ok = true;
+    for (uint32_t q = 0; q < nq && ok;) {
+        if (lens[q] >= kDirect) {
+            ok = hipMemcpyAsync(qs->d_seq + qs->h_off[q], seqs[q], lens[q], hipMemcpyHostToDevice, c->stream) == hipSuccess;
+            ++q;
+            continue;
+        }
+        uint32_t e = q;
+        while (e < nq && lens[e] < kDirect && qs->h_off[e + 1] - qs->h_off[q] <= (1ull << 30)) ++e;
+        if (e == q) e = q + 1;
+        const uint64_t bytes = qs->h_off[e] - qs->h_off[q];
+        host.resize(bytes);
+        for (uint32_t i = q; i < e; ++i) memcpy(host.data() + (qs->h_off[i] - qs->h_off[q]), seqs[i], lens[i]);
+        // synchronous: `host` is reused for the next run
+        if (bytes) ok = hipMemcpy(qs->d_seq + qs->h_off[q], host.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+        q = e;
+    }
+    if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;    // the caller's buffers are free again
+    if (!ok) {
         set_error("query upload failed");
         qset_release(qs);
         return MK_ERR_DEVICE;
