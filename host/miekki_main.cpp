@@ -348,18 +348,25 @@ struct Driver {
     void ground_truth(const string &file, const vector<Pending> &v)
     {
         if (!mkhost::file_exists(file)) { cout << "File problem: " << file << endl; return; }
-        string text;
-        mkhost::read_text(file, text);
+        // contigs split at '>' lines (Miekki.cpp:805-812), walked line by line over the raw text
+        static thread_local vector<char> text, scratch;
+        text.clear();
+        mkhost::read_file(file, text, scratch);
         vector<string> contigs;
         string ref;
-        for (const string &line : split_lines(text)) {
-            if (!line.empty() && line[0] == '>') {
-                if (ref.size() >= k) { contigs.push_back(ref); ref.clear(); }    // short contigs leak (806-812)
+        ref.reserve(text.size());
+        const char *pos = text.data(), *const end = text.data() + text.size();
+        while (pos <= end) {                                                     // getline semantics
+            const char *e = pos < end ? (const char *)memchr(pos, '\n', (size_t)(end - pos)) : nullptr;
+            if (!e) e = end;
+            if (e != pos && *pos == '>') {
+                if (ref.size() >= k) { contigs.push_back(std::move(ref)); ref = string(); }   // short contigs leak (806-812)
             } else {
-                ref += line;
+                ref.append(pos, (size_t)(e - pos));
             }
+            pos = e + 1;
         }
-        if (ref.size() >= k) contigs.push_back(ref);
+        if (ref.size() >= k) contigs.push_back(std::move(ref));
         vector<const char *> cp, qp;
         vector<uint64_t> cl, ql;
         for (auto &c : contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
