@@ -111,14 +111,30 @@ def main(argv=None):
     for b0 in range(0, len(recs), step):
         chunk = recs[b0:b0 + step]
         nq = len(chunk)
-        ptrs, lens = L.seq_arrays([s for _, s in chunk])
-        qs = C.c_void_p()
-        L.check(lib.mk_qset_upload(ix._h, ptrs, lens, nq, C.byref(qs)))
         d_count = torch.zeros(nq, dtype=torch.int32, device="cuda")
         d_cand = torch.zeros(nq * cap * mkd.HIT_BYTES, dtype=torch.uint8, device="cuda")
-        L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, float(min_inter), cap, d_count.data_ptr(), d_cand.data_ptr()))
-        L.check(lib.mk_sync(ix._h))
-        lib.mk_qset_free(ix._h, qs)
+        # short records (at most 4,096 k-mers) and long ones are run as two sets, so that the
+        # short ones keep the slab schedule (mk_query does the same for its batches)
+        short = [i for i, (_, s) in enumerate(chunk) if len(s) <= args.k + 4096]
+        long_ = [i for i, (_, s) in enumerate(chunk) if len(s) > args.k + 4096]
+        for part in (short, long_):
+            if not part:
+                continue
+            whole = len(part) == nq
+            ptrs, lens = L.seq_arrays([chunk[i][1] for i in part])
+            qs = C.c_void_p()
+            L.check(lib.mk_qset_upload(ix._h, ptrs, lens, len(part), C.byref(qs)))
+            p_count = d_count if whole else torch.zeros(len(part), dtype=torch.int32, device="cuda")
+            p_cand = d_cand if whole else torch.zeros(len(part) * cap * mkd.HIT_BYTES, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, float(min_inter), cap, p_count.data_ptr(), p_cand.data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            lib.mk_qset_free(ix._h, qs)
+            if not whole:
+                idx = torch.tensor(part, dtype=torch.int64, device="cuda")
+                d_count[idx] = p_count
+                d_cand.view(nq, cap * mkd.HIT_BYTES)[idx] = p_cand.view(len(part), cap * mkd.HIT_BYTES)
+                torch.cuda.synchronize()
         if world > 1:                                            # the one exchange step
             counts, cands = mkd.gather_rows(d_count.to(coll), d_cand.to(coll))
         else:
