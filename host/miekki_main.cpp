@@ -26,6 +26,7 @@
 #include <future>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -175,10 +176,15 @@ struct Driver {
     // one output line of query_file / query_whole_file (Miekki.cpp:440-444, 503-505)
     static string hit_text(const mk_hit *h, uint32_t n)
     {
+        // to_string(uint) \t to_string(uint) \t to_string(uint(intersection)) \t to_string(double) ";"
+        // -- std::to_string(double) is printf's %f -- in one formatting call per hit
         string s;
-        for (uint32_t i = 0; i < n; ++i)
-            s += to_string(h[i].genome) + "\t" + to_string(h[i].matches) + "\t" +
-                 to_string((unsigned)h[i].intersection) + "\t" + to_string(h[i].jaccard) + ";";
+        char buf[96];
+        for (uint32_t i = 0; i < n; ++i) {
+            const int len = snprintf(buf, sizeof buf, "%u\t%u\t%u\t%f;", h[i].genome, h[i].matches,
+                                     (unsigned)h[i].intersection, h[i].jaccard);
+            s.append(buf, (size_t)len);
+        }
         return s;
     }
 
@@ -272,6 +278,8 @@ struct Driver {
         vector<string> heads, seqs, next_heads, next_seqs;
         vector<mk_hit> hits;
         vector<uint32_t> nhits;
+        struct WriteJob { vector<string> heads; vector<mk_hit> hits; vector<uint32_t> nhits; size_t n = 0; };
+        std::future<void> writer;
         size_t done = 0;
         bool more = in.next(super, k, heads, seqs);
         while (more) {
@@ -280,16 +288,29 @@ struct Driver {
             vector<const string *> q;
             for (auto &r : seqs) q.push_back(&r);
             run_query(q, 10, 10, 0.5 * threshold, hits, nhits);
-            string text;
-            for (size_t i = 0; i < seqs.size(); ++i) {
-                text += heads[i] + ":" + hit_text(hits.data() + i * 10, nhits[i]) + "\n";
+            for (size_t i = 0; i < seqs.size(); ++i)
                 if (((done + i) % 201) == 0) cout << "-" << flush_stream();   // one mark per reference batch (345)
-            }
-            out << text;
+            // formatting and writing this batch's lines runs beside the next batch's device work
+            // (one writer at a time, in order)
+            if (writer.valid()) writer.get();
+            auto job = std::make_shared<WriteJob>();
+            job->heads.swap(heads); job->hits.swap(hits); job->nhits.swap(nhits);
+            job->n = seqs.size();
+            writer = std::async(std::launch::async, [this, job] {
+                string text;
+                for (size_t i = 0; i < job->n; ++i) {
+                    text += job->heads[i];
+                    text += ':';
+                    text += hit_text(job->hits.data() + i * 10, job->nhits[i]);
+                    text += '\n';
+                }
+                out << text;
+            });
             done += seqs.size();
             more = ahead.get();
             heads.swap(next_heads); seqs.swap(next_seqs);
         }
+        if (writer.valid()) writer.get();
         out << flush;
     }
 
