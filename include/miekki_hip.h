@@ -180,7 +180,11 @@ void mk_qset_free(mk_ctx *ctx, mk_qset *qs);
  * rows of several genome shards concatenated in shard order do too (multi-GPU
  * merge).  Output goes to device memory owned by the caller: d_count[nq] (u32; a
  * value above `cap` marks a row that overflowed) and d_cand[nq][cap] (mk_hit).
- * Asynchronous on the context's stream; mk_sync waits. */
+ * Asynchronous on the context's stream; mk_sync waits.
+ * min_score 0 over an index that holds a genome with sketch_size 0 (a sequence
+ * exactly k long) would make NaN intersections (0 / 0, Miekki.cpp:381-383), whose
+ * fate in the reference's heap follows no order: MK_ERR_UNSUPPORTED -- mk_query
+ * answers such calls, through the host's own heap calls. */
 int mk_qset_run(mk_ctx *ctx, mk_qset *qs, uint32_t nresults, uint32_t min_score,
                 double min_intersection, uint32_t cap, uint32_t *d_count, mk_hit *d_cand);
 /* Raw scores of queries [q_begin, q_end) of the set into d_scores[(q_end-q_begin)][G]. */

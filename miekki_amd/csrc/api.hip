@@ -267,6 +267,7 @@ static int settle_build(mk_ctx *c)
         gsz[g] = estimate_genome_size(act[g], c->h_back->card[g], len);
         c->h_sketch_size.push_back(act[g]);
         c->h_genome_size.push_back(gsz[g]);
+        if (act[g] == 0) c->has_empty_sketch = true;
         c->stats.build_kmers += len > c->p.k ? len - c->p.k : 0;
     }
     MK_HIP(hipMemcpy(c->d_sketch_size + c->G, act, n * 4, hipMemcpyHostToDevice));
@@ -274,6 +275,16 @@ static int settle_build(mk_ctx *c)
     c->G += n;
     c->stats.build_genomes += n;
     return MK_OK;
+}
+
+// A genome without a single stored fingerprint (its sequence is exactly k long, Miekki.cpp:162,
+// 569) has sketch_size 0: with min_score 0 its score 0 passes and jaccard = 0 / 0 is NaN
+// (Miekki.cpp:381-383).  What the reference's heap does with NaNs is whatever its comparison
+// sequence happens to yield; the device selection assumes ordered values, so such calls take
+// the host replay (dense score rows + the same std:: heap calls), which reproduces it.
+static bool nan_candidates_possible(const mk_ctx *c, uint32_t min_score)
+{
+    return min_score == 0 && c->has_empty_sketch;
 }
 
 // ---- query sets ------------------------------------------------------------------
@@ -568,7 +579,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     memset(&c->build, 0, sizeof c->build);
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
-    c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0;
+    c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0; c->nhits_cap = 0;
+    c->has_empty_sketch = false;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -798,6 +810,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
     MK_TRY(ensure_capacity(c, n));
     c->G = n;
     c->h_sketch_size.assign(n, 0); c->h_genome_size.assign(n, 0);
+    c->has_empty_sketch = false;
     if (c->d_bloom) MK_HIP(hipMemset(c->d_bloom, 0, c->bloom_dev_bytes));
     c->bloom_full_stale = true;
     return MK_OK;
@@ -816,6 +829,9 @@ int mk_index_import_sizes(mk_ctx *c, const uint64_t *genome_size, const uint32_t
     MK_TRY(use_device(c));
     c->h_genome_size.assign(genome_size, genome_size + c->G);
     c->h_sketch_size.assign(sketch_size, sketch_size + c->G);
+    c->has_empty_sketch = false;
+    for (uint32_t g = 0; g < c->G; ++g)
+        if (sketch_size[g] == 0) c->has_empty_sketch = true;
     if (c->G) {
         MK_HIP(hipMemcpy(c->d_genome_size, genome_size, (size_t)c->G * 8, hipMemcpyHostToDevice));
         MK_HIP(hipMemcpy(c->d_sketch_size, sketch_size, (size_t)c->G * 4, hipMemcpyHostToDevice));
@@ -900,6 +916,10 @@ int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, d
     if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
     if (nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
+    if (nan_candidates_possible(c, min_score)) {
+        set_error("min_score 0 over an index with empty sketches yields NaN intersections: use mk_query");
+        return MK_ERR_UNSUPPORTED;
+    }
     MK_TRY(qset_sketch(c, qs));
     if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
     if (qs->slab_ok) {
@@ -1053,7 +1073,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
     MK_TRY(qset_sketch(c, qs));
     const uint32_t cap = 256;
-    const bool on_device = nresults <= kSelectMaxResults;
+    const bool on_device = nresults <= kSelectMaxResults && !nan_candidates_possible(c, min_score);
     const bool slab = on_device && qs->slab_ok;
     const uint32_t per = slab ? chunk_queries_slab(c, nq, qs->S) : chunk_queries(c, nq);
     if (slab) {
@@ -1070,11 +1090,16 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         c->cand_cap_q = per;
     }
     if (on_device && (uint64_t)per * std::max(nresults, 1u) > c->hits_cap) {
-        dev_free(c->d_hits); dev_free(c->d_nhits);
+        dev_free(c->d_hits);
         c->hits_cap = 0;
         MK_TRY(dev_alloc(&c->d_hits, (uint64_t)per * std::max(nresults, 1u)));
-        MK_TRY(dev_alloc(&c->d_nhits, (uint64_t)per));
         c->hits_cap = (uint64_t)per * std::max(nresults, 1u);
+    }
+    if (on_device && (uint64_t)per > c->nhits_cap) {              // sized on its own: nresults differs from call to call
+        dev_free(c->d_nhits);
+        c->nhits_cap = 0;
+        MK_TRY(dev_alloc(&c->d_nhits, (uint64_t)per));
+        c->nhits_cap = per;
     }
     std::vector<uint32_t> row(c->G);
     std::vector<mk_hit> full;

@@ -52,6 +52,7 @@ struct mk_ctx {
     uint32_t capG, G;
     uint32_t *d_sketch_size;
     uint64_t *d_genome_size;
+    bool has_empty_sketch;         // some genome has sketch_size 0 (see nan_candidates_possible in api.hip)
     std::vector<uint32_t> h_sketch_size;
     std::vector<uint64_t> h_genome_size;
     // Bloom filter: only the cells a 2k-bit k-mer can reach live on the device
@@ -109,6 +110,7 @@ struct mk_ctx {
     mk_hit *d_hits;                // [queries per chunk][nresults]: K6b output of mk_query
     uint32_t *d_nhits;
     uint64_t hits_cap;             // records d_hits is sized for
+    uint64_t nhits_cap;            // queries d_nhits is sized for
     uint64_t *d_long_table;        // P keys, long-query path
     // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
     uint64_t *d_slots;

@@ -192,3 +192,43 @@ def test_pipelined_appends_from_pinned_buffers(hip):
             lib.mk_host_free(ix._h, p)
     finally:
         ref.close(); ix.close()
+
+
+def test_empty_sketch_genomes_and_min_score_zero(hip):
+    """A genome exactly k long stores no fingerprint (the last k-mer is skipped, Miekki.cpp:162):
+    sketch_size 0, and with min_score 0 its jaccard is 0/0 = NaN (Miekki.cpp:381-383).  The
+    reference's heap then does whatever its comparisons yield; mk_query must reproduce that (it
+    takes the host replay), and the device-only mk_qset_run must refuse rather than guess."""
+    from oracle import oracle as orc
+    from miekki_amd import lib as L
+    import torch
+    lib = L.load_library()
+    k, h = 23, 7
+    lens = [20000, 5000, k, 60000, k, 300]
+    seqs = [synth.genome_bases(5100 + g, 0, n) for g, n in enumerate(lens)]
+    o = orc.OracleMiekki(k, h, 8, 32, 0)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 32, 0)
+    try:
+        ix.insert_sequences(seqs)
+        assert list(ix.sketch_size) == list(o.sketch_size) and int(ix.sketch_size[2]) == 0
+        qs = [seqs[3][:900], seqs[3][:k], seqs[0][:6000], seqs[5]]
+        scores = o.query_sequences(qs)
+        for nres, ms, mi in ((1, 0, 25.0), (3, 0, 25.0), (1, 0, 0.0), (10, 0, 0.0), (2, 1, 0.0)):
+            hits, _ = ix.query(qs, nres, ms, mi)
+            for q in range(len(qs)):
+                want = o.filter_results(scores[q], nres, ms, mi)
+                assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want], (nres, ms, mi, q)
+        ptrs, lens_a = L.seq_arrays(qs)
+        qset = C.c_void_p()
+        L.check(lib.mk_qset_upload(ix._h, ptrs, lens_a, len(qs), C.byref(qset)))
+        d_count = torch.zeros(len(qs), dtype=torch.int32, device="cuda")
+        d_cand = torch.zeros(len(qs) * 16 * 24, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert lib.mk_qset_run(ix._h, qset, 5, 0, 0.0, 16, d_count.data_ptr(), d_cand.data_ptr()) == -2   # MK_ERR_UNSUPPORTED
+        assert b"NaN" in lib.mk_last_error()
+        assert lib.mk_qset_run(ix._h, qset, 5, 1, 0.0, 16, d_count.data_ptr(), d_cand.data_ptr()) == 0
+        L.check(lib.mk_sync(ix._h))
+        lib.mk_qset_free(ix._h, qset)
+    finally:
+        ix.close()

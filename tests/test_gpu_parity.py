@@ -493,3 +493,61 @@ def test_runs_of_long_queries_against_oracle(hip):
             assert [(x.genome, x.matches) for x in hits[q]] == [(y[0], y[1]) for y in w], q
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_cases_against_oracle(hip, seed):
+    """Seeded random corners: parameters, genome shapes (N, lower case, repeats, tiny), several
+    appends, and a query batch that mixes every sketch path -- short, shorter than k, runs of long
+    ones, a repetitive one, a whole genome.  Index stream, scores, active counts, hits."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.integers(6, 32)); h = int(rng.integers(5, 17)); fpb = int(rng.choice([8, 16])); b = int(rng.choice([32, 33]))
+    thr = int(rng.integers(0, 40))
+
+    def messy(seq):
+        s = bytearray(seq)
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, len(s))); n = int(rng.integers(1, 30))
+            s[p:p + n] = bytes(rng.choice(np.frombuffer(b"Nnacgtxy", np.uint8), min(n, len(s) - p)))
+        return bytes(s)
+
+    G = int(rng.integers(3, 14))
+    seqs = []
+    for g in range(G):
+        n = int(rng.choice([k, k + 1, 300, 5000, 20_000, 60_000]))
+        base = synth.genome_bases(5000 + 50 * seed + g, 0, n)
+        if rng.random() < 0.2:
+            base = (base[:97] * (n // 97 + 1))[:n]                       # period-97 repeat
+        seqs.append(messy(base))
+    o = orc.OracleMiekki(k, h, fpb, b, thr)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, fpb, b, thr)
+    try:
+        cut = int(rng.integers(0, G + 1))
+        ix.insert_sequences(seqs[:cut]); ix.insert_sequences(seqs[cut:])
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+        raw = np.frombuffer(stream_of(ix), np.uint8).copy()
+        want = o.serialize()
+        raw[32] = want[32] = 0
+        assert raw.size == want.size and sha(raw.tobytes()) == sha(want.tobytes())
+        big = max(seqs, key=len)
+        qs = [messy(big[:min(len(big), 900)]), big[:k - 1] if k > 1 else b"A", big[:k], big[:k + 1]]
+        long_len = 4096 + k + int(rng.integers(1, 3000))
+        src = synth.genome_bases(5000 + 50 * seed, 0, 60_000)
+        qs += [src[i * 500:i * 500 + long_len] for i in range(int(rng.integers(2, 5)))]      # a run of long ones
+        qs.append(synth.genome_bases(77, 0, 700))
+        qs.append((b"ACGTTG" * 2000)[:long_len])                                             # repetitive and long
+        qs.append(messy(src[:long_len + 17]))
+        qs.append(big)                                                                       # possibly dense
+        scores = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), scores)
+        nres = int(rng.choice([1, 3, 10])); ms = int(rng.integers(0, 4)); mi = float(rng.choice([0.0, 1.0, 25.0]))
+        hits, act = ix.query(qs, nres, ms, mi)
+        for q, s in enumerate(qs):
+            assert int(act[q]) == o.query_sequence(s)[1], q
+            want_h = o.filter_results(scores[q], nres, ms, mi)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want_h], q
+    finally:
+        ix.close()
