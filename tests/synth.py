@@ -194,5 +194,64 @@ def case_flush() -> Case:
     return c
 
 
-CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy}
+RND_PARAMS = [(15, 10, 3, 32, 5), (27, 16, 11, 33, 30), (31, 13, 3, 33, 0), (9, 8, 3, 32, 12)]   # k, h, f, b, threshold
+
+
+def case_rnd(i: int) -> Case:
+    """Seeded random case: odd parameters, genomes of every awkward shape (exactly k and k+1 long,
+    N / lower case / junk characters, a period-97 repeat, multi-FASTA, gzip, a header-only file) and
+    a query file that mixes all sketch paths: short, shorter than k, exactly k, runs of long reads,
+    a repetitive long one, a whole genome, a record without sequence."""
+    import numpy as np
+    k, h, f, b, thr = RND_PARAMS[i]
+    c = Case(f"rnd{i}", k, h, f, b, thr)
+    rng = np.random.default_rng(4242 + i)
+
+    def messy(seq):
+        s = bytearray(seq)
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, len(s))); n = int(rng.integers(1, 30))
+            s[p:p + n] = bytes(rng.choice(np.frombuffer(b"Nnacgtxy", np.uint8), min(n, len(s) - p)))
+        return bytes(s)
+
+    raws = []
+    # (no genome of exactly k characters: its sketch_size is 0, min_score 0 then makes 0/0 = NaN
+    # intersections, and the reference is built with -Ofast, i.e. finite-math-only: what its heap
+    # does with NaN is whatever that compiler run emitted -- nothing an oracle can pin)
+    lens = [k + 2, k + 1, 300, 5000, 20_000, 60_000, 20_000, k - 1, 5000]
+    for g, n in enumerate(lens):
+        base = genome_bases(6000 + 40 * i + g, 0, n)
+        if g == 4:
+            base = (base[:97] * (n // 97 + 1))[:n]
+        base = messy(base) if n > 100 else base
+        raws.append(base)
+        if g == 5:                                              # multi-FASTA, blank line inside
+            data = b">a\n" + base[:25_000] + b"\n\n>b second contig\n" + base[25_000:] + b"\n"
+        elif g == 6:
+            data = base + b"\n"                                 # no header at all
+        else:
+            data = fasta(f"r{i}_{g}", base, int(rng.choice([60, 80, 100000])))
+        c.genome_files.append((f"r{i}_{g}.fa", data, g in (3, 6)))
+    c.genome_files.append((f"r{i}_hdr.fa", b">only a header\n", False))
+    big = raws[5]
+    for q in range(14):
+        src = raws[int(rng.choice([3, 4, 5, 6, 8]))]
+        off = int(rng.integers(0, len(src) - 2200))
+        c.queries.append((f">s{q}".encode(), messy(src[off:off + 300 + 130 * q])))
+    c.queries.append((b">shorter_than_k", big[:k - 1]))
+    c.queries.append((b">exactly_k", big[7:7 + k]))
+    c.queries.append((b">k_plus_1", big[9:9 + k + 1]))
+    long_len = 4096 + k + 777
+    for q in range(3):                                          # a run of long reads
+        c.queries.append((f">long{q}".encode(), big[1000 * q:1000 * q + long_len + 211 * q]))
+    c.queries.append((b">miss", genome_bases(9_000_000 + i, 0, 800)))
+    c.queries.append((b">repetitive_long", (b"ACGTTGCAT" * 1500)[:long_len]))
+    c.queries.append((b">long_again", messy(raws[6][:long_len + 5])))
+    c.queries.append((b">whole", big))
+    c.queries.append((b">no_sequence", b""))
+    return c
+
+
+CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy,
+         "rnd0": lambda: case_rnd(0), "rnd1": lambda: case_rnd(1), "rnd2": lambda: case_rnd(2), "rnd3": lambda: case_rnd(3)}
 EXTRA_CASES = {"flush": case_flush}       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)

@@ -14,7 +14,7 @@ import pytest
 import synth
 from oracle import oracle as orc
 
-CASE_NAMES = ["messy", "h20", "w16", "c1"]
+CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3"]
 
 
 def sha(b):
