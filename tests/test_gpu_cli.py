@@ -101,7 +101,7 @@ def test_unsupported_fingerprint_size_message(workdirs):
     assert b"not implemented" in out
 
 
-@pytest.mark.parametrize("name,ranks", [("messy", 3), ("h20", 2)])
+@pytest.mark.parametrize("name,ranks", [("messy", 3), ("h20", 2), ("rnd2", 4), ("rnd1", 3)])
 def test_multi_rank_driver_equals_reference(workdirs, golden_dir, name, ranks):
     """miekki_amd.mgpu: genome-sharded ranks (rehearsal: gloo, every rank on GPU 0),
     Bloom merge, gather of heap entrants, rank-0 merge -> the reference's out.txt."""
