@@ -455,6 +455,7 @@ static int ensure_scores(mk_ctx *c, uint64_t rows)
     const uint64_t need = rows * score_row_entries(c);
     if (need > c->scores_cap) {
         dev_free(c->d_scores);
+        c->scores_cap = 0;
         MK_TRY(dev_alloc(&c->d_scores, need));
         c->scores_cap = need;
     }
@@ -509,6 +510,7 @@ static int ensure_partials(mk_ctx *c, uint64_t bytes)
 {
     if (bytes > c->partials_cap) {
         dev_free(c->d_partials);
+        c->partials_cap = 0;
         MK_TRY(dev_alloc(&c->d_partials, bytes));
         c->partials_cap = bytes;
     }
@@ -1085,6 +1087,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     uint32_t *const d_replay_row = c->d_scores + (slab ? 0 : (uint64_t)per * score_row_entries(c));
     if (on_device && (uint64_t)per > c->cand_cap_q) {
         dev_free(c->d_count); dev_free(c->d_cand);
+        c->cand_cap_q = 0;
         MK_TRY(dev_alloc(&c->d_count, (uint64_t)per));
         MK_TRY(dev_alloc(&c->d_cand, (uint64_t)per * cap));
         c->cand_cap_q = per;
