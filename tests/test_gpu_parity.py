@@ -495,7 +495,7 @@ def test_runs_of_long_queries_against_oracle(hip):
         ix.close()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MK_FUZZ_SEEDS", "12")))))   # MK_FUZZ_SEEDS=N for a soak run
 def test_randomised_cases_against_oracle(hip, seed):
     """Seeded random corners: parameters, genome shapes (N, lower case, repeats, tiny), several
     appends, and a query batch that mixes every sketch path -- short, shorter than k, runs of long
