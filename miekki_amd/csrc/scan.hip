@@ -54,12 +54,19 @@ int launch_scan_slab(mk_ctx *c, const SlabArgs &a)
 
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
 {
-    const uint64_t work = (uint64_t)a.ngroups * a.ntiles * a.nchunks;
+    // eight queries per pass over the matrix when there are that many, else four
+    const uint32_t gb = a.ngroups >= 2 ? 2 : 1;
+    const uint64_t work = (uint64_t)((a.ngroups + gb - 1) / gb) * a.ntiles * a.nchunks;
     if (work == 0) return MK_OK;
     if (work >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }
     const uint32_t blocks = (uint32_t)((work + 3) / 4);
-    if (c->W == 1) hipLaunchKernelGGL(scan_dense_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, a);
-    else           hipLaunchKernelGGL(scan_dense_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, a);
+    if (c->W == 1) {
+        if (gb == 2) hipLaunchKernelGGL((scan_dense_kernel<1, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else         hipLaunchKernelGGL((scan_dense_kernel<1, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+    } else {
+        if (gb == 2) hipLaunchKernelGGL((scan_dense_kernel<2, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
+        else         hipLaunchKernelGGL((scan_dense_kernel<2, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+    }
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

@@ -241,41 +241,57 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
 // ---------------------------------------------------------------- dense queries
 // Whole-genome queries (-A) have nearly every partition active: walking a sparse
 // list buys nothing and every query would stream the whole matrix on its own.
-// Here a wave owns (group of four queries, row tile, chunk of rows): each row piece is
-// loaded ONCE and compared against the four queries' fingerprints of that partition
-// (one scalar dword), which quarters the bytes per comparison.  Mismatch counters are
-// packed per query as in the sparse kernel; the wave's share of each score is added
-// to the score row with integer atomics (order-independent, exact).
-template <int W>
+// Here a wave owns (GB groups of four queries, row tile, chunk of rows): each row piece
+// is loaded ONCE and compared against the 4 * GB queries' fingerprints of that
+// partition (one scalar dword per group), which divides the bytes per comparison by
+// 4 * GB.  Mismatch counters are packed as in the sparse kernel (four byte counters per
+// word, spilled every 248 rows into two 16-bit counters per word: a chunk has at most
+// 8,192 rows); the wave's share of each score is added to the score row with integer
+// atomics (order-independent, exact).
+template <int W, int GB>
 __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
 {
-    constexpr uint32_t NCNT = 16 / W, FLUSH = W == 1 ? 248u : 65528u, QB = 4;
+    constexpr uint32_t NCNT = 16 / W, FLUSH = W == 1 ? 248u : 65528u, QB = 4 * GB;
+    constexpr uint32_t NWORD = 8;                                    // counter words per query (two counters each)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t work = blockIdx.x * 4u + wave;
-    if (work >= a.ngroups * a.ntiles * a.nchunks) return;
+    const uint32_t nsets = (a.ngroups + GB - 1) / GB;
+    if (work >= nsets * a.ntiles * a.nchunks) return;
     const uint32_t chunk = work % a.nchunks, gt = work / a.nchunks;
-    const uint32_t tile = gt % a.ntiles, group = gt / a.ntiles;
+    const uint32_t tile = gt % a.ntiles, set = gt / a.ntiles;
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     uint32_t qidx[QB];
-    bool any = false;
+    bool any = false, grp_on[GB];
 #pragma unroll
-    for (uint32_t j = 0; j < QB; ++j) {
-        qidx[j] = a.dense_q[group * QB + j];
-        any |= qidx[j] >= a.q0 && qidx[j] < a.q1;
+    for (uint32_t gb = 0; gb < (uint32_t)GB; ++gb) {
+        const uint32_t group = set * GB + gb;
+        grp_on[gb] = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t qi = group < a.ngroups ? a.dense_q[group * 4 + j] : 0xffffffffu;
+            qidx[gb * 4 + j] = qi;
+            grp_on[gb] |= qi >= a.q0 && qi < a.q1;
+        }
+        any |= grp_on[gb];
     }
     if (!any) return;
     const uint32_t row0 = chunk * a.rows_per_item, row1 = min(a.P, row0 + a.rows_per_item);
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
     const uint32_t voff = lane * 16u;
     using fp4_t = typename std::conditional<W == 1, uint32_t, uint2>::type;
-    const fp4_t *__restrict__ dv = reinterpret_cast<const fp4_t *>(a.dense) + (uint64_t)group * a.P;
-    uint32_t ne32[QB][NCNT], nact[QB];
+    const fp4_t *__restrict__ dv[GB];
+#pragma unroll
+    for (uint32_t gb = 0; gb < (uint32_t)GB; ++gb)
+        dv[gb] = reinterpret_cast<const fp4_t *>(a.dense) + (uint64_t)min(set * GB + gb, a.ngroups - 1) * a.P;
+    // W == 1: cnt[j][2w] / [2w+1] hold the even / odd byte counters of word w, 16 bits each;
+    // W == 2: cnt[j][w] is acc's word w itself (two 16-bit counters), no spill ever needed
+    uint32_t cnt[QB][NWORD], nact[QB];
 #pragma unroll
     for (uint32_t j = 0; j < QB; ++j) {
         nact[j] = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < NCNT; ++k) ne32[j][k] = 0;
+        for (uint32_t k = 0; k < NWORD; ++k) cnt[j][k] = 0;
     }
     for (uint32_t r0 = row0; r0 < row1; r0 += FLUSH) {
         const uint32_t r1 = min(row1, r0 + FLUSH);
@@ -284,11 +300,12 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
         for (uint32_t j = 0; j < QB; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0;
         for (uint32_t r = r0; r < r1; r += 4) {
             uint4 d[4];
-            fp4_t f[4];
+            fp4_t f[4][GB];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t rr = min(r + u, r1 - 1);                   // tail rows repeat the last (masked below)
-                f[u] = dv[rr];
+#pragma unroll
+                for (uint32_t gb = 0; gb < (uint32_t)GB; ++gb) f[u][gb] = dv[gb][rr];
                 d[u] = load_row16<false>(row_base(base, rr, a.ld) + voff);
             }
 #pragma unroll
@@ -296,9 +313,12 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
                 if (r + u >= r1) break;
 #pragma unroll
                 for (uint32_t j = 0; j < QB; ++j) {
+                    if (!grp_on[j / 4]) continue;                         // wave-uniform
+                    const fp4_t &fw = f[u][j / 4];
+                    const uint32_t jj = j & 3u;
                     uint32_t fp;
-                    if (W == 1) fp = (reinterpret_cast<const uint32_t &>(f[u]) >> (8 * j)) & 0xffu;
-                    else { const uint2 &ff = reinterpret_cast<const uint2 &>(f[u]); fp = ((j < 2 ? ff.x : ff.y) >> (16 * (j & 1))) & 0xffffu; }
+                    if (W == 1) fp = (reinterpret_cast<const uint32_t &>(fw) >> (8 * jj)) & 0xffu;
+                    else { const uint2 &ff = reinterpret_cast<const uint2 &>(fw); fp = ((jj < 2 ? ff.x : ff.y) >> (16 * (jj & 1))) & 0xffffu; }
                     if (fp == a.empty) continue;                          // wave-uniform
                     ++nact[j];
                     const uint32_t b = bcast_fp<W>(fp);
@@ -314,13 +334,10 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) {
                 if (W == 1) {
-                    ne32[j][4 * w + 0] += acc[j][w] & 0xffu;
-                    ne32[j][4 * w + 1] += (acc[j][w] >> 8) & 0xffu;
-                    ne32[j][4 * w + 2] += (acc[j][w] >> 16) & 0xffu;
-                    ne32[j][4 * w + 3] += acc[j][w] >> 24;
+                    cnt[j][2 * w + 0] += acc[j][w] & 0x00ff00ffu;
+                    cnt[j][2 * w + 1] += (acc[j][w] >> 8) & 0x00ff00ffu;
                 } else {
-                    ne32[j][2 * w + 0] += acc[j][w] & 0xffffu;
-                    ne32[j][2 * w + 1] += acc[j][w] >> 16;
+                    cnt[j][w] += acc[j][w];
                 }
             }
     }
@@ -331,8 +348,12 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
         uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride +
                                      (uint64_t)(qidx[j] - a.q0) * a.score_q_stride + lane * NCNT;
 #pragma unroll
-        for (uint32_t k = 0; k < NCNT; ++k)
-            if (g0 + k < a.G && nact[j] != ne32[j][k]) atomicAdd(row + k, nact[j] - ne32[j][k]);
+        for (uint32_t k = 0; k < NCNT; ++k) {
+            uint32_t ne;
+            if (W == 1) ne = (cnt[j][2 * (k / 4) + (k & 1u)] >> (16 * ((k & 3u) / 2))) & 0xffffu;   // byte k & 3 of word k / 4
+            else ne = (cnt[j][k / 2] >> (16 * (k & 1u))) & 0xffffu;
+            if (g0 + k < a.G && nact[j] != ne) atomicAdd(row + k, nact[j] - ne);
+        }
     }
 }
 
