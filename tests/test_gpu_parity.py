@@ -551,3 +551,74 @@ def test_randomised_cases_against_oracle(hip, seed):
             assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want_h], q
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MK_SHARD_SEEDS", "4")))))   # MK_SHARD_SEEDS=N for a soak run
+def test_random_shardings_merge_like_one_context(hip, seed):
+    """The multi-GPU data path on one GPU, randomised: 2-6 contexts over contiguous genome ranges
+    (uneven on purpose), duplicate genomes scattered across shards so that equal intersections meet
+    in the merge, random top-N / thresholds, both the device merge (K6b) and the host merge, against
+    ONE context holding everything."""
+    import ctypes as C
+    import torch
+    from miekki_amd import lib as L, distributed as mkd
+    lib = L.load_library()
+    rng = np.random.default_rng(777 + seed)
+    k = int(rng.integers(15, 32)); h = int(rng.integers(10, 17)); thr = int(rng.integers(0, 30))
+    G = int(rng.integers(12, 60))
+    distinct = [synth.genome_bases(8000 + 70 * seed + i, 0, int(rng.integers(3000, 30_000))) for i in range(max(3, G // 3))]
+    seqs = [distinct[int(rng.integers(0, len(distinct)))] for _ in range(G)]          # many duplicates
+    qs = [distinct[i][100:100 + int(rng.integers(200, 2500))] for i in rng.integers(0, len(distinct), 6)]
+    qs.append(synth.genome_bases(3, 0, 900))
+    nres = int(rng.choice([1, 3, 10, 25])); ms = int(rng.integers(1, 4)); mi = float(rng.choice([0.0, 5.0, 50.0]))
+    world = int(rng.integers(2, 7))
+    cuts = sorted(int(x) for x in rng.integers(0, G + 1, world - 1))
+    bounds = [0] + cuts + [G]                                                          # some shards may be empty
+    whole = hip.Miekki(k, h, 8, 33, thr)
+    shards = []
+    try:
+        whole.insert_sequences(seqs)
+        want, _ = whole.query(qs, nres, ms, mi)
+        reach = (1 << 26) + 1
+        blooms = []
+        for r in range(world):
+            ix = hip.Miekki(k, h, 8, 33, thr, genome_id_base=bounds[r])
+            ix.insert_sequences(seqs[bounds[r]:bounds[r + 1]])
+            b = np.empty(reach, np.uint8)
+            L.check(lib.mk_index_export_bloom(ix._h, 0, reach, b.ctypes.data))
+            shards.append(ix); blooms.append(b)
+        merged = blooms[0].copy()                                                      # first writer = lowest shard
+        for b in blooms[1:]:
+            merged = np.where(merged == 0, b, merged)
+        ref_bloom = np.empty(reach, np.uint8)
+        L.check(lib.mk_index_export_bloom(whole._h, 0, reach, ref_bloom.ctypes.data))
+        np.testing.assert_array_equal(merged, ref_bloom)
+        cap = 64
+        nq = len(qs)
+        counts = torch.zeros((world, nq), dtype=torch.int32, device="cuda")
+        cands = torch.zeros((world, nq * cap * 24), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for r, ix in enumerate(shards):
+            L.check(lib.mk_index_import_bloom(ix._h, 0, reach, merged.ctypes.data))
+            ptrs, lens = L.seq_arrays(qs)
+            qset = C.c_void_p()
+            L.check(lib.mk_qset_upload(ix._h, ptrs, lens, nq, C.byref(qset)))
+            L.check(lib.mk_qset_run(ix._h, qset, nres, ms, mi, cap, counts[r].data_ptr(), cands[r].data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            lib.mk_qset_free(ix._h, qset)
+        hits_h, overflow = mkd.merge_candidates(counts.cpu().numpy(), cands.cpu().numpy(), cap, nres)
+        d_hits, d_nh = mkd.merge_on_device(shards[0], counts, cands, cap, nres)
+        L.check(lib.mk_sync(shards[0]._h))
+        nh = d_nh.cpu().numpy().view(np.uint32)
+        hits_d = d_hits.cpu().numpy().view(mkd.HIT_DTYPE).reshape(nq, max(nres, 1))
+        for q in range(nq):
+            if overflow[q]:
+                assert nh[q] == mkd.MERGE_OVERFLOW
+                continue
+            w = [(x.genome, x.matches) for x in want[q]]
+            assert [(int(x["genome"]), int(x["matches"])) for x in hits_h[q]] == w, (q, "host merge")
+            assert [(int(x["genome"]), int(x["matches"])) for x in hits_d[q, :nh[q]]] == w, (q, "device merge")
+    finally:
+        whole.close()
+        for ix in shards:
+            ix.close()
