@@ -194,7 +194,8 @@ def case_flush() -> Case:
     return c
 
 
-RND_PARAMS = [(15, 10, 3, 32, 5), (27, 16, 11, 33, 30), (31, 13, 3, 33, 0), (9, 8, 3, 32, 12)]   # k, h, f, b, threshold
+RND_PARAMS = [(15, 10, 3, 32, 5), (27, 16, 11, 33, 30), (31, 13, 3, 33, 0), (9, 8, 3, 32, 12),
+              (31, 20, 3, 33, 100), (21, 17, 11, 32, 50)]   # k, h, f, b, threshold
 
 
 def case_rnd(i: int) -> Case:
@@ -253,5 +254,6 @@ def case_rnd(i: int) -> Case:
 
 
 CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy,
-         "rnd0": lambda: case_rnd(0), "rnd1": lambda: case_rnd(1), "rnd2": lambda: case_rnd(2), "rnd3": lambda: case_rnd(3)}
+         "rnd0": lambda: case_rnd(0), "rnd1": lambda: case_rnd(1), "rnd2": lambda: case_rnd(2), "rnd3": lambda: case_rnd(3),
+         "rnd4": lambda: case_rnd(4), "rnd5": lambda: case_rnd(5)}
 EXTRA_CASES = {"flush": case_flush}       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)

@@ -48,7 +48,7 @@ def workdirs(tmp_path_factory):
     return get
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3"])
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_build_query_dump_like_the_reference(workdirs, golden_dir, name):
     case, d, base = workdirs(name)
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -68,7 +68,7 @@ def test_build_query_dump_like_the_reference(workdirs, golden_dir, name):
     assert (d / "outA.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "flush", "rnd0", "rnd1", "rnd2", "rnd3"])
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "flush", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
     case, d, base = workdirs(name)
     run(["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact.txt", *base], d)
@@ -121,7 +121,7 @@ def test_multi_rank_driver_equals_reference(workdirs, golden_dir, name, ranks):
     assert (d / "out_mgpu.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd0", "rnd1", "rnd2", "rnd3"])
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_whole_file_exact_mode_like_the_reference(workdirs, golden_dir, name):
     """`-l … -A … -e`: query_file_of_file_exact / query_whole_file_exact (Miekki.cpp:616-645, 763-788)."""
     case, d, base = workdirs(name)

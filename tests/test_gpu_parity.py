@@ -15,7 +15,7 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3"]
+CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"]
 RTOL = 1e-6
 
 

@@ -14,7 +14,7 @@ import pytest
 import synth
 from oracle import oracle as orc
 
-CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3"]
+CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"]
 
 
 def sha(b):
