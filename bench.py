@@ -50,7 +50,7 @@ def cpu_baseline(h, rank0_cores):
             line = [l for l in out.splitlines() if l.startswith("{")][-1]
             r = json.loads(line)
             return {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
-                    "kind": "reference", "sample": sample}
+                    "kind": "reference", "sample": sample, "sample_seconds": r["seconds"]}
         except Exception as e:                       # fall through to the port
             sys.stderr.write(f"reference scanbench unavailable: {e}\n")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
