@@ -39,9 +39,10 @@ def cpu_baseline(h, rank0_cores):
     query_sequences), or the oracle port when the reference build is absent."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     threads = max(1, min(rank0_cores, 16))
-    G_cpu, nq = 10_000, 201 * threads
+    # sized for roughly 10-15 s of scanning on 16 threads (the reference batches 201 queries per thread)
+    G_cpu, nq = 10_000, 8 * 201 * threads
     if h >= 20:
-        G_cpu, nq = 2_000, 201 * threads
+        G_cpu, nq = 2_000, 4 * 201 * threads
     sample = f"reference query_sequences: {nq} synthetic 1 kb queries vs {G_cpu} genomes, -h {h}, saturated Bloom"
     if os.path.exists(harness):
         try:
