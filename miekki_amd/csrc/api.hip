@@ -481,7 +481,7 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     }
     if (!qs->dense_q.empty()) {
         // the sparse kernel has just written zero rows for the dense queries (scan_n = 0);
-        // the dense kernel adds their scores, four queries per pass over the matrix
+        // the dense kernel adds their scores, up to eight queries per pass over the matrix
         DenseArgs d;
         d.M = c->d_M; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
         d.rows_per_item = std::min<uint32_t>(c->P, 8192);

@@ -8,9 +8,11 @@
 // Selection rule restated: in every partition the winner is
 // the k-mer with the smallest fingerprint, earliest position first among equals,
 // and a fingerprint equal to the "empty" value can never be stored.  That is the
-// minimum of the key (fingerprint, position), which is what both paths compute:
-// genomes by 64-bit atomic minimum into a per-genome table in HBM, short queries
-// by an in-LDS sort of (partition, fingerprint, position) keys.
+// minimum of the key (fingerprint, position), which is what every path computes:
+// genomes and long queries by binning (fingerprint, position, partition) items and
+// taking per-partition minima in LDS (or, for shapes the bins do not fit, by 64-bit
+// atomic minimum into a table in HBM), short queries by an in-LDS sort of
+// (partition, fingerprint, position) keys.
 #include <cmath>
 
 #include "mk_internal.hpp"
