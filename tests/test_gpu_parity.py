@@ -622,3 +622,78 @@ def test_random_shardings_merge_like_one_context(hip, seed):
         whole.close()
         for ix in shards:
             ix.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MK_STATE_SEEDS", "4")))))   # MK_STATE_SEEDS=N for a soak run
+def test_random_operation_sequences_against_oracle(hip, seed, tmp_path):
+    """Stateful: a random sequence of appends (host sequences in calls of 0..70 genomes, device-generated
+    synthetic ones), queries in between (the build is pipelined: a query must first settle the batch in
+    flight), growth of the matrix, and dump -> load round trips that continue on the loaded context.
+    After every query and at the end: scores, hits, sizes and the whole index stream equal the oracle's."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(31000 + seed)
+    k = int(rng.integers(9, 32)); h = int(rng.integers(6, 15)); fpb = int(rng.choice([8, 16])); thr = int(rng.integers(0, 30))
+    o = orc.OracleMiekki(k, h, fpb, 32, thr)
+    ix = hip.Miekki(k, h, fpb, 32, thr)
+    pool = []                                                                # sequences inserted so far
+    next_id = 0
+
+    def check_queries():
+        if not pool:
+            return
+        qs = []
+        for _ in range(int(rng.integers(1, 6))):
+            src = pool[int(rng.integers(0, len(pool)))]
+            n = int(rng.choice([k, 200, 1500, 4096 + k + 300, len(src)]))
+            off = int(rng.integers(0, max(1, len(src) - min(n, len(src)) + 1)))
+            qs.append(src[off:off + n] if len(src) >= k else synth.genome_bases(5, 0, 300))
+        qs.append(synth.genome_bases(123456 + seed, 0, 600))
+        scores = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), scores)
+        nres = int(rng.choice([1, 5, 10])); ms = int(rng.integers(1, 4)); mi = float(rng.choice([0.0, 10.0]))
+        hits, act = ix.query(qs, nres, ms, mi)
+        for q, s in enumerate(qs):
+            assert int(act[q]) == o.query_sequence(s)[1], q
+            want_h = o.filter_results(scores[q], nres, ms, mi)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want_h], q
+
+    try:
+        for step in range(int(rng.integers(5, 10))):
+            op = rng.choice(["append", "append", "synthetic", "query", "reload"])
+            if op == "append":
+                n = int(rng.choice([0, 1, 3, 20, 64, 70]))
+                seqs = [synth.genome_bases(40_000 + 500 * seed + next_id + i, 0, int(rng.choice([k, k + 5, 800, 6000, 25_000])))
+                        for i in range(n)]
+                next_id += n
+                cut = int(rng.integers(0, n + 1))
+                ix.insert_sequences(seqs[:cut]); ix.insert_sequences(seqs[cut:])
+                o.insert_sequences(seqs)
+                pool += seqs
+            elif op == "synthetic":
+                n, length = int(rng.integers(1, 9)), int(rng.choice([k + 1, 3000, 12_000]))
+                first = 900_000 + 100 * seed + next_id
+                ix.insert_synthetic(first, n, length)
+                seqs = [synth.genome_bases(first + i, 0, length) for i in range(n)]
+                o.insert_sequences(seqs)
+                pool += seqs; next_id += n
+            elif op == "query":
+                check_queries()
+            else:
+                path = str(tmp_path / f"idx{step}.bin")
+                with open(path, "wb") as f:
+                    for piece in ix.serialize():
+                        f.write(piece)
+                ix.close()
+                ix = hip.Miekki.load(path)
+                os.remove(path)
+            assert ix.index_size == len(pool)
+        check_queries()
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+        raw = np.frombuffer(stream_of(ix), np.uint8).copy()
+        want = o.serialize()
+        raw[32] = want[32] = 0
+        raw[38] = want[38] = 0                                               # `compressed`: 1 after -l, what a load keeps
+        assert raw.size == want.size and sha(raw.tobytes()) == sha(want.tobytes())
+    finally:
+        ix.close()
