@@ -365,15 +365,16 @@ struct Driver {
     // ---- exact mode -------------------------------------------------------------
     struct Pending { string seq, head; double jaccard, intersection; };
 
-    // ground_truth_batch (Miekki.cpp:792-859) for all pending queries of one genome file
-    void ground_truth(const string &file, const vector<Pending> &v)
+    // a genome file as ground_truth_batch sees it: contigs split at '>' lines (Miekki.cpp:805-812),
+    // walked line by line over the raw text.  Callable from a helper thread.
+    struct GenomeContigs { bool exists = false; vector<string> contigs; };
+    GenomeContigs parse_contigs(const string &file) const
     {
-        if (!mkhost::file_exists(file)) { cout << "File problem: " << file << endl; return; }
-        // contigs split at '>' lines (Miekki.cpp:805-812), walked line by line over the raw text
-        static thread_local vector<char> text, scratch;
-        text.clear();
+        GenomeContigs gc;
+        gc.exists = mkhost::file_exists(file);
+        if (!gc.exists) return gc;
+        vector<char> text, scratch;
         mkhost::read_file(file, text, scratch);
-        vector<string> contigs;
         string ref;
         ref.reserve(text.size());
         const char *pos = text.data(), *const end = text.data() + text.size();
@@ -381,13 +382,23 @@ struct Driver {
             const char *e = pos < end ? (const char *)memchr(pos, '\n', (size_t)(end - pos)) : nullptr;
             if (!e) e = end;
             if (e != pos && *pos == '>') {
-                if (ref.size() >= k) { contigs.push_back(std::move(ref)); ref = string(); }   // short contigs leak (806-812)
+                if (ref.size() >= k) { gc.contigs.push_back(std::move(ref)); ref = string(); }   // short contigs leak (806-812)
             } else {
                 ref.append(pos, (size_t)(e - pos));
             }
             pos = e + 1;
         }
-        if (ref.size() >= k) contigs.push_back(std::move(ref));
+        if (ref.size() >= k) gc.contigs.push_back(std::move(ref));
+        return gc;
+    }
+
+    // ground_truth_batch (Miekki.cpp:792-859) for all pending queries of one genome file
+    void ground_truth(const string &file, const vector<Pending> &v) { ground_truth(file, v, parse_contigs(file)); }
+
+    void ground_truth(const string &file, const vector<Pending> &v, const GenomeContigs &gc)
+    {
+        if (!gc.exists) { cout << "File problem: " << file << endl; return; }
+        const vector<string> &contigs = gc.contigs;
         vector<const char *> cp, qp;
         vector<uint64_t> cl, ql;
         for (auto &c : contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
@@ -430,8 +441,18 @@ struct Driver {
                 v.push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection});
                 if (v.size() >= 100) { ground_truth(file_name, v); v.clear(); }
             }
+        // the genome file of the NEXT entry is read and split while the device works on this one
+        vector<const std::pair<const string, vector<Pending>> *> todo;
         for (auto itr = batch.begin(); itr != batch.end(); ++itr)
-            if (!itr->second.empty()) ground_truth(itr->first, itr->second);
+            if (!itr->second.empty()) todo.push_back(&*itr);
+        std::future<GenomeContigs> ahead;
+        if (!todo.empty()) ahead = std::async(std::launch::async, [this, f = todo[0]->first] { return parse_contigs(f); });
+        for (size_t i = 0; i < todo.size(); ++i) {
+            GenomeContigs gc = ahead.get();
+            if (i + 1 < todo.size())
+                ahead = std::async(std::launch::async, [this, f = todo[i + 1]->first] { return parse_contigs(f); });
+            ground_truth(todo[i]->first, todo[i]->second, gc);
+        }
         out << flush;
     }
 
