@@ -583,6 +583,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
     c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0; c->nhits_cap = 0;
     c->has_empty_sketch = false;
+    for (int i = 0; i < 10; ++i) { c->exact_buf[i] = nullptr; c->exact_cap[i] = 0; }
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -614,6 +615,7 @@ void mk_destroy(mk_ctx *c)
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     dev_free(c->d_hits); dev_free(c->d_nhits);
+    for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     dev_free(c->d_codes); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);

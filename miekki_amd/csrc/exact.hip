@@ -116,11 +116,27 @@ static uint32_t log2_slots(uint64_t n_keys)
     return l;
 }
 
+// Scratch of the exact mode, kept on the context and only ever grown: a run verifies hundreds of
+// genome files one after the other, and seven hipMalloc / hipFree pairs per file (each a device
+// synchronisation) cost more than the kernels.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(uint64_t n) { MK_HIP(hipMalloc((void **)&p, std::max<uint64_t>(n, 1) * sizeof(T))); return MK_OK; }
+    mk_ctx *c; int slot;
+    DevBuf(mk_ctx *ctx, int s) : c(ctx), slot(s) {}
+    int alloc(uint64_t n)
+    {
+        const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T);
+        if (bytes > c->exact_cap[slot]) {
+            if (c->exact_buf[slot]) (void)hipFree(c->exact_buf[slot]);
+            c->exact_buf[slot] = nullptr; c->exact_cap[slot] = 0;
+            const uint64_t want = bytes + bytes / 4;
+            MK_HIP(hipMalloc(&c->exact_buf[slot], want));
+            c->exact_cap[slot] = want;
+        }
+        p = reinterpret_cast<T *>(c->exact_buf[slot]);
+        return MK_OK;
+    }
 };
 
 static int upload_seqs(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t n, DevBuf<char> &d_seq,
@@ -130,9 +146,25 @@ static int upload_seqs(mk_ctx *c, const char *const *seqs, const uint64_t *lens,
     for (uint32_t i = 0; i < n; ++i) off[i + 1] = off[i] + lens[i];
     MK_TRY(d_seq.alloc(off[n] + 64));
     MK_TRY(d_off.alloc(n + 1));
-    std::vector<char> host(off[n]);
-    for (uint32_t i = 0; i < n; ++i) memcpy(host.data() + off[i], seqs[i], lens[i]);
-    if (off[n]) MK_HIP(hipMemcpyAsync(d_seq.p, host.data(), off[n], hipMemcpyHostToDevice, c->stream));
+    // long sequences (contigs) go straight from the caller's memory, short ones are gathered first
+    constexpr uint64_t kDirect = 256u << 10;
+    std::vector<char> host;
+    for (uint32_t i = 0; i < n;) {
+        if (lens[i] >= kDirect) {
+            MK_HIP(hipMemcpyAsync(d_seq.p + off[i], seqs[i], lens[i], hipMemcpyHostToDevice, c->stream));
+            ++i;
+            continue;
+        }
+        uint32_t e = i;
+        while (e < n && lens[e] < kDirect) ++e;
+        host.resize(off[e] - off[i]);
+        for (uint32_t j = i; j < e; ++j) memcpy(host.data() + (off[j] - off[i]), seqs[j], lens[j]);
+        if (!host.empty()) {
+            MK_HIP(hipMemcpyAsync(d_seq.p + off[i], host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+            MK_HIP(hipStreamSynchronize(c->stream));                // `host` is reused
+        }
+        i = e;
+    }
     MK_HIP(hipMemcpyAsync(d_off.p, off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     MK_HIP(hipStreamSynchronize(c->stream));
     return MK_OK;
@@ -144,7 +176,7 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
 {
     const uint32_t k = c->p.k;
     // ---- set B
-    DevBuf<char> g_seq; DevBuf<uint64_t> g_off;
+    DevBuf<char> g_seq(c, 0); DevBuf<uint64_t> g_off(c, 1);
     std::vector<uint64_t> goff;
     MK_TRY(upload_seqs(c, contigs, contig_lens, n_contigs, g_seq, g_off, goff));
     uint64_t nkB = 0, maxlen = 0;
@@ -154,7 +186,7 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
     }
     const uint32_t log2B = log2_slots(nkB);
     if (log2B > 31) { set_error("genome too large for exact mode"); return MK_ERR_ARG; }
-    DevBuf<uint64_t> setB; DevBuf<unsigned long long> d_nB;
+    DevBuf<uint64_t> setB(c, 2); DevBuf<unsigned long long> d_nB(c, 3);
     MK_TRY(setB.alloc(1ull << log2B));
     MK_TRY(d_nB.alloc(1));
     MK_HIP(hipMemsetAsync(setB.p, 0xFF, (8ull << log2B), c->stream));
@@ -169,7 +201,7 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
     MK_HIP(hipStreamSynchronize(c->stream));
     if (!nq) return MK_OK;
     // ---- sets A, one per query
-    DevBuf<char> q_seq; DevBuf<uint64_t> q_off;
+    DevBuf<char> q_seq(c, 4); DevBuf<uint64_t> q_off(c, 5);
     std::vector<uint64_t> qoff;
     MK_TRY(upload_seqs(c, queries, query_lens, nq, q_seq, q_off, qoff));
     std::vector<uint64_t> aoff(nq + 1, 0);
@@ -182,7 +214,7 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
         aoff[q + 1] = aoff[q] + (1ull << alog[q]);
         qmax = std::max(qmax, query_lens[q]);
     }
-    DevBuf<uint64_t> setA, d_aoff; DevBuf<uint32_t> d_alog; DevBuf<unsigned long long> d_cnt;
+    DevBuf<uint64_t> setA(c, 6), d_aoff(c, 7); DevBuf<uint32_t> d_alog(c, 8); DevBuf<unsigned long long> d_cnt(c, 9);
     MK_TRY(setA.alloc(aoff[nq]));
     MK_TRY(d_aoff.alloc(nq + 1));
     MK_TRY(d_alog.alloc(nq));

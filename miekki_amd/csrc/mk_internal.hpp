@@ -52,6 +52,8 @@ struct mk_ctx {
     uint32_t capG, G;
     uint32_t *d_sketch_size;
     uint64_t *d_genome_size;
+    void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
+    uint64_t exact_cap[10];
     bool has_empty_sketch;         // some genome has sketch_size 0 (see nan_candidates_possible in api.hip)
     std::vector<uint32_t> h_sketch_size;
     std::vector<uint64_t> h_genome_size;
