@@ -107,7 +107,7 @@ int mk_index_append(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, 
 int mk_host_alloc(mk_ctx *ctx, uint64_t bytes, void **out);
 void mk_host_free(mk_ctx *ctx, void *p);
 
-/* Same, for the synthetic genomes of SURVEY.md 8d generated on the device
+/* mk_index_append for the synthetic genomes of SURVEY.md 8d, generated on the device
  * (ids first_id .. first_id+n-1, `length` bases each): no PCIe traffic. */
 int mk_index_append_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length);
 
