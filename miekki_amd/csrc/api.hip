@@ -1046,6 +1046,17 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         if (active) memset(active, 0, (size_t)nq * 4);     // no column is ever compared
         return MK_OK;
     }
+    // Very large calls are answered in slices: the device-side query set (sequences, entry
+    // lists) grows with the number of queries, the result does not depend on the slicing.
+    constexpr uint32_t kMaxCall = 1u << 18;
+    if (nq > kMaxCall) {
+        for (uint32_t q0 = 0; q0 < nq; q0 += kMaxCall) {
+            const uint32_t n = std::min(kMaxCall, nq - q0);
+            MK_TRY(mk_query(c, seqs + q0, lens + q0, n, nresults, min_score, min_inter, hits + (size_t)q0 * nresults,
+                            nhits + q0, active ? active + q0 : nullptr));
+        }
+        return MK_OK;
+    }
     // A batch that mixes short queries with long ones is answered as two batches, so
     // that the short ones keep the slab schedule (long ones need the plain / dense kernels)
     {

@@ -232,3 +232,22 @@ def test_empty_sketch_genomes_and_min_score_zero(hip):
         lib.mk_qset_free(ix._h, qset)
     finally:
         ix.close()
+
+
+def test_very_large_query_call_is_sliced(hip):
+    """More than 2^18 queries in ONE mk_query call: answered in slices, same hits as smaller calls."""
+    k, h = 11, 8
+    seqs = [synth.genome_bases(6200 + g, 0, 4000) for g in range(5)]
+    ix = hip.Miekki(k, h, 8, 32, 0)
+    try:
+        ix.insert_sequences(seqs)
+        base = [seqs[q % 5][(7 * q) % 3000:(7 * q) % 3000 + 60 + q % 40] for q in range(1000)]
+        qs = base * 270                                              # 270,000 queries
+        hits, act = ix.query(qs, 3, 1, 0.0)
+        small, act_s = ix.query(base, 3, 1, 0.0)
+        assert len(hits) == len(qs)
+        for q in (0, 1, 999, 1000, 262143, 262144, 262145, 269999):
+            assert [(x.genome, x.matches) for x in hits[q]] == [(x.genome, x.matches) for x in small[q % 1000]], q
+            assert int(act[q]) == int(act_s[q % 1000])
+    finally:
+        ix.close()
