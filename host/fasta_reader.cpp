@@ -105,9 +105,7 @@ OrderedFastaReader::~OrderedFastaReader()
     cv_.notify_all();
     for (auto &w : workers_) w.join();
     for (auto &it : items_) if (it.data) recycle(it);
-    for (auto &b : pool_) {
-        if (a_.release) a_.release(a_.user, b.first); else free(b.first);
-    }
+    for (auto &b : pool_) pool_release(b.first);
 }
 
 char *OrderedFastaReader::pool_get(size_t need, size_t &cap)
@@ -128,13 +126,27 @@ char *OrderedFastaReader::pool_get(size_t need, size_t &cap)
             for (size_t i = 1; i < pool_.size(); ++i) if (pool_[i].second < pool_[small].second) small = i;
             char *p = pool_[small].first;
             pool_.erase(pool_.begin() + (long)small);
-            if (a_.release) a_.release(a_.user, p); else free(p);
+            pool_release(p);
         }
     }
     cap = std::max<size_t>(need + need / 8, 1 << 16);
-    char *p = a_.alloc ? (char *)a_.alloc(a_.user, cap) : (char *)malloc(cap);
-    if (!p) { cap = 0; return nullptr; }
+    char *p = a_.alloc ? (char *)a_.alloc(a_.user, cap) : nullptr;
+    if (!p) {                                                      // no allocator, or it is exhausted (page-lock limit):
+        p = (char *)malloc(cap);                                   // ordinary memory is slower to copy from, never wrong
+        if (!p) { cap = 0; return nullptr; }
+        if (a_.alloc) { std::lock_guard<std::mutex> g(pool_m_); plain_.insert(p); }
+    }
     return p;
+}
+
+void OrderedFastaReader::pool_release(char *p)
+{
+    bool plain = !a_.release;
+    if (!plain) {
+        auto it = plain_.find(p);
+        if (it != plain_.end()) { plain = true; plain_.erase(it); }
+    }
+    if (plain) free(p); else a_.release(a_.user, p);
 }
 
 void OrderedFastaReader::recycle(Item &it)
@@ -175,9 +187,10 @@ void OrderedFastaReader::work()
         it.exists = stat(files_[i].c_str(), &st) == 0;
         if (it.exists) {
             text.clear();
-            read_file(files_[i], text, scratch);
+            if (!read_file(files_[i], text, scratch)) it.failed = true;
             it.data = pool_get(text.size() + 1, it.cap);
             if (it.data) it.len = strip_fasta(text.data(), text.size(), it.data);
+            else it.failed = true;
         }
         { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
         cv_.notify_all();

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 namespace mkhost {
@@ -35,6 +36,7 @@ class OrderedFastaReader {
 public:
     struct Item {
         bool exists = false;
+        bool failed = false;       // the file exists but could not be read or buffered: do not treat as empty
         char *data = nullptr;      // pooled buffer: hand it back with recycle()
         size_t len = 0, cap = 0;
     };
@@ -47,6 +49,7 @@ public:
 private:
     void work();
     char *pool_get(size_t need, size_t &cap);
+    void pool_release(char *p);                    // caller holds pool_m_ or is the destructor
     std::vector<std::string> files_;
     std::vector<Item> items_;
     std::vector<std::atomic<int>> ready_;
@@ -59,6 +62,7 @@ private:
     HostAllocator a_;
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
+    std::unordered_set<char *> plain_;              // buffers that came from malloc although an allocator was given
 };
 
 }  // namespace mkhost

@@ -152,6 +152,7 @@ struct Driver {
             OrderedFastaReader::Item item = reader.take(i);
             t_wait += now() - t0;
             if (!item.exists) { cout << marks << "Missed file: " << fn << endl; marks.clear(); reader.recycle(item); continue; }
+            if (item.failed) { cout << marks << "cannot read " << fn << endl; exit(1); }
             if (item.len >= k) {
                 bytes += item.len;
                 seqs.push_back(item); names.push_back(fn);
@@ -350,6 +351,9 @@ struct Driver {
             if (!item.exists) {
                 cout << "File problem" << endl;
                 reader.recycle(item);
+            } else if (item.failed) {
+                cout << "cannot read " << files[i] << endl;
+                exit(1);
             } else if (item.len >= k) {
                 bytes += item.len;
                 names.push_back(files[i]); refs.push_back(item);
