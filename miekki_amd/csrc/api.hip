@@ -291,9 +291,8 @@ static bool nan_candidates_possible(const mk_ctx *c, uint32_t min_score)
 static void qset_release(mk_qset *qs)
 {
     if (!qs) return;
-    dev_free(qs->d_seq); dev_free(qs->d_off); dev_free(qs->d_ent_off); dev_free(qs->d_entries);
-    dev_free(qs->d_nent); dev_free(qs->d_split); dev_free(qs->d_dense); dev_free(qs->d_dense_q);
-    dev_free(qs->d_scan_n);
+    if (!qs->split_in_arena) dev_free(qs->d_split);
+    dev_free(qs->d_arena);                       // every other device array of the set lives in it
     delete qs;
 }
 
@@ -304,6 +303,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     qs->d_nent = nullptr; qs->sketched = false; qs->short_max_nk = 0;
     qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
     qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
+    qs->d_arena = nullptr; qs->split_in_arena = false; qs->split_room = 0;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
@@ -318,18 +318,34 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         else qs->short_max_nk = std::max<uint32_t>(qs->short_max_nk, (uint32_t)nk);
     }
     qs->total_len = qs->h_off[nq];
-    MK_TRY(dev_alloc(&qs->d_seq, qs->total_len + 64));
-    MK_TRY(dev_alloc(&qs->d_off, (uint64_t)nq + 1));
-    MK_TRY(dev_alloc(&qs->d_ent_off, (uint64_t)nq + 1));
-    MK_TRY(dev_alloc(&qs->d_entries, qs->h_ent_off[nq] + 1));
-    MK_TRY(dev_alloc(&qs->d_nent, (uint64_t)nq + 1));
-    MK_TRY(dev_alloc(&qs->d_scan_n, (uint64_t)nq + 1));
+    // One device allocation per set (a small call is dominated by allocator round trips, not by
+    // kernels): the arrays are carved out of it at 256-byte boundaries.
+    uint64_t dense_bytes = 0;
     if (!qs->dense_q.empty()) {
         while (qs->dense_q.size() % 4) qs->dense_q.push_back(0xffffffffu);          // pad the last group
-        const uint64_t bytes = (uint64_t)(qs->dense_q.size() / 4) * c->P * 4 * c->W;
-        MK_TRY(dev_alloc(&qs->d_dense, bytes));
-        MK_TRY(dev_alloc(&qs->d_dense_q, qs->dense_q.size()));
-        MK_HIP(hipMemsetAsync(qs->d_dense, 0xFF, bytes, c->stream));                 // every slot starts empty
+        dense_bytes = (uint64_t)(qs->dense_q.size() / 4) * c->P * 4 * c->W;
+    }
+    constexpr uint32_t kSplitS = 32;                                // room for the slab schedule's range table up to S = 32
+    qs->split_room = (uint64_t)nq * (kSplitS + 1) * 4 <= (64ull << 20) ? kSplitS : 0;
+    uint64_t at = 0;
+    auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255) / 256 * 256; return o; };
+    const uint64_t o_seq = carve(qs->total_len + 64), o_off = carve(((uint64_t)nq + 1) * 8),
+                   o_ent_off = carve(((uint64_t)nq + 1) * 8), o_entries = carve((qs->h_ent_off[nq] + 1) * 8),
+                   o_nent = carve(((uint64_t)nq + 1) * 4), o_scan_n = carve(((uint64_t)nq + 1) * 4),
+                   o_dense = carve(dense_bytes), o_dense_q = carve(qs->dense_q.size() * 4),
+                   o_split = carve(qs->split_room ? (uint64_t)nq * (qs->split_room + 1) * 4 : 0);
+    MK_TRY(dev_alloc(&qs->d_arena, at));
+    qs->d_seq = reinterpret_cast<char *>(qs->d_arena + o_seq);
+    qs->d_off = reinterpret_cast<uint64_t *>(qs->d_arena + o_off);
+    qs->d_ent_off = reinterpret_cast<uint64_t *>(qs->d_arena + o_ent_off);
+    qs->d_entries = reinterpret_cast<uint64_t *>(qs->d_arena + o_entries);
+    qs->d_nent = reinterpret_cast<uint32_t *>(qs->d_arena + o_nent);
+    qs->d_scan_n = reinterpret_cast<uint32_t *>(qs->d_arena + o_scan_n);
+    if (qs->split_room) { qs->d_split = reinterpret_cast<uint32_t *>(qs->d_arena + o_split); qs->split_in_arena = true; }
+    if (!qs->dense_q.empty()) {
+        qs->d_dense = qs->d_arena + o_dense;
+        qs->d_dense_q = reinterpret_cast<uint32_t *>(qs->d_arena + o_dense_q);
+        MK_HIP(hipMemsetAsync(qs->d_dense, 0xFF, dense_bytes, c->stream));           // every slot starts empty
         MK_HIP(hipMemcpyAsync(qs->d_dense_q, qs->dense_q.data(), qs->dense_q.size() * 4, hipMemcpyHostToDevice,
                               c->stream));
     }
@@ -425,8 +441,11 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
     const uint32_t limit = c->W == 1 ? 255u : 65535u;
     while (S < 64 && (uint64_t)qs->short_max_nk > (uint64_t)S * (limit * 7 / 10)) S <<= 1;
     if (qs->S != S) {
-        dev_free(qs->d_split);
-        MK_TRY(dev_alloc(&qs->d_split, (uint64_t)qs->nq * (S + 1)));
+        if (!(qs->split_in_arena && S <= qs->split_room)) {        // more ranges than the set reserved room for
+            if (!qs->split_in_arena) dev_free(qs->d_split);
+            qs->split_in_arena = false; qs->d_split = nullptr;
+            MK_TRY(dev_alloc(&qs->d_split, (uint64_t)qs->nq * (S + 1)));
+        }
         qs->S = S;
     }
     if (!c->d_flag) MK_TRY(dev_alloc(&c->d_flag, 1));

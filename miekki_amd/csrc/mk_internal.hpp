@@ -129,6 +129,9 @@ struct mk_ctx {
 
 struct mk_qset {
     uint32_t nq;
+    uint8_t *d_arena;              // the set's one device allocation; the arrays below point into it
+    bool split_in_arena;           // d_split too (room for split_room ranges), else it is its own allocation
+    uint32_t split_room;
     char *d_seq;
     uint64_t total_len;
     uint64_t *d_off;               // nq + 1 offsets into d_seq
