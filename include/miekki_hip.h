@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 1
+#define MK_ABI_VERSION 2
 
 typedef enum {
     MK_OK = 0,
@@ -88,6 +88,10 @@ uint32_t mk_index_size(const mk_ctx *ctx);                 /* Miekki::index_size
 int mk_get_params(const mk_ctx *ctx, mk_params *out);
 int mk_get_stats(const mk_ctx *ctx, mk_stats *out);
 int mk_reset_stats(mk_ctx *ctx);
+/* Measurement aid (bench.py): best of `rounds` read-only streaming passes (16-byte loads,
+ * eight in flight per lane) over the resident fingerprint matrix -> GB/s and the bytes one
+ * pass read.  The box's own HBM read ceiling, to put beside the 8 TB/s spec figure. */
+int mk_probe_stream_read(mk_ctx *ctx, uint32_t rounds, double *gbps, uint64_t *bytes);
 
 /* ---- index build --------------------------------------------------------- */
 
@@ -158,6 +162,16 @@ uint32_t mk_filter_candidates(const mk_hit *cand, uint32_t ncand, uint32_t nresu
 int mk_merge_entrants(mk_ctx *ctx, const uint32_t *d_count, const mk_hit *d_cand, uint32_t world,
                       uint32_t nq, uint32_t cap, uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits);
 
+/* filter_results' heap over gathered exchange rows: d_rows[world][nq][1 + cap] (what
+ * mk_qset_run_compact wrote on `world` genome shards, in shard order).  Sizes of the
+ * genomes the rows name come from mk_merge_set_sizes (all shards' sketch_size /
+ * genome_size concatenated in shard order; id_base = id of entry 0); without it, and
+ * with world == 1, the context's own index is used.  Output as mk_merge_entrants. */
+int mk_merge_set_sizes(mk_ctx *ctx, const uint64_t *genome_size, const uint32_t *sketch_size,
+                       uint32_t n_genomes, uint32_t id_base);
+int mk_merge_compact(mk_ctx *ctx, const uint64_t *d_rows, uint32_t world, uint32_t nq, uint32_t cap,
+                     uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits);
+
 /* ---- device-resident query sets (bench / multi-GPU path) ------------------- */
 
 typedef struct mk_qset mk_qset;
@@ -187,11 +201,45 @@ void mk_qset_free(mk_ctx *ctx, mk_qset *qs);
  * answers such calls, through the host's own heap calls. */
 int mk_qset_run(mk_ctx *ctx, mk_qset *qs, uint32_t nresults, uint32_t min_score,
                 double min_intersection, uint32_t cap, uint32_t *d_count, mk_hit *d_cand);
+/* The same pass with the output in the 8-byte EXCHANGE form of the multi-GPU path
+ * ("(genome_id u32, score u32)" per entrant): d_rows[nq][1 + cap] 64-bit
+ * words per query -- word 0 = number of entrants (a value above `cap` marks a row that
+ * overflowed), then genome | matches << 32 in ascending genome id.  jaccard and
+ * intersection are not shipped: the merging side recomputes them from the two sizes
+ * of the genome (mk_merge_set_sizes) with the reference's operations
+ * (Miekki.cpp:382-383), bit-identically.  One buffer, so one collective. */
+int mk_qset_run_compact(mk_ctx *ctx, mk_qset *qs, uint32_t nresults, uint32_t min_score,
+                        double min_intersection, uint32_t cap, uint64_t *d_rows);
+/* A set keeps its sketch, Bloom gate result and schedule tables until the index changes
+ * (genomes appended / imported, Bloom cells written); this forces the next run to redo
+ * them anyway (bench.py: a timed step is a complete pass). */
+int mk_qset_invalidate(mk_ctx *ctx, mk_qset *qs);
 /* Raw scores of queries [q_begin, q_end) of the set into d_scores[(q_end-q_begin)][G]. */
 int mk_qset_scores(mk_ctx *ctx, mk_qset *qs, uint32_t q_begin, uint32_t q_end, uint32_t *d_scores);
 /* active partitions per query after the last run/scores call */
 int mk_qset_active(mk_ctx *ctx, mk_qset *qs, uint32_t *active);
 int mk_sync(mk_ctx *ctx);
+
+/* ---- several GPUs in one process (the `miekki` binary; Miekki.cpp:546-581, 430-480 scale
+ * inside one executable with -t).  One context per GPU, genomes sharded in list order. ---- */
+
+int mk_device_count(void);                                  /* visible HIP devices (0 without a GPU) */
+/* ids this context reports = local index + base; may be set after the build, once the
+ * number of genomes the shards before it kept is known. */
+int mk_set_genome_id_base(mk_ctx *ctx, uint32_t base);
+/* Device memory on the context's GPU for callers without a GPU runtime of their own. */
+int mk_dev_alloc(mk_ctx *ctx, uint64_t bytes, void **d_out);
+void mk_dev_free(mk_ctx *ctx, void *d_ptr);
+int mk_dev_upload(mk_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int mk_dev_download(mk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+/* d_src on src's GPU -> d_dst on dst's GPU: a peer DMA over xGMI, ordered behind src's
+ * queued work; complete on return. */
+int mk_dev_copy(mk_ctx *dst, void *d_dst, mk_ctx *src, const void *d_src, uint64_t bytes);
+/* Bloom cells [begin, end) to / from device memory of the context's GPU. */
+int mk_index_export_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, uint8_t *d_dst);
+int mk_index_import_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *d_src);
+/* bytes of the Bloom table a 2k-bit k-mer can reach (everything above stays zero) */
+uint64_t mk_bloom_reachable_bytes(const mk_ctx *ctx);
 
 /* ---- exact mode (ground_truth_batch, Miekki.cpp:792-859) ------------------- */
 

@@ -273,6 +273,7 @@ static int settle_build(mk_ctx *c)
     MK_HIP(hipMemcpy(c->d_sketch_size + c->G, act, n * 4, hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(c->d_genome_size + c->G, gsz, n * 8, hipMemcpyHostToDevice));
     c->G += n;
+    ++c->gen;
     c->stats.build_genomes += n;
     return MK_OK;
 }
@@ -300,7 +301,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
 {
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> qs(new mk_qset(), qset_release);
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
-    qs->d_nent = nullptr; qs->sketched = false; qs->short_max_nk = 0;
+    qs->d_nent = nullptr; qs->sketched = false; qs->gen = 0; qs->short_max_nk = 0;
     qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
     qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
     qs->d_arena = nullptr; qs->split_in_arena = false; qs->split_room = 0;
@@ -401,10 +402,17 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
     return MK_OK;
 }
 
+// Sketch, Bloom gate and slab range table of a set are functions of the set and of the index
+// (Bloom cells, slab shape): they are kept until either changes (the index generation stamp)
+// or the caller asks for a fresh pass (mk_qset_invalidate).
 static int qset_sketch(mk_ctx *c, mk_qset *qs)
 {
+    if (qs->sketched && qs->gen == c->gen) return MK_OK;
+    qs->sketched = false;
     MK_TRY(qset_sketch_only(c, qs));
-    return qset_prepare_slab(c, qs);
+    MK_TRY(qset_prepare_slab(c, qs));
+    qs->gen = c->gen;
+    return MK_OK;
 }
 
 static uint32_t ntiles_of(const mk_ctx *c)
@@ -549,14 +557,14 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
 // entrants of filter_results' heap for the rows in d_scores (see select.hip)
 static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, const uint8_t *d_partials, uint32_t S,
                        const uint32_t *d_nent, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
-                       uint32_t *d_count, mk_hit *d_cand)
+                       uint32_t *d_count, mk_hit *d_cand, uint64_t *d_rows = nullptr)
 {
     SelectArgs a;
     a.scores = d_scores; a.partials = d_partials; a.nent = d_nent; a.S = S; a.W = c->W;
     a.tile_genomes = tile_genomes(c); a.G = c->G; a.nq = n; a.nresults = nresults;
     a.min_score = min_score; a.min_inter = min_inter; a.sketch_size = c->d_sketch_size;
     a.genome_size = c->d_genome_size; a.genome_id_base = c->p.genome_id_base; a.cap = cap;
-    a.count = d_count; a.cand = d_cand;
+    a.count = d_count; a.cand = d_cand; a.rows = d_rows;
     ScopedTimer t(c, 2);
     return launch_select(c, a);
 }
@@ -602,6 +610,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
     c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0; c->nhits_cap = 0;
     c->has_empty_sketch = false;
+    c->d_all_ss = nullptr; c->d_all_gs = nullptr; c->all_n = 0; c->all_base = 0; c->gen = 1;
     for (int i = 0; i < 10; ++i) { c->exact_buf[i] = nullptr; c->exact_cap[i] = 0; }
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
@@ -640,7 +649,7 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
-    dev_free(c->d_flag);
+    dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs);
     if (c->h_back) (void)hipHostFree(c->h_back);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -684,6 +693,14 @@ int mk_get_stats(const mk_ctx *cc, mk_stats *out)
     MK_TRY(mk_sync(c));
     *out = c->stats;
     return MK_OK;
+}
+
+int mk_probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes)
+{
+    if (!c || !gbps || !bytes) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return probe_stream_read(c, rounds ? rounds : 3, gbps, bytes);
 }
 
 int mk_reset_stats(mk_ctx *c)
@@ -834,6 +851,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
     c->G = n;
     c->h_sketch_size.assign(n, 0); c->h_genome_size.assign(n, 0);
     c->has_empty_sketch = false;
+    ++c->gen;
     if (c->d_bloom) MK_HIP(hipMemset(c->d_bloom, 0, c->bloom_dev_bytes));
     c->bloom_full_stale = true;
     return MK_OK;
@@ -843,6 +861,7 @@ int mk_index_import_columns(mk_ctx *c, uint32_t pb, uint32_t pe, const uint8_t *
 {
     if (!c || !src) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
+    ++c->gen;
     return staged_columns(c, true, pb, pe, const_cast<uint8_t *>(src));
 }
 
@@ -870,6 +889,7 @@ int mk_index_import_bloom(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t
     const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
     if (begin < dev_end) MK_HIP(hipMemcpy(c->d_bloom + begin, src, dev_end - begin, hipMemcpyHostToDevice));
     c->bloom_full_stale = true;
+    ++c->gen;
     return MK_OK;
 }
 
@@ -927,16 +947,23 @@ int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uin
     return MK_OK;
 }
 
+int mk_qset_invalidate(mk_ctx *c, mk_qset *qs)
+{
+    if (!c || !qs) { set_error("null argument"); return MK_ERR_ARG; }
+    qs->sketched = false;
+    return MK_OK;
+}
+
 void mk_qset_free(mk_ctx *c, mk_qset *qs)
 {
     if (c) { (void)hipSetDevice(c->p.device); (void)hipStreamSynchronize(c->stream); }
     qset_release(qs);
 }
 
-int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
-                uint32_t *d_count, mk_hit *d_cand)
+// mk_qset_run / mk_qset_run_compact: the output is either (d_count, d_cand) or d_rows
+static int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
+                    uint32_t *d_count, mk_hit *d_cand, uint64_t *d_rows)
 {
-    if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
     if (nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     if (nan_candidates_possible(c, min_score)) {
@@ -944,27 +971,46 @@ int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, d
         return MK_ERR_UNSUPPORTED;
     }
     MK_TRY(qset_sketch(c, qs));
-    if (c->G == 0) { MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream)); return MK_OK; }
-    if (qs->slab_ok) {
-        const uint32_t per = chunk_queries_slab(c, qs->nq, qs->S);
-        MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
-        for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
-            const uint32_t q1 = std::min(qs->nq, q0 + per);
-            MK_TRY(qset_scan_slab(c, qs, q0, q1));
-            MK_TRY(qset_select(c, q1 - q0, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
-                               min_inter, cap, d_count + q0, d_cand + (uint64_t)q0 * cap));
-        }
+    const uint64_t rstride = (uint64_t)cap + 1;
+    if (c->G == 0) {
+        if (d_rows) MK_HIP(hipMemsetAsync(d_rows, 0, (size_t)qs->nq * rstride * 8, c->stream));
+        else MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream));
         return MK_OK;
     }
-    const uint32_t per = chunk_queries(c, qs->nq);
-    MK_TRY(ensure_scores(c, per));
+    const bool slab = qs->slab_ok;
+    const uint32_t per = slab ? chunk_queries_slab(c, qs->nq, qs->S) : chunk_queries(c, qs->nq);
+    if (slab) MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
+    else MK_TRY(ensure_scores(c, per));
     for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
         const uint32_t q1 = std::min(qs->nq, q0 + per);
-        MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, q1 - q0)));
-        MK_TRY(qset_select(c, q1 - q0, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
-                           d_count + q0, d_cand + (uint64_t)q0 * cap));
+        uint32_t *cnt = d_rows ? nullptr : d_count + q0;
+        mk_hit *cand = d_rows ? nullptr : d_cand + (uint64_t)q0 * cap;
+        uint64_t *rows = d_rows ? d_rows + (uint64_t)q0 * rstride : nullptr;
+        if (slab) {
+            MK_TRY(qset_scan_slab(c, qs, q0, q1));
+            MK_TRY(qset_select(c, q1 - q0, nullptr, c->d_partials, qs->S, qs->d_nent + q0, nresults, min_score,
+                               min_inter, cap, cnt, cand, rows));
+        } else {
+            MK_TRY(qset_scan(c, qs, q0, q1, c->d_scores, score_layout_tiles(c->W, q1 - q0)));
+            MK_TRY(qset_select(c, q1 - q0, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
+                               cnt, cand, rows));
+        }
     }
     return MK_OK;
+}
+
+int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
+                uint32_t *d_count, mk_hit *d_cand)
+{
+    if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
+    return qset_run(c, qs, nresults, min_score, min_inter, cap, d_count, d_cand, nullptr);
+}
+
+int mk_qset_run_compact(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter,
+                        uint32_t cap, uint64_t *d_rows)
+{
+    if (!c || !qs || !d_rows || !cap) { set_error("null argument"); return MK_ERR_ARG; }
+    return qset_run(c, qs, nresults, min_score, min_inter, cap, nullptr, nullptr, d_rows);
 }
 
 int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores)
@@ -972,7 +1018,7 @@ int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d
     if (!c || !qs || !d_scores) { set_error("null argument"); return MK_ERR_ARG; }
     if (q0 > q1 || q1 > qs->nq) { set_error("query range out of bounds"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
-    if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
+    MK_TRY(qset_sketch(c, qs));
     return qset_scan(c, qs, q0, q1, d_scores, score_layout_rows(c->W, c->G, c->G));   // dense rows for the caller
 }
 
@@ -980,7 +1026,7 @@ int mk_qset_active(mk_ctx *c, mk_qset *qs, uint32_t *active)
 {
     if (!c || !qs || !active) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
-    if (!qs->sketched) MK_TRY(qset_sketch(c, qs));
+    MK_TRY(qset_sketch(c, qs));
     MK_HIP(hipStreamSynchronize(c->stream));
     if (qs->nq) MK_HIP(hipMemcpy(active, qs->d_nent, (size_t)qs->nq * 4, hipMemcpyDeviceToHost));
     return MK_OK;
@@ -1053,6 +1099,131 @@ int mk_merge_entrants(mk_ctx *c, const uint32_t *d_count, const mk_hit *d_cand, 
     MergeArgs ma{d_count, d_cand, world, nq, cap, nresults, d_hits, d_nhits};
     return launch_merge(c, ma);
 }
+
+int mk_merge_set_sizes(mk_ctx *c, const uint64_t *genome_size, const uint32_t *sketch_size, uint32_t n,
+                       uint32_t id_base)
+{
+    if (!c || (n && (!genome_size || !sketch_size))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    dev_free(c->d_all_ss); dev_free(c->d_all_gs);
+    c->all_n = 0; c->all_base = id_base;
+    if (!n) return MK_OK;
+    MK_TRY(dev_alloc(&c->d_all_ss, n));
+    MK_TRY(dev_alloc(&c->d_all_gs, n));
+    MK_HIP(hipMemcpy(c->d_all_ss, sketch_size, (size_t)n * 4, hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpy(c->d_all_gs, genome_size, (size_t)n * 8, hipMemcpyHostToDevice));
+    c->all_n = n;
+    return MK_OK;
+}
+
+int mk_merge_compact(mk_ctx *c, const uint64_t *d_rows, uint32_t world, uint32_t nq, uint32_t cap,
+                     uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits)
+{
+    if (!c || (nq && (!d_rows || !d_nhits || (nresults && !d_hits)))) { set_error("null argument"); return MK_ERR_ARG; }
+    if (!world || !cap) { set_error("world and cap must be positive"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MergeArgs ma{nullptr, nullptr, world, nq, cap, nresults, d_hits, d_nhits, d_rows, nullptr, nullptr, 0};
+    if (c->all_n) { ma.ss = c->d_all_ss; ma.gs = c->d_all_gs; ma.id_base = c->all_base; }
+    else if (world == 1) { ma.ss = c->d_sketch_size; ma.gs = c->d_genome_size; ma.id_base = c->p.genome_id_base; }
+    else { set_error("mk_merge_compact over several shards needs mk_merge_set_sizes first"); return MK_ERR_STATE; }
+    return launch_merge(c, ma);
+}
+
+int mk_set_genome_id_base(mk_ctx *c, uint32_t base)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    c->p.genome_id_base = base;
+    return MK_OK;
+}
+
+// ---- device buffers for callers that have no GPU runtime of their own
+int mk_dev_alloc(mk_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = nullptr;
+    MK_TRY(use_device(c, false));
+    MK_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return MK_OK;
+}
+
+void mk_dev_free(mk_ctx *c, void *d)
+{
+    if (!c || !d) return;
+    (void)hipSetDevice(c->p.device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+}
+
+int mk_dev_upload(mk_ctx *c, void *d_dst, const void *src, uint64_t bytes)
+{
+    if (!c || (bytes && (!d_dst || !src))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c, false));
+    if (bytes) MK_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return MK_OK;
+}
+
+int mk_dev_download(mk_ctx *c, void *dst, const void *d_src, uint64_t bytes)
+{
+    if (!c || (bytes && (!dst || !d_src))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c, false));
+    if (bytes) MK_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return MK_OK;
+}
+
+// Device-to-device copy between two contexts' GPUs (a peer DMA over xGMI when they differ),
+// queued on the SOURCE context's stream -- so behind the kernels that produced d_src -- and
+// waited for before returning: afterwards d_dst is complete for any stream of dst.
+int mk_dev_copy(mk_ctx *dst, void *d_dst, mk_ctx *src, const void *d_src, uint64_t bytes)
+{
+    if (!dst || !src || (bytes && (!d_dst || !d_src))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(src, false));
+    if (bytes) {
+        if (dst->p.device == src->p.device)
+            MK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, src->stream));
+        else
+            MK_HIP(hipMemcpyPeerAsync(d_dst, dst->p.device, d_src, src->p.device, bytes, src->stream));
+    }
+    MK_HIP(hipStreamSynchronize(src->stream));
+    return MK_OK;
+}
+
+int mk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mk_index_export_bloom_device(mk_ctx *c, uint64_t begin, uint64_t end, uint8_t *d_dst)
+{
+    if (!c || !d_dst) { set_error("null argument"); return MK_ERR_ARG; }
+    if (begin > end || end > c->bloom_bytes) { set_error("Bloom range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
+    if (begin < dev_end) MK_HIP(hipMemcpyAsync(d_dst, c->d_bloom + begin, dev_end - begin, hipMemcpyDeviceToDevice, c->stream));
+    const uint64_t zfrom = std::max(begin, dev_end);
+    if (zfrom < end) MK_HIP(hipMemsetAsync(d_dst + (zfrom - begin), 0, end - zfrom, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return MK_OK;
+}
+
+int mk_index_import_bloom_device(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_src)
+{
+    if (!c || !d_src) { set_error("null argument"); return MK_ERR_ARG; }
+    if (begin > end || end > c->bloom_bytes) { set_error("Bloom range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
+    if (begin < dev_end) MK_HIP(hipMemcpyAsync(c->d_bloom + begin, d_src, dev_end - begin, hipMemcpyDeviceToDevice, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    c->bloom_full_stale = true;
+    ++c->gen;
+    return MK_OK;
+}
+
+uint64_t mk_bloom_reachable_bytes(const mk_ctx *c) { return c ? c->bloom_dev_bytes : 0; }
 
 int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t nresults,
              uint32_t min_score, double min_inter, mk_hit *hits, uint32_t *nhits, uint32_t *active)

@@ -75,12 +75,22 @@ __device__ __forceinline__ void pop_to_back(HeapRef &h, int len)
 
 }  // namespace
 
+// COMPACT: the rows are the 8-byte exchange form ([1 + cap] words per (shard, query): count, then
+// genome | matches << 32); jaccard and intersection are recomputed here from the sizes of ALL
+// genomes (a.ss / a.gs, indexed by genome id - a.id_base) in the reference's double operations
+// (Miekki.cpp:382-383) -- the same two operations select_kernel ran on the owning shard, so the
+// keys are bit-identical to the ones the shard's own heap test saw.
+template <bool COMPACT>
 __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a)
 {
     const uint32_t q = blockIdx.x * 64u + threadIdx.x;
     if (q >= a.nq) return;
+    const uint64_t rstride = (uint64_t)a.cap + 1u;
+    auto count_of = [&](uint32_t r) -> uint32_t {
+        return COMPACT ? (uint32_t)a.rows[((uint64_t)r * a.nq + q) * rstride] : a.count[(uint64_t)r * a.nq + q];
+    };
     for (uint32_t r = 0; r < a.world; ++r)
-        if (a.count[(uint64_t)r * a.nq + q] > a.cap) {            // a shard's row lost entrants: the caller replays
+        if (count_of(r) > a.cap) {                                // a shard's row lost entrants: the caller replays
             a.nhits[q] = kMergeOverflow;
             return;
         }
@@ -88,10 +98,18 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a)
     int n = 0;
     const int N = (int)a.nresults;
     for (uint32_t r = 0; r < a.world; ++r) {
-        const uint32_t m = a.count[(uint64_t)r * a.nq + q];
-        const uint64_t row0 = ((uint64_t)r * a.nq + q) * a.cap;
+        const uint32_t m = count_of(r);
+        const uint64_t row0 = COMPACT ? ((uint64_t)r * a.nq + q) * rstride + 1u : ((uint64_t)r * a.nq + q) * a.cap;
         for (uint32_t i = 0; i < m; ++i) {
-            const double v = a.cand[row0 + i].intersection;
+            double v;
+            if (COMPACT) {
+                const uint64_t rec = a.rows[row0 + i];
+                const uint32_t g = (uint32_t)rec - a.id_base;
+                const double jac = (double)(uint32_t)(rec >> 32) / (double)a.ss[g];
+                v = jac * (double)a.gs[g];
+            } else {
+                v = a.cand[row0 + i].intersection;
+            }
             if (n >= N) {
                 if (n == 0) continue;                             // nresults == 0
                 if (h.key[0] > v) continue;                       // Miekki.cpp:387, ties replace
@@ -107,7 +125,18 @@ __global__ __launch_bounds__(64) void merge_kernel(const MergeArgs a)
     mk_hit *__restrict__ out = a.hits + (uint64_t)q * a.nresults;
     for (int i = 0; i < n; ++i) {
         const uint32_t r = h.ref[i] / a.cap, j = h.ref[i] % a.cap;
-        out[i] = a.cand[((uint64_t)r * a.nq + q) * a.cap + j];
+        if (COMPACT) {
+            const uint64_t rec = a.rows[((uint64_t)r * a.nq + q) * rstride + 1u + j];
+            const uint32_t g = (uint32_t)rec - a.id_base;
+            mk_hit o;
+            o.genome = (uint32_t)rec;
+            o.matches = (uint32_t)(rec >> 32);
+            o.jaccard = (double)o.matches / (double)a.ss[g];
+            o.intersection = o.jaccard * (double)a.gs[g];
+            out[i] = o;
+        } else {
+            out[i] = a.cand[((uint64_t)r * a.nq + q) * a.cap + j];
+        }
     }
     a.nhits[q] = (uint32_t)n;
 }
@@ -117,7 +146,8 @@ int launch_merge(mk_ctx *c, const MergeArgs &a)
     if (!a.nq) return MK_OK;
     if (a.nresults > kSelectMaxResults) { set_error("device merge supports nresults <= 64"); return MK_ERR_ARG; }
     if ((uint64_t)a.world * a.cap > 0xffffffffull) { set_error("world x cap too large"); return MK_ERR_ARG; }
-    hipLaunchKernelGGL(merge_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, c->stream, a);
+    if (a.rows) hipLaunchKernelGGL(merge_kernel<true>, dim3((a.nq + 63) / 64), dim3(64), 0, c->stream, a);
+    else        hipLaunchKernelGGL(merge_kernel<false>, dim3((a.nq + 63) / 64), dim3(64), 0, c->stream, a);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

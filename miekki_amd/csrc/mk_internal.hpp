@@ -55,6 +55,12 @@ struct mk_ctx {
     void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
     uint64_t exact_cap[10];
     bool has_empty_sketch;         // some genome has sketch_size 0 (see nan_candidates_possible in api.hip)
+    // sizes of ALL genomes of a sharded index (mk_merge_set_sizes), for the compact merge on the
+    // context that receives the gathered rows
+    uint32_t *d_all_ss;
+    uint64_t *d_all_gs;
+    uint32_t all_n, all_base;
+    uint64_t gen;                  // index generation: bumped whenever genomes or Bloom cells change
     std::vector<uint32_t> h_sketch_size;
     std::vector<uint64_t> h_genome_size;
     // Bloom filter: only the cells a 2k-bit k-mer can reach live on the device
@@ -151,6 +157,7 @@ struct mk_qset {
     uint32_t S;                    // ranges of the slab schedule (0 = not prepared)
     bool slab_ok;                  // every (query, range) fits the packed counters
     bool sketched;
+    uint64_t gen;                  // index generation the sketch / range table were made against
 };
 
 namespace mk {
@@ -244,6 +251,7 @@ struct DenseArgs {
     uint32_t empty;
 };
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a);
+int probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes);
 
 // ---- select.hip
 struct SelectArgs {
@@ -259,6 +267,7 @@ struct SelectArgs {
     uint32_t genome_id_base, cap;
     uint32_t *count;               // [nq]
     mk_hit *cand;                  // [nq][cap]
+    uint64_t *rows;                // compact form instead of count/cand: [nq][1 + cap], see mk_qset_run_compact
 };
 constexpr uint32_t kSelectMaxResults = 64;   // top-N sizes the device selection supports
 int launch_select(mk_ctx *c, const SelectArgs &a);
@@ -271,6 +280,11 @@ struct MergeArgs {
     uint32_t world, nq, cap, nresults;
     mk_hit *hits;                  // [nq][nresults]
     uint32_t *nhits;               // [nq]
+    // compact exchange form instead of count / cand (null otherwise): [world][nq][1 + cap] words
+    const uint64_t *rows;
+    const uint32_t *ss;            // sketch_size of every genome a row may name, indexed by id - id_base
+    const uint64_t *gs;            // genome_size likewise
+    uint32_t id_base;
 };
 int launch_merge(mk_ctx *c, const MergeArgs &a);
 

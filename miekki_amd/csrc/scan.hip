@@ -71,4 +71,47 @@ int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
     return MK_OK;
 }
 
+// ---- the box's read-only stream ceiling (SURVEY.md 8d asks for it next to the spec peak):
+// every lane sums 16-byte loads over the resident matrix buffer, grid-stride, eight loads in
+// flight.  Measurement aid behind mk_probe_stream_read; nothing on the query path calls it.
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16, uint32_t *sink)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) *sink = acc;                       // keeps the loads live
+}
+
+int probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes)
+{
+    const uint64_t total = (uint64_t)c->P * c->ld;
+    *gbps = 0; *bytes = total;
+    if (!c->d_M || total < (1ull << 20)) return MK_OK;
+    if (!c->d_flag) MK_HIP(hipMalloc((void **)&c->d_flag, 4));
+    hipEvent_t e0, e1;
+    MK_HIP(hipEventCreate(&e0)); MK_HIP(hipEventCreate(&e1));
+    float best = 0;
+    for (uint32_t r = 0; r <= rounds; ++r) {                    // first round warms up
+        MK_HIP(hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4 *)c->d_M, total / 16,
+                           c->d_flag);
+        MK_HIP(hipEventRecord(e1, c->stream));
+        MK_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        MK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r && (best == 0 || ms < best)) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (best > 0) *gbps = (double)total / best / 1e6;
+    return MK_OK;
+}
+
 }  // namespace mk

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     uint32_t cnt = 0, emitted = 0;   // wave-uniform
     double minval = 0.0;             // minimum of the multiset, valid when cnt == N
     float screen = 0.999f * (float)a.min_inter;
-    mk_hit *__restrict__ out = a.cand + (uint64_t)q * a.cap;
+    mk_hit *__restrict__ out = a.cand ? a.cand + (uint64_t)q * a.cap : nullptr;
+    // compact form (multi-GPU exchange): row = [count][cap x (genome | matches << 32)]
+    uint64_t *__restrict__ crow = a.rows ? a.rows + (uint64_t)q * (a.cap + 1u) : nullptr;
 
     // A step is a dependent load -> test -> ballot chain, and the kernel spends three
     // quarters of its wave cycles waiting for the loads (PMC).  With at most eight ranges of
@@ -163,12 +165,16 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
                 if (cnt >= N && minval > x) continue;                       // Miekki.cpp:387: skipped, heap untouched
                 if (N == 0) continue;
                 if (lane == l && emitted < a.cap) {
-                    mk_hit h;
-                    h.genome = gl + j + a.genome_id_base;
-                    h.matches = s[j];
-                    h.jaccard = jac[j];
-                    h.intersection = inter[j];
-                    out[emitted] = h;
+                    if (crow) {
+                        crow[1u + emitted] = (uint64_t)(gl + j + a.genome_id_base) | ((uint64_t)s[j] << 32);
+                    } else {
+                        mk_hit h;
+                        h.genome = gl + j + a.genome_id_base;
+                        h.matches = s[j];
+                        h.jaccard = jac[j];
+                        h.intersection = inter[j];
+                        out[emitted] = h;
+                    }
                 }
                 ++emitted;
                 if (cnt < N) {
@@ -187,7 +193,10 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
             }
         }
     }
-    if (lane == 0) a.count[q] = emitted;
+    if (lane == 0) {
+        if (crow) crow[0] = emitted;
+        else a.count[q] = emitted;
+    }
 }
 
 int launch_select(mk_ctx *c, const SelectArgs &a)

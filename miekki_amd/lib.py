@@ -47,6 +47,7 @@ SIGNATURES = {
     "mk_get_params": (i32, [vp, PP(Params)]),
     "mk_get_stats": (i32, [vp, PP(Stats)]),
     "mk_reset_stats": (i32, [vp]),
+    "mk_probe_stream_read": (i32, [vp, u32, PP(C.c_double), PP(u64)]),
     "mk_index_append": (i32, [vp, vp, vp, u32]),
     "mk_host_alloc": (i32, [vp, u64, PP(vp)]),
     "mk_host_free": (None, [vp, vp]),
@@ -66,6 +67,20 @@ SIGNATURES = {
     "mk_qset_synthetic": (i32, [vp, u64, u32, u64, u64, u64, PP(vp)]),
     "mk_qset_free": (None, [vp, vp]),
     "mk_qset_run": (i32, [vp, vp, u32, u32, C.c_double, u32, vp, vp]),
+    "mk_qset_run_compact": (i32, [vp, vp, u32, u32, C.c_double, u32, vp]),
+    "mk_qset_invalidate": (i32, [vp, vp]),
+    "mk_merge_set_sizes": (i32, [vp, vp, vp, u32, u32]),
+    "mk_merge_compact": (i32, [vp, vp, u32, u32, u32, u32, vp, vp]),
+    "mk_device_count": (i32, []),
+    "mk_set_genome_id_base": (i32, [vp, u32]),
+    "mk_dev_alloc": (i32, [vp, u64, PP(vp)]),
+    "mk_dev_free": (None, [vp, vp]),
+    "mk_dev_upload": (i32, [vp, vp, vp, u64]),
+    "mk_dev_download": (i32, [vp, vp, vp, u64]),
+    "mk_dev_copy": (i32, [vp, vp, vp, vp, u64]),
+    "mk_index_export_bloom_device": (i32, [vp, u64, u64, vp]),
+    "mk_index_import_bloom_device": (i32, [vp, u64, u64, vp]),
+    "mk_bloom_reachable_bytes": (u64, [vp]),
     "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
     "mk_qset_active": (i32, [vp, vp, vp]),
     "mk_sync": (i32, [vp]),

@@ -8,7 +8,7 @@ contiguous slice of the genome list on its own GPU -- genome ids are those of a
 single-process run because the slices are contiguous and every rank learns how many
 genomes the ranks before it kept (one tiny all-gather at build time).  The Bloom
 filters are merged byte-exactly (distributed.sync_bloom), every rank scans all
-queries against its shard, and the per-query heap entrants are gathered on rank 0,
+queries against its shard, and the per-query heap entrants are gathered on rank 0 as 8-byte (genome, matches) records,
 which replays the reference heap and writes the reference's out.txt
 (Miekki.cpp:440-444).  `--rehearse` runs the same program with gloo collectives and
 every rank on GPU 0 (single-GPU boxes, tests).
@@ -37,7 +37,7 @@ def main(argv=None):
     ap.add_argument("-f", type=int, default=3); ap.add_argument("-b", type=int, default=33)
     ap.add_argument("-s", type=float, default=200.0); ap.add_argument("-t", type=int, default=8)
     ap.add_argument("-e", action="store_true", help="exact mode: real intersection computed on hits (Miekki.cpp:723-759)")
-    ap.add_argument("--cap", type=int, default=128)
+    ap.add_argument("--cap", type=int, default=96)
     ap.add_argument("--rehearse", action="store_true")
     ap.add_argument("--help", action="help")
     args = ap.parse_args(argv)
@@ -80,7 +80,8 @@ def main(argv=None):
     del seqs
     if world > 1:
         mkd.sync_bloom(ix, device=coll)
-    if rank == 0:
+    mkd.share_sizes(ix, device=coll)                               # sizes of all genomes, once: the merge recomputes
+    if rank == 0:                                                  # jaccard / intersection from (genome, matches) records
         print(f"Reference indexed: {total}", flush=True)
 
     # ---- query: every rank scans all records against its shard (Miekki.cpp:426-483)
@@ -111,8 +112,8 @@ def main(argv=None):
     for b0 in range(0, len(recs), step):
         chunk = recs[b0:b0 + step]
         nq = len(chunk)
-        d_count = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        d_cand = torch.zeros(nq * cap * mkd.HIT_BYTES, dtype=torch.uint8, device="cuda")
+        rw = cap + 1                                             # 64-bit words of one exchange row
+        d_rows = torch.zeros(nq * rw, dtype=torch.int64, device="cuda")
         # short records (at most 4,096 k-mers) and long ones are run as two sets, so that the
         # short ones keep the slab schedule (mk_query does the same for its batches)
         short = [i for i, (_, s) in enumerate(chunk) if len(s) <= args.k + 4096]
@@ -124,30 +125,28 @@ def main(argv=None):
             ptrs, lens = L.seq_arrays([chunk[i][1] for i in part])
             qs = C.c_void_p()
             L.check(lib.mk_qset_upload(ix._h, ptrs, lens, len(part), C.byref(qs)))
-            p_count = d_count if whole else torch.zeros(len(part), dtype=torch.int32, device="cuda")
-            p_cand = d_cand if whole else torch.zeros(len(part) * cap * mkd.HIT_BYTES, dtype=torch.uint8, device="cuda")
+            p_rows = d_rows if whole else torch.zeros(len(part) * rw, dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
-            L.check(lib.mk_qset_run(ix._h, qs, nres, min_score, float(min_inter), cap, p_count.data_ptr(), p_cand.data_ptr()))
+            L.check(lib.mk_qset_run_compact(ix._h, qs, nres, min_score, float(min_inter), cap, p_rows.data_ptr()))
             L.check(lib.mk_sync(ix._h))
             lib.mk_qset_free(ix._h, qs)
             if not whole:
                 idx = torch.tensor(part, dtype=torch.int64, device="cuda")
-                d_count[idx] = p_count
-                d_cand.view(nq, cap * mkd.HIT_BYTES)[idx] = p_cand.view(len(part), cap * mkd.HIT_BYTES)
+                d_rows.view(nq, rw)[idx] = p_rows.view(len(part), rw)
                 torch.cuda.synchronize()
-        if world > 1:                                            # the one exchange step
-            counts, cands = mkd.gather_rows(d_count.to(coll), d_cand.to(coll))
+        if world > 1:                                            # the one exchange step: 8-byte entrant records
+            rows = mkd.gather_compact(d_rows.to(coll))
         else:
-            counts, cands = d_count.view(1, -1), d_cand.view(1, -1)
+            rows = d_rows.view(1, -1)
         # rank 0: filter_results' heap over the rows in shard order, on the GPU (K6b).
         # Rows that overflowed on some shard: every rank answers them again with its
         # complete (not just entrant) candidate list, gathered as objects
         over = None
         if rank == 0:
-            if not counts.is_cuda:
-                counts, cands = counts.cuda(), cands.cuda()
+            if not rows.is_cuda:
+                rows = rows.cuda()
             torch.cuda.current_stream().synchronize()
-            d_hits, d_nh = mkd.merge_on_device(ix, counts.contiguous(), cands.contiguous(), cap, nres)
+            d_hits, d_nh = mkd.merge_compact_on_device(ix, rows.contiguous(), nq, cap, nres)
             L.check(lib.mk_sync(ix._h))
             nh = d_nh.cpu().numpy().view(np.uint32)
             hits = d_hits.cpu().numpy().view(mkd.HIT_DTYPE).reshape(nq, max(nres, 1))

@@ -29,11 +29,12 @@ def make_inputs():
     return genomes, queries
 
 
-def shard_candidates(o, queries, g0, g1, min_score, min_inter):
+def shard_rows(o, queries, g0, g1, min_score, min_inter):
+    """The shard's rows in the 8-byte exchange form (what mk_qset_run_compact writes): per query
+    [count, genome | matches << 32 ...]; all thresholded candidates = a superset of the entrants."""
     scores = o.query_sequences(queries)
     ss, gs = o.sketch_size.astype(np.float64), o.genome_size.astype(np.float64)
-    count = np.zeros(len(queries), np.int32)
-    cand = np.zeros((len(queries), CAP), mkd.HIT_DTYPE)
+    rows = np.zeros((len(queries), CAP + 1), np.uint64)
     for q in range(len(queries)):
         n = 0
         for g in range(g1 - g0):                               # ascending genome id
@@ -42,10 +43,10 @@ def shard_candidates(o, queries, g0, g1, min_score, min_inter):
             if s < min_score or inter < min_inter:
                 continue
             if n < CAP:
-                cand[q, n] = (g + g0, s, jac, inter)
+                rows[q, 1 + n] = (g + g0) | (int(s) << 32)
             n += 1
-        count[q] = n
-    return count, cand
+        rows[q, 0] = n
+    return rows
 
 
 def worker(rank, world, port, ret):
@@ -59,12 +60,13 @@ def worker(rank, world, port, ret):
     # global Bloom gate from the shards' filters, byte-exact (first writer = lowest rank)
     merged = mkd.merge_bloom_first_writer(o.bloom[:1 << 20].copy())
     o.bloom[:1 << 20] = merged
-    count, cand = shard_candidates(o, queries, g0, g1, 1, 0.0)
-    counts, cands = mkd.gather_candidates(torch.from_numpy(count),
-                                          torch.from_numpy(cand.view(np.uint8).reshape(-1).copy()))
+    rows = shard_rows(o, queries, g0, g1, 1, 0.0)
+    ss_all, gs_all = mkd.gather_sizes(o.sketch_size, o.genome_size)         # once, after the build
+    big = mkd.gather_compact(torch.from_numpy(rows.view(np.int64).reshape(-1).copy()))   # the ONE exchange
     if rank == 0:
         ret["bloom"] = merged.tobytes()
-        hits, overflow = mkd.merge_candidates(counts, cands, CAP, NRES)
+        ret["gather_bytes_per_rank"] = rows.nbytes
+        hits, overflow = mkd.merge_compact_host(big.numpy().view(np.uint64), len(queries), CAP, NRES, ss_all, gs_all)
         ret["hits"] = [[(int(h["genome"]), int(h["matches"]), float(h["intersection"])) for h in row] for row in hits]
         ret["overflow"] = overflow.tolist()
     dist.barrier()
@@ -95,6 +97,7 @@ def test_two_rank_gloo_merge_equals_unsharded_reference():
     o.insert_sequences(genomes)
     scores = o.query_sequences(queries)
     assert not any(ret["overflow"])
+    assert ret["gather_bytes_per_rank"] == len(queries) * (CAP + 1) * 8     # 8-byte records + one header word
     # k=21, b=32: reachable cells < 2^(42-35) -- the first 2^20 bytes cover them all
     assert o.bloom[1 << 20:].max() == 0
     assert ret["bloom"] == o.bloom[:1 << 20].tobytes()

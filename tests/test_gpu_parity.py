@@ -463,6 +463,53 @@ def test_device_heap_merge_is_the_host_heap(hip):
         ix.close()
 
 
+def test_compact_device_merge_is_the_host_heap(hip):
+    """mk_merge_compact (8-byte exchange rows + sizes of all genomes) against the host's std::
+    heap calls on rows full of ties: few distinct sizes and scores, so that many records of a row
+    share one intersection value; overflowed rows; several nresults."""
+    import ctypes as C
+    import torch
+    from miekki_amd import distributed as mkd
+    from miekki_amd import lib as L
+    lib = L.load_library()
+    ix = hip.Miekki(21, 9, 8, 32, 0)
+    rng = np.random.default_rng(12)
+    try:
+        for world, nq, cap, nres in ((1, 500, 32, 10), (3, 400, 16, 5), (8, 300, 24, 64), (2, 200, 8, 1),
+                                     (4, 100, 8, 0), (5, 300, 40, 2)):
+            n_all = world * cap * 4
+            ss_all = rng.choice([1, 2, 4, 1000], n_all).astype(np.uint32)
+            gs_all = rng.choice([8, 16, 5_000_000], n_all).astype(np.uint64)
+            base = 77
+            L.check(lib.mk_merge_set_sizes(ix._h, gs_all.ctypes.data, ss_all.ctypes.data, n_all, base))
+            rows = np.zeros((world, nq, cap + 1), np.uint64)
+            counts = rng.integers(0, cap + 1, (world, nq))
+            over = rng.random(nq) < 0.03
+            counts[rng.integers(0, world, nq)[over], np.flatnonzero(over)] = cap + 1 + rng.integers(0, 5)
+            rows[:, :, 0] = counts
+            genome = base + rng.integers(0, n_all, (world, nq, cap)).astype(np.uint64)
+            matches = rng.integers(0, 6, (world, nq, cap)).astype(np.uint64)
+            rows[:, :, 1:] = genome | (matches << np.uint64(32))
+            d_rows = torch.from_numpy(rows.view(np.int64).reshape(world, -1)).cuda()
+            torch.cuda.synchronize()
+            hits, nhits = mkd.merge_compact_on_device(ix, d_rows, nq, cap, nres)
+            L.check(lib.mk_sync(ix._h))
+            nhits = nhits.cpu().numpy().view(np.uint32)
+            hits = hits.cpu().numpy().reshape(nq, -1).view(mkd.HIT_DTYPE)
+            # merge_compact_host indexes sizes by genome id: shift by the base
+            want, overflow = mkd.merge_compact_host(rows.reshape(world, -1), nq, cap, nres,
+                                                    np.concatenate([np.ones(base, np.uint32), ss_all]),
+                                                    np.concatenate([np.ones(base, np.uint64), gs_all]))
+            for q in range(nq):
+                if overflow[q]:
+                    assert nhits[q] == mkd.MERGE_OVERFLOW
+                    continue
+                assert nhits[q] == len(want[q]), (world, nres, q)
+                assert hits[q, :nhits[q]].tobytes() == want[q].tobytes(), (world, nres, q)
+    finally:
+        ix.close()
+
+
 def test_runs_of_long_queries_against_oracle(hip):
     """Queries beyond the in-LDS sketch (more than 4,096 k-mers) that sit next to each other in a
     batch are sketched together (binned K1 + one gate-and-append launch); loners go one by one.
@@ -597,6 +644,7 @@ def test_random_shardings_merge_like_one_context(hip, seed):
         nq = len(qs)
         counts = torch.zeros((world, nq), dtype=torch.int32, device="cuda")
         cands = torch.zeros((world, nq * cap * 24), dtype=torch.uint8, device="cuda")
+        rows = torch.zeros((world, nq * (cap + 1)), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         for r, ix in enumerate(shards):
             L.check(lib.mk_index_import_bloom(ix._h, 0, reach, merged.ctypes.data))
@@ -606,18 +654,39 @@ def test_random_shardings_merge_like_one_context(hip, seed):
             L.check(lib.mk_qset_run(ix._h, qset, nres, ms, mi, cap, counts[r].data_ptr(), cands[r].data_ptr()))
             L.check(lib.mk_sync(ix._h))
             lib.mk_qset_free(ix._h, qset)
+            # the same pass in the 8-byte exchange form (what the ranks gather)
+            L.check(lib.mk_qset_invalidate(ix._h, qset))
+            L.check(lib.mk_qset_run_compact(ix._h, qset, nres, ms, mi, cap, rows[r].data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            lib.mk_qset_free(ix._h, qset)
         hits_h, overflow = mkd.merge_candidates(counts.cpu().numpy(), cands.cpu().numpy(), cap, nres)
         d_hits, d_nh = mkd.merge_on_device(shards[0], counts, cands, cap, nres)
         L.check(lib.mk_sync(shards[0]._h))
         nh = d_nh.cpu().numpy().view(np.uint32)
         hits_d = d_hits.cpu().numpy().view(mkd.HIT_DTYPE).reshape(nq, max(nres, 1))
+        # compact rows: sizes of all genomes in id order, as share_sizes would gather them
+        ss_all = np.concatenate([ix.sketch_size for ix in shards]).astype(np.uint32)
+        gs_all = np.concatenate([ix.genome_size for ix in shards]).astype(np.uint64)
+        np.testing.assert_array_equal(ss_all, whole.sketch_size)
+        L.check(lib.mk_merge_set_sizes(shards[0]._h, gs_all.ctypes.data, ss_all.ctypes.data, len(ss_all), 0))
+        c_hits, c_nh = mkd.merge_compact_on_device(shards[0], rows, nq, cap, nres)
+        L.check(lib.mk_sync(shards[0]._h))
+        cnh = c_nh.cpu().numpy().view(np.uint32)
+        hits_c = c_hits.cpu().numpy().view(mkd.HIT_DTYPE).reshape(nq, max(nres, 1))
+        hits_ch, over_c = mkd.merge_compact_host(rows.cpu().numpy().view(np.uint64), nq, cap, nres, ss_all, gs_all)
+        np.testing.assert_array_equal(over_c, overflow)
         for q in range(nq):
             if overflow[q]:
-                assert nh[q] == mkd.MERGE_OVERFLOW
+                assert nh[q] == mkd.MERGE_OVERFLOW and cnh[q] == mkd.MERGE_OVERFLOW
                 continue
             w = [(x.genome, x.matches) for x in want[q]]
             assert [(int(x["genome"]), int(x["matches"])) for x in hits_h[q]] == w, (q, "host merge")
             assert [(int(x["genome"]), int(x["matches"])) for x in hits_d[q, :nh[q]]] == w, (q, "device merge")
+            # the compact merge recomputes jaccard / intersection: bit-identical records
+            assert cnh[q] == nh[q] and hits_c[q, :nh[q]].tobytes() == hits_d[q, :nh[q]].tobytes(), (q, "compact device merge")
+            assert hits_ch[q].tobytes() == hits_d[q, :nh[q]].tobytes(), (q, "compact host merge")
+            for x, y in zip(hits_c[q, :nh[q]], want[q]):
+                assert abs(float(x["intersection"]) - y.intersection) <= 1e-6 * abs(y.intersection) and float(x["jaccard"]) == y.jaccard
     finally:
         whole.close()
         for ix in shards:
