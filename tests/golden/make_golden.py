@@ -136,7 +136,8 @@ def make_case(name):
                 "-s", str(case.threshold), "-t", "1"]
         so = run([cli, "-l", "genomes.lst", "-a", "queries.fa", "-o", "out.txt", "-d", "idx.gz", *base], d)
         out_txt = open(os.path.join(d, "out.txt"), "rb").read()
-        raw2 = bytearray(gzip.decompress(open(os.path.join(d, "idx.gz"), "rb").read()))
+        ref_idx_gz = open(os.path.join(d, "idx.gz"), "rb").read()
+        raw2 = bytearray(gzip.decompress(ref_idx_gz))
         raw2[32] = 0; raw2[38] = 0
         assert sha(bytes(raw2)) == out["stream_sha_masked"], "CLI dump != harness dump"
         so_i = run([cli, "-i", "idx.gz", "-a", "queries.fa", "-o", "out_i.txt", "-t", "1"], d)
@@ -149,6 +150,9 @@ def make_case(name):
         run([cli, "-i", "idx.gz", "-A", "qfiles.lst", "-o", "outA.txt", "-t", "1"], d)
         outA_txt = open(os.path.join(d, "outA.txt"), "rb").read()
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    if name in synth.REF_INDEX_CASES:                    # the reference's own -d output, byte for byte (a data fixture)
+        with open(os.path.join(HERE, f"{name}_ref_idx.gz"), "wb") as f:
+            f.write(ref_idx_gz)
     for fn, data in ((f"{name}_out.txt", out_txt), (f"{name}_exact.txt", exact_txt),
                      (f"{name}_outA.txt", outA_txt),
                      (f"{name}_stdout_l.txt", strip_timing(so)),

@@ -111,6 +111,38 @@ def case_c1() -> Case:
     return c
 
 
+def case_c2mini() -> Case:
+    """BASELINE config 2's regime in small: 5 Mb genomes at -k 31 -h 17 have FULL sketches
+    (sketch_size = 2^17 exactly), so active * active wraps to 0 in the reference's u32 arithmetic
+    (Miekki.cpp:289, 306), every genome_size is 0, every intersection estimate is 0 and the
+    approximate mode prints empty hit lists although the scores are right."""
+    c = Case("c2mini", 31, 17, 3, 33, 200)
+    G, L = 3, 5_000_000
+    for g in range(G):
+        c.genome_files.append((f"genome{g}.fa", fasta(f"genome{g}", genome_bases(g, 0, L)), False))
+    _std_queries(c, G, L, 30)
+    c.queries.append((b">miss", genome_bases(4_000_000, 0, 1000)))
+    g, off = query_origin(31, G, L, 50_000)
+    c.queries.append((b">long31", genome_bases(g, off, 50_000)))
+    return c
+
+
+def case_h16z() -> Case:
+    """-h 16 with genomes long enough for a full sketch (65536^2 wraps to exactly 0 as well) next to
+    a short one whose sketch is partial (non-zero genome_size): both regimes in one index."""
+    c = Case("h16z", 31, 16, 3, 33, 20)
+    lens = [3_200_000, 1_000_000, 150_000, 40_000]
+    for g, n in enumerate(lens):
+        c.genome_files.append((f"z{g}.fa", fasta(f"z{g}", genome_bases(700 + g, 0, n)), g == 1))
+    for q in range(24):
+        g = q % 4
+        off = splitmix64_int(SEED_Q ^ (11000 + q)) % (lens[g] - 3000)
+        c.queries.append((f">z{q}_g{g}".encode(), genome_bases(700 + g, off, 600 + 100 * (q % 9))))
+    c.queries.append((b">whole_small", genome_bases(703, 0, 40_000)))
+    c.queries.append((b">miss", genome_bases(4_100_000, 0, 1500)))
+    return c
+
+
 def case_h20() -> Case:
     """h=20 with every awkward query shape the reference accepts."""
     c = Case("h20", 31, 20, 3, 32, 200)
@@ -253,7 +285,10 @@ def case_rnd(i: int) -> Case:
     return c
 
 
-CASES = {"c1": case_c1, "h20": case_h20, "w16": case_w16, "messy": case_messy,
+CASES = {"c1": case_c1, "c2mini": case_c2mini, "h16z": case_h16z, "h20": case_h20, "w16": case_w16, "messy": case_messy,
          "rnd0": lambda: case_rnd(0), "rnd1": lambda: case_rnd(1), "rnd2": lambda: case_rnd(2), "rnd3": lambda: case_rnd(3),
          "rnd4": lambda: case_rnd(4), "rnd5": lambda: case_rnd(5)}
-EXTRA_CASES = {"flush": case_flush}       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)
+EXTRA_CASES = {"flush": case_flush}
+# cases whose reference-WRITTEN index file (the CLI's -d output, bytes as the reference's zstr
+# writer made them) is committed as tests/golden/<name>_ref_idx.gz, for the -i loaders
+REF_INDEX_CASES = ("rnd3",)       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)

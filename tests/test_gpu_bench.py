@@ -23,14 +23,14 @@ def run_bench(*argv):
 
 
 def test_one_gpu_line_and_two_rank_rehearsal_agree():
-    common = ["--genomes", "192", "--queries", "2000", "--h", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    common = ["--genomes", "192", "--queries", "2000", "--h", "20", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     one = run_bench("--gpus", "1", *common)
     two = run_bench("--gpus", "2", "--rehearse", *common)
     for r, n in ((one, 1), (two, 2)):
         assert r["n_gpus"] == n and r["scaling"] == "strong" and r["config"]["genomes_total"] == 192
         assert r["unit"] == "comparisons/s" and r["value"] > 0
         assert r["roofline"]["frac"] == pytest.approx(r["roofline"]["achieved"] / r["roofline"]["peak"])
-        assert r["roofline"]["hbm_floor_bytes"] == (1 << 16) * r["config"]["genomes_per_gpu"]
+        assert r["roofline"]["hbm_floor_bytes"] == (1 << 20) * r["config"]["genomes_per_gpu"]
         assert r["merge"]["overflowed_queries"] == 0
         # every query comes out with its source genome on top, and the device heap is the host heap
         assert r["check"]["top_hit_is_source_genome_of_first_2000"] == 2000
