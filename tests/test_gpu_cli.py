@@ -48,7 +48,7 @@ def workdirs(tmp_path_factory):
     return get
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "c1", "c2mini", "h16z", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_build_query_dump_like_the_reference(workdirs, golden_dir, name):
     case, d, base = workdirs(name)
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -68,7 +68,7 @@ def test_build_query_dump_like_the_reference(workdirs, golden_dir, name):
     assert (d / "outA.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "flush", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "flush", "c2mini", "h16z", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"])
 def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
     case, d, base = workdirs(name)
     run(["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact.txt", *base], d)
@@ -79,10 +79,26 @@ def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
     assert got == want
 
 
-def test_reference_written_index_loads(workdirs, golden_dir, tmp_path):
-    """An index file written by the REFERENCE itself would be the strongest check;
-    the reference cannot travel, so a stream assembled from golden data stands in:
-    our loader must accept the oracle-serialised stream of the messy case."""
+@pytest.mark.parametrize("name", synth.REF_INDEX_CASES)
+def test_reference_written_index_loads(workdirs, golden_dir, tmp_path, name):
+    """tests/golden/<name>_ref_idx.gz is the `-d` output of the REAL reference (its zstr writer's
+    bytes, committed as a data fixture by make_golden.py): `-i` on it must give the reference's
+    out.txt, and dumping it again must give the same payload."""
+    _, d, _ = workdirs(name)
+    ref_idx = os.path.join(golden_dir, f"{name}_ref_idx.gz")
+    so = run(["-i", ref_idx, "-a", "queries.fa", "-o", str(tmp_path / "o.txt"), "-d", str(tmp_path / "again.gz"), "-t", "1"], d)
+    assert (tmp_path / "o.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    assert b"Load sucessful" in so
+    a = bytearray(gzip.decompress(open(ref_idx, "rb").read())); b = bytearray(gzip.decompress((tmp_path / "again.gz").read_bytes()))
+    for raw in (a, b):
+        raw[32] = 0; raw[38] = 0                     # uninitialised byte, compressed flag (SURVEY row P)
+    assert a == b
+    run(["-i", ref_idx, "-A", "qfiles.lst", "-o", str(tmp_path / "oA.txt"), "-t", "1"], d)
+    assert (tmp_path / "oA.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+
+
+def test_oracle_serialised_index_loads(workdirs, golden_dir, tmp_path):
+    """Our loader also accepts the oracle-serialised stream of the messy case (a plain gzip stream)."""
     from oracle import oracle as orc
     case = synth.CASES["messy"]()
     o = orc.OracleMiekki(case.k, case.h, case.fp_bits, case.b, case.threshold)

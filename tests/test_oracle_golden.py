@@ -14,7 +14,7 @@ import pytest
 import synth
 from oracle import oracle as orc
 
-CASE_NAMES = ["messy", "h20", "w16", "c1", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"]
+CASE_NAMES = ["messy", "h20", "w16", "c1", "c2mini", "h16z", "rnd0", "rnd1", "rnd2", "rnd3", "rnd4", "rnd5"]
 
 
 def sha(b):
@@ -163,3 +163,34 @@ def test_exact_mode_matches_reference_cli(built, name, golden_dir):
             if ni > 0:
                 got.append("%g\t%g\t%g\t%g\t%s\t%s" % (ni / nu, jac, ni, inter, hd.decode(), fn))
     assert sorted(got) == sorted(want)
+
+
+def test_config2_regime_is_pinned(built):
+    """BASELINE config 2's regime (5 Mb genomes at -h 17): full sketches, active^2 wraps to 0 in the
+    reference's u32 arithmetic (Miekki.cpp:289, 306), genome_size 0 -- so the reference reports the
+    right scores and no hits.  The fixture is the real reference's output; the oracle reproduces it."""
+    case, gold, ix = built("c2mini")
+    assert (gold["sketch_size"] == 1 << 17).all() and (gold["genome_size"] == 0).all()
+    assert int(gold["hits_approx_off"][-1]) == 0                        # not a single hit in approximate mode
+    sc = gold["scores"]
+    for q in range(30):                                                  # ... although the source genome stands out
+        assert sc[q, q % 3] >= 10 and sc[q, q % 3] > 5 * np.delete(sc[q], q % 3).max()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "c2mini_out.txt"), "rb").read().splitlines()
+    assert all(l.endswith(b":") for l in text) and len(text) == int(gold["nq"])
+    _, gz, _ = built("h16z")
+    assert (gz["sketch_size"][:2] == 1 << 16).all() and (gz["genome_size"][:2] == 0).all() and (gz["genome_size"][2:] > 0).all()
+
+
+@pytest.mark.parametrize("name", synth.REF_INDEX_CASES)
+def test_reference_written_index_file_deserialises(built, name):
+    """The reference's own `-d` file (bytes of its zstr writer) -> oracle object -> same stream."""
+    import gzip
+    case, gold, ix = built(name)
+    raw = bytearray(gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", f"{name}_ref_idx.gz"), "rb").read()))
+    assert len(raw) == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    assert sha(raw) == str(gold["stream_sha_masked"])
+    o = orc.OracleMiekki.deserialize(np.frombuffer(bytes(raw), np.uint8))
+    again = bytearray(o.serialize().tobytes()); again[32] = 0; again[38] = 0
+    assert again == raw
+    np.testing.assert_array_equal(o.sketch_size, ix.sketch_size)
