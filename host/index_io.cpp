@@ -53,11 +53,16 @@ constexpr uint64_t kChunk = 64ull << 20;
 
 }  // namespace
 
-int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned threads)
+// The shards' columns side by side give the reference's column: row p of the file is the
+// concatenation, in shard order, of every shard's row p.
+int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::string &err, unsigned threads)
 {
     mk_params p;
-    if (mk_get_params(ctx, &p) != MK_OK) { err = mk_last_error(); return -1; }
-    const uint32_t G = mk_index_size(ctx), W = p.fp_bits / 8, P = 1u << p.h;
+    if (ctxs.empty() || mk_get_params(ctxs[0], &p) != MK_OK) { err = ctxs.empty() ? "no context" : mk_last_error(); return -1; }
+    const size_t D = ctxs.size();
+    std::vector<uint32_t> Gd(D), at(D + 1, 0);
+    for (size_t d = 0; d < D; ++d) { Gd[d] = mk_index_size(ctxs[d]); at[d + 1] = at[d] + Gd[d]; }
+    const uint32_t G = at[D], W = p.fp_bits / 8, P = 1u << p.h;
     ParallelGzipWriter w(path, threads);
     if (!w.ok()) { err = "cannot open " + path; return -1; }
     Header hd{p.k, p.h, p.fp_bits, 5, G, p.bloom_log2, p.bloom_log2 ? 1ull << p.bloom_log2 : 0, 0, 0, p.threshold, 1};
@@ -65,21 +70,34 @@ int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned 
     bool ok = true;
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
-    std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1));
+    std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1)), part;
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
-        if (G && mk_index_export_columns(ctx, pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
+        if (D == 1) {
+            if (G && mk_index_export_columns(ctxs[0], pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
+        } else {
+            for (size_t d = 0; ok && d < D; ++d) {
+                if (!Gd[d]) continue;
+                const uint64_t prow = (uint64_t)Gd[d] * W;
+                part.resize((size_t)(pe - pb) * prow);
+                if (mk_index_export_columns(ctxs[d], pb, pe, part.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
+                for (uint32_t r = 0; r < pe - pb; ++r)
+                    memcpy(buf.data() + (uint64_t)r * row + (uint64_t)at[d] * W, part.data() + (uint64_t)r * prow, prow);
+            }
+            if (!ok) break;
+        }
         w.write(buf.data(), (size_t)(pe - pb) * row);
     }
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
-    if (ok && mk_index_export_sizes(ctx, gs.data(), ss.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+    for (size_t d = 0; ok && d < D; ++d)
+        if (mk_index_export_sizes(ctxs[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) { err = mk_last_error(); ok = false; }
     if (ok) w.write(gs.data(), (size_t)G * 8);
     const uint64_t nb = hd.bloom_bits / 8;
     buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(nb, 1)));
-    for (uint64_t o = 0; ok && o < nb; o += kChunk) {
+    for (uint64_t o = 0; ok && o < nb; o += kChunk) {              // every shard holds the global filter
         const uint64_t e = std::min(nb, o + kChunk);
-        if (mk_index_export_bloom(ctx, o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
+        if (mk_index_export_bloom(ctxs[0], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
         w.write(buf.data(), (size_t)(e - o));
     }
     if (ok) w.write(ss.data(), (size_t)G * 4);
@@ -88,29 +106,50 @@ int dump_index(mk_ctx *ctx, const std::string &path, std::string &err, unsigned 
     return ok ? 0 : -1;
 }
 
-int load_index(const std::string &path, int device, mk_ctx **out, std::string &err, unsigned threads)
+int load_index(const std::string &path, const std::vector<int> &devices, std::vector<mk_ctx *> &out, std::string &err,
+               unsigned threads)
 {
-    *out = nullptr;
+    out.clear();
     ParallelGzipReader f(path, threads);
     if (!f.ok()) { err = "cannot open " + path; return -1; }
     Header hd;
-    mk_ctx *ctx = nullptr;
     bool ok = f.read(&hd, sizeof hd);
-    if (!ok) err = "truncated index header";
-    if (ok) {
-        mk_params p{hd.kmer_size, hd.h, hd.fp_bits, hd.bloom_log2, hd.threshold, device, 0, 0};
-        if (mk_create(&p, &ctx) != MK_OK) { err = mk_last_error(); ok = false; }
+    if (!ok) { err = "truncated index header"; return -1; }
+    const uint32_t G = hd.index_size, W = hd.fp_bits / 8;
+    // genomes split over the devices in id order; never more shards than genomes
+    const size_t D = std::max<size_t>(1, std::min<size_t>(devices.size(), std::max<uint32_t>(G, 1)));
+    std::vector<uint32_t> at(D + 1, 0);
+    for (size_t d = 0; d < D; ++d) {
+        const uint64_t base = G / D, rem = G % D;
+        at[d + 1] = at[d] + (uint32_t)(base + (d < rem ? 1 : 0));
     }
-    const uint32_t G = hd.index_size, W = hd.fp_bits / 8, P = ok ? 1u << hd.h : 0;
-    if (ok && mk_index_import_begin(ctx, G) != MK_OK) { err = mk_last_error(); ok = false; }
+    for (size_t d = 0; ok && d < D; ++d) {
+        mk_params p{hd.kmer_size, hd.h, hd.fp_bits, hd.bloom_log2, hd.threshold, devices[d], at[d], 0};
+        mk_ctx *ctx = nullptr;
+        if (mk_create(&p, &ctx) != MK_OK) { err = mk_last_error(); ok = false; break; }
+        out.push_back(ctx);
+        if (mk_index_import_begin(ctx, at[d + 1] - at[d]) != MK_OK) { err = mk_last_error(); ok = false; }
+    }
+    const uint32_t P = ok ? 1u << hd.h : 0;
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
-    std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1));
+    std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1)), part;
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
         ok = f.read(buf.data(), (size_t)(pe - pb) * row);
         if (!ok) { err = "truncated index columns"; break; }
-        if (G && mk_index_import_columns(ctx, pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+        if (D == 1) {
+            if (G && mk_index_import_columns(out[0], pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+            continue;
+        }
+        for (size_t d = 0; ok && d < D; ++d) {
+            const uint64_t prow = (uint64_t)(at[d + 1] - at[d]) * W;
+            if (!prow) continue;
+            part.resize((size_t)(pe - pb) * prow);
+            for (uint32_t r = 0; r < pe - pb; ++r)
+                memcpy(part.data() + (uint64_t)r * prow, buf.data() + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
+            if (mk_index_import_columns(out[d], pb, pe, part.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+        }
     }
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
@@ -121,12 +160,20 @@ int load_index(const std::string &path, int device, mk_ctx **out, std::string &e
         const uint64_t e = std::min(nb, o + kChunk);
         ok = f.read(buf.data(), (size_t)(e - o));
         if (!ok) { err = "truncated Bloom filter"; break; }
-        if (mk_index_import_bloom(ctx, o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+        for (size_t d = 0; ok && d < D; ++d)                        // the one global filter, on every shard
+            if (mk_index_import_bloom(out[d], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
     }
     if (ok && !(ok = f.read(ss.data(), (size_t)G * 4))) err = "truncated sketch sizes";
-    if (ok && G && mk_index_import_sizes(ctx, gs.data(), ss.data()) != MK_OK) { err = mk_last_error(); ok = false; }
-    if (!ok) { mk_destroy(ctx); return -1; }
-    *out = ctx;
+    for (size_t d = 0; ok && d < D; ++d)
+        if (at[d + 1] > at[d] && mk_index_import_sizes(out[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) {
+            err = mk_last_error();
+            ok = false;
+        }
+    if (!ok) {
+        for (mk_ctx *c : out) mk_destroy(c);
+        out.clear();
+        return -1;
+    }
     return 0;
 }
 

@@ -12,7 +12,11 @@
 //   * `-i ... -e` reports that genome file names are not stored in an index
 //     instead of crashing,
 //   * no zlib re-compression of the in-memory columns (main.cpp:198): they live
-//     raw in HBM.
+//     raw in HBM,
+//   * where the reference scales with -t threads inside the one process, this one
+//     scales over the visible GPUs inside the one process (MIEKKI_DEVICES=0,1,..
+//     restricts them): genome shards in list order, one context per GPU
+//     (multi_gpu.hpp); ids, hits and files are those of one GPU.
 #include <getopt.h>
 #include <unistd.h>
 
@@ -39,6 +43,7 @@
 
 #include "index_io.hpp"
 #include "miekki_hip.h"
+#include "multi_gpu.hpp"
 
 using namespace std;
 
@@ -110,66 +115,120 @@ void *pinned_alloc(void *ctx, size_t bytes)
 void pinned_free(void *ctx, void *p) { mk_host_free((mk_ctx *)ctx, p); }
 
 struct Driver {
-    mk_ctx *ctx = nullptr;
+    mkhost::DeviceGroup group;                   // one context per GPU, genome shards in list order
+    mk_ctx *ctx0() const { return group.ctx(0); }
     unsigned threads = 8;                        // -t: host reader threads
     uint32_t k = 31, threshold = 200;
     vector<string> file_names;                   // Miekki.h:59, never persisted
     ofstream out;
 
-    // ---- Miekki.cpp:540-588
-    void index_file_of_file(const string &list)
+    // one shard's share of index_file_of_file: files [f0, f1) of the list into ctx, in order.
+    // `log` collects what the reference prints meanwhile (one '-' per genome kept, the
+    // "Missed file" lines) so that several shards' output can be shown in list order.
+    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0; };
+    void build_shard(mk_ctx *ctx, const vector<string> &files, unsigned nthreads, bool live, ShardBuild &sb)
     {
-        if (!mkhost::file_exists(list)) { cout << "Missed file of file: " << list << endl; return; }
-        string text;
-        mkhost::read_text(list, text);
         vector<OrderedFastaReader::Item> seqs;
         vector<string> names;
         uint64_t bytes = 0;
-        vector<string> files;
-        for (const string &fn : split_lines(text))
-            if (fn.size() > 3) files.push_back(fn);
+        // a doubling matrix would hold old and new copy at once: size it for the whole list up front
+        if (!files.empty() && mk_reserve(ctx, (uint32_t)files.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return; }
         // readers parse into pinned buffers, three device batches ahead; the append of one
         // batch returns as soon as its copy is done, so parsing, copying and sketching overlap
-        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64);
-        double t_append = 0, t_wait = 0;                           // where the host thread spends its time
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
+        auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         auto flush = [&]() {
-            if (seqs.empty()) return;
+            if (seqs.empty()) return true;
             vector<const char *> p;
             vector<uint64_t> l;
             for (auto &s : seqs) { p.push_back(s.data); l.push_back(s.len); }
             const double t0 = now();
-            if (mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size()) != MK_OK) die("index build failed");
-            t_append += now() - t0;
-            file_names.insert(file_names.end(), names.begin(), names.end());
+            if (mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size()) != MK_OK) {
+                sb.error = string("index build failed: ") + mk_last_error();
+                return false;
+            }
+            sb.t_append += now() - t0;
+            sb.names.insert(sb.names.end(), names.begin(), names.end());
             for (auto &s : seqs) reader.recycle(s);
             seqs.clear(); names.clear(); bytes = 0;
+            return true;
         };
-        string marks;
         for (size_t i = 0; i < files.size(); ++i) {
             const string &fn = files[i];
             const double t0 = now();
             OrderedFastaReader::Item item = reader.take(i);
-            t_wait += now() - t0;
-            if (!item.exists) { cout << marks << "Missed file: " << fn << endl; marks.clear(); reader.recycle(item); continue; }
-            if (item.failed) { cout << marks << "cannot read " << fn << endl; exit(1); }
+            sb.t_wait += now() - t0;
+            if (!item.exists) { sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
+            if (item.failed) { sb.error = "cannot read " + fn; return; }
             if (item.len >= k) {
                 bytes += item.len;
                 seqs.push_back(item); names.push_back(fn);
-                if (seqs.size() >= 64 || bytes > (1ull << 30)) { flush(); cout << marks << flush_stream(); marks.clear(); }
-                marks += '-';
+                if (seqs.size() >= 64 || bytes > (1ull << 30)) { if (!flush()) return; show(); }
+                sb.log += '-';
             } else {
                 reader.recycle(item);
             }
         }
-        flush();
-        cout << marks << endl;
+        if (!flush()) return;
+        if (mk_index_size(ctx) != sb.names.size()) sb.error = string("index build failed: ") + mk_last_error();   // settles the last batch
+    }
+
+    // ---- Miekki.cpp:540-588.  `make_ctx(device ordinal)` creates one shard's context.
+    template <typename MakeCtx>
+    void index_file_of_file(const string &list, const vector<int> &devices, MakeCtx make_ctx)
+    {
+        vector<string> files;
+        const bool have_list = mkhost::file_exists(list);
+        if (have_list) {
+            string text;
+            mkhost::read_text(list, text);
+            for (const string &fn : split_lines(text))
+                if (fn.size() > 3) files.push_back(fn);
+        }
+        // genome shards = contiguous runs of the list, one per GPU (never more shards than files)
+        const size_t D = std::max<size_t>(1, std::min<size_t>(devices.size(), files.size()));
+        vector<mk_ctx *> ctxs;
+        for (size_t d = 0; d < D; ++d) ctxs.push_back(make_ctx(devices[d]));
+        group.adopt(ctxs);
+        if (!have_list) { cout << "Missed file of file: " << list << endl; finish_index(true); return; }
+        vector<ShardBuild> sb(D);
+        vector<vector<string>> part(D);
+        for (size_t d = 0; d < D; ++d) {
+            uint64_t b, e;
+            mkhost::shard_range(files.size(), (uint32_t)d, (uint32_t)D, b, e);
+            part[d].assign(files.begin() + b, files.begin() + e);
+        }
+        const unsigned per = std::max(1u, threads / (unsigned)D);
+        if (D == 1) {
+            build_shard(ctxs[0], part[0], per, true, sb[0]);
+        } else {                                                   // the shards build side by side
+            vector<std::thread> th;
+            for (size_t d = 0; d < D; ++d) th.emplace_back([&, d] { build_shard(ctxs[d], part[d], per, false, sb[d]); });
+            for (auto &t : th) t.join();
+        }
+        for (size_t d = 0; d < D; ++d) {                           // what the reference prints, in list order
+            cout << sb[d].log;
+            if (!sb[d].error.empty()) { cout << endl << sb[d].error << endl; exit(1); }
+            file_names.insert(file_names.end(), sb[d].names.begin(), sb[d].names.end());
+        }
+        cout << endl;
         if (getenv("MIEKKI_VERBOSE"))
-            cout << "[ingest] waited for the readers " << t_wait << "s, in mk_index_append " << t_append << "s" << endl;
-        cout << "Reference indexed: " << mk_index_size(ctx) << endl;
+            for (size_t d = 0; d < D; ++d)
+                cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
+                     << "s, in mk_index_append " << sb[d].t_append << "s" << endl;
+        finish_index(true);
+        cout << "Reference indexed: " << group.total() << endl;
         mk_params p;
-        mk_get_params(ctx, &p);
+        mk_get_params(ctx0(), &p);
         if (p.bloom_log2) cout << "BF size:" << int_to_string(1ull << p.bloom_log2) << endl;
+    }
+
+    // id bases, the global Bloom filter and the sizes of all genomes on the merging GPU
+    void finish_index(bool merge_bloom)
+    {
+        string err;
+        if (group.finish(merge_bloom, err) != 0) { cout << "multi-GPU setup failed: " << err << endl; exit(1); }
     }
 
     static const char *flush_stream() { cout.flush(); return ""; }
@@ -195,9 +254,11 @@ struct Driver {
         hits.assign((size_t)p.size() * nres + 1, mk_hit{});
         nhits.assign(p.size() + 1, 0);
         if (p.empty()) return;
-        if (mk_query(ctx, p.data(), l.data(), (uint32_t)p.size(), nres, min_score, min_inter, hits.data(),
-                     nhits.data(), nullptr) != MK_OK)
-            die("query failed");
+        string err;
+        if (group.query(p.data(), l.data(), (uint32_t)p.size(), nres, min_score, min_inter, hits.data(), nhits.data(), err) != 0) {
+            cout << "query failed: " << err << endl;
+            exit(1);
+        }
     }
 
     void run_query(const vector<const string *> &seqs, uint32_t nres, uint32_t min_score, double min_inter,
@@ -326,7 +387,7 @@ struct Driver {
             if (fn.size() > 3) files.push_back(fn);
         // readers parse into pinned buffers, two batches ahead: the upload of a batch is a DMA
         // straight out of them
-        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 2 * 32);
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx0()}, 2 * 32);
         // whole files are queried in batches so that the dense kernel can take four per
         // pass over the matrix; output stays in list order
         vector<string> names;
@@ -367,7 +428,7 @@ struct Driver {
     }
 
     // ---- exact mode -------------------------------------------------------------
-    struct Pending { string seq, head; double jaccard, intersection; };
+    struct Pending { string seq, head; double jaccard, intersection; uint32_t genome; };
 
     // a genome file as ground_truth_batch sees it: contigs split at '>' lines (Miekki.cpp:805-812),
     // walked line by line over the raw text.  Callable from a helper thread.
@@ -408,6 +469,8 @@ struct Driver {
         for (auto &c : contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
         for (auto &q : v) { qp.push_back(q.seq.data()); ql.push_back(q.seq.size()); }
         vector<uint64_t> inter(v.size()), uni(v.size());
+        // K7 runs on the GPU that owns the genome (any would do: the sets come from the file itself)
+        mk_ctx *ctx = group.ctx(v.empty() ? 0 : group.owner(v[0].genome));
         if (mk_exact(ctx, cp.data(), cl.data(), (uint32_t)contigs.size(), qp.data(), ql.data(), (uint32_t)v.size(),
                      inter.data(), uni.data()) != MK_OK)
             die("exact mode failed");
@@ -421,7 +484,7 @@ struct Driver {
 
     bool need_names()
     {
-        if (file_names.size() == mk_index_size(ctx)) return true;
+        if (file_names.size() == group.total()) return true;
         cout << "exact mode needs the genome files of the index: build it with -l in the same run "
                 "(file names are not stored in an index file)" << endl;
         return false;
@@ -442,7 +505,7 @@ struct Driver {
                 const mk_hit &h = hits[q * nres + i];
                 const string &file_name = file_names[h.genome];
                 vector<Pending> &v = batch[file_name];
-                v.push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection});
+                v.push_back(Pending{*seqs[q], heads[q], h.jaccard, h.intersection, h.genome});
                 if (v.size() >= 100) { ground_truth(file_name, v); v.clear(); }
             }
         // the genome file of the NEXT entry is read and split while the device works on this one
@@ -512,8 +575,6 @@ int main(int argc, char **argv)
     uint64_t H = 17, core_number = 8, kmer_size = 31, bloom_size = 33, fingerprint_size = 3;   // main.cpp:131
     double threshold = 200;
     bool exact_mode = false;
-    int device = 0;
-    if (const char *d = getenv("MIEKKI_DEVICE")) device = atoi(d);
     int c;
     while ((c = getopt(argc, argv, "i:l:a:h:t:f:k:s:b:o:ed:A:")) != -1) {
         switch (c) {
@@ -532,6 +593,7 @@ int main(int argc, char **argv)
         case 'd': index_dump = optarg; break;
         }
     }
+    const vector<int> devices = mkhost::device_list();          // every visible GPU, or MIEKKI_DEVICES
     const unsigned reader_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(core_number, 64));
     const uint32_t bit_per_min = (uint32_t)(5 + fingerprint_size);                              // main.cpp:184
     cout << "Using " << bit_per_min << " bits per minimizer, " << int_to_string(1ull << H) << " minimizers so "
@@ -545,22 +607,28 @@ int main(int argc, char **argv)
             return 1;
         }
         string err;
-        if (mkhost::load_index(index_file, device, &drv.ctx, err, reader_threads) != 0) { cout << "Index load failed: " << err << endl; return 1; }
+        vector<mk_ctx *> ctxs;
+        if (mkhost::load_index(index_file, devices, ctxs, err, reader_threads) != 0) { cout << "Index load failed: " << err << endl; return 1; }
+        drv.group.adopt(ctxs);
+        drv.finish_index(false);                            // the file holds the global Bloom filter already
         mk_params p;
-        mk_get_params(drv.ctx, &p);
+        mk_get_params(drv.ctx0(), &p);
         drv.k = p.k; drv.threshold = p.threshold;          // -k -h -f -b -s come from the file (main.cpp:189-194)
         drv.out.open(output_file.c_str());
         cout << "I output results in " << output_file << endl;
         cout << "Load sucessful" << endl;
     } else if (!list_file.empty()) {
-        mk_params p{(uint32_t)kmer_size, (uint32_t)H, bit_per_min, (uint32_t)bloom_size, (uint32_t)threshold, device, 0, 0};
         drv.out.open(output_file.c_str());
         cout << "I output results in " << output_file << endl;
-        const int st = mk_create(&p, &drv.ctx);
-        if (st == MK_ERR_UNSUPPORTED) { cout << "not implemented" << endl; return 0; }       // Miekki.cpp:235-237
-        if (st != MK_OK) die("cannot create the index");
-        drv.k = p.k; drv.threshold = p.threshold;
-        drv.index_file_of_file(list_file);
+        drv.k = (uint32_t)kmer_size; drv.threshold = (uint32_t)threshold;
+        drv.index_file_of_file(list_file, devices, [&](int device) {
+            mk_params p{(uint32_t)kmer_size, (uint32_t)H, bit_per_min, (uint32_t)bloom_size, (uint32_t)threshold, device, 0, 0};
+            mk_ctx *ctx = nullptr;
+            const int st = mk_create(&p, &ctx);
+            if (st == MK_ERR_UNSUPPORTED) { cout << "not implemented" << endl; exit(0); }          // Miekki.cpp:235-237
+            if (st != MK_OK) die("cannot create the index");
+            return ctx;
+        });
     } else {
         cout << "What am I supposed to index ? use either -i or -l options please" << endl;
         help();
@@ -569,7 +637,7 @@ int main(int argc, char **argv)
     if (!index_dump.empty()) {
         cout << "I write this index on the disk for later" << endl;
         string err;
-        if (mkhost::dump_index(drv.ctx, index_dump, err, reader_threads) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
+        if (mkhost::dump_index(drv.group.contexts(), index_dump, err, reader_threads) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
     }
     auto end_index = chrono::system_clock::now();
     cout << "elapsed time: " << chrono::duration<double>(end_index - start).count() << "s\n";
@@ -596,6 +664,5 @@ int main(int argc, char **argv)
     cout << "elapsed time: " << chrono::duration<double>(end_query - end_index).count() << "s\n";
     cout << "The end" << endl;
     drv.out.close();
-    mk_destroy(drv.ctx);
-    return 0;
+    return 0;                                                // ~DeviceGroup releases the contexts
 }

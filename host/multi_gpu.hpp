@@ -1,0 +1,82 @@
+// Several GPUs inside the one `miekki` process -- the reference scales inside one
+// executable too (-t, main.cpp:190-196; drivers Miekki.cpp:546-581, 430-480).
+//
+// One mk_ctx per GPU.  The genomes are sharded in LIST order: shard d holds a contiguous
+// run of the list, so genome ids (= list positions of the genomes that were kept) and the
+// order in which filter_results meets the genomes (Miekki.cpp:379) are those of a single
+// context.  The Bloom filter is the one global structure: the shards' filters are folded
+// first-writer-wins in shard order (Miekki.cpp:125-129) and handed back to every shard.
+// A query batch is scanned by every GPU against its shard; each emits the heap entrants
+// of its shard as 8-byte (genome, matches) records (mk_qset_run_compact); the rows are
+// copied GPU-to-GPU over xGMI into the first shard's memory (mk_dev_copy: the single
+// exchange step) and merged there by filter_results' heap on the device
+// (mk_merge_compact).  Plain C++ above the C ABI: no GPU runtime calls in here.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "miekki_hip.h"
+
+namespace mkhost {
+
+// device ordinals to use: MIEKKI_DEVICES=0,1,2 (an ordinal may repeat: several shards on
+// one GPU, which is how a one-GPU box rehearses the multi-GPU path), else every visible GPU
+std::vector<int> device_list();
+
+// contiguous, ordered split of n items over `parts` shards (sizes differ by at most one)
+inline void shard_range(uint64_t n, uint32_t shard, uint32_t parts, uint64_t &b, uint64_t &e)
+{
+    const uint64_t base = n / parts, rem = n % parts;
+    b = shard * base + (shard < rem ? shard : rem);
+    e = b + base + (shard < rem ? 1 : 0);
+}
+
+class DeviceGroup {
+public:
+    DeviceGroup() = default;
+    ~DeviceGroup();
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+
+    // takes ownership of the contexts (shard order)
+    void adopt(std::vector<mk_ctx *> ctxs) { ctx_ = std::move(ctxs); }
+    size_t shards() const { return ctx_.size(); }
+    mk_ctx *ctx(size_t d) const { return ctx_[d]; }
+    const std::vector<mk_ctx *> &contexts() const { return ctx_; }
+    uint32_t total() const;                                   // genomes in all shards
+    // shard that holds genome id g (after finish())
+    size_t owner(uint32_t genome) const;
+
+    // After the shards were built (or loaded): id bases by prefix sum, and for more than one
+    // shard the global Bloom filter (unless the shards were loaded with it) and the sizes of
+    // all genomes on the merging shard.  0 or -1 (+ err).
+    int finish(bool merge_bloom, std::string &err);
+
+    // filter_results(query_sequences(batch), nresults, min_score, min_intersection) over the
+    // whole sharded index: hits[nq][nresults], nhits[nq].  One shard: mk_query.
+    int query(const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t nresults, uint32_t min_score,
+              double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
+
+    uint64_t gather_bytes() const { return gather_bytes_; }  // bytes copied between GPUs by query() so far
+
+private:
+    int query_part(const std::vector<uint32_t> &idx, const char *const *seqs, const uint64_t *lens, uint32_t nresults,
+                   uint32_t min_score, double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
+    int replay(const std::vector<uint32_t> &idx, const char *const *seqs, const uint64_t *lens, uint32_t nresults,
+               uint32_t min_score, double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
+    int ensure_buffers(uint32_t nq, uint32_t nresults, std::string &err);
+
+    std::vector<mk_ctx *> ctx_;
+    std::vector<uint32_t> base_;                              // shards() + 1 id boundaries
+    std::vector<uint64_t> gs_all_;                            // sizes of all genomes (for replays)
+    std::vector<uint32_t> ss_all_;
+    // per-shard row buffers and, on shard 0, the gather buffer / merge output
+    std::vector<void *> d_rows_;
+    void *d_gather_ = nullptr, *d_hits_ = nullptr, *d_nhits_ = nullptr;
+    uint64_t rows_cap_ = 0, hits_cap_ = 0;                    // queries / hit records the buffers hold
+    uint64_t gather_bytes_ = 0;
+    static constexpr uint32_t kCap = 96;                      // entrant slots per query per shard
+};
+
+}  // namespace mkhost

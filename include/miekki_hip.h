@@ -238,6 +238,11 @@ int mk_dev_copy(mk_ctx *dst, void *d_dst, mk_ctx *src, const void *d_src, uint64
 /* Bloom cells [begin, end) to / from device memory of the context's GPU. */
 int mk_index_export_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, uint8_t *d_dst);
 int mk_index_import_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *d_src);
+/* First-writer fold of a genome-sharded build (the reference's single filter keeps the byte of a
+ * cell's first inserter in genome order, Miekki.cpp:125-129): cells [begin, end) of this context
+ * keep their byte where it is non-zero and take d_later's otherwise.  Called on the first shard
+ * with the filters of the later shards in shard order; begin must be a multiple of 16. */
+int mk_index_merge_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *d_later);
 /* bytes of the Bloom table a 2k-bit k-mer can reach (everything above stays zero) */
 uint64_t mk_bloom_reachable_bytes(const mk_ctx *ctx);
 

@@ -1223,6 +1223,19 @@ int mk_index_import_bloom_device(mk_ctx *c, uint64_t begin, uint64_t end, const 
     return MK_OK;
 }
 
+int mk_index_merge_bloom_device(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later)
+{
+    if (!c || !d_later) { set_error("null argument"); return MK_ERR_ARG; }
+    if (begin > end || end > c->bloom_bytes) { set_error("Bloom range out of bounds"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
+    if (begin < dev_end) MK_TRY(launch_bloom_merge(c, begin, dev_end, d_later));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    c->bloom_full_stale = true;
+    ++c->gen;
+    return MK_OK;
+}
+
 uint64_t mk_bloom_reachable_bytes(const mk_ctx *c) { return c ? c->bloom_dev_bytes : 0; }
 
 int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, uint32_t nresults,

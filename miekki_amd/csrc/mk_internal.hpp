@@ -183,6 +183,7 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
                         const uint64_t *d_code_off);
 int launch_bloom_summary(mk_ctx *c);
+int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes);
 int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);

@@ -630,6 +630,41 @@ int launch_bloom_summary(mk_ctx *c)
     return MK_OK;
 }
 
+// Genome-sharded builds: the reference has ONE filter whose cells keep the byte of their FIRST
+// inserter in genome order (Miekki.cpp:125-129).  Folding the shards' filters in shard order
+// with "an occupied cell keeps its byte, an empty one takes the later shard's" gives exactly that.
+__global__ void bloom_merge_kernel(uint8_t *__restrict__ cells, const uint8_t *__restrict__ later, uint64_t n)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i + 16 <= n) {
+        uint4 a = *reinterpret_cast<const uint4 *>(cells + i);
+        const uint4 b = *reinterpret_cast<const uint4 *>(later + i);
+        auto fold = [](uint32_t x, uint32_t y) {
+            // per byte: x != 0 ? x : y  (mask = 0xff where the byte of x is zero)
+            const uint32_t nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;          // high bit set iff byte non-zero
+            const uint32_t zero_mask = (((~nz) >> 7) & 0x01010101u) * 0xffu;
+            return x | (y & zero_mask);
+        };
+        a.x = fold(a.x, b.x); a.y = fold(a.y, b.y); a.z = fold(a.z, b.z); a.w = fold(a.w, b.w);
+        *reinterpret_cast<uint4 *>(cells + i) = a;
+    } else {
+        for (uint64_t j = i; j < n; ++j)
+            if (cells[j] == 0) cells[j] = later[j];
+    }
+}
+
+int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later)
+{
+    if (!c->d_bloom || end <= begin) return MK_OK;
+    const uint64_t n = end - begin;
+    if ((begin & 15u) || ((uintptr_t)d_later & 15u)) { set_error("Bloom merge needs 16-byte aligned ranges"); return MK_ERR_ARG; }
+    const uint64_t threads = (n + 15) / 16;
+    hipLaunchKernelGGL(bloom_merge_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom + begin,
+                       d_later, n);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
                         const uint64_t *d_code_off)

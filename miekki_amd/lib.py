@@ -80,6 +80,7 @@ SIGNATURES = {
     "mk_dev_copy": (i32, [vp, vp, vp, vp, u64]),
     "mk_index_export_bloom_device": (i32, [vp, u64, u64, vp]),
     "mk_index_import_bloom_device": (i32, [vp, u64, u64, vp]),
+    "mk_index_merge_bloom_device": (i32, [vp, u64, u64, vp]),
     "mk_bloom_reachable_bytes": (u64, [vp]),
     "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
     "mk_qset_active": (i32, [vp, vp, vp]),

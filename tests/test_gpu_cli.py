@@ -21,8 +21,12 @@ def norm(out: bytes) -> bytes:
     return re.sub(rb"elapsed time: [0-9.e+-]+s", b"elapsed time: Xs", out)
 
 
-def run(args, cwd):
-    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+def run(args, cwd, devices=None):
+    env = dict(os.environ)
+    env.pop("MIEKKI_DEVICES", None)
+    if devices:
+        env["MIEKKI_DEVICES"] = devices
+    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
     assert r.returncode == 0, r.stdout.decode(errors="replace")
     return r.stdout
 
@@ -77,6 +81,35 @@ def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
     # the reference's line order comes from an unordered_map keyed by file name and a flush at 100
     # pending queries per file; the host driver uses the same container and rule, so: same order
     assert got == want
+
+
+@pytest.mark.parametrize("name,devices", [("messy", "0,0,0"), ("h20", "0,0"), ("w16", "0,0,0"), ("c2mini", "0,0"),
+                                          ("h16z", "0,0,0,0,0"), ("rnd1", "0,0,0"), ("rnd2", "0,0,0,0"), ("rnd4", "0,0,0"),
+                                          ("rnd5", "0,0")])
+def test_several_gpus_in_one_process_like_the_reference(workdirs, golden_dir, name, devices):
+    """The `miekki` binary over several contexts (MIEKKI_DEVICES repeats GPU 0: genome shards in list
+    order, Bloom first-writer fold, 8-byte entrant rows copied GPU-to-GPU, device merge): every file and
+    banner must be what ONE GPU -- i.e. the reference -- produces, for -l/-a/-d, -i, -A, -e and -A -e."""
+    case, d, base = workdirs(name)
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    so = run(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_m.txt", "-d", "idx_m.gz", *base], d, devices)
+    assert (d / "out_m.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    raw = bytearray(gzip.decompress((d / "idx_m.gz").read_bytes()))
+    assert len(raw) == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    assert hashlib.sha256(bytes(raw)).hexdigest() == str(gold["stream_sha_masked"])          # Bloom bytes included
+    assert norm(so).replace(b"out_m.txt", b"out.txt") == open(os.path.join(golden_dir, f"{name}_stdout_l.txt"), "rb").read()
+    so_i = run(["-i", "idx_m.gz", "-a", "queries.fa", "-o", "out_mi.txt", "-t", "1"], d, devices)   # sharded load
+    assert (d / "out_mi.txt").read_bytes() == (d / "out_m.txt").read_bytes()
+    assert norm(so_i).replace(b"out_mi.txt", b"out_i.txt") == open(os.path.join(golden_dir, f"{name}_stdout_i.txt"), "rb").read()
+    run(["-i", "idx_m.gz", "-A", "qfiles.lst", "-o", "outA_m.txt", "-t", "1"], d, devices)
+    assert (d / "outA_m.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+    run(["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact_m.txt", *base], d, devices)
+    assert (d / "exact_m.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_exact.txt"), "rb").read()
+    exa = os.path.join(golden_dir, f"{name}_exactA.txt")
+    if os.path.exists(exa):
+        run(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA_m.txt", *base], d, devices)
+        assert (d / "exactA_m.txt").read_bytes() == open(exa, "rb").read()
 
 
 @pytest.mark.parametrize("name", synth.REF_INDEX_CASES)
