@@ -101,7 +101,7 @@ OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned 
 
 OrderedFastaReader::~OrderedFastaReader()
 {
-    { std::lock_guard<std::mutex> g(m_); consumed_ = files_.size() + window_; }
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
     cv_.notify_all();
     for (auto &w : workers_) w.join();
     for (auto &it : items_) if (it.data) recycle(it);
@@ -141,12 +141,13 @@ char *OrderedFastaReader::pool_get(size_t need, size_t &cap)
 
 void OrderedFastaReader::pool_release(char *p)
 {
-    bool plain = !a_.release;
-    if (!plain) {
-        auto it = plain_.find(p);
-        if (it != plain_.end()) { plain = true; plain_.erase(it); }
+    auto it = plain_.find(p);
+    if (it != plain_.end() || !a_.alloc) {                         // came from malloc
+        if (it != plain_.end()) plain_.erase(it);
+        free(p);
+        return;
     }
-    if (plain) free(p); else a_.release(a_.user, p);
+    if (a_.release) a_.release(a_.user, p);                        // allocator-owned; without a release hook not ours to free
 }
 
 void OrderedFastaReader::recycle(Item &it)
@@ -179,8 +180,8 @@ void OrderedFastaReader::work()
         {
             std::unique_lock<std::mutex> lk(m_);
             // bounded read-ahead, in files and in bytes (the file the consumer waits for always goes)
-            cv_.wait(lk, [&] { return i < consumed_ + window_ && (ahead_bytes_ < kAheadBytes || i == consumed_); });
-            if (consumed_ >= files_.size() + window_) return;           // shutting down
+            cv_.wait(lk, [&] { return stop_ || (i < consumed_ + window_ && (ahead_bytes_ < kAheadBytes || i == consumed_)); });
+            if (stop_) return;                                          // destroyed before every item was taken
         }
         Item it;
         struct stat st;

@@ -56,6 +56,7 @@ private:
     std::vector<std::thread> workers_;
     std::atomic<size_t> next_{0};
     size_t consumed_ = 0, window_ = 8, ahead_bytes_ = 0;
+    bool stop_ = false;                            // set by the destructor: parked workers leave
     static constexpr size_t kAheadBytes = 4ull << 30;
     std::mutex m_;
     std::condition_variable cv_;

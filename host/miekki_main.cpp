@@ -457,22 +457,49 @@ struct Driver {
         return gc;
     }
 
-    // ground_truth_batch (Miekki.cpp:792-859) for all pending queries of one genome file
-    void ground_truth(const string &file, const vector<Pending> &v) { ground_truth(file, v, parse_contigs(file)); }
+    // ground_truth_batch (Miekki.cpp:792-859) for all pending queries of one genome file.  The
+    // reference rebuilds the file's k-mer set at every call (~7 s); here the set stays resident on
+    // the GPU that verified the file last, so a file whose queries are flushed in several batches
+    // (the flush-at-100 rule) is read, split and hashed once.
+    vector<string> resident;                                     // per shard: file whose set B is loaded
+    mk_ctx *exact_ctx(const vector<Pending> &v, size_t &shard)
+    {
+        // K7 runs on the GPU that owns the genome (any would do: the sets come from the file itself)
+        shard = v.empty() ? 0 : group.owner(v[0].genome);
+        if (resident.size() != group.shards()) resident.assign(group.shards(), string());
+        return group.ctx(shard);
+    }
+    bool is_resident(const string &file, const vector<Pending> &v)
+    {
+        size_t shard;
+        exact_ctx(v, shard);
+        return !file.empty() && resident[shard] == file;
+    }
+
+    void ground_truth(const string &file, const vector<Pending> &v)
+    {
+        if (is_resident(file, v)) ground_truth(file, v, GenomeContigs{});
+        else ground_truth(file, v, parse_contigs(file));
+    }
 
     void ground_truth(const string &file, const vector<Pending> &v, const GenomeContigs &gc)
     {
-        if (!gc.exists) { cout << "File problem: " << file << endl; return; }
-        const vector<string> &contigs = gc.contigs;
-        vector<const char *> cp, qp;
-        vector<uint64_t> cl, ql;
-        for (auto &c : contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
+        size_t shard;
+        mk_ctx *ctx = exact_ctx(v, shard);
+        if (resident[shard] != file) {
+            if (!gc.exists) { cout << "File problem: " << file << endl; return; }
+            vector<const char *> cp;
+            vector<uint64_t> cl;
+            for (auto &c : gc.contigs) { cp.push_back(c.data()); cl.push_back(c.size()); }
+            resident[shard].clear();
+            if (mk_exact_load_genome(ctx, cp.data(), cl.data(), (uint32_t)gc.contigs.size()) != MK_OK) die("exact mode failed");
+            resident[shard] = file;
+        }
+        vector<const char *> qp;
+        vector<uint64_t> ql;
         for (auto &q : v) { qp.push_back(q.seq.data()); ql.push_back(q.seq.size()); }
         vector<uint64_t> inter(v.size()), uni(v.size());
-        // K7 runs on the GPU that owns the genome (any would do: the sets come from the file itself)
-        mk_ctx *ctx = group.ctx(v.empty() ? 0 : group.owner(v[0].genome));
-        if (mk_exact(ctx, cp.data(), cl.data(), (uint32_t)contigs.size(), qp.data(), ql.data(), (uint32_t)v.size(),
-                     inter.data(), uni.data()) != MK_OK)
+        if (mk_exact_query(ctx, qp.data(), ql.data(), (uint32_t)v.size(), inter.data(), uni.data()) != MK_OK)
             die("exact mode failed");
         for (size_t i = 0; i < v.size(); ++i) {
             if (!inter[i]) continue;                                             // 843
@@ -513,11 +540,14 @@ struct Driver {
         for (auto itr = batch.begin(); itr != batch.end(); ++itr)
             if (!itr->second.empty()) todo.push_back(&*itr);
         std::future<GenomeContigs> ahead;
-        if (!todo.empty()) ahead = std::async(std::launch::async, [this, f = todo[0]->first] { return parse_contigs(f); });
+        // (a file whose set is still resident from a flush above is not read again)
+        auto parse_unless_resident = [this](const string &f, bool res) { return res ? GenomeContigs{} : parse_contigs(f); };
+        if (!todo.empty())
+            ahead = std::async(std::launch::async, parse_unless_resident, todo[0]->first, is_resident(todo[0]->first, todo[0]->second));
         for (size_t i = 0; i < todo.size(); ++i) {
             GenomeContigs gc = ahead.get();
             if (i + 1 < todo.size())
-                ahead = std::async(std::launch::async, [this, f = todo[i + 1]->first] { return parse_contigs(f); });
+                ahead = std::async(std::launch::async, parse_unless_resident, todo[i + 1]->first, false);
             ground_truth(todo[i]->first, todo[i]->second, gc);
         }
         out << flush;

@@ -253,6 +253,14 @@ uint64_t mk_bloom_reachable_bytes(const mk_ctx *ctx);
 int mk_exact(mk_ctx *ctx, const char *const *contigs, const uint64_t *contig_lens,
              uint32_t n_contigs, const char *const *queries, const uint64_t *query_lens,
              uint32_t nq, uint64_t *inter, uint64_t *uni);
+/* The same in two steps, for callers that verify several batches of queries against one
+ * genome file (the reference rebuilds its unordered_set at every flush of 100 pending
+ * queries, Miekki.cpp:745-748, ~7 s each): the genome's k-mer set stays resident on the
+ * context until the next load.  Any number of contigs and queries per call. */
+int mk_exact_load_genome(mk_ctx *ctx, const char *const *contigs, const uint64_t *contig_lens,
+                         uint32_t n_contigs);
+int mk_exact_query(mk_ctx *ctx, const char *const *queries, const uint64_t *query_lens, uint32_t nq,
+                   uint64_t *inter, uint64_t *uni);
 
 #ifdef __cplusplus
 }

@@ -99,14 +99,22 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     if (need <= c->capG) return MK_OK;
     uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(256, (uint64_t)c->capG * 2));
     cap = std::min<uint64_t>(cap, 0xffffff00ull);
-    const uint64_t ld = (cap * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
+    uint64_t ld = (cap * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
     cap = ld / c->W;
     uint8_t *nM = nullptr;
     uint32_t *nss = nullptr;
     uint64_t *ngs = nullptr;
-    MK_TRY(dev_alloc(&nM, (uint64_t)c->P * ld));
-    MK_TRY(dev_alloc(&nss, cap));
-    MK_TRY(dev_alloc(&ngs, cap));
+    if (hipMalloc((void **)&nM, (uint64_t)c->P * ld) != hipSuccess) {
+        // the doubled matrix does not fit beside the old one: take exactly what is needed
+        (void)hipGetLastError();
+        ld = ((uint64_t)need * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
+        cap = ld / c->W;
+        MK_TRY(dev_alloc(&nM, (uint64_t)c->P * ld));
+    }
+    if (dev_alloc(&nss, cap) != MK_OK || dev_alloc(&ngs, cap) != MK_OK) {
+        dev_free(nM); dev_free(nss); dev_free(ngs);
+        return MK_ERR_NOMEM;
+    }
     MK_HIP(hipMemsetAsync(nM, 0, (uint64_t)c->P * ld, c->stream));
     if (c->G) {
         MK_HIP(hipMemcpy2DAsync(nM, ld, c->d_M, c->ld, (size_t)c->G * c->W, c->P, hipMemcpyDeviceToDevice,
@@ -163,7 +171,9 @@ int ensure_bloom_summary(mk_ctx *c)
     return MK_OK;
 }
 
-static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
+// for_append = false: the long-query sketches borrow the tables / codes / slots only; the Bloom
+// first-writer keys (8 bytes per reachable cell: 512 MiB at -b 33) are build-only.
+static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool for_append = true)
 {
     if (!c->d_tables) {
         const uint64_t budget = 1ull << 30;                       // table bytes per batch
@@ -172,18 +182,19 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0)
         MK_TRY(dev_alloc(&c->d_active, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_cardsum, kBuildBatch));
         MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
-        if (c->d_bloom) {
-            MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
-            MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
-        }
+    }
+    if (for_append && c->d_bloom && !c->d_bloom_order) {
+        MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
+        MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
     }
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
     if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
     MK_TRY(ensure_codes(c, seq_bytes));
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
+        const uint64_t old_cap = c->seq_cap[buf];
         dev_free(c->d_seq[buf]);
         c->seq_cap[buf] = 0;
-        const uint64_t cap = std::max<uint64_t>(seq_bytes, std::max(c->seq_cap[buf ^ 1], c->seq_cap[buf] * 2));
+        const uint64_t cap = std::max<uint64_t>(seq_bytes, std::max(c->seq_cap[buf ^ 1], old_cap * 2));
         MK_TRY(dev_alloc(&c->d_seq[buf], cap + 64));
         c->seq_cap[buf] = cap;
     }
@@ -369,7 +380,7 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
         // neighbours in the set share one binned K1 run and one gate-and-append launch
-        MK_TRY(ensure_build_scratch(c, 0, 0));
+        MK_TRY(ensure_build_scratch(c, 0, 0, false));
         for (size_t i = 0; i < qs->long_q.size();) {
             uint32_t n = 1;
             while (i + n < qs->long_q.size() && n < c->build_batch && qs->long_q[i + n] == qs->long_q[i] + n) ++n;
@@ -385,7 +396,7 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
         // neighbours in the set go through the binned genome sketch together (K1), up to a
         // build batch at a time; loners and shapes the bins do not fit go one by one
-        MK_TRY(ensure_build_scratch(c, 0, 0));
+        MK_TRY(ensure_build_scratch(c, 0, 0, false));
         for (uint32_t slot = 0; slot < qs->dense_q.size();) {
             if (qs->dense_q[slot] == 0xffffffffu) { ++slot; continue; }
             uint32_t n = 1;
@@ -471,9 +482,20 @@ static uint32_t tile_genomes(const mk_ctx *c) { return kTileBytes / c->W; }
 static uint64_t score_row_entries(const mk_ctx *c) { return (uint64_t)ntiles_of(c) * tile_genomes(c); }
 
 // queries per chunk so that the chunk's score matrix stays within ~4 GiB
+// Bytes a query chunk's score / partial buffer may take: `want`, but never more than what is
+// already allocated or a third of the free device memory (a nearly full GPU scans in smaller
+// chunks instead of failing).
+static uint64_t chunk_budget(uint64_t want, uint64_t have)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
+    return std::max<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(have, free_b / 3)), 64ull << 20);
+}
+
 static uint32_t chunk_queries(const mk_ctx *c, uint32_t nq)
 {
-    const uint64_t per = std::max<uint64_t>(1, (1ull << 30) / std::max<uint64_t>(score_row_entries(c), 1));
+    const uint64_t budget = chunk_budget(4ull << 30, c->scores_cap * 4) / 4;
+    const uint64_t per = std::max<uint64_t>(1, budget / std::max<uint64_t>(score_row_entries(c), 1));
     return (uint32_t)std::min<uint64_t>(per, std::max<uint32_t>(nq, 1));
 }
 
@@ -527,7 +549,7 @@ static uint64_t partial_bytes_per_query(const mk_ctx *c, uint32_t S) { return (u
 
 static uint32_t chunk_queries_slab(const mk_ctx *c, uint32_t nq, uint32_t S)
 {
-    const uint64_t budget = 16ull << 30;
+    const uint64_t budget = chunk_budget(16ull << 30, c->partials_cap);
     uint64_t per = std::max<uint64_t>(1, budget / std::max<uint64_t>(partial_bytes_per_query(c, S), 1));
     per = std::min<uint64_t>(per, 0x7ffffff0ull / std::max<uint64_t>((uint64_t)ntiles_of(c) * S, 1));   // one launch
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), std::max<uint32_t>(nq, 1));
@@ -612,6 +634,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->has_empty_sketch = false;
     c->d_all_ss = nullptr; c->d_all_gs = nullptr; c->all_n = 0; c->all_base = 0; c->gen = 1;
     for (int i = 0; i < 10; ++i) { c->exact_buf[i] = nullptr; c->exact_cap[i] = 0; }
+    c->exact_have_B = false; c->exact_nB = 0; c->exact_log2B = 0;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -822,6 +845,7 @@ int mk_index_export_columns(mk_ctx *c, uint32_t pb, uint32_t pe, uint8_t *dst)
 int mk_index_export_sizes(mk_ctx *c, uint64_t *genome_size, uint32_t *sketch_size)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));                                       // counts the batch still in flight
     if (genome_size) memcpy(genome_size, c->h_genome_size.data(), (size_t)c->G * 8);
     if (sketch_size) memcpy(sketch_size, c->h_sketch_size.data(), (size_t)c->G * 4);
     return MK_OK;
@@ -1377,7 +1401,23 @@ int mk_exact(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens,
         return MK_ERR_ARG;
     }
     MK_TRY(use_device(c));
-    return exact_sets(c, contigs, contig_lens, n_contigs, queries, query_lens, nq, inter, uni);
+    MK_TRY(exact_load_genome(c, contigs, contig_lens, n_contigs));
+    return exact_queries(c, queries, query_lens, nq, inter, uni);
+}
+
+int mk_exact_load_genome(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs)
+{
+    if (!c || (n_contigs && (!contigs || !contig_lens))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return exact_load_genome(c, contigs, contig_lens, n_contigs);
+}
+
+int mk_exact_query(mk_ctx *c, const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
+                   uint64_t *uni)
+{
+    if (!c || (nq && (!queries || !query_lens || !inter || !uni))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return exact_queries(c, queries, query_lens, nq, inter, uni);
 }
 
 }  // extern "C"

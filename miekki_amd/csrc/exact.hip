@@ -18,22 +18,6 @@ namespace mk {
 
 constexpr uint64_t kSlotEmpty = ~0ULL;     // k <= 31: no k-mer word reaches 2^64-1
 
-__device__ __forceinline__ uint64_t exact_canon(const char *__restrict__ s, uint32_t k)
-{
-    uint64_t F = 0, R = 0;
-    bool valid = true;
-    for (uint32_t j = 0; j < k; ++j) {
-        const uint32_t sc = seed_code((uint8_t)s[j]);      // same table as str2numstrand
-        valid &= sc != 4u;
-        F = (F << 2) | (sc & 3u);
-        // digit of the reverse complement contributed by this character
-        const uint32_t rd = sc == 1u ? 2u : sc == 2u ? 1u : sc == 3u ? 0u : 3u;
-        R |= (uint64_t)rd << (2 * j);
-    }
-    if (!valid) F = 0;
-    return F < R ? F : R;
-}
-
 __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t log2size)
 {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - log2size));
@@ -67,46 +51,108 @@ __device__ __forceinline__ bool set_contains(const uint64_t *__restrict__ tab, u
     return false;
 }
 
-// grid.y = sequence; every k-mer position (len-k+1 of them, Miekki.cpp:807/818)
-__global__ __launch_bounds__(256) void exact_genome_kernel(const char *__restrict__ seq,
-                                                           const uint64_t *__restrict__ off, uint32_t k,
-                                                           uint64_t *__restrict__ setB, uint32_t log2B,
-                                                           unsigned long long *__restrict__ nB)
+// Both kernels walk ONE flat position space: the sequences (contigs of the genome file, or
+// the queries of a call) lie end to end in `seq`, off[0..nseq] are their boundaries, and a
+// position i is a k-mer start iff i + k <= the end of the sequence it lies in (every one of
+// the len-k+1 positions, Miekki.cpp:807/818/832 -- unlike the sketch, the last k-mer counts).
+// So the grid is ceil(total / 4096) workgroups whatever the number or shape of the
+// sequences: 100,000 tiny contigs, one 1 Mb contig among 10,000 short ones, 100,000 queries.
+// A workgroup stages its 4096 (+ k-1) characters once, as str2numstrand codes in LDS, and a
+// thread rolls 16 consecutive k-mers from them: k-1 LDS reads to seed, one per k-mer after.
+constexpr uint32_t kExTile = 4096, kExPer = 16;
+
+// largest s < nseq with off[s] <= pos (pos < off[nseq])
+__device__ __forceinline__ uint32_t seq_of(const uint64_t *__restrict__ off, uint32_t nseq, uint64_t pos)
 {
-    const uint32_t s = blockIdx.y;
-    const uint64_t len = off[s + 1] - off[s];
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool fresh = false;
-    if (len >= k && i + k <= len) fresh = set_insert(setB, log2B, exact_canon(seq + off[s] + i, k));
-    const uint64_t m = __ballot(fresh);
-    if (m && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(nB, (unsigned long long)__popcll(m));
+    uint32_t lo = 0, hi = nseq;                               // invariant: off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
-// grid.y = query; set A of query q lives at setA + aoff[q], 2^alog[q] slots
-__global__ __launch_bounds__(256) void exact_query_kernel(const char *__restrict__ seq,
-                                                          const uint64_t *__restrict__ off, uint32_t k,
-                                                          const uint64_t *__restrict__ setB, uint32_t log2B,
-                                                          uint64_t *__restrict__ setA,
-                                                          const uint64_t *__restrict__ aoff,
-                                                          const uint32_t *__restrict__ alog,
-                                                          unsigned long long *__restrict__ inter,
-                                                          unsigned long long *__restrict__ extra)
+struct ExactArgs {
+    const char *seq;               // padded with 64 readable bytes past `total`
+    const uint64_t *off;           // nseq + 1
+    uint32_t nseq, k;
+    uint64_t total;
+    uint64_t *setB;
+    uint32_t log2B;
+    unsigned long long *nB;        // genome pass: distinct k-mers inserted
+    uint64_t *setA;                // query pass: per-query sets, aoff / alog
+    const uint64_t *aoff;
+    const uint32_t *alog;
+    unsigned long long *inter, *extra;
+};
+
+template <bool QUERY>
+__global__ __launch_bounds__(256) void exact_kernel(const ExactArgs a)
 {
-    const uint32_t q = blockIdx.y;
-    const uint64_t len = off[q + 1] - off[q];
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool in_b = false, not_b = false;
-    if (len >= k && i + k <= len) {
-        const uint64_t key = exact_canon(seq + off[q] + i, k);
-        if (set_insert(setA + aoff[q], alog[q], key)) {           // Miekki.cpp:834-840
-            in_b = set_contains(setB, log2B, key);
-            not_b = !in_b;
+    __shared__ uint8_t codes[kExTile + 48];
+    const uint64_t base = (uint64_t)blockIdx.x * kExTile;
+    const uint32_t k = a.k;
+    const uint32_t span = (uint32_t)min((uint64_t)(kExTile + k - 1), a.total - base);
+    // 16 characters per lane-load (base is a multiple of 4096, the buffer is allocated aligned and padded)
+    for (uint32_t i = threadIdx.x * 16u; i < span; i += 256u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(a.seq + base + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) codes[i + j] = (uint8_t)seed_code((uint8_t)(w[j >> 2] >> (8 * (j & 3u))));
+    }
+    __syncthreads();
+    const uint32_t t0 = threadIdx.x * kExPer;
+    if (base + t0 >= a.total) return;
+    uint32_t s = seq_of(a.off, a.nseq, base + t0);
+    uint64_t send = a.off[s + 1];
+    const uint64_t fmask = (1ULL << (2 * k)) - 1ULL;
+    const uint32_t top = 2 * (k - 1);
+    uint64_t F = 0, R = 0;
+    int last_bad = -1;                                         // tile index of the last non-ACGTacgt character seen
+    auto push = [&](uint32_t idx) {
+        const uint32_t sc = idx < span ? codes[idx] : 4u;
+        F = ((F << 2) | (sc & 3u)) & fmask;
+        // digit of the reverse complement: revCompChar maps everything outside ACGT to 'T' (utils.cpp:203-215)
+        const uint32_t rd = sc == 1u ? 2u : sc == 2u ? 1u : sc == 3u ? 0u : 3u;
+        R = (R >> 2) | ((uint64_t)rd << top);
+        if (sc == 4u) last_bad = (int)idx;
+    };
+    for (uint32_t j = 0; j + 1 < k; ++j) push(t0 + j);
+    uint32_t fresh = 0, cin = 0, cnot = 0;
+    auto flush_counts = [&]() {
+        if (QUERY) {
+            if (cin) atomicAdd(&a.inter[s], (unsigned long long)cin);
+            if (cnot) atomicAdd(&a.extra[s], (unsigned long long)cnot);
+            cin = cnot = 0;
+        }
+    };
+#pragma unroll 4
+    for (uint32_t u = 0; u < kExPer; ++u) {
+        const uint32_t i = t0 + u;
+        const uint64_t p = base + i;
+        if (p >= a.total) break;
+        push(i + k - 1);
+        if (p >= send) {
+            flush_counts();
+            do { ++s; send = a.off[s + 1]; } while (p >= send);  // empty sequences are stepped over
+        }
+        if (p + k > send) continue;                              // the window would run into the next sequence
+        // str2num: min(forward word -- 0 if any character is outside ACGTacgt --, reverse strand word)
+        const uint64_t fw = last_bad >= (int)i ? 0ULL : F;
+        const uint64_t key = fw < R ? fw : R;
+        if (QUERY) {
+            if (set_insert(a.setA + a.aoff[s], a.alog[s], key)) {    // Miekki.cpp:834-840: first sight of this k-mer
+                if (set_contains(a.setB, a.log2B, key)) ++cin; else ++cnot;
+            }
+        } else {
+            fresh += set_insert(a.setB, a.log2B, key) ? 1u : 0u;
         }
     }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t mi = __ballot(in_b), mn = __ballot(not_b);
-    if (mi && lane == (uint32_t)__ffsll((long long)mi) - 1u) atomicAdd(&inter[q], (unsigned long long)__popcll(mi));
-    if (mn && lane == (uint32_t)__ffsll((long long)mn) - 1u) atomicAdd(&extra[q], (unsigned long long)__popcll(mn));
+    flush_counts();
+    if (!QUERY) {
+        for (int o = 32; o > 0; o >>= 1) fresh += __shfl_xor(fresh, o);
+        if ((threadIdx.x & 63u) == 0 && fresh) atomicAdd(a.nB, (unsigned long long)fresh);
+    }
 }
 
 static uint32_t log2_slots(uint64_t n_keys)
@@ -170,20 +216,18 @@ static int upload_seqs(mk_ctx *c, const char *const *seqs, const uint64_t *lens,
     return MK_OK;
 }
 
-int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,
-               const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
-               uint64_t *uni)
+// ground_truth_batch's genome side (Miekki.cpp:803-822): set B of the contigs, left resident on the
+// context until the next call.
+int exact_load_genome(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs)
 {
     const uint32_t k = c->p.k;
-    // ---- set B
+    c->exact_have_B = false;
     DevBuf<char> g_seq(c, 0); DevBuf<uint64_t> g_off(c, 1);
     std::vector<uint64_t> goff;
     MK_TRY(upload_seqs(c, contigs, contig_lens, n_contigs, g_seq, g_off, goff));
-    uint64_t nkB = 0, maxlen = 0;
-    for (uint32_t i = 0; i < n_contigs; ++i) {
+    uint64_t nkB = 0;
+    for (uint32_t i = 0; i < n_contigs; ++i)
         if (contig_lens[i] >= k) nkB += contig_lens[i] - k + 1;
-        maxlen = std::max(maxlen, contig_lens[i]);
-    }
     const uint32_t log2B = log2_slots(nkB);
     if (log2B > 31) { set_error("genome too large for exact mode"); return MK_ERR_ARG; }
     DevBuf<uint64_t> setB(c, 2); DevBuf<unsigned long long> d_nB(c, 3);
@@ -191,28 +235,42 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
     MK_TRY(d_nB.alloc(1));
     MK_HIP(hipMemsetAsync(setB.p, 0xFF, (8ull << log2B), c->stream));
     MK_HIP(hipMemsetAsync(d_nB.p, 0, 8, c->stream));
-    if (n_contigs && maxlen >= k) {
-        hipLaunchKernelGGL(exact_genome_kernel, dim3((uint32_t)((maxlen - k + 1 + 255) / 256), n_contigs), dim3(256),
-                           0, c->stream, g_seq.p, g_off.p, k, setB.p, log2B, d_nB.p);
+    const uint64_t total = goff[n_contigs];
+    if (nkB) {
+        ExactArgs a{};
+        a.seq = g_seq.p; a.off = g_off.p; a.nseq = n_contigs; a.k = k; a.total = total;
+        a.setB = setB.p; a.log2B = log2B; a.nB = d_nB.p;
+        const uint64_t blocks = (total + kExTile - 1) / kExTile;
+        if (blocks > 0x7fffffffull) { set_error("genome too large for exact mode"); return MK_ERR_ARG; }
+        hipLaunchKernelGGL(exact_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, c->stream, a);
         MK_HIP(hipGetLastError());
     }
     unsigned long long nB = 0;
     MK_HIP(hipMemcpyAsync(&nB, d_nB.p, 8, hipMemcpyDeviceToHost, c->stream));
     MK_HIP(hipStreamSynchronize(c->stream));
+    c->exact_nB = nB; c->exact_log2B = log2B; c->exact_have_B = true;
+    return MK_OK;
+}
+
+// ground_truth_batch's query side (Miekki.cpp:826-842) against the resident set B
+int exact_queries(mk_ctx *c, const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
+                  uint64_t *uni)
+{
+    if (!c->exact_have_B) { set_error("no genome loaded for exact mode"); return MK_ERR_STATE; }
     if (!nq) return MK_OK;
-    // ---- sets A, one per query
+    const uint32_t k = c->p.k;
     DevBuf<char> q_seq(c, 4); DevBuf<uint64_t> q_off(c, 5);
     std::vector<uint64_t> qoff;
     MK_TRY(upload_seqs(c, queries, query_lens, nq, q_seq, q_off, qoff));
     std::vector<uint64_t> aoff(nq + 1, 0);
     std::vector<uint32_t> alog(nq);
-    uint64_t qmax = 0;
+    uint64_t nk_all = 0;
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = query_lens[q] >= k ? query_lens[q] - k + 1 : 0;
         alog[q] = log2_slots(nk);
         if (alog[q] > 31) { set_error("query too large for exact mode"); return MK_ERR_ARG; }
         aoff[q + 1] = aoff[q] + (1ull << alog[q]);
-        qmax = std::max(qmax, query_lens[q]);
+        nk_all += nk;
     }
     DevBuf<uint64_t> setA(c, 6), d_aoff(c, 7); DevBuf<uint32_t> d_alog(c, 8); DevBuf<unsigned long long> d_cnt(c, 9);
     MK_TRY(setA.alloc(aoff[nq]));
@@ -223,10 +281,15 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
     MK_HIP(hipMemsetAsync(d_cnt.p, 0, 16ull * nq, c->stream));
     MK_HIP(hipMemcpyAsync(d_aoff.p, aoff.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     MK_HIP(hipMemcpyAsync(d_alog.p, alog.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));
-    if (qmax >= k) {
-        hipLaunchKernelGGL(exact_query_kernel, dim3((uint32_t)((qmax - k + 1 + 255) / 256), nq), dim3(256), 0,
-                           c->stream, q_seq.p, q_off.p, k, setB.p, log2B, setA.p, d_aoff.p, d_alog.p, d_cnt.p,
-                           d_cnt.p + nq);
+    const uint64_t total = qoff[nq];
+    if (nk_all) {
+        ExactArgs a{};
+        a.seq = q_seq.p; a.off = q_off.p; a.nseq = nq; a.k = k; a.total = total;
+        a.setB = reinterpret_cast<uint64_t *>(c->exact_buf[2]); a.log2B = c->exact_log2B;
+        a.setA = setA.p; a.aoff = d_aoff.p; a.alog = d_alog.p; a.inter = d_cnt.p; a.extra = d_cnt.p + nq;
+        const uint64_t blocks = (total + kExTile - 1) / kExTile;
+        if (blocks > 0x7fffffffull) { set_error("query batch too large for exact mode"); return MK_ERR_ARG; }
+        hipLaunchKernelGGL(exact_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, c->stream, a);
         MK_HIP(hipGetLastError());
     }
     std::vector<unsigned long long> cnt(2ull * nq);
@@ -234,7 +297,7 @@ int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_len
     MK_HIP(hipStreamSynchronize(c->stream));
     for (uint32_t q = 0; q < nq; ++q) {
         inter[q] = cnt[q];
-        uni[q] = nB + cnt[nq + q];                                  // nb_union = |B| + |A \ B|
+        uni[q] = c->exact_nB + cnt[nq + q];                         // nb_union = |B| + |A \ B|
     }
     return MK_OK;
 }

@@ -54,6 +54,9 @@ struct mk_ctx {
     uint64_t *d_genome_size;
     void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
     uint64_t exact_cap[10];
+    bool exact_have_B;             // set B of the genome loaded last (mk_exact_load_genome) is resident
+    uint64_t exact_nB;             // its number of distinct k-mers
+    uint32_t exact_log2B;
     bool has_empty_sketch;         // some genome has sketch_size 0 (see nan_candidates_possible in api.hip)
     // sizes of ALL genomes of a sharded index (mk_merge_set_sizes), for the compact merge on the
     // context that receives the gathered rows
@@ -290,8 +293,8 @@ struct MergeArgs {
 int launch_merge(mk_ctx *c, const MergeArgs &a);
 
 // ---- exact.hip
-int exact_sets(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,
-               const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
-               uint64_t *uni);
+int exact_load_genome(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs);
+int exact_queries(mk_ctx *c, const char *const *queries, const uint64_t *query_lens, uint32_t nq, uint64_t *inter,
+                  uint64_t *uni);
 
 }  // namespace mk

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mk_qset_active": (i32, [vp, vp, vp]),
     "mk_sync": (i32, [vp]),
     "mk_exact": (i32, [vp, vp, vp, u32, vp, vp, u32, vp, vp]),
+    "mk_exact_load_genome": (i32, [vp, vp, vp, u32]),
+    "mk_exact_query": (i32, [vp, vp, vp, u32, vp, vp]),
 }
 
 _lib = None

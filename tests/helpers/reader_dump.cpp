@@ -1,12 +1,28 @@
 // Test helper: run the host driver's OrderedFastaReader over a list of files and print,
-// per file in list order, "<exists> <length> <fnv1a64 of the sequence>".
+// per file in list order, "<exists> <length> <fnv1a64 of the sequence> <failed>".
+//   reader_dump <list> <threads> [window] [allocator budget in bytes, 0 = no allocator] [take only the first N]
+// With a budget the reader gets an allocator that hands out at most that many bytes and then
+// fails (the page-lock limit of pinned memory); with "take only N" the reader is destroyed
+// while workers are still parked on the read-ahead bound (must not hang).
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 #include <vector>
 
 #include "fasta_reader.hpp"
+
+static std::atomic<long long> g_budget{0};
+static std::atomic<long> g_live{0};
+static void *budget_alloc(void *, size_t bytes)
+{
+    if (g_budget.fetch_sub((long long)bytes) < (long long)bytes) return nullptr;
+    ++g_live;
+    return malloc(bytes);
+}
+static void budget_free(void *, void *p) { --g_live; free(p); }
 
 int main(int argc, char **argv)
 {
@@ -14,14 +30,21 @@ int main(int argc, char **argv)
     std::vector<std::string> files;
     std::ifstream in(argv[1]);
     for (std::string l; std::getline(in, l);) if (!l.empty()) files.push_back(l);
-    mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), mkhost::HostAllocator{nullptr, nullptr, nullptr},
-                                      argc > 3 ? (size_t)atoi(argv[3]) : 4);
-    for (size_t i = 0; i < files.size(); ++i) {
-        mkhost::OrderedFastaReader::Item it = reader.take(i);
-        uint64_t h = 1469598103934665603ull;
-        for (size_t j = 0; j < it.len; ++j) { h ^= (unsigned char)it.data[j]; h *= 1099511628211ull; }
-        printf("%d %zu %016llx\n", it.exists ? 1 : 0, it.len, (unsigned long long)h);
-        reader.recycle(it);
-    }
+    const long long budget = argc > 4 ? atoll(argv[4]) : 0;
+    const size_t only = argc > 5 ? (size_t)atoll(argv[5]) : files.size();
+    g_budget = budget;
+    {
+        mkhost::HostAllocator a{nullptr, nullptr, nullptr};
+        if (budget > 0) a = mkhost::HostAllocator{budget_alloc, budget_free, nullptr};
+        mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), a, argc > 3 ? (size_t)atoi(argv[3]) : 4);
+        for (size_t i = 0; i < files.size() && i < only; ++i) {
+            mkhost::OrderedFastaReader::Item it = reader.take(i);
+            uint64_t h = 1469598103934665603ull;
+            for (size_t j = 0; j < it.len; ++j) { h ^= (unsigned char)it.data[j]; h *= 1099511628211ull; }
+            printf("%d %zu %016llx %d\n", it.exists ? 1 : 0, it.len, (unsigned long long)h, it.failed ? 1 : 0);
+            reader.recycle(it);
+        }
+    }                                                  // destructor: joins the workers, releases the pool
+    printf("done live=%ld\n", (long)g_live.load());
     return 0;
 }

@@ -251,3 +251,54 @@ def test_very_large_query_call_is_sliced(hip):
             assert int(act[q]) == int(act_s[q % 1000])
     finally:
         ix.close()
+
+
+def test_exact_mode_many_tiny_contigs_and_many_queries(hip):
+    """K7 over shapes the first version could not launch: a genome file of 100,000 contigs (most a
+    few dozen bases, some shorter than k -- those leak into the next contig, Miekki.cpp:806-812 --
+    one of 300 kb, N and lower case inside) and 100,000 queries in ONE call; then a second batch of
+    queries against the still-resident genome set.  |A n B| and |A u B| against the oracle."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from miekki_amd import lib as L
+    lib = L.load_library()
+    rng = np.random.default_rng(2026)
+    k = 21
+    big = bytearray(synth.genome_bases(4242, 0, 300_000))
+    big[1000] = ord("N"); big[5000:5050] = bytes(big[5000:5050]).lower(); big[70_000] = ord("x")
+    pool = synth.genome_bases(4243, 0, 4_000_000)
+    lens = rng.integers(5, 70, 100_000)
+    lens[50_000] = 0                                                     # an empty record
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    parts = []
+    for i in range(100_000):
+        parts.append(b">c%d\n" % i)
+        parts.append(pool[starts[i]:starts[i] + lens[i]] + b"\n")
+        if i == 31_337:
+            parts.append(b">big\n" + bytes(big) + b"\n")
+    fasta = b"".join(parts)
+    ix = hip.Miekki(k, 10, 8, 32, 0)
+    try:
+        qs = []
+        for q in range(100_000):
+            src = pool if q % 3 else bytes(big)
+            n = int(rng.integers(k - 2, 160))
+            off = int(rng.integers(0, len(src) - n))
+            qs.append(src[off:off + n])
+        qs[7] = b"ACGTNNNNNNNNNNNNNNNNNNNNNNNNNACGT"
+        qs[8] = qs[9]                                                     # duplicates keep their own sets
+        inter, uni = ix.ground_truth_batch(qs, fasta)
+        kset = orc.exact_genome_set(fasta, k)
+        for q in list(range(0, 100_000, 37)) + [7, 8, 9, 99_999]:
+            wi, wu = orc.exact_query(kset, qs[q], k)
+            assert (int(inter[q]), int(uni[q])) == (wi, wu), q
+        # second batch against the resident genome set (the CLI's flush-at-100 path)
+        qs2 = [bytes(big[1000 * i:1000 * i + 500]) for i in range(64)]
+        ptrs, lens2 = L.seq_arrays(qs2)
+        i2 = np.zeros(64, np.uint64); u2 = np.zeros(64, np.uint64)
+        L.check(lib.mk_exact_query(ix._h, ptrs, lens2, 64, i2.ctypes.data, u2.ctypes.data))
+        for q in range(64):
+            assert (int(i2[q]), int(u2[q])) == orc.exact_query(kset, qs2[q], k), q
+        assert int(i2[10]) > 400                                          # really shared
+    finally:
+        ix.close()

@@ -80,8 +80,33 @@ def test_reader_matches_getline_semantics(dumper, tmp_path):
     for threads, window in ((1, 1), (3, 2), (8, 64)):
         out = subprocess.run([dumper, lst, str(threads), str(window)], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
         for i, w in enumerate(want):
-            ex, ln, h = out[i].split()
+            ex, ln, h, failed = out[i].split()
             if w is None:
                 assert ex == "0", i
             else:
-                assert (ex, int(ln), int(h, 16)) == ("1", len(w), fnv1a(w)), (i, names[i], threads)
+                assert (ex, int(ln), int(h, 16), failed) == ("1", len(w), fnv1a(w), "0"), (i, names[i], threads)
+    # an allocator that runs dry after 100 kB (the page-lock limit): later buffers come from malloc, same
+    # sequences, and every allocator-owned buffer goes back through the allocator's release hook
+    out = subprocess.run([dumper, lst, "4", "8", "100000"], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
+    for i, w in enumerate(want):
+        ex, ln, h, failed = out[i].split()
+        if w is not None:
+            assert (ex, int(ln), int(h, 16), failed) == ("1", len(w), fnv1a(w), "0"), (i, "dry allocator")
+    assert out[len(want)] == "done live=0"
+    # destroyed after three items while the workers are parked on the read-ahead bound: must return
+    out = subprocess.run([dumper, lst, "8", "2", "0", "3"], check=True, stdout=subprocess.PIPE, timeout=60).stdout.decode().split("\n")
+    assert out[3] == "done live=0"
+
+
+def test_unreadable_and_truncated_files_are_flagged_not_read_as_empty(dumper, tmp_path):
+    good = b">g\nACGTACGTAC\n"
+    (tmp_path / "good.fa").write_bytes(good)
+    gz = gzip.compress(b">t\n" + b"ACGT" * 5000 + b"\n")
+    (tmp_path / "trunc.fa.gz").write_bytes(gz[:len(gz) // 2])               # cut inside the deflate stream
+    (tmp_path / "dir.fa").mkdir()                                           # exists, cannot be read as a file
+    lst = tmp_path / "l.txt"
+    lst.write_text("\n".join(str(tmp_path / n) for n in ("good.fa", "trunc.fa.gz", "dir.fa", "good.fa")) + "\n")
+    out = subprocess.run([dumper, str(lst), "2", "4"], check=True, stdout=subprocess.PIPE, timeout=60).stdout.decode().split("\n")
+    assert out[0].split()[3] == "0" and out[3].split()[3] == "0" and int(out[0].split()[1]) == 10
+    assert out[1].split()[0] == "1" and out[1].split()[3] == "1"             # truncated gzip: failed, not empty
+    assert out[2].split()[0] == "1" and out[2].split()[3] == "1"             # a directory: failed
