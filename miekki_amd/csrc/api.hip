@@ -304,13 +304,15 @@ static void qset_release(mk_qset *qs)
 {
     if (!qs) return;
     if (!qs->split_in_arena) dev_free(qs->d_split);
-    dev_free(qs->d_arena);                       // every other device array of the set lives in it
+    if (qs->arena_borrowed) qs->owner->qarena_busy = false;      // the context keeps its arena for the next call
+    else dev_free(qs->d_arena);                  // every other device array of the set lives in it
     delete qs;
 }
 
-static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **out)
+static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **out, bool transient = false)
 {
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> qs(new mk_qset(), qset_release);
+    qs->owner = c; qs->arena_borrowed = false; qs->head_bytes = 0; qs->o_off = qs->o_ent_off = 0;
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
     qs->d_nent = nullptr; qs->sketched = false; qs->gen = 0; qs->short_max_nk = 0;
     qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
@@ -346,7 +348,21 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
                    o_nent = carve(((uint64_t)nq + 1) * 4), o_scan_n = carve(((uint64_t)nq + 1) * 4),
                    o_dense = carve(dense_bytes), o_dense_q = carve(qs->dense_q.size() * 4),
                    o_split = carve(qs->split_room ? (uint64_t)nq * (qs->split_room + 1) * 4 : 0);
-    MK_TRY(dev_alloc(&qs->d_arena, at));
+    if (transient && !c->qarena_busy) {
+        if (at > c->qarena_cap) {
+            MK_HIP(hipStreamSynchronize(c->stream));
+            dev_free(c->d_qarena);
+            c->qarena_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(at + at / 2, 4ull << 20);
+            MK_TRY(dev_alloc(&c->d_qarena, cap));
+            c->qarena_cap = cap;
+        }
+        qs->d_arena = c->d_qarena; qs->arena_borrowed = true; c->qarena_busy = true;
+    } else {
+        MK_TRY(dev_alloc(&qs->d_arena, at));
+    }
+    qs->o_off = o_off; qs->o_ent_off = o_ent_off;
+    qs->head_bytes = o_ent_off + ((uint64_t)nq + 1) * 8;          // o_seq == 0: sequences, offsets, entry offsets in a row
     qs->d_seq = reinterpret_cast<char *>(qs->d_arena + o_seq);
     qs->d_off = reinterpret_cast<uint64_t *>(qs->d_arena + o_off);
     qs->d_ent_off = reinterpret_cast<uint64_t *>(qs->d_arena + o_ent_off);
@@ -361,11 +377,27 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         MK_HIP(hipMemcpyAsync(qs->d_dense_q, qs->dense_q.data(), qs->dense_q.size() * 4, hipMemcpyHostToDevice,
                               c->stream));
     }
-    MK_HIP(hipMemcpyAsync(qs->d_off, qs->h_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    MK_HIP(hipMemcpyAsync(qs->d_ent_off, qs->h_ent_off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice,
+    *out = qs.release();                                         // offsets travel with the sequences (qset_upload)
+    return MK_OK;
+}
+
+static int qset_copy_offsets(mk_ctx *c, mk_qset *qs)
+{
+    MK_HIP(hipMemcpyAsync(qs->d_off, qs->h_off.data(), (size_t)(qs->nq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipMemcpyAsync(qs->d_ent_off, qs->h_ent_off.data(), (size_t)(qs->nq + 1) * 8, hipMemcpyHostToDevice,
                           c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
-    *out = qs.release();
+    MK_HIP(hipStreamSynchronize(c->stream));                     // the host vectors are pageable
+    return MK_OK;
+}
+
+static int ensure_pinned(uint8_t *&p, uint64_t &cap, uint64_t need)
+{
+    if (need <= cap) return MK_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const uint64_t want = std::max<uint64_t>(need + need / 2, 1ull << 20);
+    MK_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+    cap = want;
     return MK_OK;
 }
 
@@ -453,7 +485,11 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
 {
     uint32_t S = slab_ranges(c);
     qs->slab_ok = false;
-    if (S < 2 || !qs->long_q.empty() || !qs->dense_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
+    // (a handful of queries gain nothing from the slab order -- there is no reuse to schedule --
+    // and would pay a range table and a host round trip for the eligibility flag)
+    uint32_t kSlabMinQueries = 512;
+    if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) kSlabMinQueries = (uint32_t)std::max(0L, atol(e));   // tests force the slab path
+    if (S < 2 || !qs->long_q.empty() || !qs->dense_q.empty() || qs->nq < kSlabMinQueries) { qs->S = S; return MK_OK; }
     // longer queries need more (smaller) ranges to keep every (query, range) within the
     // packed counters: aim at <= 180 entries per range on average, the device check
     // below still decides
@@ -635,6 +671,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_all_ss = nullptr; c->d_all_gs = nullptr; c->all_n = 0; c->all_base = 0; c->gen = 1;
     for (int i = 0; i < 10; ++i) { c->exact_buf[i] = nullptr; c->exact_cap[i] = 0; }
     c->exact_have_B = false; c->exact_nB = 0; c->exact_log2B = 0;
+    c->d_qarena = nullptr; c->qarena_cap = 0; c->qarena_busy = false;
+    c->h_stage = nullptr; c->stage_cap = 0; c->h_res = nullptr; c->res_cap = 0;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -673,6 +711,9 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
     dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs);
+    dev_free(c->d_qarena);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_back) (void)hipHostFree(c->h_back);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -918,12 +959,28 @@ int mk_index_import_bloom(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t
 }
 
 // ------------------------------------------------------------------ queries
-int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, mk_qset **out)
+}  // extern "C"
+
+// transient: the set lives for one mk_query call -- borrowed arena, and no wait for the copy
+// (the caller's buffers have been copied into the pinned image; the call's own final wait covers it)
+static int qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, mk_qset **out, bool transient)
 {
-    if (!c || !out || (nq && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
-    MK_TRY(use_device(c));
     mk_qset *qs = nullptr;
-    MK_TRY(qset_alloc(c, lens, nq, &qs));
+    MK_TRY(qset_alloc(c, lens, nq, &qs, transient));
+    std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
+    constexpr uint64_t kImageMax = 8ull << 20;
+    if (qs->head_bytes <= kImageMax) {
+        // small batch: ONE copy of a pinned image of (sequences, offsets, entry offsets)
+        MK_TRY(ensure_pinned(c->h_stage, c->stage_cap, qs->head_bytes));
+        for (uint32_t q = 0; q < nq; ++q) memcpy(c->h_stage + qs->h_off[q], seqs[q], lens[q]);
+        memcpy(c->h_stage + qs->o_off, qs->h_off.data(), ((size_t)nq + 1) * 8);
+        memcpy(c->h_stage + qs->o_ent_off, qs->h_ent_off.data(), ((size_t)nq + 1) * 8);
+        MK_HIP(hipMemcpyAsync(qs->d_arena, c->h_stage, qs->head_bytes, hipMemcpyHostToDevice, c->stream));
+        if (!transient) MK_HIP(hipStreamSynchronize(c->stream));    // the image is reused by the next upload
+        *out = guard.release();
+        return MK_OK;
+    }
+    MK_TRY(qset_copy_offsets(c, qs));
     // Short sequences are gathered so that a run of them is ONE copy (100,000 reads must not be
     // 100,000 copies); a long one (a contig, a whole genome) goes straight from the caller's
     // buffer -- a DMA when that buffer is pinned (mk_host_alloc), and no extra pass over it.
@@ -947,13 +1004,18 @@ int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uin
         q = e;
     }
     if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;    // the caller's buffers are free again
-    if (!ok) {
-        set_error("query upload failed");
-        qset_release(qs);
-        return MK_ERR_DEVICE;
-    }
-    *out = qs;
+    if (!ok) { set_error("query upload failed"); return MK_ERR_DEVICE; }
+    *out = guard.release();
     return MK_OK;
+}
+
+extern "C" {
+
+int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, mk_qset **out)
+{
+    if (!c || !out || (nq && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return qset_upload(c, seqs, lens, nq, out, false);
 }
 
 int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
@@ -965,7 +1027,8 @@ int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uin
     std::vector<uint64_t> lens(nq, qlen);
     mk_qset *qs = nullptr;
     MK_TRY(qset_alloc(c, lens.data(), nq, &qs));
-    int rc = launch_synth_queries(c, first_id, nq, G, L, qlen, qs->d_seq);
+    int rc = qset_copy_offsets(c, qs);
+    if (rc == MK_OK) rc = launch_synth_queries(c, first_id, nq, G, L, qlen, qs->d_seq);
     if (rc != MK_OK) { qset_release(qs); return rc; }
     *out = qs;
     return MK_OK;
@@ -1074,7 +1137,7 @@ int mk_query_scores(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
     MK_TRY(use_device(c));
     if (!nq || !c->G) return MK_OK;
     mk_qset *qs = nullptr;
-    MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
+    MK_TRY(qset_upload(c, seqs, lens, nq, &qs, true));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
     MK_TRY(qset_sketch(c, qs));
     const uint32_t per = chunk_queries(c, nq);
@@ -1311,7 +1374,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         }
     }
     mk_qset *qs = nullptr;
-    MK_TRY(mk_qset_upload(c, seqs, lens, nq, &qs));
+    MK_TRY(qset_upload(c, seqs, lens, nq, &qs, true));
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> guard(qs, qset_release);
     MK_TRY(qset_sketch(c, qs));
     const uint32_t cap = 256;
@@ -1344,10 +1407,17 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
         MK_TRY(dev_alloc(&c->d_nhits, (uint64_t)per));
         c->nhits_cap = per;
     }
-    std::vector<uint32_t> row(c->G);
+    std::vector<uint32_t> row;
     std::vector<mk_hit> full;
+    std::vector<uint32_t> act(nq);
     for (uint32_t q0 = 0; q0 < nq; q0 += per) {
         const uint32_t q1 = std::min(nq, q0 + per), n = q1 - q0;
+        // results of a small chunk come back through one pinned block (counts, active partitions,
+        // hits): three queued copies and ONE wait, instead of a blocking copy per array
+        const uint64_t res_bytes = (uint64_t)n * (8 + (uint64_t)nresults * sizeof(mk_hit));
+        const bool pinned = on_device && res_bytes <= (1ull << 20);
+        uint32_t *p_nh = nullptr, *p_act = nullptr;
+        mk_hit *p_hits = nullptr;
         if (on_device) {
             if (slab) {
                 MK_TRY(qset_scan_slab(c, qs, q0, q1));
@@ -1361,18 +1431,33 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
             // the heap over the entrants runs on the device too (K6b): only the hits come back
             MergeArgs ma{c->d_count, c->d_cand, 1, n, cap, nresults, c->d_hits, c->d_nhits};
             MK_TRY(launch_merge(c, ma));
-            MK_HIP(hipMemcpyAsync(nhits + q0, c->d_nhits, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (pinned) {
+                MK_TRY(ensure_pinned(c->h_res, c->res_cap, res_bytes + 64));
+                p_hits = reinterpret_cast<mk_hit *>(c->h_res);
+                p_nh = reinterpret_cast<uint32_t *>(c->h_res + (uint64_t)n * nresults * sizeof(mk_hit));
+                p_act = p_nh + n;
+            } else {
+                p_hits = hits + (size_t)q0 * nresults; p_nh = nhits + q0; p_act = act.data() + q0;
+            }
+            MK_HIP(hipMemcpyAsync(p_nh, c->d_nhits, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            MK_HIP(hipMemcpyAsync(p_act, qs->d_nent + q0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
             if (nresults)
-                MK_HIP(hipMemcpyAsync(hits + (size_t)q0 * nresults, c->d_hits, (size_t)n * nresults * sizeof(mk_hit),
-                                      hipMemcpyDeviceToHost, c->stream));
+                MK_HIP(hipMemcpyAsync(p_hits, c->d_hits, (size_t)n * nresults * sizeof(mk_hit), hipMemcpyDeviceToHost,
+                                      c->stream));
         }
         MK_HIP(hipStreamSynchronize(c->stream));
+        if (pinned) {
+            memcpy(nhits + q0, p_nh, (size_t)n * 4);
+            memcpy(act.data() + q0, p_act, (size_t)n * 4);
+            if (nresults) memcpy(hits + (size_t)q0 * nresults, p_hits, (size_t)n * nresults * sizeof(mk_hit));
+        }
         for (uint32_t i = 0; i < n; ++i) {
             mk_hit *out = hits + (size_t)(q0 + i) * nresults;
             if (on_device && nhits[q0 + i] != kMergeOverflow) continue;
             // more heap entrants than the device row holds (or a top-N beyond the device
             // selection): replay this query over a dense score row of its own
             uint32_t *d_row = d_replay_row;
+            row.resize(c->G);
             MK_TRY(qset_scan(c, qs, q0 + i, q0 + i + 1, d_row, score_layout_rows(c->W, score_row_entries(c), c->G)));
             MK_HIP(hipMemcpyAsync(row.data(), d_row, (size_t)c->G * 4, hipMemcpyDeviceToHost, c->stream));
             MK_HIP(hipStreamSynchronize(c->stream));
@@ -1387,10 +1472,16 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
             nhits[q0 + i] = mk_filter_candidates(full.data(), (uint32_t)full.size(), nresults, out);
         }
     }
-    std::vector<uint32_t> act;
-    MK_TRY(account(c, qs, act));
+    if (!on_device) MK_HIP(hipMemcpy(act.data(), qs->d_nent, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    {
+        uint64_t a = 0;
+        for (uint32_t v : act) a += v;
+        c->stats.active_partitions += a;
+        c->stats.comparisons += a * c->G;
+        c->stats.scan_algo_bytes += a * c->G * c->W + 4ull * nq * c->G;
+    }
     if (active) memcpy(active, act.data(), (size_t)nq * 4);
-    return MK_OK;
+    return drain_timers(c);                                      // every event has fired: fold them in, keep the list short
 }
 
 int mk_exact(mk_ctx *c, const char *const *contigs, const uint64_t *contig_lens, uint32_t n_contigs,

@@ -122,6 +122,16 @@ struct mk_ctx {
     uint32_t *d_nhits;
     uint64_t hits_cap;             // records d_hits is sized for
     uint64_t nhits_cap;            // queries d_nhits is sized for
+    // small calls (mk_query with a handful of queries) are round trips, not kernels: one cached
+    // device arena for the call's transient query set, one pinned block for its upload image and
+    // one for its results, so that a call is one copy in, the kernels, one sync, one copy out
+    uint8_t *d_qarena;
+    uint64_t qarena_cap;
+    bool qarena_busy;
+    uint8_t *h_stage;              // pinned
+    uint64_t stage_cap;
+    uint8_t *h_res;                // pinned
+    uint64_t res_cap;
     uint64_t *d_long_table;        // P keys, long-query path
     // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
     uint64_t *d_slots;
@@ -138,6 +148,10 @@ struct mk_ctx {
 
 struct mk_qset {
     uint32_t nq;
+    mk_ctx *owner;
+    bool arena_borrowed;           // d_arena is the context's cached arena (transient sets of mk_query)
+    uint64_t head_bytes;           // arena bytes [0, head_bytes) = sequences, offsets, entry offsets: the upload image
+    uint64_t o_off, o_ent_off;     // byte offsets of d_off / d_ent_off in the arena (d_seq is at 0)
     uint8_t *d_arena;              // the set's one device allocation; the arrays below point into it
     bool split_in_arena;           // d_split too (room for split_room ranges), else it is its own allocation
     uint32_t split_room;

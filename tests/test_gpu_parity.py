@@ -23,6 +23,14 @@ def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 
 
+@pytest.fixture(autouse=True)
+def force_slab_schedule(monkeypatch):
+    """Sets below 512 queries take the plain scan schedule by default (nothing to reuse, and the slab
+    range table costs a host round trip); the cases here are small, so the threshold is lifted to keep
+    the slab kernel + partial-count selection under test.  test_small_sets_* covers the default."""
+    monkeypatch.setenv("MIEKKI_SLAB_MIN_QUERIES", "1")
+
+
 @pytest.fixture(scope="module")
 def hip():
     import miekki_amd
@@ -415,6 +423,33 @@ def test_slab_schedule_longer_queries(hip):
             assert int(act[q]) == o.query_sequence(s)[1]
             want = o.filter_results(scores[q], 10, 5, 15.0)
             assert [(x.genome, x.matches) for x in hits[q]] == [(w[0], w[1]) for w in want], q
+    finally:
+        ix.close()
+
+
+def test_small_sets_plain_and_slab_schedules_agree(hip, monkeypatch):
+    """Default dispatch (plain schedule below 512 queries, slab from there on) against the forced
+    slab schedule and the oracle: same hits from one query, sixteen, and 600."""
+    from oracle import oracle as orc
+    k, h, G = 31, 20, 20
+    seqs = [synth.genome_bases(6200 + g, 0, 100_000) for g in range(G)]
+    o = orc.OracleMiekki(k, h, 8, 33, 30)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 33, 30)
+    try:
+        ix.insert_sequences(seqs)
+        qs = [seqs[q % G][(97 * q) % 90_000:(97 * q) % 90_000 + 800 + q % 300] for q in range(600)]
+        scores = o.query_sequences(qs[:40])
+        for n in (1, 16, 600):
+            monkeypatch.setenv("MIEKKI_SLAB_MIN_QUERIES", "1")
+            slab, act_s = ix.query(qs[:n], 10, 5, 15.0)
+            monkeypatch.delenv("MIEKKI_SLAB_MIN_QUERIES")
+            dflt, act_d = ix.query(qs[:n], 10, 5, 15.0)
+            assert slab == dflt and (act_s == act_d).all(), n
+            for q in range(min(n, 40)):
+                want = o.filter_results(scores[q], 10, 5, 15.0)
+                assert [(x.genome, x.matches) for x in dflt[q]] == [(w[0], w[1]) for w in want], (n, q)
+                assert int(act_d[q]) == o.query_sequence(qs[q])[1]
     finally:
         ix.close()
 
