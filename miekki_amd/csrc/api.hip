@@ -315,7 +315,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     qs->owner = c; qs->arena_borrowed = false; qs->head_bytes = 0; qs->o_off = qs->o_ent_off = 0;
     qs->nq = nq; qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr;
     qs->d_nent = nullptr; qs->sketched = false; qs->gen = 0; qs->short_max_nk = 0;
-    qs->d_split = nullptr; qs->S = 0; qs->slab_ok = false;
+    qs->d_split = nullptr; qs->S = 0; qs->chunk = 0; qs->slab_ok = false;
     qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
     qs->d_arena = nullptr; qs->split_in_arena = false; qs->split_room = 0;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
@@ -485,17 +485,32 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
 {
     uint32_t S = slab_ranges(c);
     qs->slab_ok = false;
-    // (a handful of queries gain nothing from the slab order -- there is no reuse to schedule --
-    // and would pay a range table and a host round trip for the eligibility flag)
-    uint32_t kSlabMinQueries = 512;
-    if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) kSlabMinQueries = (uint32_t)std::max(0L, atol(e));   // tests force the slab path
-    if (S < 2 || !qs->long_q.empty() || !qs->dense_q.empty() || qs->nq < kSlabMinQueries) { qs->S = S; return MK_OK; }
+    qs->chunk = 0;
+    if (!qs->long_q.empty() || !qs->dense_q.empty() || !qs->nq) { qs->S = S; return MK_OK; }
+    const uint32_t limit = c->W == 1 ? 255u : 65535u;
+    // A handful of queries has no reuse to schedule -- what it needs is parallelism: one wave per
+    // (query, tile) would walk ~900 entries in ~110 dependent steps (a single query: 13 waves on
+    // 256 CUs).  So small sets cut every entry list into S pieces BY COUNT: S x as many waves, each
+    // a few steps long, no range table, and no eligibility check (a piece holds at most `chunk`
+    // <= 255 entries by construction), i.e. no host round trip either.
+    uint32_t small_below = 512;
+    if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) small_below = (uint32_t)std::max(0L, atol(e));   // tests force the range-table path
+    if (qs->nq < small_below) {
+        const uint64_t waves = (uint64_t)ntiles_of(c) * qs->nq;
+        uint32_t Sc = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (4096 + waves - 1) / std::max<uint64_t>(waves, 1)));
+        Sc = std::max<uint32_t>(Sc, (qs->short_max_nk + limit - 1) / limit);
+        Sc = std::max<uint32_t>(Sc, 1);
+        qs->S = Sc;
+        qs->chunk = std::max<uint32_t>(1, (qs->short_max_nk + Sc - 1) / Sc);
+        qs->slab_ok = true;
+        return MK_OK;
+    }
+    if (S < 2) { qs->S = S; return MK_OK; }
     // longer queries need more (smaller) ranges to keep every (query, range) within the
     // packed counters: aim at <= 180 entries per range on average, the device check
     // below still decides
-    const uint32_t limit = c->W == 1 ? 255u : 65535u;
     while (S < 64 && (uint64_t)qs->short_max_nk > (uint64_t)S * (limit * 7 / 10)) S <<= 1;
-    if (qs->S != S) {
+    if (qs->S != S || !qs->d_split) {
         if (!(qs->split_in_arena && S <= qs->split_room)) {        // more ranges than the set reserved room for
             if (!qs->split_in_arena) dev_free(qs->d_split);
             qs->split_in_arena = false; qs->d_split = nullptr;
@@ -607,6 +622,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     SlabArgs a;
     a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c); a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S;
     a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
+    a.chunk = qs->chunk; a.nent = qs->d_scan_n;
     c->stats.scan_slab_launches++;
     ScopedTimer t(c, 1);
     return launch_scan_slab(c, a);

@@ -172,6 +172,7 @@ struct mk_qset {
     uint32_t short_max_nk;         // longest short query (k-mers)
     uint32_t *d_split;             // [nq][S + 1] entry index of each partition-range boundary
     uint32_t S;                    // ranges of the slab schedule (0 = not prepared)
+    uint32_t chunk;                // small sets: entries per range, ranges cut by count (0 = by partition, d_split)
     bool slab_ok;                  // every (query, range) fits the packed counters
     bool sketched;
     uint64_t gen;                  // index generation the sketch / range table were made against
@@ -241,6 +242,8 @@ struct SlabArgs {
     const uint64_t *ent_off;
     const uint32_t *split;         // [query][S + 1] entry indices of the range boundaries
     uint8_t *partials;             // [tile][range][query][1 KiB]
+    uint32_t chunk;                // != 0: range r of a query = its entries [r * chunk, (r + 1) * chunk) instead of the table
+    const uint32_t *nent;          // entries per query (chunk mode)
 };
 int launch_scan_slab(mk_ctx *c, const SlabArgs &a);
 // the two layouts the pipeline uses

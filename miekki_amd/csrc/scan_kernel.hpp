@@ -190,7 +190,15 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
     const uint32_t tile = tr / a.S, r = tr - tile * a.S;
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     const uint32_t q = a.q_begin + ql;
-    const uint32_t lo = a.split[(uint64_t)q * (a.S + 1) + r], hi = a.split[(uint64_t)q * (a.S + 1) + r + 1];
+    uint32_t lo, hi;
+    if (a.chunk) {                                      // small sets: ranges by entry COUNT (no range table, no eligibility check)
+        const uint32_t n = a.nent[q];
+        lo = min(r * a.chunk, n);
+        hi = min(lo + a.chunk, n);
+    } else {
+        lo = a.split[(uint64_t)q * (a.S + 1) + r];
+        hi = a.split[(uint64_t)q * (a.S + 1) + r + 1];
+    }
     const uint64_t *__restrict__ e = a.entries + a.ent_off[q] + lo;
     const uint32_t m = hi - lo;
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;

@@ -237,6 +237,20 @@ __device__ __forceinline__ uint64_t item_to_key(uint64_t item)
     return ((item >> 48) << kPosBits) | ((item >> kBinBits) & ((1ULL << kItemPosBits) - 1));
 }
 
+// 16 bytes that hold one 4-bit code each -> one 64-bit word, code j at bits 4j
+__device__ __forceinline__ uint32_t squeeze8(uint64_t x)
+{
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    return (uint32_t)(x | (x >> 16));
+}
+
+// Instruction budget (the kernel is issue-bound: rocprofv3 PMC): a character is
+// classified by ONE look-up in a 256-entry LDS table (the compare chains of nuc2int / nuc2intrc
+// cost ~55 instructions per character), the codes are packed 16 per 64-bit word, and a thread
+// fetches its 16 + k-1 positions as three words: the k-1 seed digits and the sixteen incoming
+// digits then come out of registers with a handful of shifts (`pairs`, one bit reversal) instead
+// of k-1 + 16 LDS reads and a 30-step seed loop per thread.
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict__ seq,
                                                           const uint64_t *__restrict__ off,
                                                           const uint32_t *__restrict__ valid,
@@ -246,64 +260,83 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
                                                           uint8_t *__restrict__ packed, const uint64_t *__restrict__ code_off,
                                                           SketchParams sp, BinParams bp)
 {
-    __shared__ uint8_t codes[kSegKmers + 64];
+    static_assert(kPerThread == 16 && kSegKmers == 256 * kPerThread, "one 64-bit word of 4-bit codes per thread");
+    constexpr uint32_t kWords = kSegKmers / 16 + 2;                  // words a workgroup's threads look at
+    __shared__ __attribute__((aligned(16))) uint8_t codes[kSegKmers + 64];
+    __shared__ uint64_t pk[kWords + 2];
     __shared__ uint32_t bin_count[kMaxBins];
-    const uint32_t g = blockIdx.y, wg = blockIdx.x;
+    __shared__ uint8_t lut[256];
+    const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
     const uint64_t len = off[g + 1] - off[g];
     const uint64_t nk = len > sp.k ? len - sp.k : 0;
     const uint64_t seg0 = (uint64_t)wg * kSegKmers;
-    for (uint32_t b = threadIdx.x; b < bp.nbins; b += 256) bin_count[b] = 0;
-    uint32_t cnt = 0;
+    lut[tid] = (uint8_t)(fwd_code((uint8_t)tid) | (rc_code((uint8_t)tid) << 2));   // nuc2int / nuc2intrc, once per character value
+    for (uint32_t b = tid; b < bp.nbins; b += 256) bin_count[b] = 0;
+    __syncthreads();
+    uint32_t cnt = 0, nchar = 0;
     if (seg0 < nk) {
         cnt = (uint32_t)min((uint64_t)kSegKmers, nk - seg0);
+        nchar = cnt + sp.k - 1;
         const char *__restrict__ s = seq + off[g];
-        const bool sv = valid[g] != 0;
-        const uint32_t nchar = cnt + sp.k - 1;
-        for (uint32_t j = threadIdx.x; j < nchar; j += 256)
-            codes[j] = (uint8_t)pos_codes((uint8_t)s[seg0 + j], seg0 + j, sp.k, sv);
+        for (uint32_t j = tid; j < nchar; j += 256) codes[j] = lut[(uint8_t)s[seg0 + j]];
+        for (uint32_t j = nchar + tid; j < kWords * 16u; j += 256) codes[j] = 0;
+        // the k-1 characters of the sequence's seed go through str2numstrand / rcb instead
+        // (Miekki.cpp:158-164): only the first workgroup of a genome sees them
+        if (seg0 == 0 && tid + 1 < sp.k && tid < nchar) codes[tid] = (uint8_t)pos_codes((uint8_t)s[tid], tid, sp.k, valid[g] != 0);
     }
     __syncthreads();
-    const uint32_t i0 = threadIdx.x * kPerThread;
-    if (cnt && packed) {
-        // this workgroup's own 4096 positions, 16 per thread, as 4-bit (forward, reverse)
-        // codes: what the Bloom pass reads back for the winners.  The k-1 characters past
-        // them belong to the next workgroup -- or to this one if it is the sequence's last.
-        static_assert(kPerThread == 16, "one 64-bit word of 4-bit codes per thread");
-        const uint32_t nchar = cnt + sp.k - 1;
-        uint64_t *__restrict__ dst = reinterpret_cast<uint64_t *>(packed + code_off[g] + seg0 / 2);
-        auto pack16 = [&](uint32_t c0) {
-            uint64_t w = 0;
-#pragma unroll
-            for (uint32_t e = 0; e < kPerThread; ++e)
-                if (c0 + e < nchar) w |= (uint64_t)codes[c0 + e] << (4 * e);
-            dst[c0 / kPerThread] = w;
+    if (cnt) {
+        auto pack_word = [&](uint32_t w) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(codes + 16u * w);
+            return (uint64_t)squeeze8(((uint64_t)v.y << 32) | v.x) | ((uint64_t)squeeze8(((uint64_t)v.w << 32) | v.z) << 32);
         };
-        if (i0 < nchar) pack16(i0);
-        if (seg0 + cnt == nk && kSegKmers + i0 < nchar) pack16(kSegKmers + i0);
-    }
-    if (i0 < cnt) {
-        const uint32_t i1 = min(i0 + kPerThread, cnt);
-        uint64_t S = 0, RC = 0;
-        for (uint32_t j = 0; j + 1 < sp.k; ++j) {
-            const uint32_t cd = codes[i0 + j];
-            S = (S << 2) | (cd & 3u);
-            RC |= (uint64_t)(cd >> 2) << (2 * (j + 1));
+        // this workgroup's own 4096 positions as 4-bit (forward, reverse) codes: what the Bloom
+        // pass reads back for the winners.  The k-1 characters past them belong to the next
+        // workgroup -- or to this one if it is the sequence's last.
+        uint64_t *__restrict__ dst = packed ? reinterpret_cast<uint64_t *>(packed + code_off[g] + seg0 / 2) : nullptr;
+        const uint64_t mine = pack_word(tid);
+        pk[tid] = mine;
+        if (dst && 16u * tid < nchar) dst[tid] = mine;
+        if (tid < 2) {
+            const uint64_t extra = pack_word(256 + tid);
+            pk[256 + tid] = extra;
+            if (dst && seg0 + cnt == nk && kSegKmers + 16u * tid < nchar) dst[256 + tid] = extra;
         }
+    }
+    __syncthreads();
+    const uint32_t i0 = tid * kPerThread;
+    if (i0 < cnt) {
+        const uint64_t w0 = pk[tid], w1 = pk[tid + 1], w2 = pk[tid + 2];
+        // digit j of the thread's 48 positions at bits 2j: forward codes (F) and reverse-strand codes (R)
+        const uint64_t F = ((uint64_t)pairs(w1) << 32) | pairs(w0), R = ((uint64_t)pairs(w1 >> 2) << 32) | pairs(w0 >> 2);
+        const uint32_t F2 = pairs(w2), R2 = pairs(w2 >> 2);
+        const uint32_t km1 = sp.k - 1;                            // 1..30 digits of seed
+        const uint64_t seedmask = (1ULL << (2 * km1)) - 1;
+        // state after the k-1 seed digits, as the reference's loop leaves it (Miekki.cpp:158-164)
+        uint64_t r = __builtin_bitreverse64(F & seedmask);
+        r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
+        uint64_t S = r >> (64 - 2 * km1);
+        uint64_t RC = (R & seedmask) << 2;
+        // the sixteen digits that enter, one per k-mer
+        const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)F2 << (64 - 2 * km1)));
+        const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
         const uint32_t topshift = 2 * sp.k - 2;
-        uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome;
-        for (uint32_t i = i0; i < i1; ++i) {
-            const uint32_t cd = codes[i + sp.k - 1];
-            S = ((S << 2) | (cd & 3u)) & sp.kmask;
-            RC = (RC >> 2) | ((uint64_t)(cd >> 2) << topshift);
+        uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)wg * bp.cap;
+        const uint32_t bin_stride = bp.nwg * bp.cap;              // < 2^24 (launch_genome_sketch_binned checks)
+        const uint32_t lowmask = (1u << bp.low_bits) - 1u;
+#pragma unroll
+        for (uint32_t u = 0; u < kPerThread; ++u) {
+            S = ((S << 2) | ((fnew >> (2 * u)) & 3u)) & sp.kmask;               // update_kmer, Miekki.cpp:51-55
+            RC = (RC >> 2) | ((uint64_t)((rnew >> (2 * u)) & 3u) << topshift);  // update_kmer_RC, Miekki.cpp:59-62
             const uint64_t anc = revhash64(S < RC ? S : RC);
             uint32_t bucket, fp;
             bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
-            if (fp == sp.empty) continue;
+            if (fp == sp.empty || i0 + u >= cnt) continue;          // (past the segment's end only in a sequence's last workgroup)
             const uint32_t bin = bucket >> bp.low_bits;
-            const uint64_t item = ((uint64_t)fp << 48) | ((seg0 + i) << kBinBits) | (bucket & ((1u << bp.low_bits) - 1u));
+            const uint64_t item = ((uint64_t)fp << 48) | ((seg0 + i0 + u) << kBinBits) | (bucket & lowmask);
             const uint32_t rank = atomicAdd(&bin_count[bin], 1u);
             if (rank < bp.cap) {
-                gslots[((uint64_t)bin * bp.nwg + wg) * bp.cap + rank] = item;
+                gslots[__umul24(bin, bin_stride) + rank] = item;
             } else {
                 const uint32_t o = atomicAdd(ovf_count, 1u);
                 if (o < kOvfCap) {
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
     }
     __syncthreads();
     uint16_t *__restrict__ gc = slot_counts + (uint64_t)g * bp.nbins * bp.nwg;
-    for (uint32_t b = threadIdx.x; b < bp.nbins; b += 256)
+    for (uint32_t b = tid; b < bp.nbins; b += 256)
         gc[(uint64_t)b * bp.nwg + wg] = (uint16_t)min(bin_count[b], bp.cap);
 }
 
@@ -394,6 +427,7 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     bp.cap = bp.nbins == 1 ? kSegKmers
                            : std::min<uint32_t>(kSegKmers, (uint32_t)((mean + 6.0 * std::sqrt(mean) + 8.0 + 7.0) / 8.0) * 8u);
     bp.slots_per_genome = (uint64_t)bp.nbins * bp.nwg * bp.cap;
+    if ((uint64_t)bp.nwg * bp.cap >= (1u << 24)) return MK_OK;     // the scatter kernel's 24-bit slot arithmetic
     const uint64_t need = bp.slots_per_genome * n;
     if (need * 8 > (12ull << 30)) return MK_OK;                    // slot memory budget
     if (need > c->slots_cap) {

@@ -349,6 +349,59 @@ def test_config3_shard_scale_properties(hip):
         ix.close()
 
 
+def test_config2_full_size_properties(hip):
+    """BASELINE config 2 at full size (1,000 synthetic 5 Mb genomes, -k 31 -h 17, 10,000 x 1 kb queries)
+    through size-independent properties.  The regime is the one c2mini pins against the real reference:
+    every sketch is full (2^17 partitions), active^2 wraps to 0 (Miekki.cpp:289, 306), every genome_size is
+    0 -- so the scores single out the source genome and the approximate mode still reports NO hit."""
+    G, L_, nq = 1000, 5_000_000, 10_000
+    ix = hip.Miekki(31, 17, 8, 33, 200)
+    try:
+        ix.reserve(G)
+        ix.insert_synthetic(0, G, L_)
+        assert (ix.sketch_size == 1 << 17).all() and (ix.genome_size == 0).all()
+        qs = [synth.genome_bases(*synth.query_origin(q, G, L_, 1000), 1000) for q in range(nq)]
+        hits, active = ix.query(qs, 10, 10, 100.0)                      # query_file's parameters: slab schedule
+        assert all(h == [] for h in hits)                               # intersection estimate 0 < min_intersection
+        loose, _ = ix.query(qs[:200], 10, 10, 0.0)                      # thresholds off: the heap sees score >= 10
+        for q in range(200):
+            assert loose[q] and all(x.intersection == 0.0 for x in loose[q])
+            assert any(x.genome == q % G and x.matches > 20 for x in loose[q]) or len(loose[q]) == 10
+        scores = ix.query_sequences(qs[:128])                           # plain kernel, dense rows
+        for q in range(128):
+            src = q % G
+            assert scores[q, src] > 20 and scores[q, src] > 2 * np.delete(scores[q], src).max(), q
+            want = ix.filter_results(scores[q], 10, 10, 0.0)            # all-equal intersections: pure tie order
+            assert [(a.genome, a.matches) for a in loose[q]] == [(b.genome, b.matches) for b in want], q
+        assert 100 < active.mean() < 969
+    finally:
+        ix.close()
+
+
+def test_config4_full_size_properties(hip):
+    """BASELINE config 4 at full size (10,000 synthetic 5 Mb genomes, -h 20, 2-byte fingerprints: -f 11):
+    the top hit of every query is its source genome, chance matches all but vanish at 16 bits, and the
+    slab pipeline (16-bit partial counters + device selection) agrees with the plain kernel's dense rows."""
+    G, L_, nq = 10_000, 5_000_000, 600
+    ix = hip.Miekki(31, 20, 16, 33, 200)
+    try:
+        ix.reserve(G)
+        ix.insert_synthetic(0, G, L_)
+        assert (ix.genome_size == L_).all()
+        qs = [synth.genome_bases(*synth.query_origin(q, G, L_, 1000), 1000) for q in range(nq)]
+        hits, active = ix.query(qs, 10, 10, 100.0)
+        assert all(h and h[0].genome == q % G and len(h) == 1 for q, h in enumerate(hits))
+        scores = ix.query_sequences(qs[:64])
+        for q in range(64):
+            src = q % G
+            assert scores[q, src] == hits[q][0].matches > 150
+            assert np.delete(scores[q], src).max() <= 8                 # 16-bit fingerprints: chance matches ~ 900 / 2^11 / 3
+            want = ix.filter_results(scores[q], 10, 10, 100.0)
+            assert [(a.genome, a.matches) for a in hits[q]] == [(b.genome, b.matches) for b in want], q
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("k,h,fpb,b", [(11, 6, 8, 32), (21, 13, 16, 33), (31, 15, 8, 36), (27, 22, 8, 33), (5, 3, 16, 32)])
 def test_parameter_sweep_against_oracle(hip, k, h, fpb, b):
     """Odd corners of the parameter space (tiny and large h, small k, both widths,

@@ -237,6 +237,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_split, split.data(), split.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc((void **)&d_part, (uint64_t)a.ntiles * slabS * Q * kTileBytes));
     SlabArgs sa;
+    sa.chunk = 0; sa.nent = nullptr;
     sa.M = M; sa.ld = ld; sa.G = G; sa.ntiles = a.ntiles; sa.nq = Q; sa.q_begin = 0; sa.S = slabS;
     sa.entries = d_ent; sa.ent_off = d_off; sa.split = d_split; sa.partials = d_part;
     std::vector<float> slab_ms;
