@@ -228,17 +228,16 @@ static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
     MK_TRY(launch_seed_valid(c, d_seq, c->d_seq_off, n, c->d_seed_valid));
     MK_TRY(ensure_bloom_summary(c));
     {
+        // binned form: scatter, then ONE kernel that reduces, emits fingerprints and sizes and runs
+        // Bloom pass A, the matrix rows, Bloom pass B
         ScopedTimer t(c, 3);
-        MK_TRY(launch_genome_sketch_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables, &b.binned));
-        if (!b.binned)
-            MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables));
+        MK_TRY(launch_genome_build_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->G, &b.binned));
     }
-    const uint32_t *d_abort = b.binned ? c->d_ovf_count : nullptr;
-    {
+    if (!b.binned) {                                             // shapes the bins do not fit: atomic kernel + separate passes
+        { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
         ScopedTimer t(c, 4);
-        MK_TRY(launch_finalize(c, c->d_tables, n, c->G, d_abort));
-        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, d_abort,
-                                   b.binned ? c->d_codes : nullptr, c->d_code_off));
+        MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
+        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, c->d_code_off));
     }
     c->h_back->ovf = 0;
     MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -256,7 +255,7 @@ static int settle_build(mk_ctx *c)
     b.on = false;
     MK_HIP(hipStreamSynchronize(c->stream));
     const uint32_t n = b.n;
-    if (b.binned && binned_overflowed(c->h_back->ovf)) {
+    if (b.binned && binned_build_overflowed(c->h_back->ovf)) {
         // the overflow list of the binned sketch ran over (very repetitive sequence): the
         // batch's later kernels saw the same mark and did nothing; redo it with the atomic kernel
         const char *d_seq = c->d_seq[b.buf];
@@ -497,7 +496,9 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
     if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) small_below = (uint32_t)std::max(0L, atol(e));   // tests force the range-table path
     if (qs->nq < small_below) {
         const uint64_t waves = (uint64_t)ntiles_of(c) * qs->nq;
-        uint32_t Sc = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (4096 + waves - 1) / std::max<uint64_t>(waves, 1)));
+        // (up to eight pieces: that is what select_kernel sums with its words prefetched; more only
+        // when the packed counters ask for it)
+        uint32_t Sc = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (4096 + waves - 1) / std::max<uint64_t>(waves, 1)));
         Sc = std::max<uint32_t>(Sc, (qs->short_max_nk + limit - 1) / limit);
         Sc = std::max<uint32_t>(Sc, 1);
         qs->S = Sc;
@@ -691,6 +692,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->h_stage = nullptr; c->stage_cap = 0; c->h_res = nullptr; c->res_cap = 0;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
     c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
+    c->d_fpT = nullptr; c->d_posted_blk = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
@@ -726,7 +728,7 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
-    dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs);
+    dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_posted_blk);
     dev_free(c->d_qarena);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_res) (void)hipHostFree(c->h_res);

@@ -138,7 +138,9 @@ struct mk_ctx {
     uint64_t slots_cap;            // entries
     uint16_t *d_slot_counts;
     uint64_t slot_counts_cap;
-    uint64_t *d_ovf;               // (genome << 32 | bucket, key) pairs that missed their slot
+    uint8_t *d_fpT;                // build: fingerprints of the batch, genome-major [build_batch][P] (fused build kernel)
+    uint8_t *d_posted_blk;         // build: per (genome, 256 partitions) "a Bloom first-writer key was posted here"
+    uint64_t *d_ovf;               // (genome << 32 | bucket, item) pairs that missed their slot
     uint32_t *d_ovf_count;
     // stats
     mk_stats stats;
@@ -196,6 +198,11 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
 // d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 bool binned_overflowed(uint32_t ovf_count);
+bool binned_build_overflowed(uint32_t ovf_count);
+// the index build's own binned form: scatter, then reduce + fingerprints + sizes + Bloom pass A fused,
+// matrix rows, Bloom pass B (results in c->d_active / c->d_cardsum like launch_finalize)
+int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
+                               const uint32_t *d_valid, uint32_t n, uint32_t g0, bool *used);
 // d_codes != nullptr: the winners' k-mers are read from the packed code array of the batch
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,

@@ -366,11 +366,11 @@ def test_config2_full_size_properties(hip):
         loose, _ = ix.query(qs[:200], 10, 10, 0.0)                      # thresholds off: the heap sees score >= 10
         for q in range(200):
             assert loose[q] and all(x.intersection == 0.0 for x in loose[q])
-            assert any(x.genome == q % G and x.matches > 20 for x in loose[q]) or len(loose[q]) == 10
+            assert any(x.genome == q % G and x.matches >= 10 for x in loose[q]) or len(loose[q]) == 10
         scores = ix.query_sequences(qs[:128])                           # plain kernel, dense rows
         for q in range(128):
             src = q % G
-            assert scores[q, src] > 20 and scores[q, src] > 2 * np.delete(scores[q], src).max(), q
+            assert scores[q, src] >= 10 and scores[q, src] > 2 * np.delete(scores[q], src).max(), q
             want = ix.filter_results(scores[q], 10, 10, 0.0)            # all-equal intersections: pure tie order
             assert [(a.genome, a.matches) for a in loose[q]] == [(b.genome, b.matches) for b in want], q
         assert 100 < active.mean() < 969
