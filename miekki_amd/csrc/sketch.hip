@@ -245,12 +245,19 @@ __device__ __forceinline__ uint32_t squeeze8(uint64_t x)
     return (uint32_t)(x | (x >> 16));
 }
 
-// Instruction budget (the kernel is issue-bound: rocprofv3 PMC): a character is
-// classified by ONE look-up in a 256-entry LDS table (the compare chains of nuc2int / nuc2intrc
-// cost ~55 instructions per character), the codes are packed 16 per 64-bit word, and a thread
-// fetches its 16 + k-1 positions as three words: the k-1 seed digits and the sixteen incoming
-// digits then come out of registers with a handful of shifts (`pairs`, one bit reversal) instead
-// of k-1 + 16 LDS reads and a 30-step seed loop per thread.
+// What bounds this kernel is not arithmetic but the number of write REQUESTS at the L2: an item
+// stored by each lane to "its" bin is one 8-byte request per k-mer (3.2e8 per 64-genome batch,
+// ~2e11/s -- the rate the Bloom pass ran into as well), and halving the instruction count alone
+// changed nothing (round 2).  So the workgroup sorts its 4096 items by bin in LDS first
+// -- a counting sort whose rank is the LDS atomic the slot position needs anyway -- and writes each
+// bin's run with consecutive lanes: ~32 items = 256 contiguous bytes, four 64-byte requests
+// instead of 32.  The items wait in registers (16 per thread) while the bin counts settle, and go
+// through a 2048-entry stage in two rounds, so that five workgroups still fit a CU.
+// Arithmetic: a character is classified by ONE look-up in a 256-entry LDS table (the compare
+// chains of nuc2int / nuc2intrc cost ~55 instructions per character), the codes are packed 16 per
+// 64-bit word, and a thread fetches its 16 + k-1 positions as three words: the k-1 seed digits and
+// the sixteen incoming digits come out of registers with a handful of shifts (`pairs`, one bit
+// reversal) instead of k-1 + 16 LDS reads and a 30-step seed loop per thread.
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict__ seq,
                                                           const uint64_t *__restrict__ off,
                                                           const uint32_t *__restrict__ valid,
@@ -262,10 +269,15 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
 {
     static_assert(kPerThread == 16 && kSegKmers == 256 * kPerThread, "one 64-bit word of 4-bit codes per thread");
     constexpr uint32_t kWords = kSegKmers / 16 + 2;                  // words a workgroup's threads look at
-    __shared__ __attribute__((aligned(16))) uint8_t codes[kSegKmers + 64];
+    constexpr uint32_t kStage = 2048;                                // items per write-out round
+    __shared__ __attribute__((aligned(16))) uint64_t stage[kStage];  // first the character codes, later the sorted items
     __shared__ uint64_t pk[kWords + 2];
     __shared__ uint32_t bin_count[kMaxBins];
+    __shared__ uint32_t bin_start[kMaxBins];
+    __shared__ uint32_t wave_sum[4];
     __shared__ uint8_t lut[256];
+    uint8_t *codes = reinterpret_cast<uint8_t *>(stage);             // kWords * 16 bytes, dead once pk is built
+    static_assert(kWords * 16 <= kStage * 8, "codes fit the stage");
     const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
     const uint64_t len = off[g + 1] - off[g];
     const uint64_t nk = len > sp.k ? len - sp.k : 0;
@@ -304,7 +316,12 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
         }
     }
     __syncthreads();
+    // ---- hash: sixteen items per thread, kept in registers.  Register item:
+    //      fingerprint << 48 | rank in bin << 35 | bin << 25 | position in segment << 13 | partition in bin
     const uint32_t i0 = tid * kPerThread;
+    uint64_t reg[kPerThread];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerThread; ++u) reg[u] = ~0ULL;
     if (i0 < cnt) {
         const uint64_t w0 = pk[tid], w1 = pk[tid + 1], w2 = pk[tid + 2];
         // digit j of the thread's 48 positions at bits 2j: forward codes (F) and reverse-strand codes (R)
@@ -321,8 +338,6 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
         const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)F2 << (64 - 2 * km1)));
         const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
         const uint32_t topshift = 2 * sp.k - 2;
-        uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)wg * bp.cap;
-        const uint32_t bin_stride = bp.nwg * bp.cap;              // < 2^24 (launch_genome_sketch_binned checks)
         const uint32_t lowmask = (1u << bp.low_bits) - 1u;
 #pragma unroll
         for (uint32_t u = 0; u < kPerThread; ++u) {
@@ -333,20 +348,68 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
             bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
             if (fp == sp.empty || i0 + u >= cnt) continue;          // (past the segment's end only in a sequence's last workgroup)
             const uint32_t bin = bucket >> bp.low_bits;
-            const uint64_t item = ((uint64_t)fp << 48) | ((seg0 + i0 + u) << kBinBits) | (bucket & lowmask);
             const uint32_t rank = atomicAdd(&bin_count[bin], 1u);
             if (rank < bp.cap) {
-                gslots[__umul24(bin, bin_stride) + rank] = item;
-            } else {
+                reg[u] = ((uint64_t)fp << 48) | ((uint64_t)rank << 35) | ((uint64_t)bin << 25) | ((uint64_t)(i0 + u) << kBinBits) |
+                         (bucket & lowmask);
+            } else {                                                // slot full (very repetitive sequence): overflow list
                 const uint32_t o = atomicAdd(ovf_count, 1u);
                 if (o < kOvfCap) {
                     ovf[2 * (uint64_t)o] = ((uint64_t)g << 32) | bucket;
-                    ovf[2 * (uint64_t)o + 1] = item;
+                    ovf[2 * (uint64_t)o + 1] = ((uint64_t)fp << 48) | ((seg0 + i0 + u) << kBinBits) | (bucket & lowmask);
                 }
             }
         }
     }
     __syncthreads();
+    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of min(count, cap)
+    {
+        uint32_t c4[4], sum = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t b = tid * 4 + e;
+            c4[e] = b < bp.nbins ? min(bin_count[b], bp.cap) : 0u;
+            sum += c4[e];
+        }
+        uint32_t incl = sum;
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t b = tid * 4 + e;
+            if (b < bp.nbins) bin_start[b] = base;
+            base += c4[e];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)wg * bp.cap;
+    const uint32_t bin_stride = bp.nwg * bp.cap;                  // < 2^24 (binned_setup checks)
+    for (uint32_t h0 = 0; h0 < total; h0 += kStage) {             // wave-uniform trip count
+#pragma unroll
+        for (uint32_t u = 0; u < kPerThread; ++u) {
+            if (reg[u] == ~0ULL) continue;
+            const uint32_t d = bin_start[(uint32_t)(reg[u] >> 25) & 1023u] + ((uint32_t)(reg[u] >> 35) & 4095u);
+            if (d - h0 < kStage) stage[d - h0] = reg[u];          // (d < h0 wraps around to a huge value)
+        }
+        __syncthreads();
+        const uint32_t m = min(kStage, total - h0);
+        for (uint32_t i = tid; i < m; i += 256) {
+            const uint64_t it = stage[i];
+            const uint32_t bin = (uint32_t)(it >> 25) & 1023u, rank = (uint32_t)(it >> 35) & 4095u;
+            const uint64_t pos = seg0 + ((uint32_t)(it >> kBinBits) & 4095u);
+            // consecutive i of one bin are consecutive ranks: consecutive lanes write consecutive words
+            gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
+        }
+        __syncthreads();
+    }
     uint16_t *__restrict__ gc = slot_counts + (uint64_t)g * bp.nbins * bp.nwg;
     for (uint32_t b = tid; b < bp.nbins; b += 256)
         gc[(uint64_t)b * bp.nwg + wg] = (uint16_t)min(bin_count[b], bp.cap);
