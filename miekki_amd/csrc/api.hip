@@ -134,24 +134,27 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes)
 {
     if (!c->d_code_off) MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
-    const uint64_t code_bytes = seq_bytes / 2 + 16ull * (kBuildBatch + 1) + 64;
+    if (!c->d_dirty) MK_TRY(dev_alloc(&c->d_dirty, kBuildBatch));
+    const uint64_t code_bytes = seq_bytes / 2 + 32ull * (kBuildBatch + 1) + 64;
     if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
         MK_HIP(hipStreamSynchronize(c->stream));
-        dev_free(c->d_codes);
+        dev_free(c->d_codes); dev_free(c->d_codes2);
         c->codes_cap = 0;
         MK_TRY(dev_alloc(&c->d_codes, code_bytes + code_bytes / 4));
+        MK_TRY(dev_alloc(&c->d_codes2, (code_bytes + code_bytes / 4) / 2 + 64));   // 2-bit forward codes, at half the offsets
         c->codes_cap = code_bytes + code_bytes / 4;
     }
     return MK_OK;
 }
 
-// offsets of the sequences' code arrays inside d_codes: 8-byte aligned, 8 bytes of slack each
+// offsets of the sequences' code arrays inside d_codes: 16-byte aligned (so that half of one, the offset into
+// the 2-bit array d_codes2, is 8-byte aligned), at least 8 bytes of slack each
 int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n)
 {
     uint64_t code_off[kBuildBatch + 1];
     code_off[0] = 0;
     for (uint32_t g = 0; g < n; ++g)
-        code_off[g + 1] = (code_off[g] + (h_off[g + 1] - h_off[g] + 1) / 2 + 8 + 7) / 8 * 8;
+        code_off[g + 1] = (code_off[g] + (h_off[g + 1] - h_off[g] + 1) / 2 + 16 + 15) / 16 * 16;
     MK_HIP(hipMemcpyAsync(c->d_code_off, code_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     return MK_OK;
 }
@@ -679,7 +682,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
     c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
-    c->d_codes = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
+    c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
@@ -723,7 +726,7 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
-    dev_free(c->d_codes); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
+    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_dirty); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
     dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);

@@ -70,6 +70,35 @@ MK_HD uint32_t mantis(uint64_t n, uint32_t h, uint32_t f, uint32_t empty)
     return (uint32_t)(suffix + ((uint64_t)e << f)) & empty;
 }
 
+// The same fingerprint from the two 32-bit halves of n with 32-bit operations only (64-bit shifts
+// and adds cost two to four issue slots each on CDNA; the build's hash loop is issue-bound).
+// funnel(hi, lo, s) = low word of ({hi, lo} >> s), 0 < s < 32.
+MK_HD uint32_t funnel_shift(uint32_t hi, uint32_t lo, uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+MK_HD uint32_t mantis_halves(uint32_t nhi, uint32_t nlo, uint32_t h, uint32_t f, uint32_t empty)
+{
+    if ((nhi | nlo) == 0) return empty;
+    uint32_t prefix, top;                      // top: n shifted up so that its leading one sits at bit 31
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nhi) { const uint32_t lz = (uint32_t)__clz((int)nhi); prefix = 63u - lz; top = lz ? funnel_shift(nhi, nlo, 32u - lz) : nhi; }
+    else     { const uint32_t lz = (uint32_t)__clz((int)nlo); prefix = 31u - lz; top = nlo << lz; }
+#else
+    if (nhi) { const uint32_t lz = (uint32_t)__builtin_clz(nhi); prefix = 63u - lz; top = lz ? funnel_shift(nhi, nlo, 32u - lz) : nhi; }
+    else     { const uint32_t lz = (uint32_t)__builtin_clz(nlo); prefix = 31u - lz; top = nlo << lz; }
+#endif
+    const int e = (int)prefix - 32 + (int)h;
+    uint32_t suffix;
+    if (prefix >= f) suffix = (top << 1) >> (32u - f);         // the f bits below the leading one
+    else suffix = nlo - (1u << prefix);                        // fewer than f bits exist (n < 2^f): all of them
+    return (suffix + ((uint32_t)(e < 0 ? 0 : e) << f)) & empty;
+}
+
 // anc -> (bucket, fingerprint)  (Miekki.cpp:169-171)
 MK_HD void bucket_fp(uint64_t anc, uint32_t h, uint32_t f, uint32_t empty, uint32_t &bucket,
                      uint32_t &fp)

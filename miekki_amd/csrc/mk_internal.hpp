@@ -86,6 +86,8 @@ struct mk_ctx {
     // binned sketch for the Bloom pass: 2.5 MB per 5 Mb genome, which stays in one XCD's L2
     // while that genome's winners are looked up (the characters, 5 MB, do not)
     uint8_t *d_codes;
+    uint8_t *d_codes2;             // the same positions as 2-bit forward codes (enough for plain ACGT genomes), at half the offsets
+    uint32_t *d_dirty;             // per batch genome: some character is not A, C, G or T (the 4-bit codes are needed)
     uint64_t codes_cap;            // bytes
     uint64_t *d_code_off;          // kBuildBatch + 1 byte offsets (8-byte aligned)
     // one bit per 8 Bloom cells: all eight are non-zero (so none of them can change any more).

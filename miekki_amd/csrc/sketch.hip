@@ -117,6 +117,27 @@ __device__ __forceinline__ uint64_t canon_from_codes(const uint8_t *__restrict__
     return S < RC ? S : RC;
 }
 
+// The build's Bloom pass is bound by the L2's request rate (one request per lane-load): for
+// sequences made of A, C, G, T only -- the reverse-strand code is then always 3 - forward code --
+// the forward codes alone, 2 bits per position, say it all, and a k-mer (62 bits) is ONE 16-byte
+// load from an 8-byte boundary instead of two loads from the 4-bit array.  The scatter kernel
+// writes this second array and flags every genome that has any other character (N, lower case:
+// those keep the 4-bit path).
+__device__ __forceinline__ uint64_t canon_from_codes2(const uint8_t *__restrict__ codes2, uint64_t pos, uint32_t k)
+{
+    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(codes2) + (pos >> 5);
+    const uint32_t sh = (uint32_t)(pos & 31u) * 2u;
+    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
+    const u64x2_a8 x = *reinterpret_cast<const u64x2_a8 *>(w);
+    const uint64_t kmask = (1ULL << (2 * k)) - 1;
+    const uint64_t F = (sh ? (x.x >> sh) | (x.y << (64 - sh)) : x.x) & kmask;      // digit j of the k-mer at bits 2j
+    const uint64_t RC = ~F & kmask;                                                // 3 - digit, as update_kmer_RC leaves it
+    uint64_t r = __builtin_bitreverse64(F);
+    r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
+    const uint64_t S = r >> (64 - 2 * k);
+    return S < RC ? S : RC;
+}
+
 // ---------------------------------------------------------------- seed validity
 __global__ void seed_valid_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
                                   uint32_t n, uint32_t k, uint32_t *__restrict__ valid)
@@ -229,6 +250,7 @@ constexpr uint32_t kOvfCap = 1u << 20;
 struct BinParams {
     uint32_t nbins, low_bits, cap, nwg;           // low_bits = min(h, 13); nwg = workgroups per genome
     uint64_t slots_per_genome;                    // nbins * nwg * cap
+    uint32_t tune;                                // timing experiments only (MIEKKI_TUNE_SCATTER): 1 no slot stores, 2 no hashing
 };
 
 // item = fingerprint << 48 | position << 13 | partition-within-bin
@@ -265,6 +287,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
                                                           uint16_t *__restrict__ slot_counts,
                                                           uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count,
                                                           uint8_t *__restrict__ packed, const uint64_t *__restrict__ code_off,
+                                                          uint8_t *__restrict__ packed2, uint32_t *__restrict__ dirty,
                                                           SketchParams sp, BinParams bp)
 {
     static_assert(kPerThread == 16 && kSegKmers == 256 * kPerThread, "one 64-bit word of 4-bit codes per thread");
@@ -306,13 +329,26 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
         // pass reads back for the winners.  The k-1 characters past them belong to the next
         // workgroup -- or to this one if it is the sequence's last.
         uint64_t *__restrict__ dst = packed ? reinterpret_cast<uint64_t *>(packed + code_off[g] + seg0 / 2) : nullptr;
+        // ... and once more as 2-bit forward codes (canon_from_codes2), with the genome flagged as soon
+        // as one position is not plain A, C, G, T (reverse code != 3 - forward code)
+        uint32_t *__restrict__ dst2 = packed2 ? reinterpret_cast<uint32_t *>(packed2 + code_off[g] / 2 + seg0 / 4) : nullptr;
+        auto emit = [&](uint32_t w, uint64_t word) {
+            if (dst) dst[w] = word;
+            if (dst2) {
+                const uint32_t f2 = pairs(word), r2 = pairs(word >> 2);
+                dst2[w] = f2;
+                const uint32_t nd = min(16u, nchar - 16u * w);
+                const uint32_t m = nd == 16u ? 0xffffffffu : (1u << (2u * nd)) - 1u;
+                if (((f2 ^ r2) & m) != m) atomicOr(&dirty[g], 1u);
+            }
+        };
         const uint64_t mine = pack_word(tid);
         pk[tid] = mine;
-        if (dst && 16u * tid < nchar) dst[tid] = mine;
+        if (16u * tid < nchar) emit(tid, mine);
         if (tid < 2) {
             const uint64_t extra = pack_word(256 + tid);
             pk[256 + tid] = extra;
-            if (dst && seg0 + cnt == nk && kSegKmers + 16u * tid < nchar) dst[256 + tid] = extra;
+            if (seg0 + cnt == nk && kSegKmers + 16u * tid < nchar) emit(256 + tid, extra);
         }
     }
     __syncthreads();
@@ -322,7 +358,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
     uint64_t reg[kPerThread];
 #pragma unroll
     for (uint32_t u = 0; u < kPerThread; ++u) reg[u] = ~0ULL;
-    if (i0 < cnt) {
+    if (i0 < cnt && bp.tune != 2) {
         const uint64_t w0 = pk[tid], w1 = pk[tid + 1], w2 = pk[tid + 2];
         // digit j of the thread's 48 positions at bits 2j: forward codes (F) and reverse-strand codes (R)
         const uint64_t F = ((uint64_t)pairs(w1) << 32) | pairs(w0), R = ((uint64_t)pairs(w1 >> 2) << 32) | pairs(w0 >> 2);
@@ -332,26 +368,40 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
         // state after the k-1 seed digits, as the reference's loop leaves it (Miekki.cpp:158-164)
         uint64_t r = __builtin_bitreverse64(F & seedmask);
         r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
-        uint64_t S = r >> (64 - 2 * km1);
-        uint64_t RC = (R & seedmask) << 2;
+        const uint64_t S0 = r >> (64 - 2 * km1), RC0 = (R & seedmask) << 2;
         // the sixteen digits that enter, one per k-mer
         const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)F2 << (64 - 2 * km1)));
         const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
-        const uint32_t topshift = 2 * sp.k - 2;
+        // The rolling state lives in 32-bit halves: a 64-bit shift / add / and is two to four issue
+        // slots on this hardware, a funnel shift (v_alignbit) is one, and the loop is issue-bound.
+        uint32_t Slo = (uint32_t)S0, Shi = (uint32_t)(S0 >> 32), Rlo = (uint32_t)RC0, Rhi = (uint32_t)(RC0 >> 32);
+        const uint32_t mlo = (uint32_t)sp.kmask, mhi = (uint32_t)(sp.kmask >> 32);
+        const uint32_t topshift = 2 * sp.k - 2;                   // even: the entering reverse digit lies within ONE half
+        const bool top_hi = topshift >= 32;
+        const uint32_t tsh = top_hi ? topshift - 32 : topshift;
         const uint32_t lowmask = (1u << bp.low_bits) - 1u;
+        const uint32_t vmask_hi = (1u << (32 - sp.h)) - 1u;       // h <= 28: the fingerprint's operand is anc's low 64-h bits
 #pragma unroll
         for (uint32_t u = 0; u < kPerThread; ++u) {
-            S = ((S << 2) | ((fnew >> (2 * u)) & 3u)) & sp.kmask;               // update_kmer, Miekki.cpp:51-55
-            RC = (RC >> 2) | ((uint64_t)((rnew >> (2 * u)) & 3u) << topshift);  // update_kmer_RC, Miekki.cpp:59-62
+            Shi = (funnel_shift(Shi, Slo, 30) ) & mhi;                          // update_kmer, Miekki.cpp:51-55
+            Slo = ((Slo << 2) | ((fnew >> (2 * u)) & 3u)) & mlo;
+            Rlo = funnel_shift(Rhi, Rlo, 2);                                    // update_kmer_RC, Miekki.cpp:59-62
+            Rhi >>= 2;
+            const uint32_t rd = ((rnew >> (2 * u)) & 3u) << tsh;
+            if (top_hi) Rhi |= rd; else Rlo |= rd;
+            const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
             const uint64_t anc = revhash64(S < RC ? S : RC);
-            uint32_t bucket, fp;
-            bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+            const uint32_t ahi = (uint32_t)(anc >> 32);
+            const uint32_t bucket = ahi >> (32 - sp.h);                         // Miekki.cpp:169
+            const uint32_t fp = mantis_halves(ahi & vmask_hi, (uint32_t)anc, sp.h, sp.f, sp.empty);
             if (fp == sp.empty || i0 + u >= cnt) continue;          // (past the segment's end only in a sequence's last workgroup)
             const uint32_t bin = bucket >> bp.low_bits;
             const uint32_t rank = atomicAdd(&bin_count[bin], 1u);
             if (rank < bp.cap) {
-                reg[u] = ((uint64_t)fp << 48) | ((uint64_t)rank << 35) | ((uint64_t)bin << 25) | ((uint64_t)(i0 + u) << kBinBits) |
-                         (bucket & lowmask);
+                // two words built side by side: fingerprint << 16 | rank << 3 | bin >> 7   and   bin << 25 | position << 13 | partition
+                const uint32_t hi32 = (fp << 16) | (rank << 3) | (bin >> 7);
+                const uint32_t lo32 = (bin << 25) | ((i0 + u) << kBinBits) | (bucket & lowmask);
+                reg[u] = ((uint64_t)hi32 << 32) | lo32;
             } else {                                                // slot full (very repetitive sequence): overflow list
                 const uint32_t o = atomicAdd(ovf_count, 1u);
                 if (o < kOvfCap) {
@@ -406,7 +456,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
             const uint32_t bin = (uint32_t)(it >> 25) & 1023u, rank = (uint32_t)(it >> 35) & 4095u;
             const uint64_t pos = seg0 + ((uint32_t)(it >> kBinBits) & 4095u);
             // consecutive i of one bin are consecutive ranks: consecutive lanes write consecutive words
-            gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
+            if (bp.tune != 1)
+                gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
         }
         __syncthreads();
     }
@@ -485,6 +536,7 @@ template <int W>
 __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
     const uint64_t *__restrict__ slots, const uint16_t *__restrict__ slot_counts, const uint64_t *__restrict__ ovf,
     const uint32_t *__restrict__ ovf_count, const uint8_t *__restrict__ codes, const uint64_t *__restrict__ code_off,
+    const uint8_t *__restrict__ codes2, const uint32_t *__restrict__ dirty,
     const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order, const uint32_t *__restrict__ full,
     uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables, uint8_t *__restrict__ posted_blk,
     uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum, SketchParams sp, BinParams bp)
@@ -541,6 +593,8 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
     uint32_t posted_mask = 0, act = 0;
     unsigned long long card = 0;
     const uint8_t *__restrict__ gcodes = codes + code_off[g];
+    const uint8_t *__restrict__ gcodes2 = codes2 + code_off[g] / 2;
+    const bool plain_acgt = dirty[g] == 0;                           // workgroup-uniform
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) {
         const uint32_t i = threadIdx.x + 1024u * j;
@@ -555,7 +609,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
         if (!bloom) continue;
         // pass A of the Bloom insert for this winner (see bloom_kernel<false>)
         const uint64_t pos = (it >> kBinBits) & ((1ULL << kItemPosBits) - 1);
-        const uint64_t cn = canon_from_codes(gcodes, pos, sp.k);
+        const uint64_t cn = plain_acgt ? canon_from_codes2(gcodes2, pos, sp.k) : canon_from_codes(gcodes, pos, sp.k);
         canon[j] = cn;
         const uint64_t anc = revhash64(cn);
         const uint32_t p = bin * R + i;
@@ -657,6 +711,8 @@ static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams 
     bp.cap = bp.nbins == 1 ? kSegKmers
                            : std::min<uint32_t>(kSegKmers, (uint32_t)((mean + 6.0 * std::sqrt(mean) + 8.0 + 7.0) / 8.0) * 8u);
     bp.slots_per_genome = (uint64_t)bp.nbins * bp.nwg * bp.cap;
+    bp.tune = 0;
+    if (const char *e = getenv("MIEKKI_TUNE_SCATTER")) bp.tune = (uint32_t)atoi(e);   // timing experiments (results are wrong)
     if ((uint64_t)bp.nwg * bp.cap >= (1u << 24)) return MK_OK;     // the scatter kernel's 24-bit slot arithmetic
     const uint64_t need = bp.slots_per_genome * n;
     if (need * 8 > (12ull << 30)) return MK_OK;                    // slot memory budget
@@ -694,7 +750,7 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
                        c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, write_codes ? c->d_codes : nullptr,
-                       c->d_code_off, sp, bp);
+                       c->d_code_off, (uint8_t *)nullptr, (uint32_t *)nullptr, sp, bp);
     hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
                        c->d_slot_counts, d_tables, sp, bp);
     hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
@@ -732,21 +788,23 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
         MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
     MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
+    MK_HIP(hipMemsetAsync(c->d_dirty, 0, kBuildBatch * sizeof(uint32_t), c->stream));
     MK_HIP(hipMemsetAsync(c->d_active, 0, kBuildBatch * sizeof(uint32_t), c->stream));
     MK_HIP(hipMemsetAsync(c->d_cardsum, 0, kBuildBatch * sizeof(uint64_t), c->stream));
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
-                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, sp, bp);
+                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
+                       sp, bp);
     if (c->W == 1)
         hipLaunchKernelGGL(bin_reduce_build_kernel<1>, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
-                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_bloom,
-                           c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_posted_blk,
-                           c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
+                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
+                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables,
+                           c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
     else
         hipLaunchKernelGGL(bin_reduce_build_kernel<2>, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
-                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_bloom,
-                           c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_posted_blk,
-                           c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
+                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
+                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables,
+                           c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
     const uint32_t rows = 1024 / c->W;
     if (c->W == 1)
         hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(256), 0, c->stream, c->d_fpT, n, g0,
