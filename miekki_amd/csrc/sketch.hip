@@ -250,7 +250,6 @@ constexpr uint32_t kOvfCap = 1u << 20;
 struct BinParams {
     uint32_t nbins, low_bits, cap, nwg;           // low_bits = min(h, 13); nwg = workgroups per genome
     uint64_t slots_per_genome;                    // nbins * nwg * cap
-    uint32_t tune;                                // timing experiments only (MIEKKI_TUNE_SCATTER): 1 no slot stores, 2 no hashing
 };
 
 // item = fingerprint << 48 | position << 13 | partition-within-bin
@@ -274,13 +273,13 @@ __device__ __forceinline__ uint32_t squeeze8(uint64_t x)
 // -- a counting sort whose rank is the LDS atomic the slot position needs anyway -- and writes each
 // bin's run with consecutive lanes: ~32 items = 256 contiguous bytes, four 64-byte requests
 // instead of 32.  The items wait in registers (16 per thread) while the bin counts settle, and go
-// through a 2048-entry stage in two rounds, so that five workgroups still fit a CU.
+// through a 1024-entry stage in four rounds, so that eight workgroups fit a CU.
 // Arithmetic: a character is classified by ONE look-up in a 256-entry LDS table (the compare
 // chains of nuc2int / nuc2intrc cost ~55 instructions per character), the codes are packed 16 per
 // 64-bit word, and a thread fetches its 16 + k-1 positions as three words: the k-1 seed digits and
 // the sixteen incoming digits come out of registers with a handful of shifts (`pairs`, one bit
 // reversal) instead of k-1 + 16 LDS reads and a 30-step seed loop per thread.
-__global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict__ seq,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bin_scatter_kernel(const char *__restrict__ seq,
                                                           const uint64_t *__restrict__ off,
                                                           const uint32_t *__restrict__ valid,
                                                           uint64_t *__restrict__ slots,
@@ -292,7 +291,11 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
 {
     static_assert(kPerThread == 16 && kSegKmers == 256 * kPerThread, "one 64-bit word of 4-bit codes per thread");
     constexpr uint32_t kWords = kSegKmers / 16 + 2;                  // words a workgroup's threads look at
-    constexpr uint32_t kStage = 2048;                                // items per write-out round
+    // items per write-out round.  Measured (round 2, 64 x 5 Mb per batch): 4096 (one round, 3 workgroups
+    // per CU) 15.9k sketches/s, 2048 17.7k, 1024 with the registers held to 64 (8 workgroups per CU, the
+    // most the SIMDs take) 19.6k: the kernel lives on occupancy -- its LDS atomics and barriers are
+    // latency, not throughput -- and the extra rounds cost less than the waves they make room for
+    constexpr uint32_t kStage = 1024;
     __shared__ __attribute__((aligned(16))) uint64_t stage[kStage];  // first the character codes, later the sorted items
     __shared__ uint64_t pk[kWords + 2];
     __shared__ uint32_t bin_count[kMaxBins];
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
     uint64_t reg[kPerThread];
 #pragma unroll
     for (uint32_t u = 0; u < kPerThread; ++u) reg[u] = ~0ULL;
-    if (i0 < cnt && bp.tune != 2) {
+    if (i0 < cnt) {
         const uint64_t w0 = pk[tid], w1 = pk[tid + 1], w2 = pk[tid + 2];
         // digit j of the thread's 48 positions at bits 2j: forward codes (F) and reverse-strand codes (R)
         const uint64_t F = ((uint64_t)pairs(w1) << 32) | pairs(w0), R = ((uint64_t)pairs(w1 >> 2) << 32) | pairs(w0 >> 2);
@@ -456,8 +459,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const char *__restrict
             const uint32_t bin = (uint32_t)(it >> 25) & 1023u, rank = (uint32_t)(it >> 35) & 4095u;
             const uint64_t pos = seg0 + ((uint32_t)(it >> kBinBits) & 4095u);
             // consecutive i of one bin are consecutive ranks: consecutive lanes write consecutive words
-            if (bp.tune != 1)
-                gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
+            gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
         }
         __syncthreads();
     }
@@ -711,8 +713,6 @@ static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams 
     bp.cap = bp.nbins == 1 ? kSegKmers
                            : std::min<uint32_t>(kSegKmers, (uint32_t)((mean + 6.0 * std::sqrt(mean) + 8.0 + 7.0) / 8.0) * 8u);
     bp.slots_per_genome = (uint64_t)bp.nbins * bp.nwg * bp.cap;
-    bp.tune = 0;
-    if (const char *e = getenv("MIEKKI_TUNE_SCATTER")) bp.tune = (uint32_t)atoi(e);   // timing experiments (results are wrong)
     if ((uint64_t)bp.nwg * bp.cap >= (1u << 24)) return MK_OK;     // the scatter kernel's 24-bit slot arithmetic
     const uint64_t need = bp.slots_per_genome * n;
     if (need * 8 > (12ull << 30)) return MK_OK;                    // slot memory budget
