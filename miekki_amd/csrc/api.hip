@@ -94,6 +94,15 @@ static int use_device(const mk_ctx *cc, bool settle = true)
 }
 
 // ---- matrix capacity -----------------------------------------------------------
+// rows that fit the matrix's HBM budget at pitch ld: all P, or a multiple of P / 64 (so that every
+// partition range of the slab schedule, S <= 64, is hot or cold as a whole)
+static uint32_t hot_rows_for(const mk_ctx *c, uint64_t ld, uint64_t budget)
+{
+    if (!budget || (uint64_t)c->P * ld <= budget) return c->P;
+    const uint32_t unit = std::max<uint32_t>(1, c->P / 64);
+    return (uint32_t)std::min<uint64_t>(c->P, budget / ld / unit * unit);
+}
+
 static int ensure_capacity(mk_ctx *c, uint32_t need)
 {
     if (need <= c->capG) return MK_OK;
@@ -101,30 +110,63 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     cap = std::min<uint64_t>(cap, 0xffffff00ull);
     uint64_t ld = (cap * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
     cap = ld / c->W;
-    uint8_t *nM = nullptr;
+    uint8_t *nM = nullptr, *nH = nullptr;
     uint32_t *nss = nullptr;
     uint64_t *ngs = nullptr;
-    if (hipMalloc((void **)&nM, (uint64_t)c->P * ld) != hipSuccess) {
-        // the doubled matrix does not fit beside the old one: take exactly what is needed
+    uint32_t P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
+    if (P_hot < c->P) {                                            // over budget at the doubled size: take exactly what is needed
+        ld = ((uint64_t)need * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
+        cap = ld / c->W;
+        P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
+    }
+    if (hipMalloc((void **)&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)) != hipSuccess) {
+        // the doubled matrix does not fit beside the old one: take exactly what is needed, and if
+        // even that does not fit the free memory, keep the rows that do and put the rest in host memory
         (void)hipGetLastError();
         ld = ((uint64_t)need * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
         cap = ld / c->W;
-        MK_TRY(dev_alloc(&nM, (uint64_t)c->P * ld));
+        P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
+        if (hipMalloc((void **)&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            size_t free_b = 0, total_b = 0;
+            MK_HIP(hipMemGetInfo(&free_b, &total_b));
+            P_hot = hot_rows_for(c, ld, (uint64_t)free_b * 3 / 4);
+            MK_TRY(dev_alloc(&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)));
+        }
     }
+    if (P_hot < c->P)                                              // cold rows: page-locked host memory the GPU can address
+        if (hipHostMalloc((void **)&nH, (uint64_t)(c->P - P_hot) * ld, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            dev_free(nM);
+            set_error("matrix of %llu bytes exceeds its HBM budget and the cold rows (%llu bytes) do not fit page-locked host memory",
+                      (unsigned long long)c->P * ld, (unsigned long long)(c->P - P_hot) * ld);
+            return MK_ERR_NOMEM;
+        }
     if (dev_alloc(&nss, cap) != MK_OK || dev_alloc(&ngs, cap) != MK_OK) {
         dev_free(nM); dev_free(nss); dev_free(ngs);
+        if (nH) (void)hipHostFree(nH);
         return MK_ERR_NOMEM;
     }
-    MK_HIP(hipMemsetAsync(nM, 0, (uint64_t)c->P * ld, c->stream));
+    MK_HIP(hipMemsetAsync(nM, 0, std::max<uint64_t>((uint64_t)P_hot * ld, 16), c->stream));
+    if (nH) memset(nH, 0, (uint64_t)(c->P - P_hot) * ld);
     if (c->G) {
-        MK_HIP(hipMemcpy2DAsync(nM, ld, c->d_M, c->ld, (size_t)c->G * c->W, c->P, hipMemcpyDeviceToDevice,
-                                c->stream));
+        // old row p -> new row p, whichever side either lives on
+        const size_t w = (size_t)c->G * c->W;
+        auto old_row = [&](uint32_t p) { return p < c->P_hot ? c->d_M + (uint64_t)p * c->ld : c->h_M + (uint64_t)(p - c->P_hot) * c->ld; };
+        auto new_row = [&](uint32_t p) { return p < P_hot ? nM + (uint64_t)p * ld : nH + (uint64_t)(p - P_hot) * ld; };
+        const uint32_t cuts[4] = {0, std::min(c->P_hot, P_hot), std::max(c->P_hot, P_hot), c->P};
+        for (int i = 0; i < 3; ++i)
+            if (cuts[i + 1] > cuts[i])
+                MK_HIP(hipMemcpy2DAsync(new_row(cuts[i]), ld, old_row(cuts[i]), c->ld, w, cuts[i + 1] - cuts[i], hipMemcpyDefault,
+                                        c->stream));
         MK_HIP(hipMemcpyAsync(nss, c->d_sketch_size, (size_t)c->G * 4, hipMemcpyDeviceToDevice, c->stream));
         MK_HIP(hipMemcpyAsync(ngs, c->d_genome_size, (size_t)c->G * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     MK_HIP(hipStreamSynchronize(c->stream));
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size);
-    c->d_M = nM; c->d_sketch_size = nss; c->d_genome_size = ngs;
+    if (c->h_M) (void)hipHostFree(c->h_M);
+    dev_free(c->d_cold_stage); c->cold_stage_rows = 0;             // sized for the old pitch
+    c->d_M = nM; c->h_M = nH; c->P_hot = P_hot; c->d_sketch_size = nss; c->d_genome_size = ngs;
     c->ld = ld; c->capG = (uint32_t)cap;
     return MK_OK;
 }
@@ -576,7 +618,7 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     for (uint32_t q = q0; q < q1; q += per_launch) {
         const uint32_t n = std::min(per_launch, q1 - q);
         ScanArgs a;
-        a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
+        a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
         a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_scan_n;
         a.scores = d_scores + (uint64_t)(q - q0) * lay.q_stride;
         a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
@@ -587,7 +629,7 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         // the sparse kernel has just written zero rows for the dense queries (scan_n = 0);
         // the dense kernel adds their scores, up to eight queries per pass over the matrix
         DenseArgs d;
-        d.M = c->d_M; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
+        d.M = c->d_M; d.Mc = mat_ref(c).cold_m; d.P_hot = c->P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
         d.rows_per_item = std::min<uint32_t>(c->P, 8192);
         d.nchunks = (c->P + d.rows_per_item - 1) / d.rows_per_item;
         d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
@@ -624,12 +666,51 @@ static int ensure_partials(mk_ctx *c, uint64_t bytes)
 static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
 {
     SlabArgs a;
-    a.M = c->d_M; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c); a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S;
+    a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c);
+    a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S; a.r_begin = 0; a.r_count = qs->S;
     a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
     a.chunk = qs->chunk; a.nent = qs->d_scan_n;
     c->stats.scan_slab_launches++;
-    ScopedTimer t(c, 1);
-    return launch_scan_slab(c, a);
+    const uint32_t rows_per_range = qs->S ? c->P / qs->S : c->P;
+    if (!c->h_M || qs->chunk || qs->S < 2 || rows_per_range == 0 || c->P_hot % rows_per_range) {
+        // everything in HBM -- or ranges cut by count (small sets), which do not map to partition
+        // ranges: cold rows, if any, are then read in place over PCIe
+        ScopedTimer t(c, 1);
+        return launch_scan_slab(c, a);
+    }
+    // Cold partition ranges are STREAMED: a range's rows are copied once into a staging buffer in
+    // HBM and every query of the chunk scans them there, instead of each wave fetching its 1 KiB
+    // pieces over PCIe.  (P_hot is a multiple of P / 64, so a range is hot or cold as a whole.)
+    const uint32_t S_hot = c->P_hot / rows_per_range;
+    if (S_hot) {
+        a.r_begin = 0; a.r_count = S_hot;
+        ScopedTimer t(c, 1);
+        MK_TRY(launch_scan_slab(c, a));
+    }
+    if (!c->d_cold_stage) {
+        // as many ranges as fit an eighth of the hot part (at least one range, at most all cold rows)
+        uint64_t rows = std::max<uint64_t>(rows_per_range, (uint64_t)c->P_hot / 8 / rows_per_range * rows_per_range);
+        rows = std::min<uint64_t>(rows, c->P - c->P_hot);
+        MK_TRY(dev_alloc(&c->d_cold_stage, rows * c->ld));
+        c->cold_stage_rows = rows;
+    }
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, c->cold_stage_rows / rows_per_range);
+    for (uint32_t r = S_hot; r < qs->S; r += per) {
+        const uint32_t nr = std::min(per, qs->S - r);
+        const uint64_t first = (uint64_t)r * rows_per_range;
+        if ((uint64_t)nr * rows_per_range > c->cold_stage_rows) {   // a range larger than the stage (huge P / S): in place
+            a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot;
+        } else {
+            MK_HIP(hipMemcpyAsync(c->d_cold_stage, c->h_M + (first - c->P_hot) * c->ld, (uint64_t)nr * rows_per_range * c->ld,
+                                  hipMemcpyHostToDevice, c->stream));
+            // row p of these ranges now lives at stage + (p - first) * ld: present the stage as "the matrix"
+            a.M = c->d_cold_stage - first * c->ld; a.Mc = nullptr; a.P_hot = c->P;
+        }
+        a.r_begin = r; a.r_count = nr;
+        ScopedTimer t(c, 1);
+        MK_TRY(launch_scan_slab(c, a));
+    }
+    return MK_OK;
 }
 
 // entrants of filter_results' heap for the rows in d_scores (see select.hip)
@@ -678,6 +759,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->P = 1u << p->h; c->W = p->fp_bits / 8; c->f = p->fp_bits - kMantisBits;
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
+    c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
+    if (const char *e = getenv("MIEKKI_HBM_MATRIX_MIB")) { const long v = atol(e); if (v > 0) c->hbm_matrix_budget = (uint64_t)v << 20; }
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
@@ -724,6 +807,8 @@ void mk_destroy(mk_ctx *c)
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
+    if (c->h_M) (void)hipHostFree(c->h_M);
+    dev_free(c->d_cold_stage);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_dirty); dev_free(c->d_code_off); dev_free(c->d_bloom_full);

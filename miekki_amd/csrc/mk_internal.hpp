@@ -42,6 +42,22 @@ struct Timer {
 
 }  // namespace mk
 
+// Where the rows of the fingerprint matrix live (SURVEY 8f row N4 -- what compress_index /
+// decompress_index were for in the reference, Miekki.cpp:863-877: a collection larger than fast
+// memory).  Rows [0, P_hot) are in HBM; when the matrix exceeds its HBM budget the remaining COLD
+// rows sit in page-locked host memory (device-visible).  Kernels address row p through mat_row;
+// the slab schedule streams whole cold partition ranges through a staging buffer in HBM instead
+// of reading them piecemeal over PCIe (api.hip: qset_scan_slab).
+struct MatRef {
+    uint8_t *hot;                  // row p < P_hot at hot + p * ld
+    uint8_t *cold_m;               // row p >= P_hot at cold_m + p * ld (= cold rows' base - P_hot * ld); null when all rows are hot
+    uint32_t P_hot;
+};
+__device__ __forceinline__ uint8_t *mat_row(const MatRef &m, uint32_t p, uint64_t ld)
+{
+    return (p < m.P_hot ? m.hot : m.cold_m) + (uint64_t)p * ld;
+}
+
 struct mk_ctx {
     mk_params p;
     uint32_t P, W, f, empty;
@@ -49,6 +65,11 @@ struct mk_ctx {
     // fingerprint matrix, partition-major: row p at d_M + p * ld (bytes); 16-bit values native LE
     uint8_t *d_M;
     uint64_t ld;
+    uint8_t *h_M;                  // cold rows [P_hot, P) in page-locked host memory, same pitch (null: all rows in HBM)
+    uint32_t P_hot;                // rows kept in HBM (= P when the matrix fits its budget)
+    uint64_t hbm_matrix_budget;    // bytes of HBM the matrix may take (MIEKKI_HBM_MATRIX_MIB; 0 = whatever is free)
+    uint8_t *d_cold_stage;         // HBM staging for cold partition ranges (slab schedule)
+    uint64_t cold_stage_rows;
     uint32_t capG, G;
     uint32_t *d_sketch_size;
     uint64_t *d_genome_size;
@@ -184,6 +205,15 @@ struct mk_qset {
 
 namespace mk {
 
+inline MatRef mat_ref(const mk_ctx *c)
+{
+    MatRef m;
+    m.hot = c->d_M;
+    m.P_hot = c->P_hot;
+    m.cold_m = c->h_M ? c->h_M - (uint64_t)c->P_hot * c->ld : nullptr;
+    return m;
+}
+
 // timing helpers (api.hip)
 int timer_begin(mk_ctx *c, int kind, Timer &t);
 int timer_end(mk_ctx *c, Timer &t);
@@ -228,10 +258,13 @@ int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len,
 int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
                          char *d_out);
 int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging);
+inline MatRef mat_ref(const mk_ctx *c);
 
 // ---- scan.hip
 struct ScanArgs {
     const uint8_t *M;
+    const uint8_t *Mc;             // cold rows (MatRef::cold_m) or null
+    uint32_t P_hot;
     uint64_t ld;
     uint32_t G, ntiles, nq, q_begin;
     const uint64_t *entries;
@@ -245,6 +278,9 @@ int launch_scan(mk_ctx *c, const ScanArgs &a);
 // slab schedule (scan_kernel.hpp: scan_slab_kernel)
 struct SlabArgs {
     const uint8_t *M;
+    const uint8_t *Mc;             // cold rows (MatRef::cold_m) or null
+    uint32_t P_hot;
+    uint32_t r_begin, r_count;     // ranges [r_begin, r_begin + r_count) of the S this launch walks
     uint64_t ld;
     uint32_t G, ntiles, nq, q_begin, S;
     const uint64_t *entries;
@@ -271,6 +307,8 @@ inline ScoreLayout score_layout_tiles(uint32_t W, uint32_t nq)                  
 // dense long queries (scan_kernel.hpp: scan_dense_kernel): adds into the score rows
 struct DenseArgs {
     const uint8_t *M;
+    const uint8_t *Mc;             // cold rows (MatRef::cold_m) or null
+    uint32_t P_hot;
     uint64_t ld;
     uint32_t G, ntiles, P, rows_per_item, nchunks, ngroups;
     const uint8_t *dense;          // [group][P][4] fingerprints (W bytes each), empty = inactive

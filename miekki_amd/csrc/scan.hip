@@ -42,7 +42,7 @@ int launch_scan(mk_ctx *c, const ScanArgs &a)
 
 int launch_scan_slab(mk_ctx *c, const SlabArgs &a)
 {
-    const uint64_t work = (uint64_t)a.ntiles * a.S * a.nq;
+    const uint64_t work = (uint64_t)a.ntiles * a.r_count * a.nq;
     if (work == 0) return MK_OK;
     if (work >= (1ull << 31)) { set_error("scan launch too large"); return MK_ERR_ARG; }
     const uint32_t blocks = (uint32_t)((work + 3) / 4);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restric
 
 int probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes)
 {
-    const uint64_t total = (uint64_t)c->P * c->ld;
+    const uint64_t total = (uint64_t)c->P_hot * c->ld;             // the rows resident in HBM
     *gbps = 0; *bytes = total;
     if (!c->d_M || total < (1ull << 20)) return MK_OK;
     if (!c->d_flag) MK_HIP(hipMalloc((void **)&c->d_flag, 4));

@@ -49,6 +49,15 @@ __device__ __forceinline__ const uint8_t *row_base(const uint8_t *base, uint32_t
     return base + (((uint64_t)hi << 32) | lo);
 }
 
+// the same with the row's home chosen first: rows below P_hot in HBM, the rest in (device-visible)
+// host memory (MatRef).  p is wave-uniform, so the choice is scalar arithmetic too.
+__device__ __forceinline__ const uint8_t *row_base(const uint8_t *hot, const uint8_t *cold, uint32_t P_hot, uint32_t p,
+                                                   uint64_t ld)
+{
+    const uint32_t pu = __builtin_amdgcn_readfirstlane(p);
+    return row_base(pu < P_hot ? hot : cold, pu, ld);
+}
+
 // One work item: query `ql` of the launch against row tile `tile`.
 template <int W, int UNROLL, bool NT>
 __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32_t tile, uint32_t lane)
@@ -63,6 +72,8 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
     const uint32_t n = a.nent[q];
     // scalar row base + 32-bit per-lane offset -> global_load_dwordx4 v, v_off, s[base]
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
+    const uint32_t P_hot = a.P_hot;
     const uint32_t voff = lane * 16u;
     const uint64_t ld = a.ld;
 
@@ -82,7 +93,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
             for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                d[u] = load_row16<NT>(row_base(base, (uint32_t)ev[u], ld) + voff);
+                d[u] = load_row16<NT>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
@@ -99,7 +110,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
             for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                d[u] = load_row16<NT>(row_base(base, (uint32_t)ev[u], ld) + voff);
+                d[u] = load_row16<NT>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const uint32_t keep = j + u < m ? 0xffffffffu : 0u;
@@ -185,9 +196,10 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t work = blockIdx.x * 4u + wave;
-    if (work >= a.ntiles * a.S * a.nq) return;           // wave-uniform exit
-    const uint32_t tr = work / a.nq, ql = work - tr * a.nq;
-    const uint32_t tile = tr / a.S, r = tr - tile * a.S;
+    if (work >= a.ntiles * a.r_count * a.nq) return;     // wave-uniform exit
+    const uint32_t trl = work / a.nq, ql = work - trl * a.nq;
+    const uint32_t tile = trl / a.r_count, r = a.r_begin + (trl - tile * a.r_count);   // this launch walks ranges [r_begin, r_begin + r_count)
+    const uint32_t tr = tile * a.S + r;
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     const uint32_t q = a.q_begin + ql;
     uint32_t lo, hi;
@@ -202,6 +214,8 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
     const uint64_t *__restrict__ e = a.entries + a.ent_off[q] + lo;
     const uint32_t m = hi - lo;
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
+    const uint32_t P_hot = a.P_hot;
     const uint32_t voff = lane * 16u;
     const uint64_t ld = a.ld;
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, (uint32_t)ev[u], ld) + voff);
+        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void scan_slab_kernel(const SlabArgs a)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, (uint32_t)ev[u], ld) + voff);
+        for (int u = 0; u < UNROLL; ++u) d[u] = load_row16<false>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const uint32_t keep = j + u < m ? 0xffffffffu : 0u;           // wave-uniform
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
     if (!any) return;
     const uint32_t row0 = chunk * a.rows_per_item, row1 = min(a.P, row0 + a.rows_per_item);
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
     const uint32_t voff = lane * 16u;
     using fp4_t = typename std::conditional<W == 1, uint32_t, uint2>::type;
     const fp4_t *__restrict__ dv[GB];
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
                 const uint32_t rr = min(r + u, r1 - 1);                   // tail rows repeat the last (masked below)
 #pragma unroll
                 for (uint32_t gb = 0; gb < (uint32_t)GB; ++gb) f[u][gb] = dv[gb][rr];
-                d[u] = load_row16<false>(row_base(base, rr, a.ld) + voff);
+                d[u] = load_row16<false>(row_base(base, cbase, a.P_hot, rr, a.ld) + voff);
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {

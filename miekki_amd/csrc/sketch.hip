@@ -650,7 +650,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
 // partitions, transposed through LDS, 16-byte row pieces out (K2's layout work; its sums are done).
 template <int W>
 __global__ __launch_bounds__(256) void fp_transpose_kernel(const uint8_t *__restrict__ fp_in, uint32_t n, uint32_t g0,
-                                                           uint8_t *__restrict__ M, uint64_t ld,
+                                                           MatRef M, uint64_t ld,
                                                            const uint32_t *__restrict__ ovf_count, SketchParams sp)
 {
     if (*ovf_count > kOvfScan) return;
@@ -681,13 +681,13 @@ __global__ __launch_bounds__(256) void fp_transpose_kernel(const uint8_t *__rest
         const uint32_t vec_per_row = n * W / 16;
         for (uint32_t idx = threadIdx.x; idx < rows * vec_per_row; idx += 256) {
             const uint32_t r = idx / vec_per_row, v = idx - r * vec_per_row;
-            *reinterpret_cast<uint4 *>(M + (uint64_t)(p0 + r) * ld + col0 + v * 16) =
+            *reinterpret_cast<uint4 *>(mat_row(M, p0 + r, ld) + col0 + v * 16) =
                 *reinterpret_cast<const uint4 *>(tile + r * kPitch + v * 16);
         }
     } else {
         for (uint32_t idx = threadIdx.x; idx < rows * n; idx += 256) {
             const uint32_t r = idx / n, g = idx - r * n;
-            *reinterpret_cast<fp_t *>(M + (uint64_t)(p0 + r) * ld + col0 + (uint64_t)g * W) =
+            *reinterpret_cast<fp_t *>(mat_row(M, p0 + r, ld) + col0 + (uint64_t)g * W) =
                 *reinterpret_cast<const fp_t *>(tile + r * kPitch + g * W);
         }
     }
@@ -808,10 +808,10 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
     const uint32_t rows = 1024 / c->W;
     if (c->W == 1)
         hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(256), 0, c->stream, c->d_fpT, n, g0,
-                           c->d_M, c->ld, c->d_ovf_count, sp);
+                           mat_ref(c), c->ld, c->d_ovf_count, sp);
     else
         hipLaunchKernelGGL(fp_transpose_kernel<2>, dim3((c->P + rows - 1) / rows), dim3(256), 0, c->stream, c->d_fpT, n, g0,
-                           c->d_M, c->ld, c->d_ovf_count, sp);
+                           mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
         hipLaunchKernelGGL(bloom_kernel<true>, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables, d_seq, d_off,
                            d_valid, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_ovf_count, c->d_codes,
@@ -836,7 +836,7 @@ constexpr uint32_t kFinTiles = 16;       // tiles per workgroup
 
 template <int W>
 __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t *__restrict__ tables, uint32_t n,
-                                                       uint32_t g0, uint8_t *__restrict__ M, uint64_t ld,
+                                                       uint32_t g0, MatRef M, uint64_t ld,
                                                        uint32_t *__restrict__ active,
                                                        unsigned long long *__restrict__ cardsum,
                                                        const uint32_t *__restrict__ ovf_count, SketchParams sp)
@@ -879,13 +879,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t *__restric
                 alignas(16) fp_t tmp[16 / W];
 #pragma unroll
                 for (uint32_t e = 0; e < 16 / W; ++e) tmp[e] = tile[r][v * (16 / W) + e];
-                *reinterpret_cast<uint4 *>(M + (uint64_t)(p0 + r) * ld + col0 + v * 16) =
+                *reinterpret_cast<uint4 *>(mat_row(M, p0 + r, ld) + col0 + v * 16) =
                     *reinterpret_cast<const uint4 *>(tmp);
             }
         } else {
             for (uint32_t idx = threadIdx.x; idx < rows * n; idx += 256) {
                 const uint32_t r = idx / n, g = idx - r * n;
-                *reinterpret_cast<fp_t *>(M + (uint64_t)(p0 + r) * ld + col0 + (uint64_t)g * W) = tile[r][g];
+                *reinterpret_cast<fp_t *>(mat_row(M, p0 + r, ld) + col0 + (uint64_t)g * W) = tile[r][g];
             }
         }
         __syncthreads();
@@ -904,10 +904,10 @@ int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0
     const uint32_t per_block = kFinRows * kFinTiles;
     const uint32_t blocks = (c->P + per_block - 1) / per_block;
     if (c->W == 1)
-        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, mat_ref(c),
                            c->ld, c->d_active, (unsigned long long *)c->d_cardsum, d_abort, make_sp(c));
     else
-        hipLaunchKernelGGL(finalize_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, c->d_M,
+        hipLaunchKernelGGL(finalize_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d_tables, n, g0, mat_ref(c),
                            c->ld, c->d_active, (unsigned long long *)c->d_cardsum, d_abort, make_sp(c));
     MK_HIP(hipGetLastError());
     return MK_OK;
@@ -1661,14 +1661,14 @@ int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, 
 // ---------------------------------------------------------------- column import / export
 // dense staging [rows][G*W] (reference byte order: 16-bit big-endian) <-> M rows
 template <int W, bool TO_DEVICE>
-__global__ void convert_columns_kernel(uint8_t *__restrict__ M, uint64_t ld, uint32_t G, uint32_t p_begin,
+__global__ void convert_columns_kernel(MatRef M, uint64_t ld, uint32_t G, uint32_t p_begin,
                                        uint32_t rows, uint8_t *__restrict__ staging)
 {
     const uint64_t total = (uint64_t)rows * G;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(idx / G), g = (uint32_t)(idx - (uint64_t)r * G);
-        uint8_t *m = M + (uint64_t)(p_begin + r) * ld + (uint64_t)g * W;
+        uint8_t *m = mat_row(M, p_begin + r, ld) + (uint64_t)g * W;
         uint8_t *s = staging + idx * W;
         if (W == 1) {
             if (TO_DEVICE) *m = *s; else *s = *m;
@@ -1685,7 +1685,7 @@ int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t
     const uint64_t total = (uint64_t)rows * c->G;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 8192);
 #define MK_CONV(Wv, TD)                                                                                 \
-    hipLaunchKernelGGL((convert_columns_kernel<Wv, TD>), dim3(blocks), dim3(256), 0, c->stream, c->d_M, \
+    hipLaunchKernelGGL((convert_columns_kernel<Wv, TD>), dim3(blocks), dim3(256), 0, c->stream, mat_ref(c), \
                        c->ld, c->G, p_begin, rows, d_staging)
     if (c->W == 1) { if (to_device) MK_CONV(1, true); else MK_CONV(1, false); }
     else           { if (to_device) MK_CONV(2, true); else MK_CONV(2, false); }

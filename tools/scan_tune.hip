@@ -209,7 +209,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nent, nent.data(), Q * 4, hipMemcpyHostToDevice));
     ScanArgs a;
-    a.M = M; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
+    a.M = M; a.Mc = nullptr; a.P_hot = 0xffffffffu; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
     a.ntiles = (G + kTileBytes - 1) / kTileBytes;
     a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores;
     const bool tile_major_scores = getenv("SCORES_ROWS") == nullptr;
@@ -237,8 +237,8 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_split, split.data(), split.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc((void **)&d_part, (uint64_t)a.ntiles * slabS * Q * kTileBytes));
     SlabArgs sa;
-    sa.chunk = 0; sa.nent = nullptr;
-    sa.M = M; sa.ld = ld; sa.G = G; sa.ntiles = a.ntiles; sa.nq = Q; sa.q_begin = 0; sa.S = slabS;
+    sa.chunk = 0; sa.nent = nullptr; sa.Mc = nullptr; sa.P_hot = 0xffffffffu; sa.r_begin = 0;
+    sa.M = M; sa.ld = ld; sa.G = G; sa.ntiles = a.ntiles; sa.nq = Q; sa.q_begin = 0; sa.S = slabS; sa.r_count = slabS;
     sa.entries = d_ent; sa.ent_off = d_off; sa.split = d_split; sa.partials = d_part;
     std::vector<float> slab_ms;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
