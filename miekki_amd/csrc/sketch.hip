@@ -649,7 +649,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
 // fp_out[n][P] (genome-major, W bytes) -> M[p][g0 .. g0+n): 16-byte loads of one genome's run of
 // partitions, transposed through LDS, 16-byte row pieces out (K2's layout work; its sums are done).
 template <int W>
-__global__ __launch_bounds__(256) void fp_transpose_kernel(const uint8_t *__restrict__ fp_in, uint32_t n, uint32_t g0,
+__global__ __launch_bounds__(1024) void fp_transpose_kernel(const uint8_t *__restrict__ fp_in, uint32_t n, uint32_t g0,
                                                            MatRef M, uint64_t ld,
                                                            const uint32_t *__restrict__ ovf_count, SketchParams sp)
 {
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void fp_transpose_kernel(const uint8_t *__rest
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t p0 = blockIdx.x * kRows;
     const uint32_t rows = min(kRows, sp.P - p0);
-    for (uint32_t g = wave; g < n; g += 4) {
+    for (uint32_t g = wave; g < n; g += 16) {                       // sixteen waves: the tile is little work, what it needs is loads in flight
         const uint32_t e0 = lane * (16 / W);                       // first partition (within the tile) of this lane
         fp_t v[16 / W];
         if (e0 + 16 / W <= rows) {
@@ -679,13 +679,13 @@ __global__ __launch_bounds__(256) void fp_transpose_kernel(const uint8_t *__rest
     const uint64_t col0 = (uint64_t)g0 * W;
     if (((col0 | ((uint64_t)n * W)) & 15u) == 0) {
         const uint32_t vec_per_row = n * W / 16;
-        for (uint32_t idx = threadIdx.x; idx < rows * vec_per_row; idx += 256) {
+        for (uint32_t idx = threadIdx.x; idx < rows * vec_per_row; idx += 1024) {
             const uint32_t r = idx / vec_per_row, v = idx - r * vec_per_row;
             *reinterpret_cast<uint4 *>(mat_row(M, p0 + r, ld) + col0 + v * 16) =
                 *reinterpret_cast<const uint4 *>(tile + r * kPitch + v * 16);
         }
     } else {
-        for (uint32_t idx = threadIdx.x; idx < rows * n; idx += 256) {
+        for (uint32_t idx = threadIdx.x; idx < rows * n; idx += 1024) {
             const uint32_t r = idx / n, g = idx - r * n;
             *reinterpret_cast<fp_t *>(mat_row(M, p0 + r, ld) + col0 + (uint64_t)g * W) =
                 *reinterpret_cast<const fp_t *>(tile + r * kPitch + g * W);
@@ -807,10 +807,10 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
                            c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
     const uint32_t rows = 1024 / c->W;
     if (c->W == 1)
-        hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(256), 0, c->stream, c->d_fpT, n, g0,
+        hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     else
-        hipLaunchKernelGGL(fp_transpose_kernel<2>, dim3((c->P + rows - 1) / rows), dim3(256), 0, c->stream, c->d_fpT, n, g0,
+        hipLaunchKernelGGL(fp_transpose_kernel<2>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
         hipLaunchKernelGGL(bloom_kernel<true>, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables, d_seq, d_off,
@@ -1621,6 +1621,23 @@ __global__ void synth_genomes_kernel(uint64_t first_id, uint32_t n, uint64_t len
     const uint64_t bits = genome_word(first_id + g, w);
     char *dst = out + (uint64_t)g * len + w * 32;
     const uint32_t m = (uint32_t)min((uint64_t)32, len - w * 32);
+    if (m == 32 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        // 32 characters as two 16-byte stores: 2-bit code c -> 'A' 'C' 'G' 'T' = 0x41 + (0x13060200 >> 8c & 0xff)
+        uint32_t wd[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t cd = (uint32_t)(bits >> (62 - 2 * (4 * j + e))) & 3u;
+                v |= (0x41u + ((0x13060200u >> (8 * cd)) & 0xffu)) << (8 * e);
+            }
+            wd[j] = v;
+        }
+        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+        return;
+    }
     for (uint32_t i = 0; i < m; ++i) dst[i] = "ACGT"[(bits >> (62 - 2 * i)) & 3];
 }
 

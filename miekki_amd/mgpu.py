@@ -75,6 +75,7 @@ def main(argv=None):
     else:
         base, total = 0, len(seqs)
     ix = Miekki(args.k, args.h, 5 + args.f, args.b, int(args.s), device=local, genome_id_base=base)
+    ix.reserve(max(len(seqs), 1))                                # no doubling re-layouts (each holds old and new matrix at once)
     for i in range(0, len(seqs), 64):
         ix.insert_sequences(seqs[i:i + 64])
     del seqs
