@@ -92,6 +92,9 @@ int mk_reset_stats(mk_ctx *ctx);
  * eight in flight per lane) over the resident fingerprint matrix -> GB/s and the bytes one
  * pass read.  The box's own HBM read ceiling, to put beside the 8 TB/s spec figure. */
 int mk_probe_stream_read(mk_ctx *ctx, uint32_t rounds, double *gbps, uint64_t *bytes);
+/* Measurement aid (bench.py's PCIe-fed build sample): the synthetic genomes of SURVEY.md 8d
+ * (ids first_id .., `length` bases each, concatenated) written to host memory dst. */
+int mk_probe_synth_genomes(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length, char *dst);
 
 /* ---- index build --------------------------------------------------------- */
 

@@ -873,6 +873,20 @@ int mk_probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *byt
     return probe_stream_read(c, rounds ? rounds : 3, gbps, bytes);
 }
 
+int mk_probe_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length, char *dst)
+{
+    if (!c || (n && !dst)) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    char *d = nullptr;
+    MK_TRY(dev_alloc(&d, (uint64_t)n * length + 64));
+    int rc = launch_synth_genomes(c, first_id, n, length, d);
+    if (rc == MK_OK && hipMemcpyAsync(dst, d, (uint64_t)n * length, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+    if (rc == MK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+    if (rc == MK_ERR_DEVICE) set_error("synthetic genome download failed");
+    dev_free(d);
+    return rc;
+}
+
 int mk_reset_stats(mk_ctx *c)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }

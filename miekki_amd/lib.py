@@ -48,6 +48,7 @@ SIGNATURES = {
     "mk_get_stats": (i32, [vp, PP(Stats)]),
     "mk_reset_stats": (i32, [vp]),
     "mk_probe_stream_read": (i32, [vp, u32, PP(C.c_double), PP(u64)]),
+    "mk_probe_synth_genomes": (i32, [vp, u64, u32, u64, vp]),
     "mk_index_append": (i32, [vp, vp, vp, u32]),
     "mk_host_alloc": (i32, [vp, u64, PP(vp)]),
     "mk_host_free": (None, [vp, vp]),

@@ -188,6 +188,14 @@ def test_pipelined_appends_from_pinned_buffers(hip):
         assert stream_of(ix) == want
         q = [seqs[5][100:1100], seqs[149][:900]]
         np.testing.assert_array_equal(ix.query_sequences(q), ref.query_sequences(q))
+        # ... and that one build is the oracle's (not merely the HIP path agreeing with itself)
+        from oracle import oracle as orc
+        o = orc.OracleMiekki(k, h, 8, 33, 20)
+        o.insert_sequences(seqs)
+        got = bytearray(stream_of(ix)); exp = bytearray(o.serialize().tobytes())
+        got[32] = exp[32] = 0; got[38] = exp[38] = 0
+        assert bytes(got) == bytes(exp)
+        np.testing.assert_array_equal(ix.query_sequences(q), o.query_sequences(q))
         for p in slots:
             lib.mk_host_free(ix._h, p)
     finally:
