@@ -205,6 +205,30 @@ def make_exact_only(name):
     print(f"{name}: -a -e output {len(txt)}B, {len(txt.splitlines())} lines")
 
 
+def make_out_only(name):
+    """`-l … -a … -o out.txt` (and `-A`) of an EXTRA_CASES entry: only the output files are kept."""
+    case = synth.EXTRA_CASES[name]()
+    cli = os.path.join(REFDIR, "Miekki" + ("16" if case.fp_bits == 16 else ""))
+    with tempfile.TemporaryDirectory(prefix="mkgold_") as d:
+        seen = set()
+        for fn, data, gz in case.genome_files:
+            if fn not in seen:
+                seen.add(fn)
+                with open(os.path.join(d, fn), "wb") as f:
+                    f.write(gzip.compress(data, 1) if gz else data)
+        with open(os.path.join(d, "genomes.lst"), "wb") as f:
+            f.write(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files))
+        with open(os.path.join(d, "queries.fa"), "wb") as f:
+            f.write(b"".join(h + b"\n" + s + b"\n" for h, s in case.queries))
+        base = ["-k", str(case.k), "-h", str(case.h), "-f", str(case.f), "-b", str(case.b),
+                "-s", str(case.threshold), "-t", "1"]
+        run([cli, "-l", "genomes.lst", "-a", "queries.fa", "-o", "out.txt", *base], d)
+        txt = open(os.path.join(d, "out.txt"), "rb").read()
+    with open(os.path.join(HERE, f"{name}_out.txt"), "wb") as f:
+        f.write(txt)
+    print(f"{name}: -a output {len(txt)}B, {len(txt.splitlines())} lines")
+
+
 def make_filter_cases():
     """Synthetic filter_results inputs built to hit heap ties and replacement."""
     rng = np.random.default_rng(20261003)
@@ -235,10 +259,12 @@ def make_filter_cases():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16", "exact:flush"])
+    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16", "exact:flush", "out:dups"])
     for n in names:
         if n == "filter":
             make_filter_cases()
+        elif n.startswith("out:"):
+            make_out_only(n.split(":", 1)[1])
         elif n.startswith("exact:"):
             make_exact_only(n.split(":", 1)[1])
         elif n.startswith("exactA:"):

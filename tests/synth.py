@@ -226,6 +226,26 @@ def case_flush() -> Case:
     return c
 
 
+def case_dups() -> Case:
+    """Three hundred copies of one genome (the same file listed again and again) among a few others: every copy
+    ties with every other, ties REPLACE in the reference's heap (Miekki.cpp:387-391), so each copy is a heap
+    entrant -- far more than an entrant row holds on any shard.  Pins the overflow replays (dense score rows ->
+    the host heap) of the single-context and of the sharded paths to the reference's own tie order."""
+    c = Case("dups", 21, 12, 3, 32, 20)
+    L = 30_000
+    c.genome_files.append(("other0.fa", fasta("other0", genome_bases(810, 0, L)), False))
+    for i in range(300):
+        c.genome_files.append(("dup.fa", fasta("dup", genome_bases(800, 0, L)), False))
+        if i % 97 == 50:
+            c.genome_files.append((f"other{i}.fa", fasta(f"other{i}", genome_bases(811 + i, 0, L)), False))
+    for q in range(12):
+        src = 800 if q % 3 else 810
+        off = splitmix64_int(SEED_Q ^ (12000 + q)) % (L - 2500)
+        c.queries.append((f">d{q}".encode(), genome_bases(src, off, 500 + 150 * q)))
+    c.queries.append((b">whole_dup", genome_bases(800, 0, L)))
+    return c
+
+
 RND_PARAMS = [(15, 10, 3, 32, 5), (27, 16, 11, 33, 30), (31, 13, 3, 33, 0), (9, 8, 3, 32, 12),
               (31, 20, 3, 33, 100), (21, 17, 11, 32, 50)]   # k, h, f, b, threshold
 
@@ -288,7 +308,7 @@ def case_rnd(i: int) -> Case:
 CASES = {"c1": case_c1, "c2mini": case_c2mini, "h16z": case_h16z, "h20": case_h20, "w16": case_w16, "messy": case_messy,
          "rnd0": lambda: case_rnd(0), "rnd1": lambda: case_rnd(1), "rnd2": lambda: case_rnd(2), "rnd3": lambda: case_rnd(3),
          "rnd4": lambda: case_rnd(4), "rnd5": lambda: case_rnd(5)}
-EXTRA_CASES = {"flush": case_flush}
+EXTRA_CASES = {"flush": case_flush, "dups": case_dups}
 # cases whose reference-WRITTEN index file (the CLI's -d output, bytes as the reference's zstr
 # writer made them) is committed as tests/golden/<name>_ref_idx.gz, for the -i loaders
 REF_INDEX_CASES = ("rnd3",)       # exact-mode-only fixtures (tests/golden/<name>_exact.txt)

@@ -39,7 +39,7 @@ def workdirs(tmp_path_factory):
         if name not in dirs:
             case = (synth.CASES.get(name) or synth.EXTRA_CASES[name])()
             d = tmp_path_factory.mktemp(name)
-            for fn, data, gz in case.genome_files:
+            for fn, data, gz in dict((f[0], f) for f in case.genome_files).values():     # (a file may be listed many times)
                 (d / fn).write_bytes(gzip.compress(data, 1) if gz else data)
             (d / "genomes.lst").write_bytes(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files)
                                             + b"missing_file.fa\nab\n")
@@ -110,6 +110,16 @@ def test_several_gpus_in_one_process_like_the_reference(workdirs, golden_dir, na
     if os.path.exists(exa):
         run(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA_m.txt", *base], d, devices)
         assert (d / "exactA_m.txt").read_bytes() == open(exa, "rb").read()
+
+
+@pytest.mark.parametrize("devices", [None, "0,0,0", "0,0,0,0,0,0,0"])
+def test_tie_heavy_collection_overflows_every_entrant_row(workdirs, golden_dir, devices):
+    """`dups`: 300 copies of one genome tie, every copy is a heap entrant, so every entrant row overflows
+    (256 slots on one context, 96 per shard) and the answer comes from the replay over dense score rows --
+    on one context (mk_query) and on three and seven shards (DeviceGroup::replay).  The reference's lines."""
+    case, d, base = workdirs("dups")
+    run(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_d.txt", *base], d, devices)
+    assert (d / "out_d.txt").read_bytes() == open(os.path.join(golden_dir, "dups_out.txt"), "rb").read()
 
 
 @pytest.mark.parametrize("name", synth.REF_INDEX_CASES)

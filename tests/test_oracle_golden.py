@@ -194,3 +194,18 @@ def test_reference_written_index_file_deserialises(built, name):
     again = bytearray(o.serialize().tobytes()); again[32] = 0; again[38] = 0
     assert again == raw
     np.testing.assert_array_equal(o.sketch_size, ix.sketch_size)
+
+
+def test_tie_heavy_collection_matches_reference_cli(golden_dir):
+    """`dups`: 300 copies of one genome -- every copy ties, ties replace in the reference's heap, so the
+    printed ten are decided by its sift sequence alone.  The oracle must print the reference's lines."""
+    case = synth.EXTRA_CASES["dups"]()
+    ix = orc.OracleMiekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+    seqs = case.genome_sequences()
+    for i in range(0, len(seqs), 11):
+        ix.insert_sequences(seqs[i:i + 11])
+    recs = case.query_sequences()
+    scores = ix.query_sequences([s for _, s in recs])
+    got = b"".join(ix.format_query_line(hd, ix.filter_results(scores[q], 10, 10, 0.5 * case.threshold))
+                   for q, (hd, _) in enumerate(recs))
+    assert got == open(os.path.join(golden_dir, "dups_out.txt"), "rb").read()
