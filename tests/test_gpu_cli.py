@@ -22,10 +22,12 @@ def norm(out: bytes) -> bytes:
 
 
 def run(args, cwd, devices=None):
+    """devices: MIEKKI_DEVICES of the run.  None = "0": ONE context on GPU 0, whatever the box has (the binary's
+    own default is every visible GPU; test_every_visible_gpu covers that where there is more than one)."""
     env = dict(os.environ)
-    env.pop("MIEKKI_DEVICES", None)
-    if devices:
-        env["MIEKKI_DEVICES"] = devices
+    env["MIEKKI_DEVICES"] = devices or "0"
+    if devices == "all":
+        env.pop("MIEKKI_DEVICES")
     r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
     assert r.returncode == 0, r.stdout.decode(errors="replace")
     return r.stdout
@@ -110,6 +112,20 @@ def test_several_gpus_in_one_process_like_the_reference(workdirs, golden_dir, na
     if os.path.exists(exa):
         run(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA_m.txt", *base], d, devices)
         assert (d / "exactA_m.txt").read_bytes() == open(exa, "rb").read()
+
+
+def test_every_visible_gpu(workdirs, golden_dir):
+    """The binary's default: one context per VISIBLE GPU, rows exchanged by peer DMA between distinct devices.
+    Needs a box with at least two GPUs (the one-GPU boxes rehearse the path with repeated ordinals above)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    for name in ("h20", "messy", "dups"):
+        case, d, base = workdirs(name)
+        run(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_all.txt", "-d", "idx_all.gz", *base], d, "all")
+        assert (d / "out_all.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+        run(["-i", "idx_all.gz", "-a", "queries.fa", "-o", "out_all_i.txt", "-t", "1"], d, "all")
+        assert (d / "out_all_i.txt").read_bytes() == (d / "out_all.txt").read_bytes()
 
 
 @pytest.mark.parametrize("devices", [None, "0,0,0", "0,0,0,0,0,0,0"])
