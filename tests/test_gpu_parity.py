@@ -402,6 +402,43 @@ def test_config4_full_size_properties(hip):
         ix.close()
 
 
+def test_config5_exact_mode_full_size_properties(hip):
+    """BASELINE config 5 at full size (exact mode: 1,000 synthetic 5 Mb genomes, candidate filter on the GPU +
+    exact k-mer set intersection on the GPU).  As written (-h 17) the candidate stage finds NOTHING -- the
+    config-2 regime: genome_size 0, no estimate reaches the threshold (pinned by c2mini / its empty
+    exact.txt) -- so K7 is never asked; at -h 20 every query's source genome is a candidate and K7 confirms
+    it: |A n B| = all k-mers of the query, |A u B| = the genome's distinct k-mers (+ none), against the oracle
+    for a sample."""
+    from oracle import oracle as orc
+    G, L_, nq = 1000, 5_000_000, 400
+    qs = [synth.genome_bases(*synth.query_origin(q, G, L_, 1000), 1000) for q in range(nq)]
+    ix = hip.Miekki(31, 17, 8, 33, 200)
+    try:
+        ix.reserve(G); ix.insert_synthetic(0, G, L_)
+        hits, _ = ix.query(qs, 5, 10, 200.0)                             # query_file_exact's filter (Miekki.cpp:741)
+        assert all(h == [] for h in hits)
+    finally:
+        ix.close()
+    ix = hip.Miekki(31, 20, 8, 33, 200)
+    try:
+        ix.reserve(G); ix.insert_synthetic(0, G, L_)
+        hits, _ = ix.query(qs, 5, 10, 200.0)
+        assert all(h and h[0].genome == q % G for q, h in enumerate(hits))
+        for g in (0, 7, 399):                                            # verify three genome files' worth of hits
+            fasta = synth.fasta(f"genome{g}", synth.genome_bases(g, 0, L_))
+            mine = [q for q in range(nq) if any(x.genome == g for x in hits[q])]
+            inter, uni = ix.ground_truth_batch([qs[q] for q in mine], fasta)
+            kset = orc.exact_genome_set(fasta, 31) if g == 7 else None
+            for j, q in enumerate(mine):
+                if q % G == g:
+                    assert int(inter[j]) == 1000 - 31 + 1              # every k-mer of the query lies in its source
+                if kset is not None:
+                    assert (int(inter[j]), int(uni[j])) == orc.exact_query(kset, qs[q], 31), q
+            assert mine and 4_999_000 < int(uni[0]) <= L_ - 31 + 1 + 970
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("k,h,fpb,b", [(11, 6, 8, 32), (21, 13, 16, 33), (31, 15, 8, 36), (27, 22, 8, 33), (5, 3, 16, 32)])
 def test_parameter_sweep_against_oracle(hip, k, h, fpb, b):
     """Odd corners of the parameter space (tiny and large h, small k, both widths,
