@@ -171,6 +171,60 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restric
     if (acc == 0x12345678u) *sink = acc;                       // keeps the loads live
 }
 
+// ---- experiment: one wave owns TWO adjacent row tiles of a (query, range): the entry list is walked once per
+// 2 KiB of row instead of once per 1 KiB (half the scalar work and half the waves per byte), 2 x UNROLL loads
+// in flight per wave
+template <int UNROLL>
+__global__ __launch_bounds__(256) void scan_slab2_kernel(const SlabArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    const uint32_t npairs = (a.ntiles + 1) / 2;
+    if (work >= npairs * a.S * a.nq) return;
+    const uint32_t tr = work / a.nq, ql = work - tr * a.nq;
+    const uint32_t pair = tr / a.S, r = tr - pair * a.S;
+    const uint32_t tile0 = 2 * pair, tile1 = 2 * pair + 1;
+    const bool on0 = (uint64_t)tile0 * kTileBytes + lane * 16u < (uint64_t)a.G;
+    const bool on1 = tile1 < a.ntiles && (uint64_t)tile1 * kTileBytes + lane * 16u < (uint64_t)a.G;
+    if (!on0) return;
+    const uint32_t q = a.q_begin + ql;
+    const uint32_t lo = a.split[(uint64_t)q * (a.S + 1) + r], hi = a.split[(uint64_t)q * (a.S + 1) + r + 1];
+    const uint64_t *__restrict__ e = a.entries + a.ent_off[q] + lo;
+    const uint32_t m = hi - lo;
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile0 * kTileBytes;
+    const uint32_t voff = lane * 16u, voff1 = on1 ? voff + kTileBytes : voff;
+    const uint64_t ld = a.ld;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t j = 0; j < m; j += UNROLL) {
+        uint64_t ev[UNROLL];
+        uint4 d0[UNROLL], d1[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint8_t *rb = row_base(base, (uint32_t)ev[u], ld);
+            d0[u] = load_row16<false>(rb + voff);
+            d1[u] = load_row16<false>(rb + voff1);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t keep = j + u < m ? 0xffffffffu : 0u;
+            const uint32_t b = bcast_fp<1>((uint32_t)(ev[u] >> 32));
+            acc[0] += ne_lanes<1>(d0[u].x, b) & keep; acc[1] += ne_lanes<1>(d0[u].y, b) & keep;
+            acc[2] += ne_lanes<1>(d0[u].z, b) & keep; acc[3] += ne_lanes<1>(d0[u].w, b) & keep;
+            acc[4] += ne_lanes<1>(d1[u].x, b) & keep; acc[5] += ne_lanes<1>(d1[u].y, b) & keep;
+            acc[6] += ne_lanes<1>(d1[u].z, b) & keep; acc[7] += ne_lanes<1>(d1[u].w, b) & keep;
+        }
+    }
+    uint8_t *__restrict__ out0 = a.partials + (((uint64_t)tile0 * a.S + r) * a.nq + ql) * kTileBytes + voff;
+    *reinterpret_cast<uint4 *>(out0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    if (on1) {
+        uint8_t *__restrict__ out1 = a.partials + (((uint64_t)tile1 * a.S + r) * a.nq + ql) * kTileBytes + voff;
+        *reinterpret_cast<uint4 *>(out1) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 struct Variant { const char *name; void (*fn)(const ScanArgs); uint32_t blocks_per_cu; uint32_t lane_bytes; };   // blocks_per_cu > 0: sweep grid
 
 #define V(U, O, N) {"u" #U "_o" #O "_nt" #N, scan_kernel<1, U, O, N>, 0, 16}
@@ -277,6 +331,23 @@ int main(int argc, char **argv)
         CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
         if (r) slab_ms.push_back(t);
+    }
+    std::vector<float> slab2_ms[2];
+    for (int r = 0; r < rounds + 1; ++r)
+        for (int v = 0; v < 2; ++v) {
+            const uint64_t sw = (uint64_t)((a.ntiles + 1) / 2) * slabS * Q;
+            CK(hipEventRecord(e0, 0));
+            if (v == 0) hipLaunchKernelGGL((scan_slab2_kernel<4>), dim3((uint32_t)((sw + 3) / 4)), dim3(256), 0, 0, sa);
+            else        hipLaunchKernelGGL((scan_slab2_kernel<8>), dim3((uint32_t)((sw + 3) / 4)), dim3(256), 0, 0, sa);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            if (r) slab2_ms[v].push_back(t);
+        }
+    for (int v = 0; v < 2; ++v) {
+        std::sort(slab2_ms[v].begin(), slab2_ms[v].end());
+        printf("slab2_u%d       median %8.3f ms  min %8.3f ms  -> %7.1f GB/s (median)  [two tiles per wave]\n", v ? 8 : 4,
+               slab2_ms[v][slab2_ms[v].size() / 2], slab2_ms[v][0], algo / slab2_ms[v][slab2_ms[v].size() / 2] / 1e6);
     }
     // check the slab partials against the plain kernel's scores for the first queries
     if (a.scores) {
