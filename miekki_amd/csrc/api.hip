@@ -172,11 +172,23 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
 }
 
 // ---- index build ---------------------------------------------------------------
+int ensure_build_counters(mk_ctx *c)
+{
+    if (c->d_counters) return MK_OK;
+    MK_TRY(dev_alloc(&c->d_counters, 1));
+    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));
+    c->d_ovf_count = &c->d_counters->ovf;
+    c->d_dirty = c->d_counters->dirty;
+    c->d_active = c->d_counters->act;
+    c->d_cardsum = c->d_counters->card;
+    return MK_OK;
+}
+
 // packed 4-bit codes of up to a build batch of sequences totalling seq_bytes characters
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes)
 {
     if (!c->d_code_off) MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
-    if (!c->d_dirty) MK_TRY(dev_alloc(&c->d_dirty, kBuildBatch));
+    MK_TRY(ensure_build_counters(c));
     const uint64_t code_bytes = seq_bytes / 2 + 32ull * (kBuildBatch + 1) + 64;
     if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
         MK_HIP(hipStreamSynchronize(c->stream));
@@ -224,8 +236,7 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
         const uint64_t budget = 1ull << 30;                       // table bytes per batch
         c->build_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kBuildBatch, budget / ((uint64_t)c->P * 8)));
         MK_TRY(dev_alloc(&c->d_tables, (uint64_t)c->build_batch * c->P));
-        MK_TRY(dev_alloc(&c->d_active, kBuildBatch));
-        MK_TRY(dev_alloc(&c->d_cardsum, kBuildBatch));
+        MK_TRY(ensure_build_counters(c));
         MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
     }
     if (for_append && c->d_bloom && !c->d_bloom_order) {
@@ -234,6 +245,7 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
     }
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
     if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
+    if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
     MK_TRY(ensure_codes(c, seq_bytes));
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
         const uint64_t old_cap = c->seq_cap[buf];
@@ -284,10 +296,8 @@ static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
         MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
         MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, c->d_code_off));
     }
-    c->h_back->ovf = 0;
-    MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipMemcpyAsync(c->h_back->card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
-    if (b.binned) MK_HIP(hipMemcpyAsync(&c->h_back->ovf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
+    // one copy back of the batch's counters (overflow mark, active counts, cardinality sums)
+    MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
     b.on = true;
     return MK_OK;
 }
@@ -310,23 +320,23 @@ static int settle_build(mk_ctx *c)
             MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
             MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr));
         }
-        MK_HIP(hipMemcpyAsync(c->h_back->act, c->d_active, n * 4, hipMemcpyDeviceToHost, c->stream));
-        MK_HIP(hipMemcpyAsync(c->h_back->card, c->d_cardsum, n * 8, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
         MK_HIP(hipStreamSynchronize(c->stream));
     }
-    uint32_t act[kBuildBatch];
-    uint64_t gsz[kBuildBatch];
+    // the sizes go to the device from a pinned block of their own (two, alternating: the copies are queued
+    // behind this batch and not waited for -- the next batch is enqueued meanwhile)
+    mk_ctx::SizeUpload &up = c->h_sizes[c->size_parity ^= 1];
     for (uint32_t g = 0; g < n; ++g) {
         const uint64_t len = b.off[g + 1] - b.off[g];
-        act[g] = c->h_back->act[g];
-        gsz[g] = estimate_genome_size(act[g], c->h_back->card[g], len);
-        c->h_sketch_size.push_back(act[g]);
-        c->h_genome_size.push_back(gsz[g]);
-        if (act[g] == 0) c->has_empty_sketch = true;
+        up.ss[g] = c->h_back->act[g];
+        up.gs[g] = estimate_genome_size(up.ss[g], c->h_back->card[g], len);
+        c->h_sketch_size.push_back(up.ss[g]);
+        c->h_genome_size.push_back(up.gs[g]);
+        if (up.ss[g] == 0) c->has_empty_sketch = true;
         c->stats.build_kmers += len > c->p.k ? len - c->p.k : 0;
     }
-    MK_HIP(hipMemcpy(c->d_sketch_size + c->G, act, n * 4, hipMemcpyHostToDevice));
-    MK_HIP(hipMemcpy(c->d_genome_size + c->G, gsz, n * 8, hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpyAsync(c->d_sketch_size + c->G, up.ss, n * 4, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipMemcpyAsync(c->d_genome_size + c->G, up.gs, n * 8, hipMemcpyHostToDevice, c->stream));
     c->G += n;
     ++c->gen;
     c->stats.build_genomes += n;
@@ -762,7 +772,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
     if (const char *e = getenv("MIEKKI_HBM_MATRIX_MIB")) { const long v = atol(e); if (v > 0) c->hbm_matrix_budget = (uint64_t)v << 20; }
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
-    c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr;
+    c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_counters = nullptr; c->h_sizes = nullptr; c->size_parity = 0;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
     c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
     c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
@@ -811,16 +821,17 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_cold_stage);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
-    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_dirty); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
-    dev_free(c->d_bloom_order); dev_free(c->d_tables); dev_free(c->d_active); dev_free(c->d_cardsum);
+    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_counters); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
+    dev_free(c->d_bloom_order); dev_free(c->d_tables);
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
-    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_ovf_count); dev_free(c->d_partials);
+    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_partials);
     dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_posted_blk);
     dev_free(c->d_qarena);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_back) (void)hipHostFree(c->h_back);
+    if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);

@@ -127,11 +127,21 @@ struct mk_ctx {
         int buf;
         uint64_t off[mk::kBuildBatch + 1];
     } build;
-    struct BuildReadback {         // pinned, so that the copy back does not block the host
+    // Per-batch counters of the build live in ONE device block (one memset before a batch, one copy
+    // back after it): d_ovf_count, d_dirty, d_active, d_cardsum point into d_counters.  BuildCounters
+    // is its layout, and that of the pinned read-back block.
+    struct BuildCounters {
+        uint32_t ovf, pad;
+        uint32_t dirty[mk::kBuildBatch];
         uint32_t act[mk::kBuildBatch];
         uint64_t card[mk::kBuildBatch];
-        uint32_t ovf;
-    } *h_back;
+    };
+    BuildCounters *d_counters;
+    BuildCounters *h_back;         // pinned, so that the copy back does not block the host
+    // sizes of the batch just settled on their way to the device (pinned, one per buffer parity: the copy
+    // is queued, not waited for)
+    struct SizeUpload { uint32_t ss[mk::kBuildBatch]; uint64_t gs[mk::kBuildBatch]; } *h_sizes;
+    int size_parity;
     // query scratch
     uint32_t *d_scores;            // score matrix of the query chunk in flight
     uint64_t scores_cap;
@@ -243,6 +253,7 @@ int launch_bloom_summary(mk_ctx *c);
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes);
+int ensure_build_counters(mk_ctx *c);
 int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);
 int ensure_bloom_summary(mk_ctx *c);
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);

@@ -729,10 +729,8 @@ static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams 
         MK_HIP(hipMalloc((void **)&c->d_slot_counts, ncnt * 2));
         c->slot_counts_cap = ncnt;
     }
-    if (!c->d_ovf) {
-        MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfCap * 16));
-        MK_HIP(hipMalloc((void **)&c->d_ovf_count, 4));
-    }
+    if (!c->d_ovf) MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfCap * 16));
+    MK_TRY(ensure_build_counters(c));
     *fits = true;
     return MK_OK;
 }
@@ -787,10 +785,7 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
         MK_HIP(hipMalloc((void **)&c->d_fpT, fp_bytes + 64));
         MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
-    MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
-    MK_HIP(hipMemsetAsync(c->d_dirty, 0, kBuildBatch * sizeof(uint32_t), c->stream));
-    MK_HIP(hipMemsetAsync(c->d_active, 0, kBuildBatch * sizeof(uint32_t), c->stream));
-    MK_HIP(hipMemsetAsync(c->d_cardsum, 0, kBuildBatch * sizeof(uint64_t), c->stream));
+    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));      // overflow mark, dirty flags, sums: one block
     const SketchParams sp = make_sp(c);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
                        c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
