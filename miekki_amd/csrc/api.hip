@@ -972,8 +972,10 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
         const int buf = c->seq_cur ^ 1;
         MK_TRY(ensure_build_scratch(c, off[nb], buf));
-        MK_TRY(settle_build(c));
+        // the generator fills the buffer the batch in flight does NOT read: queue it behind that batch's
+        // kernels before waiting for them, so that the device is never idle while the host settles
         MK_TRY(launch_synth_genomes(c, first_id + g0, nb, length, c->d_seq[buf]));
+        MK_TRY(settle_build(c));
         MK_TRY(enqueue_batch(c, off, nb, buf));
         c->seq_cur = buf;
     }
