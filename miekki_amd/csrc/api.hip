@@ -682,7 +682,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     a.chunk = qs->chunk; a.nent = qs->d_scan_n;
     c->stats.scan_slab_launches++;
     const uint32_t rows_per_range = qs->S ? c->P / qs->S : c->P;
-    if (!c->h_M || qs->chunk || qs->S < 2 || rows_per_range == 0 || c->P_hot % rows_per_range) {
+    if (!c->h_M || qs->chunk || qs->S < 2 || rows_per_range == 0) {
         // everything in HBM -- or ranges cut by count (small sets), which do not map to partition
         // ranges: cold rows, if any, are then read in place over PCIe
         ScopedTimer t(c, 1);
@@ -690,8 +690,9 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     }
     // Cold partition ranges are STREAMED: a range's rows are copied once into a staging buffer in
     // HBM and every query of the chunk scans them there, instead of each wave fetching its 1 KiB
-    // pieces over PCIe.  (P_hot is a multiple of P / 64, so a range is hot or cold as a whole.)
-    const uint32_t S_hot = c->P_hot / rows_per_range;
+    // pieces over PCIe.  The range the hot / cold boundary falls into is staged as a whole (its hot
+    // rows by a device copy, the rest from host memory).
+    const uint32_t S_hot = c->P_hot / rows_per_range;               // ranges that lie in HBM completely
     if (S_hot) {
         a.r_begin = 0; a.r_count = S_hot;
         ScopedTimer t(c, 1);
@@ -700,7 +701,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     if (!c->d_cold_stage) {
         // as many ranges as fit an eighth of the hot part (at least one range, at most all cold rows)
         uint64_t rows = std::max<uint64_t>(rows_per_range, (uint64_t)c->P_hot / 8 / rows_per_range * rows_per_range);
-        rows = std::min<uint64_t>(rows, c->P - c->P_hot);
+        rows = std::min<uint64_t>(rows, (uint64_t)c->P - (uint64_t)S_hot * rows_per_range);
         MK_TRY(dev_alloc(&c->d_cold_stage, rows * c->ld));
         c->cold_stage_rows = rows;
     }
@@ -711,8 +712,13 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
         if ((uint64_t)nr * rows_per_range > c->cold_stage_rows) {   // a range larger than the stage (huge P / S): in place
             a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot;
         } else {
-            MK_HIP(hipMemcpyAsync(c->d_cold_stage, c->h_M + (first - c->P_hot) * c->ld, (uint64_t)nr * rows_per_range * c->ld,
-                                  hipMemcpyHostToDevice, c->stream));
+            const uint64_t last = first + (uint64_t)nr * rows_per_range;          // rows [first, last)
+            const uint64_t hot_rows = first < c->P_hot ? std::min<uint64_t>(last, c->P_hot) - first : 0;
+            if (hot_rows)
+                MK_HIP(hipMemcpyAsync(c->d_cold_stage, c->d_M + first * c->ld, hot_rows * c->ld, hipMemcpyDeviceToDevice, c->stream));
+            if (first + hot_rows < last)
+                MK_HIP(hipMemcpyAsync(c->d_cold_stage + hot_rows * c->ld, c->h_M + (first + hot_rows - c->P_hot) * c->ld,
+                                      (last - first - hot_rows) * c->ld, hipMemcpyHostToDevice, c->stream));
             // row p of these ranges now lives at stage + (p - first) * ld: present the stage as "the matrix"
             a.M = c->d_cold_stage - first * c->ld; a.Mc = nullptr; a.P_hot = c->P;
         }
