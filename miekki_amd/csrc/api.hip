@@ -165,7 +165,8 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     MK_HIP(hipStreamSynchronize(c->stream));
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size);
     if (c->h_M) (void)hipHostFree(c->h_M);
-    dev_free(c->d_cold_stage); c->cold_stage_rows = 0;             // sized for the old pitch
+    dev_free(c->d_cold_stage);
+    for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]); c->cold_stage_rows = 0;             // sized for the old pitch
     c->d_M = nM; c->h_M = nH; c->P_hot = P_hot; c->d_sketch_size = nss; c->d_genome_size = ngs;
     c->ld = ld; c->capG = (uint32_t)cap;
     return MK_OK;
@@ -693,38 +694,55 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     // pieces over PCIe.  The range the hot / cold boundary falls into is staged as a whole (its hot
     // rows by a device copy, the rest from host memory).
     const uint32_t S_hot = c->P_hot / rows_per_range;               // ranges that lie in HBM completely
-    if (S_hot) {
+    if (!c->d_cold_stage) {
+        // two staging buffers (the copy of one group of ranges runs beside the scan of the previous one),
+        // each as many ranges as fit a sixteenth of the hot part -- at least one range
+        uint64_t rows = std::max<uint64_t>(rows_per_range, (uint64_t)c->P_hot / 16 / rows_per_range * rows_per_range);
+        rows = std::min<uint64_t>(rows, (uint64_t)c->P - (uint64_t)S_hot * rows_per_range);
+        MK_TRY(dev_alloc(&c->d_cold_stage, 2 * rows * c->ld));
+        c->cold_stage_rows = rows;
+        for (int i = 0; i < 5; ++i)
+            if (!c->ev_cold[i]) MK_HIP(hipEventCreateWithFlags(&c->ev_cold[i], hipEventDisableTiming));
+    }
+    hipEvent_t ev_enter = c->ev_cold[4];
+    hipEvent_t *ev_copy = c->ev_cold, *ev_scan = c->ev_cold + 2;
+    // the copies may start as soon as everything queued so far (earlier scans out of the stage) is done
+    MK_HIP(hipEventRecord(ev_enter, c->stream));
+    MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_enter, 0));
+    if (S_hot) {                                                    // ... i.e. beside the launch over the hot ranges
         a.r_begin = 0; a.r_count = S_hot;
         ScopedTimer t(c, 1);
         MK_TRY(launch_scan_slab(c, a));
     }
-    if (!c->d_cold_stage) {
-        // as many ranges as fit an eighth of the hot part (at least one range, at most all cold rows)
-        uint64_t rows = std::max<uint64_t>(rows_per_range, (uint64_t)c->P_hot / 8 / rows_per_range * rows_per_range);
-        rows = std::min<uint64_t>(rows, (uint64_t)c->P - (uint64_t)S_hot * rows_per_range);
-        MK_TRY(dev_alloc(&c->d_cold_stage, rows * c->ld));
-        c->cold_stage_rows = rows;
-    }
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, c->cold_stage_rows / rows_per_range);
-    for (uint32_t r = S_hot; r < qs->S; r += per) {
+    uint32_t i = 0;
+    for (uint32_t r = S_hot; r < qs->S; r += per, ++i) {
         const uint32_t nr = std::min(per, qs->S - r);
         const uint64_t first = (uint64_t)r * rows_per_range;
-        if ((uint64_t)nr * rows_per_range > c->cold_stage_rows) {   // a range larger than the stage (huge P / S): in place
+        if ((uint64_t)nr * rows_per_range > c->cold_stage_rows) {   // a range larger than a stage (a set with few, huge ranges): in place
             a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot;
         } else {
+            const int b = (int)(i & 1u);
+            uint8_t *stage = c->d_cold_stage + (uint64_t)b * c->cold_stage_rows * c->ld;
             const uint64_t last = first + (uint64_t)nr * rows_per_range;          // rows [first, last)
             const uint64_t hot_rows = first < c->P_hot ? std::min<uint64_t>(last, c->P_hot) - first : 0;
+            if (i >= 2) MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_scan[b], 0));   // the scan that read this buffer last
             if (hot_rows)
-                MK_HIP(hipMemcpyAsync(c->d_cold_stage, c->d_M + first * c->ld, hot_rows * c->ld, hipMemcpyDeviceToDevice, c->stream));
+                MK_HIP(hipMemcpyAsync(stage, c->d_M + first * c->ld, hot_rows * c->ld, hipMemcpyDeviceToDevice, c->copy_stream));
             if (first + hot_rows < last)
-                MK_HIP(hipMemcpyAsync(c->d_cold_stage + hot_rows * c->ld, c->h_M + (first + hot_rows - c->P_hot) * c->ld,
-                                      (last - first - hot_rows) * c->ld, hipMemcpyHostToDevice, c->stream));
+                MK_HIP(hipMemcpyAsync(stage + hot_rows * c->ld, c->h_M + (first + hot_rows - c->P_hot) * c->ld,
+                                      (last - first - hot_rows) * c->ld, hipMemcpyHostToDevice, c->copy_stream));
+            MK_HIP(hipEventRecord(ev_copy[b], c->copy_stream));
+            MK_HIP(hipStreamWaitEvent(c->stream, ev_copy[b], 0));
             // row p of these ranges now lives at stage + (p - first) * ld: present the stage as "the matrix"
-            a.M = c->d_cold_stage - first * c->ld; a.Mc = nullptr; a.P_hot = c->P;
+            a.M = stage - first * c->ld; a.Mc = nullptr; a.P_hot = c->P;
         }
         a.r_begin = r; a.r_count = nr;
-        ScopedTimer t(c, 1);
-        MK_TRY(launch_scan_slab(c, a));
+        {
+            ScopedTimer t(c, 1);
+            MK_TRY(launch_scan_slab(c, a));
+        }
+        MK_HIP(hipEventRecord(ev_scan[i & 1u], c->stream));
     }
     return MK_OK;
 }
@@ -776,6 +794,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
     c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
+    for (int i = 0; i < 5; ++i) c->ev_cold[i] = nullptr;
     if (const char *e = getenv("MIEKKI_HBM_MATRIX_MIB")) { const long v = atol(e); if (v > 0) c->hbm_matrix_budget = (uint64_t)v << 20; }
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_counters = nullptr; c->h_sizes = nullptr; c->size_parity = 0;
@@ -825,6 +844,7 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     if (c->h_M) (void)hipHostFree(c->h_M);
     dev_free(c->d_cold_stage);
+    for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_counters); dev_free(c->d_code_off); dev_free(c->d_bloom_full);

@@ -69,7 +69,8 @@ struct mk_ctx {
     uint32_t P_hot;                // rows kept in HBM (= P when the matrix fits its budget)
     uint64_t hbm_matrix_budget;    // bytes of HBM the matrix may take (MIEKKI_HBM_MATRIX_MIB; 0 = whatever is free)
     uint8_t *d_cold_stage;         // HBM staging for cold partition ranges (slab schedule)
-    uint64_t cold_stage_rows;
+    uint64_t cold_stage_rows;      // rows of ONE of its two halves
+    hipEvent_t ev_cold[5];         // copy done [2], scan done [2], entry
     uint32_t capG, G;
     uint32_t *d_sketch_size;
     uint64_t *d_genome_size;
