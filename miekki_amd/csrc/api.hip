@@ -94,8 +94,9 @@ static int use_device(const mk_ctx *cc, bool settle = true)
 }
 
 // ---- matrix capacity -----------------------------------------------------------
-// rows that fit the matrix's HBM budget at pitch ld: all P, or a multiple of P / 64 (so that every
-// partition range of the slab schedule, S <= 64, is hot or cold as a whole)
+// rows that fit the matrix's HBM budget at pitch ld: all P, or a multiple of P / 64 (the boundary then falls
+// between two of the slab schedule's finest partition ranges, S = 64; with coarser ranges the one it falls
+// into is staged as a whole, qset_scan_slab)
 static uint32_t hot_rows_for(const mk_ctx *c, uint64_t ld, uint64_t budget)
 {
     if (!budget || (uint64_t)c->P * ld <= budget) return c->P;
