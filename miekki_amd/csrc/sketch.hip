@@ -123,19 +123,6 @@ __device__ __forceinline__ uint64_t canon_from_codes(const uint8_t *__restrict__
 // load from an 8-byte boundary instead of two loads from the 4-bit array.  The scatter kernel
 // writes this second array and flags every genome that has any other character (N, lower case:
 // those keep the 4-bit path).
-// (the two words that hold the k-mer at `pos`, already loaded)
-__device__ __forceinline__ uint64_t canon_from_words2(uint64_t x0, uint64_t x1, uint64_t pos, uint32_t k)
-{
-    const uint32_t sh = (uint32_t)(pos & 31u) * 2u;
-    const uint64_t kmask = (1ULL << (2 * k)) - 1;
-    const uint64_t F = (sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0) & kmask;         // digit j of the k-mer at bits 2j
-    const uint64_t RC = ~F & kmask;                                                // 3 - digit, as update_kmer_RC leaves it
-    uint64_t r = __builtin_bitreverse64(F);
-    r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
-    const uint64_t S = r >> (64 - 2 * k);
-    return S < RC ? S : RC;
-}
-
 __device__ __forceinline__ uint64_t canon_from_codes2(const uint8_t *__restrict__ codes2, uint64_t pos, uint32_t k)
 {
     const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(codes2) + (pos >> 5);
@@ -604,19 +591,32 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
     __syncthreads();
     const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
     fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
+    uint64_t canon[kPer];
     uint32_t posted_mask = 0, act = 0;
     unsigned long long card = 0;
     const uint8_t *__restrict__ gcodes = codes + code_off[g];
     const uint8_t *__restrict__ gcodes2 = codes2 + code_off[g] / 2;
     const bool plain_acgt = dirty[g] == 0;                           // workgroup-uniform
-    // Pass A of the Bloom insert for this thread's winners (see bloom_kernel<false>).  A winner is a chain of
-    // dependent accesses -- LDS item -> its codes -> hash -> summary word -> (rarely) the cell -- and the kernel
-    // is latency-bound, so the winners go through it FOUR ABREAST: four code loads are in flight together, then
-    // four summary words, instead of eight chains one after the other.
-    constexpr uint32_t kAbreast = 4;
-    auto post = [&](uint32_t j, uint32_t i, uint64_t cn, uint64_t anc, uint64_t sum_idx, uint32_t sum_word) {
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        canon[j] = kEmptyKey;
+        if (i >= R) continue;
+        const uint64_t it = table[i];
+        const uint32_t fp = it == kEmptyKey ? sp.empty : (uint32_t)(it >> 48);
+        fpo[i] = (fp_t)fp;
+        if (it == kEmptyKey) continue;
+        ++act;
+        card += 1ull << (31u - (fp >> sp.f));
+        if (!bloom) continue;
+        // pass A of the Bloom insert for this winner (see bloom_kernel<false>)
+        const uint64_t pos = (it >> kBinBits) & ((1ULL << kItemPosBits) - 1);
+        const uint64_t cn = plain_acgt ? canon_from_codes2(gcodes2, pos, sp.k) : canon_from_codes(gcodes, pos, sp.k);
+        canon[j] = cn;
+        const uint64_t anc = revhash64(cn);
         const uint32_t p = bin * R + i;
-        bool posted = false;
+        uint64_t sum_idx = ~0ull;
+        uint32_t sum_word = 0;
         for (uint32_t hi = 0; hi < kNumHash; ++hi) {
             const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
             const uint64_t cell = hsh >> 3;
@@ -627,69 +627,20 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
             if (bloom[cell] == 0) {
                 const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (hi << 4) | (uint32_t)(hsh & 7);
                 atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
-                posted = true;
+                posted_mask |= 1u << j;
             }
         }
-        if (posted) { posted_mask |= 1u << j; blk_posted[i >> 8] = 1; }
-    };
-    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
-#pragma unroll
-    for (uint32_t j0 = 0; j0 < kPer; j0 += kAbreast) {
-        uint64_t pos[kAbreast];
-        u64x2_a8 raw[kAbreast];
-        bool live[kAbreast];
-        // step 1: the items, their fingerprints, and the requests for their codes
-#pragma unroll
-        for (uint32_t u = 0; u < kAbreast; ++u) {
-            const uint32_t i = threadIdx.x + 1024u * (j0 + u);
-            live[u] = false;
-            pos[u] = 0;
-            raw[u] = u64x2_a8{0, 0};
-            if (i >= R) continue;
-            const uint64_t it = table[i];
-            const uint32_t fp = it == kEmptyKey ? sp.empty : (uint32_t)(it >> 48);
-            fpo[i] = (fp_t)fp;
-            if (it == kEmptyKey) continue;
-            ++act;
-            card += 1ull << (31u - (fp >> sp.f));
-            if (!bloom) continue;
-            live[u] = true;
-            pos[u] = (it >> kBinBits) & ((1ULL << kItemPosBits) - 1);
-            if (plain_acgt) raw[u] = *reinterpret_cast<const u64x2_a8 *>(reinterpret_cast<const uint64_t *>(gcodes2) + (pos[u] >> 5));
-        }
-        // step 2: canonical k-mers and hashes, and the requests for the first summary words
-        uint64_t cn[kAbreast], anc[kAbreast], sidx[kAbreast];
-        uint32_t sword[kAbreast];
-#pragma unroll
-        for (uint32_t u = 0; u < kAbreast; ++u) {
-            cn[u] = anc[u] = 0; sidx[u] = ~0ull; sword[u] = 0;
-            if (!live[u]) continue;
-            cn[u] = plain_acgt ? canon_from_words2(raw[u].x, raw[u].y, pos[u], sp.k) : canon_from_codes(gcodes, pos[u], sp.k);
-            anc[u] = revhash64(cn[u]);
-            const uint64_t cell = bloom_pos(cn[u], anc[u], 0, sp.bloom_log2) >> 3;
-            if (cell < bloom_dev_bytes) { sidx[u] = cell >> 8; sword[u] = full[sidx[u]]; }
-        }
-        // step 3: the probes
-#pragma unroll
-        for (uint32_t u = 0; u < kAbreast; ++u)
-            if (live[u]) post(j0 + u, threadIdx.x + 1024u * (j0 + u), cn[u], anc[u], sidx[u], sword[u]);
+        if ((posted_mask >> j) & 1u) blk_posted[i >> 8] = 1;
     }
     for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); card += __shfl_xor(card, o); }
     if (lane == 0 && act) { atomicAdd(&s_act, act); atomicAdd(&s_card, card); }
     __syncthreads();
     if (threadIdx.x == 0 && s_act) { atomicAdd(&active[g], s_act); atomicAdd(&cardsum[g], s_card); }
-    // what pass B needs: the canonical k-mers of the blocks in which something was posted (none once the
-    // filter has filled up, so the k-mer is derived again here rather than kept in registers all along)
+    // what pass B needs: the canonical k-mers of the blocks in which something was posted
 #pragma unroll
     for (uint32_t j = 0; j < kPer; ++j) {
         const uint32_t i = threadIdx.x + 1024u * j;
-        if (i >= R || !blk_posted[i >> 8]) continue;
-        uint64_t out = kEmptyKey;
-        if ((posted_mask >> j) & 1u) {
-            const uint64_t ps = (table[i] >> kBinBits) & ((1ULL << kItemPosBits) - 1);
-            out = plain_acgt ? canon_from_codes2(gcodes2, ps, sp.k) : canon_from_codes(gcodes, ps, sp.k);
-        }
-        tables[row0 + i] = out;
+        if (i < R && blk_posted[i >> 8]) tables[row0 + i] = ((posted_mask >> j) & 1u) ? canon[j] : kEmptyKey;
     }
     const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
     if (threadIdx.x < nblk) posted_blk[(uint64_t)g * blk_per_genome + (uint64_t)bin * nblk + threadIdx.x] = (uint8_t)blk_posted[threadIdx.x];
