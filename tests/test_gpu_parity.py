@@ -540,6 +540,16 @@ def test_small_sets_plain_and_slab_schedules_agree(hip, monkeypatch):
                 want = o.filter_results(scores[q], 10, 5, 15.0)
                 assert [(x.genome, x.matches) for x in dflt[q]] == [(w[0], w[1]) for w in want], (n, q)
                 assert int(act_d[q]) == o.query_sequence(qs[q])[1]
+        # a handful of 3-4 kb queries: more than eight pieces by count (the packed counters hold 255 entries),
+        # i.e. the selection kernel's general summing path
+        ql = [seqs[g][100:100 + 3000 + 230 * g] for g in range(5)]
+        monkeypatch.delenv("MIEKKI_SLAB_MIN_QUERIES", raising=False)
+        got, act = ix.query(ql, 10, 5, 15.0)
+        sc = o.query_sequences(ql)
+        for q in range(len(ql)):
+            want = o.filter_results(sc[q], 10, 5, 15.0)
+            assert [(x.genome, x.matches) for x in got[q]] == [(w[0], w[1]) for w in want], q
+            assert int(act[q]) == o.query_sequence(ql[q])[1]
     finally:
         ix.close()
 
