@@ -81,7 +81,12 @@ int mk_create(const mk_params *params, mk_ctx **out);
 void mk_destroy(mk_ctx *ctx);
 
 /* Pre-size the fingerprint matrix for n_genomes rows per partition.  Optional;
- * appending past the reservation re-lays the matrix out (needs 2x memory). */
+ * appending past the reservation re-lays the matrix out (needs 2x memory).
+ * A matrix larger than its HBM budget (environment MIEKKI_HBM_MATRIX_MIB, or simply
+ * more than the free device memory) keeps its first partition rows in HBM and the rest
+ * in page-locked host memory; every entry point works unchanged, queries over the cold
+ * partition ranges are streamed at PCIe speed.  (What compress_index / decompress_index,
+ * Miekki.cpp:863-877, were for in the reference: a collection beyond fast memory.) */
 int mk_reserve(mk_ctx *ctx, uint32_t n_genomes);
 
 uint32_t mk_index_size(const mk_ctx *ctx);                 /* Miekki::index_size */
