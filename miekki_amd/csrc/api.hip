@@ -1428,10 +1428,19 @@ int mk_dev_copy(mk_ctx *dst, void *d_dst, mk_ctx *src, const void *d_src, uint64
     if (!dst || !src || (bytes && (!d_dst || !d_src))) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(src, false));
     if (bytes) {
-        if (dst->p.device == src->p.device)
+        if (dst->p.device == src->p.device) {
             MK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, src->stream));
-        else
-            MK_HIP(hipMemcpyPeerAsync(d_dst, dst->p.device, d_src, src->p.device, bytes, src->stream));
+        } else if (hipMemcpyPeerAsync(d_dst, dst->p.device, d_src, src->p.device, bytes, src->stream) != hipSuccess) {
+            // no peer path between the two GPUs (a restricted container, say): through host memory
+            (void)hipGetLastError();
+            MK_HIP(hipStreamSynchronize(src->stream));
+            std::vector<uint8_t> tmp(bytes);
+            MK_HIP(hipMemcpy(tmp.data(), d_src, bytes, hipMemcpyDeviceToHost));
+            MK_HIP(hipSetDevice(dst->p.device));
+            MK_HIP(hipMemcpy(d_dst, tmp.data(), bytes, hipMemcpyHostToDevice));
+            MK_HIP(hipSetDevice(src->p.device));
+            return MK_OK;
+        }
     }
     MK_HIP(hipStreamSynchronize(src->stream));
     return MK_OK;
