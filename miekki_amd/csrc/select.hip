@@ -43,8 +43,10 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-// SRC 0: u32 scores (plain schedule); 1 / 2: per-range mismatch counts, 1 / 2 bytes each
-template <int SRC>
+// SRC 0: u32 scores (plain schedule); 1 / 2: per-range mismatch counts, 1 / 2 bytes each.
+// PF: ranges whose counter words are requested one step ahead (8 for the default slab shape, 16 for sets of
+// 2-4 kb queries, which get twice the ranges)
+template <int SRC, uint32_t PF = 8>
 __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -67,7 +69,6 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     // quarters of its wave cycles waiting for the loads (PMC).  With at most eight ranges of
     // byte counters (the default slab shape) the RAW words of a step are therefore
     // requested one step ahead and only summed when their turn comes.
-    constexpr uint32_t PF = 8;
     const bool prefetch = SRC == 1 && a.S <= PF;
     uint32_t raw[PF];
     auto request = [&](uint32_t g0) {
@@ -205,6 +206,7 @@ int launch_select(mk_ctx *c, const SelectArgs &a)
     if (a.nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     const dim3 grid((a.nq + 3) / 4), block(256);
     if (!a.partials)     hipLaunchKernelGGL(select_kernel<0>, grid, block, 0, c->stream, a);
+    else if (a.W == 1 && a.S > 8 && a.S <= 16) hipLaunchKernelGGL((select_kernel<1, 16>), grid, block, 0, c->stream, a);
     else if (a.W == 1)   hipLaunchKernelGGL(select_kernel<1>, grid, block, 0, c->stream, a);
     else                 hipLaunchKernelGGL(select_kernel<2>, grid, block, 0, c->stream, a);
     MK_HIP(hipGetLastError());
