@@ -115,6 +115,14 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
     Header hd;
     bool ok = f.read(&hd, sizeof hd);
     if (!ok) { err = "truncated index header"; return -1; }
+    if (devices.empty()) { err = "no device to load the index onto"; return -1; }
+    // the header decides shapes and the shard table below: check it before it is used (mk_create would
+    // reject the same values, but only after P, W and the split were computed from them)
+    if (hd.h < 1 || hd.h > 28 || (hd.fp_bits != 8 && hd.fp_bits != 16)) {
+        err = "index header is not one this build reads (h " + std::to_string(hd.h) + ", " + std::to_string(hd.fp_bits) +
+              " bits per fingerprint)";
+        return -1;
+    }
     const uint32_t G = hd.index_size, W = hd.fp_bits / 8;
     // genomes split over the devices in id order; never more shards than genomes
     const size_t D = std::max<size_t>(1, std::min<size_t>(devices.size(), std::max<uint32_t>(G, 1)));

@@ -692,6 +692,10 @@ int main(int argc, char **argv)
     }
     auto end_query = chrono::system_clock::now();
     cout << "elapsed time: " << chrono::duration<double>(end_query - end_index).count() << "s\n";
+    if (getenv("MIEKKI_VERBOSE") && drv.group.shards() > 1)
+        cout << "[exchange] " << drv.group.shards() << " shards: " << drv.group.gather_bytes() << " bytes gathered, "
+             << drv.group.rerun_queries() << " queries rerun with wide rows, " << drv.group.replayed_queries()
+             << " answered from dense score rows" << endl;
     cout << "The end" << endl;
     drv.out.close();
     return 0;                                                // ~DeviceGroup releases the contexts

@@ -96,25 +96,36 @@ int DeviceGroup::finish(bool merge_bloom, std::string &err)
     return rc;
 }
 
-int DeviceGroup::ensure_buffers(uint32_t nq, uint32_t nresults, std::string &err)
+int DeviceGroup::ensure_buffers(uint32_t nq, uint32_t nresults, uint32_t cap, std::string &err)
 {
     const size_t D = ctx_.size();
-    const uint64_t row_bytes = (uint64_t)(kCap + 1) * 8;
-    if (nq > rows_cap_) {
+    const uint64_t words = (uint64_t)std::max<uint64_t>(nq, 1024) * (cap + 1);      // 8-byte row words per shard
+    if (words > rows_cap_) {
         for (size_t d = 1; d < d_rows_.size(); ++d) mk_dev_free(ctx_[d], d_rows_[d]);
         mk_dev_free(ctx_[0], d_gather_);
-        mk_dev_free(ctx_[0], d_nhits_);
         d_rows_.assign(D, nullptr);
-        d_gather_ = d_nhits_ = nullptr;
+        d_gather_ = nullptr;
         rows_cap_ = 0;
-        const uint64_t cap = std::max<uint64_t>(nq, 1024);
-        if (mk_dev_alloc(ctx_[0], D * cap * row_bytes, &d_gather_) != MK_OK ||
-            mk_dev_alloc(ctx_[0], cap * 4, &d_nhits_) != MK_OK) { err = mk_last_error(); return -1; }
+        if (mk_dev_alloc(ctx_[0], D * words * 8, &d_gather_) != MK_OK) { err = mk_last_error(); return -1; }
         for (size_t d = 1; d < D; ++d)
-            if (mk_dev_alloc(ctx_[d], cap * row_bytes, &d_rows_[d]) != MK_OK) { err = mk_last_error(); return -1; }
-        rows_cap_ = cap;
+            if (mk_dev_alloc(ctx_[d], words * 8, &d_rows_[d]) != MK_OK) {
+                // leave nothing half-made behind: the next call starts from empty buffers
+                err = mk_last_error();
+                for (size_t e = 1; e < D; ++e) { mk_dev_free(ctx_[e], d_rows_[e]); d_rows_[e] = nullptr; }
+                mk_dev_free(ctx_[0], d_gather_);
+                d_gather_ = nullptr;
+                return -1;
+            }
+        rows_cap_ = words;
     }
-    const uint64_t need_hits = (uint64_t)std::max<uint64_t>(nq, 1024) * std::max(nresults, 1u);
+    const uint64_t need_nh = std::max<uint64_t>(nq, 1024);
+    if (need_nh > nhits_cap_) {
+        mk_dev_free(ctx_[0], d_nhits_);
+        d_nhits_ = nullptr; nhits_cap_ = 0;
+        if (mk_dev_alloc(ctx_[0], need_nh * 4, &d_nhits_) != MK_OK) { err = mk_last_error(); return -1; }
+        nhits_cap_ = need_nh;
+    }
+    const uint64_t need_hits = need_nh * std::max(nresults, 1u);
     if (need_hits > hits_cap_) {
         mk_dev_free(ctx_[0], d_hits_);
         d_hits_ = nullptr; hits_cap_ = 0;
@@ -145,7 +156,7 @@ int DeviceGroup::query(const char *const *seqs, const uint64_t *lens, uint32_t n
         if (part->empty()) continue;
         if (nresults > 64) {
             if (replay(*part, seqs, lens, nresults, min_score, min_inter, hits, nhits, err)) return -1;
-        } else if (query_part(*part, seqs, lens, nresults, min_score, min_inter, hits, nhits, err)) {
+        } else if (query_part(*part, seqs, lens, nresults, min_score, min_inter, hits, nhits, kCap, err)) {
             return -1;
         }
     }
@@ -154,15 +165,15 @@ int DeviceGroup::query(const char *const *seqs, const uint64_t *lens, uint32_t n
 
 int DeviceGroup::query_part(const std::vector<uint32_t> &idx, const char *const *seqs, const uint64_t *lens,
                             uint32_t nresults, uint32_t min_score, double min_inter, mk_hit *hits, uint32_t *nhits,
-                            std::string &err)
+                            uint32_t cap, std::string &err)
 {
     const size_t D = ctx_.size();
     const uint32_t n = (uint32_t)idx.size();
-    if (ensure_buffers(n, nresults, err)) return -1;
+    if (ensure_buffers(n, nresults, cap, err)) return -1;
     std::vector<const char *> s(n);
     std::vector<uint64_t> l(n);
     for (uint32_t i = 0; i < n; ++i) { s[i] = seqs[idx[i]]; l[i] = lens[idx[i]]; }
-    const uint64_t part_bytes = (uint64_t)n * (kCap + 1) * 8;
+    const uint64_t part_bytes = (uint64_t)n * (cap + 1) * 8;
     std::vector<int> rc(D, MK_OK);
     std::vector<std::string> msg(D);
     std::vector<std::thread> th;
@@ -172,7 +183,7 @@ int DeviceGroup::query_part(const std::vector<uint32_t> &idx, const char *const 
             uint64_t *rows = d == 0 ? (uint64_t *)d_gather_ : (uint64_t *)d_rows_[d];
             mk_qset *qs = nullptr;
             int r = mk_qset_upload(ctx_[d], s.data(), l.data(), n, &qs);
-            if (r == MK_OK) r = mk_qset_run_compact(ctx_[d], qs, nresults, min_score, min_inter, kCap, rows);
+            if (r == MK_OK) r = mk_qset_run_compact(ctx_[d], qs, nresults, min_score, min_inter, cap, rows);
             // the ONE exchange step: this shard's entrant rows -> the merging GPU (peer DMA over xGMI)
             if (r == MK_OK && d != 0)
                 r = mk_dev_copy(ctx_[0], (uint8_t *)d_gather_ + d * part_bytes, ctx_[d], rows, part_bytes);
@@ -189,7 +200,7 @@ int DeviceGroup::query_part(const std::vector<uint32_t> &idx, const char *const 
     }
     if (unsupported) return replay(idx, seqs, lens, nresults, min_score, min_inter, hits, nhits, err);
     gather_bytes_ += (D - 1) * part_bytes;
-    if (mk_merge_compact(ctx_[0], (const uint64_t *)d_gather_, (uint32_t)D, n, kCap, nresults, (mk_hit *)d_hits_,
+    if (mk_merge_compact(ctx_[0], (const uint64_t *)d_gather_, (uint32_t)D, n, cap, nresults, (mk_hit *)d_hits_,
                          (uint32_t *)d_nhits_) != MK_OK) { err = mk_last_error(); return -1; }
     std::vector<uint32_t> nh(n);
     std::vector<mk_hit> hh((size_t)n * std::max(nresults, 1u));
@@ -204,9 +215,22 @@ int DeviceGroup::query_part(const std::vector<uint32_t> &idx, const char *const 
         nhits[idx[i]] = nh[i];
         std::copy(hh.begin() + (size_t)i * nresults, hh.begin() + (size_t)i * nresults + nh[i], hits + (size_t)idx[i] * nresults);
     }
-    // more entrants than a row holds on some shard: answer those queries from dense score rows
-    if (!over.empty()) return replay(over, seqs, lens, nresults, min_score, min_inter, hits, nhits, err);
-    return 0;
+    if (over.empty()) return 0;
+    // More entrants than a row holds on some shard (tie-heavy collections: every copy of a genome is an
+    // entrant).  Such queries run once more with wide rows -- still 8 bytes per entrant, still one exchange
+    // step -- before anything falls back to dense score rows of every shard, which cost n x G words per
+    // shard and the host's heap.  MIEKKI_SHARD_WIDE_ROWS=0 skips the second pass (the tests use it to keep
+    // the dense replay covered).
+    static const bool wide = [] { const char *e = getenv("MIEKKI_SHARD_WIDE_ROWS"); return !e || atoi(e) != 0; }();
+    if (wide && cap < kCapWide) {
+        rerun_queries_ += over.size();
+        for (size_t i0 = 0; i0 < over.size(); i0 += 4096) {           // bounded buffers: 4096 x 4097 x 8 B = 134 MB per shard
+            const std::vector<uint32_t> piece(over.begin() + i0, over.begin() + std::min(over.size(), i0 + 4096));
+            if (query_part(piece, seqs, lens, nresults, min_score, min_inter, hits, nhits, kCapWide, err)) return -1;
+        }
+        return 0;
+    }
+    return replay(over, seqs, lens, nresults, min_score, min_inter, hits, nhits, err);
 }
 
 // filter_results over complete score rows of every shard (Miekki.cpp:376-397 as written): the
@@ -217,6 +241,7 @@ int DeviceGroup::replay(const std::vector<uint32_t> &idx, const char *const *seq
 {
     const size_t D = ctx_.size();
     const uint32_t step = 64;
+    replayed_queries_ += idx.size();
     for (size_t i0 = 0; i0 < idx.size(); i0 += step) {
         const uint32_t n = (uint32_t)std::min<size_t>(step, idx.size() - i0);
         std::vector<const char *> s(n);

@@ -59,13 +59,20 @@ public:
               double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
 
     uint64_t gather_bytes() const { return gather_bytes_; }  // bytes copied between GPUs by query() so far
+    // queries whose entrant row overflowed the first pass (kCap slots per shard) and were run again with
+    // kCapWide slots, and queries answered from dense score rows of every shard (rows that overflowed
+    // even then, NaN corners, top-N sizes beyond the device selection): the slow paths, counted so that
+    // a run can say how often it took them (MIEKKI_VERBOSE prints them)
+    uint64_t rerun_queries() const { return rerun_queries_; }
+    uint64_t replayed_queries() const { return replayed_queries_; }
 
 private:
     int query_part(const std::vector<uint32_t> &idx, const char *const *seqs, const uint64_t *lens, uint32_t nresults,
-                   uint32_t min_score, double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
+                   uint32_t min_score, double min_intersection, mk_hit *hits, uint32_t *nhits, uint32_t cap,
+                   std::string &err);
     int replay(const std::vector<uint32_t> &idx, const char *const *seqs, const uint64_t *lens, uint32_t nresults,
                uint32_t min_score, double min_intersection, mk_hit *hits, uint32_t *nhits, std::string &err);
-    int ensure_buffers(uint32_t nq, uint32_t nresults, std::string &err);
+    int ensure_buffers(uint32_t nq, uint32_t nresults, uint32_t cap, std::string &err);
 
     std::vector<mk_ctx *> ctx_;
     std::vector<uint32_t> base_;                              // shards() + 1 id boundaries
@@ -74,9 +81,11 @@ private:
     // per-shard row buffers and, on shard 0, the gather buffer / merge output
     std::vector<void *> d_rows_;
     void *d_gather_ = nullptr, *d_hits_ = nullptr, *d_nhits_ = nullptr;
-    uint64_t rows_cap_ = 0, hits_cap_ = 0;                    // queries / hit records the buffers hold
-    uint64_t gather_bytes_ = 0;
+    uint64_t rows_cap_ = 0, hits_cap_ = 0;                    // row words per shard / hit records the buffers hold
+    uint64_t nhits_cap_ = 0;
+    uint64_t gather_bytes_ = 0, rerun_queries_ = 0, replayed_queries_ = 0;
     static constexpr uint32_t kCap = 96;                      // entrant slots per query per shard
+    static constexpr uint32_t kCapWide = 4096;                // ... for the second pass over rows that overflowed
 };
 
 }  // namespace mkhost

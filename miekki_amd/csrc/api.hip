@@ -115,8 +115,12 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     uint32_t *nss = nullptr;
     uint64_t *ngs = nullptr;
     uint32_t P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
-    if (P_hot < c->P) {                                            // over budget at the doubled size: take exactly what is needed
-        ld = ((uint64_t)need * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
+    if (P_hot < c->P) {
+        // over budget at the doubled size: grow by a quarter instead (still geometric -- a build that appends
+        // batch after batch past its reservation must not re-lay the cold rows out every 64 genomes: each
+        // re-layout is a second page-locked copy of all of them)
+        const uint64_t want = std::min<uint64_t>(0xffffff00ull, std::max<uint64_t>(need, (uint64_t)c->capG + c->capG / 4));
+        ld = (want * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
         cap = ld / c->W;
         P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
     }
@@ -137,6 +141,8 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     }
     if (P_hot < c->P)                                              // cold rows: page-locked host memory the GPU can address
         if (hipHostMalloc((void **)&nH, (uint64_t)(c->P - P_hot) * ld, hipHostMallocDefault) != hipSuccess) {
+            // (the old cold rows are still page-locked beside the new ones: an index this close to the host's
+            // limit has to be reserved up front, mk_reserve)
             (void)hipGetLastError();
             dev_free(nM);
             set_error("matrix of %llu bytes exceeds its HBM budget and the cold rows (%llu bytes) do not fit page-locked host memory",
@@ -167,7 +173,7 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size);
     if (c->h_M) (void)hipHostFree(c->h_M);
     dev_free(c->d_cold_stage);
-    for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]); c->cold_stage_rows = 0;             // sized for the old pitch
+    c->cold_stage_rows = 0;                                        // the stage was sized for the old pitch; its events do not depend on it and stay
     c->d_M = nM; c->h_M = nH; c->P_hot = P_hot; c->d_sketch_size = nss; c->d_genome_size = ngs;
     c->ld = ld; c->capG = (uint32_t)cap;
     return MK_OK;

@@ -14,6 +14,7 @@
 // atomic minimum into a table in HBM), short queries by an in-LDS sort of
 // (partition, fingerprint, position) keys.
 #include <cmath>
+#include <cstdlib>
 
 #include "mk_internal.hpp"
 
@@ -249,6 +250,7 @@ constexpr uint32_t kOvfCap = 1u << 20;
 
 struct BinParams {
     uint32_t nbins, low_bits, cap, nwg;           // low_bits = min(h, 13); nwg = workgroups per genome
+    uint32_t tune;                                // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no slot reads
     uint64_t slots_per_genome;                    // nbins * nwg * cap
 };
 
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
     const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr uint32_t NW = 16, UN = 8;
-    for (uint32_t w0 = wave; w0 < bp.nwg; w0 += NW * UN) {           // as bin_reduce_kernel
+    for (uint32_t w0 = wave; w0 < ((bp.tune & 2u) ? 0u : bp.nwg); w0 += NW * UN) {           // as bin_reduce_kernel
         uint32_t cw[UN];
         uint64_t item[UN];
 #pragma unroll
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
         if (it == kEmptyKey) continue;
         ++act;
         card += 1ull << (31u - (fp >> sp.f));
-        if (!bloom) continue;
+        if (!bloom || (bp.tune & 1u)) continue;
         // pass A of the Bloom insert for this winner (see bloom_kernel<false>)
         const uint64_t pos = (it >> kBinBits) & ((1ULL << kItemPosBits) - 1);
         const uint64_t cn = plain_acgt ? canon_from_codes2(gcodes2, pos, sp.k) : canon_from_codes(gcodes, pos, sp.k);
@@ -705,6 +707,8 @@ static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams 
         if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
     }
     bp.low_bits = std::min<uint32_t>(c->p.h, kBinBits);
+    static const uint32_t tune = [] { const char *e = getenv("MIEKKI_TUNE_BUILD"); return e ? (uint32_t)atoi(e) : 0u; }();
+    bp.tune = tune;
     bp.nbins = c->P >> bp.low_bits;
     if (bp.nbins > kMaxBins || max_len >= (1ULL << kItemPosBits) || max_nk == 0) return MK_OK;
     bp.nwg = (uint32_t)((max_nk + kSegKmers - 1) / kSegKmers);

@@ -1,14 +1,22 @@
 """a fingerprint matrix larger than its HBM budget.  The reference's answer to a
 collection that outgrows fast memory was to keep columns zlib-compressed in RAM (compress_index /
-decompress_index, Miekki.cpp:863-877); here the partition rows beyond the budget live in page-locked
-host memory and the slab schedule streams whole cold partition ranges through a staging buffer.
-MIEKKI_HBM_MATRIX_MIB forces a tiny budget: every result must equal that of an all-in-HBM context."""
+decompress_index, Miekki.cpp:863-877, inflated per batch by get_minimizers, 881-898); here the
+partition rows beyond the budget live in page-locked host memory and whole cold partition ranges
+are streamed through staging buffers in HBM.  MIEKKI_HBM_MATRIX_MIB forces a tiny budget.
+
+Every result of the cold context is compared with the CPU ORACLE on the same seeded genomes (index
+stream, raw score rows, hits) -- not with another HIP context: the staged path presents a shifted
+base pointer as "the matrix", splits the range the hot / cold boundary falls into, and re-lays hot
+and cold rows out when the matrix grows, none of which an all-in-HBM context exercises."""
+import hashlib
+
 import numpy as np
 import pytest
 
 import synth
 
 pytestmark = pytest.mark.gpu
+RTOL = 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -17,40 +25,107 @@ def hip():
     return miekki_amd
 
 
-@pytest.mark.parametrize("fpb", [8, 16])
-def test_matrix_beyond_its_hbm_budget(hip, monkeypatch, tmp_path, fpb):
-    k, h, G = 21, 12, 600
-    seqs = [synth.genome_bases(9000 + g, 0, 12_000 + 37 * g) for g in range(G)]
+def masked_sha(raw):
+    raw = np.frombuffer(bytes(raw), np.uint8).copy()
+    raw[32] = 0                                                  # uninitialised jaccard_estimation byte
+    return hashlib.sha256(raw.tobytes()).hexdigest()
+
+
+def same_hits(got, o, rows, nres, ms, mi):
+    for q, row in enumerate(rows):
+        want = o.filter_results(row, nres, ms, mi)
+        assert [(x.genome, x.matches) for x in got[q]] == [(w[0], w[1]) for w in want], q
+        np.testing.assert_allclose([x.jaccard for x in got[q]], [w[2] for w in want], rtol=RTOL, atol=0)
+        np.testing.assert_allclose([x.intersection for x in got[q]], [w[3] for w in want], rtol=RTOL, atol=0)
+
+
+def check_against_oracle(ix, o, seqs, rng, nq_stream=700):
+    """index stream, plain / dense / long score rows, streamed and by-count hits of `ix` vs the oracle `o`"""
+    G = len(seqs)
+    assert ix.index_size == o.index_size == G
+    np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+    np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+    assert masked_sha(b"".join(ix.serialize())) == masked_sha(o.serialize().tobytes())     # export of hot and cold rows, Bloom, sizes
+    qs = []
+    for q in range(nq_stream):                                   # >= 512 short queries: ranges by partition, cold ranges streamed
+        g = int(rng.integers(0, G)); s = seqs[g]
+        off = int(rng.integers(0, max(1, len(s) - 1300)))
+        qs.append(s[off:off + 300 + q % 900])
+    rows = o.query_sequences(qs)
+    got, act = ix.query(qs, 10, 3, 5.0)
+    same_hits(got, o, rows, 10, 3, 5.0)
+    assert [int(a) for a in act[:40]] == [o.query_sequence(s)[1] for s in qs[:40]]         # active_minimizer, Miekki.cpp:318-340
+    got16, _ = ix.query(qs[:16], 10, 3, 5.0)                     # a handful of queries: the small-set schedule over cold rows
+    same_hits(got16, o, rows[:16], 10, 3, 5.0)
+    np.testing.assert_array_equal(ix.query_sequences(qs[:48]), rows[:48])                   # plain kernel, dense rows out
+    long_q = [seqs[7][:9000], seqs[8], seqs[G - 1], seqs[G // 2][100:6000]]                 # sparse long path and dense (whole-genome) path
+    lrows = o.query_sequences(long_q)
+    np.testing.assert_array_equal(ix.query_sequences(long_q), lrows)
+    same_hits(ix.query(long_q, 5, 3, 5.0)[0], o, lrows, 5, 3, 5.0)
+    return qs, rows
+
+
+# (bits per fingerprint, genomes, what the 1 MiB budget does at k = 21, h = 12, four partition ranges of 1024 rows)
+SHAPES = [
+    (8, 600, "pitch 1 KiB: rows [0, 1024) hot = range 0 exactly"),
+    (8, 1100, "pitch 2 KiB from 1,025 genomes on: the boundary moves from row 1024 to row 512, inside range 0"),
+    (16, 600, "pitch 1 KiB, then 2 KiB: boundary at row 512, inside range 0, after it was at 1024"),
+]
+
+
+@pytest.mark.parametrize("fpb,G,what", SHAPES)
+def test_matrix_beyond_its_hbm_budget_against_oracle(hip, monkeypatch, tmp_path, fpb, G, what):
+    from oracle import oracle as orc
+    k, h = 21, 12
+    seqs = [synth.genome_bases(9000 + g, 0, 12_000 + 37 * (g % 600)) for g in range(G)]
+    seqs[5] = seqs[5][:40].lower() + seqs[5][40:6000] + b"NNNNNNNNNN" + seqs[5][6000:]      # a genome that is not plain ACGT
     monkeypatch.setenv("MIEKKI_SLAB_MIB", "1")                   # four partition ranges at h = 12: the slab schedule is in play
-    full = hip.Miekki(k, h, fpb, 32, 10)
-    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "1")             # 1 MiB of a 4 MiB (8 MiB at 2 bytes) matrix stays in HBM
+    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "1")             # 1 MiB of a 4 ... 8 MiB matrix stays in HBM
+    o = orc.OracleMiekki(k, h, fpb, 32, 10)
     cold = hip.Miekki(k, h, fpb, 32, 10)
     loaded = None
+    rng = np.random.default_rng(5 + G + fpb)
     try:
-        full.insert_sequences(seqs)
-        for i in range(0, G, 150):                               # no reserve: the matrix is re-laid out (hot and cold rows) as it grows
-            cold.insert_sequences(seqs[i:i + 150])
-        assert b"".join(cold.serialize()) == b"".join(full.serialize())      # export of hot and cold rows, Bloom, sizes
-        rng = np.random.default_rng(5)
-        qs = []
-        for q in range(700):                                     # >= 512 short queries: ranges by partition, cold ranges streamed
-            g = int(rng.integers(0, G)); o = int(rng.integers(0, 10_000))
-            qs.append(seqs[g][o:o + 300 + q % 900])
-        want, wact = full.query(qs, 10, 3, 5.0)
-        got, gact = cold.query(qs, 10, 3, 5.0)
-        assert got == want and (gact == wact).all()
-        got16, _ = cold.query(qs[:16], 10, 3, 5.0)               # a handful: ranges by count, cold rows read in place
-        assert got16 == want[:16]
-        np.testing.assert_array_equal(cold.query_sequences(qs[:40]), full.query_sequences(qs[:40]))     # plain kernel
-        long_q = [seqs[7][:9000], seqs[8]]                       # sparse long path and dense (whole-genome) path
-        np.testing.assert_array_equal(cold.query_sequences(long_q), full.query_sequences(long_q))
-        assert cold.query(long_q, 5, 3, 5.0)[0] == full.query(long_q, 5, 3, 5.0)[0]
+        step = 150
+        for i in range(0, G, step):                              # no reserve: the matrix is re-laid out (hot and cold rows) as it grows
+            cold.insert_sequences(seqs[i:i + step])
+            o.insert_sequences(seqs[i:i + step])
+            if i == step:                                        # a streamed query BETWEEN growth steps: the staging buffers and their
+                mid = [s[200:900] for s in seqs[:2 * step:3]] * 6                # events must survive the re-layout that follows
+                assert len(mid) >= 512
+                same_hits(cold.query(mid, 10, 3, 5.0)[0], o, o.query_sequences(mid), 10, 3, 5.0)
+        qs, rows = check_against_oracle(cold, o, seqs, rng)
         # dump -> load under the same budget: import of hot and cold rows
         cold.dump_disk(str(tmp_path / "cold.gz"))
         loaded = hip.Miekki.load(str(tmp_path / "cold.gz"))
-        assert loaded.query(qs, 10, 3, 5.0)[0] == want
-        assert b"".join(loaded.serialize()) == b"".join(full.serialize())
+        same_hits(loaded.query(qs, 10, 3, 5.0)[0], o, rows, 10, 3, 5.0)
+        assert masked_sha(b"".join(loaded.serialize())) == masked_sha(o.serialize().tobytes())
+        # append past the capacity AFTER streamed queries, then query again (ADVICE r2: the staging events)
+        more = [synth.genome_bases(20_000 + g, 0, 9000 + 11 * g) for g in range(500)]
+        cold.insert_sequences(more)
+        o.insert_sequences(more)
+        check_against_oracle(cold, o, seqs + more, rng, nq_stream=520)
     finally:
-        full.close(); cold.close()
+        cold.close()
         if loaded is not None:
             loaded.close()
+
+
+def test_reserved_cold_matrix_against_oracle(hip, monkeypatch):
+    """mk_reserve up front (what the CLI does): one layout, boundary inside a range, 2-byte fingerprints,
+    and a budget that leaves most of the matrix cold."""
+    from oracle import oracle as orc
+    k, h, G, fpb = 15, 13, 700, 16
+    seqs = [synth.genome_bases(31_000 + g, 0, 7000 + 13 * g) for g in range(G)]
+    monkeypatch.setenv("MIEKKI_SLAB_MIB", "1")                   # eight ranges of 1024 rows
+    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "3")             # pitch 2 KiB: 1,536 hot rows = one and a half ranges of 8,192 rows
+    o = orc.OracleMiekki(k, h, fpb, 32, 10)
+    ix = hip.Miekki(k, h, fpb, 32, 10)
+    try:
+        ix.reserve(G)
+        for i in range(0, G, 64):
+            ix.insert_sequences(seqs[i:i + 64])
+        o.insert_sequences(seqs)
+        check_against_oracle(ix, o, seqs, np.random.default_rng(77))
+    finally:
+        ix.close()
