@@ -93,45 +93,75 @@ def self_launch(args, argv):
 
 
 def cpu_baseline(h, host_cores):
-    """The reference's scan timed on this host's cores on a bounded sample of the same
-    workload: oracle/_ref/ref_harness scanbench = the real reference's query_sequences
-    (Miekki.cpp:344-372) on an index padded to G_cpu genomes with a saturated Bloom filter
-    (kind "reference"); when that build is absent, the oracle's restatement on the SAME
-    sample shape, one core (kind "port")."""
+    """The reference's own code timed on ALL of this host's cores (and on one, for the per-core figure),
+    on bounded samples of the same workload, by oracle/_ref/ref_harness (the unmodified reference,
+    compiled in the authoring container; kind "reference"):
+      scan    query_sequences (Miekki.cpp:344-372) the way query_file's threads call it, 201 queries a
+              batch, on an index padded to G_cpu genomes with a saturated Bloom filter;
+      sketch  insert_sequences (Miekki.cpp:277-314) the way index_file_of_file's threads call it
+              (546-581), eleven genomes a batch -- its append is the reference's global critical
+              section, which is what bounds it on many cores.
+    When that build is absent: the oracle's scalar restatement of the scan on the same sample shape,
+    one core (kind "port"), and no sketch leg."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    threads = max(1, min(host_cores, 16))
-    # sized for roughly 10-15 s of scanning on 16 threads (the reference batches 201 queries per thread)
-    G_cpu, nq = 10_000, 8 * 201 * threads
-    if h >= 20:
-        G_cpu, nq = 2_000, 4 * 201 * threads
-    shape = f"synthetic 1 kb queries vs {G_cpu} genomes (4 sketched 5 Mb genomes, columns padded cyclically), -h {h}, saturated Bloom"
+    threads = max(1, host_cores)
+    # G_cpu: the regime the metric is quoted in (>= 10^4 genomes: the per-genome compare dominates the
+    # O(2^h x batch) sweep); two batches of 201 queries per thread, ~10-20 s on the box's cores
+    G_cpu = 20_000 if h >= 19 else 10_000
+    per = 2
+    shape = (f"synthetic 1 kb queries vs {G_cpu} genomes (4 sketched 5 Mb genomes, columns padded cyclically), "
+             f"-h {h}, saturated Bloom")
     if os.path.exists(harness):
         try:
-            out = subprocess.run([harness, "scanbench", str(h), str(G_cpu), str(nq), str(threads)],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900).stdout.decode()
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+            out = subprocess.run([harness, "scanbench", str(h), str(G_cpu), str(per), str(threads)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1500, env=env).stdout.decode()
             r = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-            return {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
-                    "host_cores": host_cores, "kind": "reference",
-                    "sample": f"reference query_sequences, {nq} {shape}", "sample_seconds": r["seconds"]}
+            res = {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
+                   "host_cores": host_cores, "kind": "reference",
+                   "all_core": r["comparisons"] / r["seconds"],
+                   "per_core": r["one_thread_comparisons"] / r["one_thread_seconds"],
+                   "sample": f"reference query_sequences on {threads} threads, {r['queries']} {shape}; per_core = one thread, 201 queries",
+                   "sample_seconds": r["seconds"] + r["one_thread_seconds"]}
+            try:
+                n_gen = max(64, min(threads, 192))
+                out = subprocess.run([harness, "sketchbench", str(h), str(n_gen), str(threads)],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1500, env=env).stdout.decode()
+                k = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+                res["sketch"] = {"value": k["genomes"] / k["seconds"], "unit": "sketches/s", "cores": threads,
+                                 "all_core": k["genomes"] / k["seconds"],
+                                 "per_core": k["one_thread_genomes"] / k["one_thread_seconds"],
+                                 "sample": f"reference insert_sequences on {threads} threads (batches of 11 as index_file_of_file "
+                                           f"makes them), {k['genomes']} synthetic 5 Mb genomes from memory, -h {h}; "
+                                           f"per_core = one thread, {k['one_thread_genomes']} genomes",
+                                 "sample_seconds": k["seconds"] + k["one_thread_seconds"]}
+            except Exception as e:
+                sys.stderr.write(f"reference sketchbench unavailable: {e}\n")
+            return res
         except Exception as e:                       # fall through to the port
             sys.stderr.write(f"reference scanbench unavailable: {e}\n")
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import scanbench
-        nq1 = 2 * 201                                 # one core: two of the reference's batches
-        r = scanbench.run(h, G_cpu, nq1)
-        return {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": 1,
-                "host_cores": host_cores, "kind": "port",
-                "sample": f"oracle query_sequences (scalar C restatement), {nq1} {shape}", "sample_seconds": r["seconds"]}
+        nq1 = 201                                     # one core: one of the reference's batches
+        G_port = min(G_cpu, 4_000)                    # the scalar port is slow: a smaller index, said so
+        r = scanbench.run(h, G_port, nq1)
+        v = r["comparisons"] / r["seconds"]
+        return {"value": v, "unit": "comparisons/s", "cores": 1, "host_cores": host_cores, "kind": "port",
+                "per_core": v, "all_core": None,
+                "sample": f"oracle query_sequences (scalar C restatement, one core), {nq1} "
+                          + shape.replace(str(G_cpu), str(G_port)),
+                "sample_seconds": r["seconds"]}
     except Exception as e:
         sys.stderr.write(f"oracle scanbench unavailable: {e}\n")
         return None
 
 
-def host_fed_build_rate(lib, L, device, h, fp_bits, n=64, rounds=6):
+def host_fed_build_rate(lib, L, device, h, fp_bits, packed, n=64, rounds=6):
     """PCIe-inclusive build rate (DESIGN.md section 5 asks for it next to `value`, never as `value`): the same
-    synthetic genomes, but handed to mk_index_append as HOST buffers (page-locked, mk_host_alloc) the way the
-    `miekki` binary feeds it, into a scratch context of its own.  Returns sketches/s over `rounds` batches."""
+    synthetic genomes, but handed over as HOST buffers (page-locked, mk_host_alloc) the way the `miekki`
+    binary feeds them, into a scratch context of its own: packed (mk_index_append_packed: 2 bits per base, what
+    the binary's readers produce) or as characters (mk_index_append).  Returns sketches/s over `rounds` batches."""
     import miekki_amd
     ix = miekki_amd.Miekki(31, h, fp_bits, 33, 200, device=device)
     try:
@@ -139,16 +169,33 @@ def host_fed_build_rate(lib, L, device, h, fp_bits, n=64, rounds=6):
         buf = C.c_void_p()
         L.check(lib.mk_host_alloc(ix._h, n * GENOME_LEN, C.byref(buf)))
         L.check(lib.mk_probe_synth_genomes(ix._h, 10_000_000, n, GENOME_LEN, buf))
-        ptrs = (C.c_char_p * n)(*[C.cast(buf.value + i * GENOME_LEN, C.c_char_p) for i in range(n)])
-        lens = (C.c_uint64 * n)(*([GENOME_LEN] * n))
-        L.check(lib.mk_index_append(ix._h, ptrs, lens, n))       # warm-up: scratch allocations
+        pk = C.c_void_p()
+        if packed:
+            cw, xw = lib.mk_pack_code_words(GENOME_LEN), lib.mk_pack_except_words(GENOME_LEN)
+            L.check(lib.mk_host_alloc(ix._h, n * (cw + xw) * 8, C.byref(pk)))
+            arr = (L.PackedSeq * n)()
+            for i in range(n):                                     # packed once, outside the timed region (the
+                codes = pk.value + i * (cw + xw) * 8               # binary's reader threads do it while they parse)
+                exc = codes + cw * 8
+                if lib.mk_pack_append(codes, exc, 0, buf.value + i * GENOME_LEN, GENOME_LEN) != 0:
+                    raise RuntimeError("synthetic genomes are plain ACGT")
+                arr[i].codes, arr[i].except_, arr[i].len = codes, None, GENOME_LEN
+                arr[i].head = C.string_at(buf.value + i * GENOME_LEN, 32)
+            append = lambda: L.check(lib.mk_index_append_packed(ix._h, arr, n))
+        else:
+            ptrs = (C.c_char_p * n)(*[C.cast(buf.value + i * GENOME_LEN, C.c_char_p) for i in range(n)])
+            lens = (C.c_uint64 * n)(*([GENOME_LEN] * n))
+            append = lambda: L.check(lib.mk_index_append(ix._h, ptrs, lens, n))
+        append()                                                   # warm-up: scratch allocations
         L.check(lib.mk_sync(ix._h))
         t0 = time.perf_counter()
         for _ in range(rounds):
-            L.check(lib.mk_index_append(ix._h, ptrs, lens, n))
+            append()
         L.check(lib.mk_sync(ix._h))
         dt = time.perf_counter() - t0
         lib.mk_host_free(ix._h, buf)
+        if pk:
+            lib.mk_host_free(ix._h, pk)
         return n * rounds / dt
     finally:
         ix.close()
@@ -274,6 +321,18 @@ def main(argv=None):
         dt = float(t.item())
 
     st = ix.stats()
+    # what every rank spent where (ms per step), so that a scaling record explains itself: max and min over ranks
+    mine = [st["scan_ms"] / args.steps, st["filter_ms"] / args.steps, st["sketch_ms"] / args.steps,
+            gather_s[0] / args.steps * 1e3, merge_s[0] / args.steps * 1e3, build_s]
+    per_rank = [mine]
+    if world > 1:
+        tt = torch.tensor(mine, dtype=torch.float64, device=coll_dev)
+        parts = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        per_rank = [[float(x) for x in p_.cpu()] for p_ in parts]
+    rank_ms = {name: {"max": max(r[i] for r in per_rank), "min": min(r[i] for r in per_rank)}
+               for i, name in enumerate(("scan", "select", "query_sketch", "gather", "merge"))}
+    rank_ms["build_s"] = {"max": max(r[5] for r in per_rank), "min": min(r[5] for r in per_rank)}
     active = np.zeros(Q, np.uint32)
     L.check(lib.mk_qset_active(ix._h, qs, active.ctypes.data))
     a_sum = int(active.sum())
@@ -355,16 +414,24 @@ def main(argv=None):
             "merge": {"kernel": "merge_kernel", "ms_per_step": merge_s[0] / args.steps * 1e3, "overflowed_queries": n_over,
                       "cap": cap, "gather_bytes_per_rank": Q * rw * 8 if world > 1 else 0,
                       "gather_ms_per_step": gather_s[0] / args.steps * 1e3,
+                      "backend": (dist.get_backend() if world > 1 else None),
+                      "ranks": (dist.get_world_size() if world > 1 else 1),
+                      "collective": ("torch.distributed.gather over %s" % dist.get_backend()) if world > 1 else None,
+                      "per_rank_ms_per_step": rank_ms,
                       "note": "rank 0: filter_results heap over the (gathered) 8-byte entrant rows, inside the timed step"},
             "check": {"queries_with_hits": n_hit, "top_hit_is_source_genome_of_first_2000": merged_ok,
                       "device_heap_equals_host_heap_of_first_2000": host_heap_ok},
         }
         if world == 1:
             try:                                       # outside the timed region, a context of its own
-                rate = host_fed_build_rate(lib, L, local_rank, args.h, args.fp_bits)
+                rate = host_fed_build_rate(lib, L, local_rank, args.h, args.fp_bits, packed=True)
+                rate_c = host_fed_build_rate(lib, L, local_rank, args.h, args.fp_bits, packed=False)
                 out["sketch"]["host_fed_sketches_per_s"] = rate
-                out["sketch"]["host_fed_note"] = ("PCIe-inclusive: 6 batches of 64 x 5 Mb genomes handed to mk_index_append from "
-                                                  "page-locked host buffers (%.1f GB/s of sequence); not part of `value`" % (rate * GENOME_LEN / 1e9))
+                out["sketch"]["host_fed_chars_sketches_per_s"] = rate_c
+                out["sketch"]["host_fed_note"] = ("PCIe-inclusive: 6 batches of 64 x 5 Mb genomes from page-locked host buffers, "
+                                                  "packed 2 bits per base through mk_index_append_packed (%.1f GB/s over PCIe) and, "
+                                                  "second figure, as characters through mk_index_append (%.1f GB/s); not part of `value`"
+                                                  % (rate * GENOME_LEN / 4 / 1e9, rate_c * GENOME_LEN / 1e9))
             except Exception as e:
                 sys.stderr.write(f"host-fed build sample skipped: {e}\n")
         if world == 1 and not args.no_cpu_baseline:

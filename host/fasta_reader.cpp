@@ -27,6 +27,28 @@ size_t strip_fasta(const char *text, size_t n, char *dst)
     return (size_t)(o - dst);
 }
 
+size_t pack_fasta(const char *text, size_t n, PackAppendFn pack, uint64_t *codes, uint64_t *except, char head[32], bool *dirty)
+{
+    const char *p = text, *const end = text + n;
+    size_t at = 0;
+    bool any = false;
+    codes[0] = 0; except[0] = 0;                                   // an empty sequence is all-zero words
+    memset(head, 0, 32);
+    while (p <= end) {                                             // the line rules of strip_fasta
+        const char *e = p < end ? (const char *)memchr(p, '\n', (size_t)(end - p)) : nullptr;
+        if (!e) e = end;
+        if (e > p && *p != '>') {
+            const size_t m = (size_t)(e - p);
+            if (at < 32) memcpy(head + at, p, std::min<size_t>(m, 32 - at));
+            if (pack(codes, except, at, p, m) > 0) any = true;
+            at += m;
+        }
+        p = e + 1;
+    }
+    *dirty = any;
+    return at;
+}
+
 static bool gunzip_all(const std::vector<char> &in, std::vector<char> &out)
 {
     z_stream zs;
@@ -90,8 +112,9 @@ bool read_file(const std::string &path, std::vector<char> &out, std::vector<char
     return true;
 }
 
-OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window)
-    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a)
+OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window,
+                                       PackAppendFn pack)
+    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(pack)
 {
     for (auto &r : ready_) r.store(0);
     const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
@@ -156,6 +179,7 @@ void OrderedFastaReader::recycle(Item &it)
     std::lock_guard<std::mutex> g(pool_m_);
     pool_.emplace_back(it.data, it.cap);
     it.data = nullptr; it.len = it.cap = 0;
+    it.codes = it.except = nullptr;
 }
 
 OrderedFastaReader::Item OrderedFastaReader::take(size_t i)
@@ -189,9 +213,23 @@ void OrderedFastaReader::work()
         if (it.exists) {
             text.clear();
             if (!read_file(files_[i], text, scratch)) it.failed = true;
-            it.data = pool_get(text.size() + 1, it.cap);
-            if (it.data) it.len = strip_fasta(text.data(), text.size(), it.data);
-            else it.failed = true;
+            if (pack_) {
+                // no more than text.size() bases: two arrays of that many positions, 8-byte aligned in one buffer
+                const size_t cw = packed_code_words(text.size()), xw = packed_except_words(text.size());
+                it.data = pool_get((cw + xw) * 8, it.cap);
+                if (it.data) {
+                    it.packed = true;
+                    it.codes = reinterpret_cast<uint64_t *>(it.data);
+                    it.except = it.codes + cw;
+                    it.len = pack_fasta(text.data(), text.size(), pack_, it.codes, it.except, it.head, &it.dirty);
+                } else {
+                    it.failed = true;
+                }
+            } else {
+                it.data = pool_get(text.size() + 1, it.cap);
+                if (it.data) it.len = strip_fasta(text.data(), text.size(), it.data);
+                else it.failed = true;
+            }
         }
         { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
         cv_.notify_all();

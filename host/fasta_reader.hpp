@@ -12,6 +12,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -29,6 +30,15 @@ struct HostAllocator {
 // all non-'>' lines of text[0..n) concatenated into dst (room for n bytes); getline semantics
 size_t strip_fasta(const char *text, size_t n, char *dst);
 
+// The same sequence, packed line by line as it is parsed (include/miekki_hip.h, mk_packed_seq: 2 bits
+// per base, one exception bit per base, the first 32 characters).  `pack` is the library's
+// mk_pack_append; the reader takes it as a pointer so that it builds without the library (tests).
+typedef int (*PackAppendFn)(uint64_t *codes, uint64_t *except, uint64_t at, const char *chars, uint64_t n);
+inline size_t packed_code_words(size_t len) { return (len + 31) / 32 + 1; }
+inline size_t packed_except_words(size_t len) { return (len + 63) / 64 + 1; }
+// returns the sequence's length; *dirty = it holds characters other than A, C, G, T
+size_t pack_fasta(const char *text, size_t n, PackAppendFn pack, uint64_t *codes, uint64_t *except, char head[32], bool *dirty);
+
 // whole file into `out`, gunzipped when it starts with the gzip magic (any number of members)
 bool read_file(const std::string &path, std::vector<char> &out, std::vector<char> &scratch);
 
@@ -39,9 +49,15 @@ public:
         bool failed = false;       // the file exists but could not be read or buffered: do not treat as empty
         char *data = nullptr;      // pooled buffer: hand it back with recycle()
         size_t len = 0, cap = 0;
+        // packed items (a reader made with a PackAppendFn): `data` holds the two arrays, no characters
+        bool packed = false, dirty = false;
+        uint64_t *codes = nullptr, *except = nullptr;
+        char head[32] = {0};
     };
-    // window = how many files may be parsed ahead of the consumer (each holds one buffer)
-    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window);
+    // window = how many files may be parsed ahead of the consumer (each holds one buffer);
+    // pack != nullptr: items come packed (a quarter of the bytes to buffer and to copy to the GPU)
+    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window,
+                       PackAppendFn pack = nullptr);
     ~OrderedFastaReader();
     // blocks until file i (called with i = 0, 1, 2, ...) has been read
     Item take(size_t i);
@@ -61,6 +77,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     HostAllocator a_;
+    PackAppendFn pack_ = nullptr;
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
     std::unordered_set<char *> plain_;              // buffers that came from malloc although an allocator was given

@@ -135,16 +135,31 @@ struct Driver {
         if (!files.empty() && mk_reserve(ctx, (uint32_t)files.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return; }
         // readers parse into pinned buffers, three device batches ahead; the append of one
         // batch returns as soon as its copy is done, so parsing, copying and sketching overlap
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64);
+        // ... and pack as they parse (2 bits per base, mk_index_append_packed): a quarter of the bytes to buffer and
+        // to move over PCIe, and the device skips its own packing pass.  MIEKKI_INGEST=chars keeps the characters.
+        static const bool as_chars = [] { const char *e = getenv("MIEKKI_INGEST"); return e && string(e) == "chars"; }();
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64,
+                                  as_chars ? nullptr : &mk_pack_append);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         auto flush = [&]() {
             if (seqs.empty()) return true;
-            vector<const char *> p;
-            vector<uint64_t> l;
-            for (auto &s : seqs) { p.push_back(s.data); l.push_back(s.len); }
             const double t0 = now();
-            if (mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size()) != MK_OK) {
+            int rc;
+            if (seqs[0].packed) {
+                vector<mk_packed_seq> p(seqs.size());
+                for (size_t i = 0; i < seqs.size(); ++i) {
+                    p[i].codes = seqs[i].codes; p[i].except = seqs[i].dirty ? seqs[i].except : nullptr; p[i].len = seqs[i].len;
+                    memcpy(p[i].head, seqs[i].head, 32);
+                }
+                rc = mk_index_append_packed(ctx, p.data(), (uint32_t)p.size());
+            } else {
+                vector<const char *> p;
+                vector<uint64_t> l;
+                for (auto &s : seqs) { p.push_back(s.data); l.push_back(s.len); }
+                rc = mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size());
+            }
+            if (rc != MK_OK) {
                 sb.error = string("index build failed: ") + mk_last_error();
                 return false;
             }
@@ -199,7 +214,12 @@ struct Driver {
             mkhost::shard_range(files.size(), (uint32_t)d, (uint32_t)D, b, e);
             part[d].assign(files.begin() + b, files.begin() + e);
         }
-        const unsigned per = std::max(1u, threads / (unsigned)D);
+        // reader threads per shard: -t as given for one GPU; with several, -t divided by the shards would leave each
+        // with a reader or two (the default -t 8 on 8 GPUs: one), far below what a GPU sketches -- so at least eight
+        // per shard, as far as the host's cores go
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned per = D == 1 ? std::max(1u, threads)
+                                    : std::max(1u, std::max(threads / (unsigned)D, std::min(8u, hw / (unsigned)D)));
         if (D == 1) {
             build_shard(ctxs[0], part[0], per, true, sb[0]);
         } else {                                                   // the shards build side by side

@@ -10,8 +10,11 @@
  * negative mk_status and leaves a message for mk_last_error() (thread-local).
  * Host pointers unless a parameter name starts with `d_` (device memory of the
  * context's GPU).  One context owns one GPU; calls on one context must not
- * overlap.  There is no CPU fallback: without a usable HIP device mk_create
- * fails.
+ * overlap -- with one exception: mk_dev_copy may run with a context as its
+ * DESTINATION while another thread uses that context (it reads nothing of the
+ * destination but its device ordinal; the multi-GPU driver gathers the shards'
+ * rows into the first GPU that way while that GPU still scans).  There is no
+ * CPU fallback: without a usable HIP device mk_create fails.
  */
 #ifndef MIEKKI_HIP_H
 #define MIEKKI_HIP_H
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 2
+#define MK_ABI_VERSION 3
 
 typedef enum {
     MK_OK = 0,
@@ -71,6 +74,11 @@ typedef struct {
     uint64_t build_kmers;
     uint64_t build_genomes;
     uint64_t scan_slab_launches; /* of scan_launches: launches of the slab schedule (scan_slab_kernel) */
+    /* mk_dev_copy calls with this context as the SOURCE, by the path they took: a direct GPU-to-GPU
+     * copy (same GPU, or peer access over xGMI), or through host memory because the two GPUs have
+     * no peer access -- a staged exchange would otherwise just look like a slow xGMI */
+    uint64_t peer_copies, staged_copies;
+    uint64_t peer_copy_bytes, staged_copy_bytes;
 } mk_stats;
 
 const char *mk_last_error(void);
@@ -111,6 +119,40 @@ int mk_probe_synth_genomes(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t 
  * leaves this batch's kernels in flight.  Every other entry point first settles
  * the batch in flight, so results are always those of a synchronous build. */
 int mk_index_append(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t n);
+
+/* ---- packed ingest (2-bit packing overlapped with the copy to the GPU) ----
+ * A sequence as 2 bits per base and, only when it holds characters other than A, C, G, T, one
+ * exception bit per base -- a quarter (three eighths) of the bytes mk_index_append moves:
+ *   codes   base i at bits 2 * (i % 32) of 64-bit word i / 32: A 0, C 1, G 2, T 3, anything else 0
+ *           (nuc2int, utils.cpp:31-49)
+ *   except  bit i % 64 of word i / 64 is set where the character is not one of "ACGT" (upper case):
+ *           for those the reverse strand's digit is 0 as well, not 3 - code (nuc2intrc,
+ *           utils.cpp:107-125); NULL when the sequence has none
+ *   head    the first min(len, 32) characters as they came: the k-1 characters of the seed go
+ *           through str2numstrand (utils.cpp:252-272: case-insensitive, any other character zeroes
+ *           the whole seed), which codes and exception bits cannot express
+ * Results are those of mk_index_append on the characters, bit for bit. */
+typedef struct {
+    const uint64_t *codes;    /* (len + 31) / 32 words */
+    const uint64_t *except;   /* (len + 63) / 64 words, or NULL */
+    uint64_t len;             /* bases */
+    char head[32];
+} mk_packed_seq;
+
+/* Host-side packer (no GPU involved; thread-safe, AVX2 when the CPU has it): appends n characters at
+ * base position `at` of a sequence being packed, e.g. FASTA line by FASTA line straight into
+ * page-locked buffers (mk_host_alloc).  The words that hold position `at` keep their lower positions,
+ * everything above at + n in the words written becomes zero: pack in ascending order, nothing needs
+ * clearing first.  Both arrays must have room for mk_pack_code_words / mk_pack_except_words of the
+ * final length.  Returns 1 when any of the n characters was an exception (hand `except` over then),
+ * 0 when none was, -1 on a null argument. */
+uint64_t mk_pack_code_words(uint64_t len);
+uint64_t mk_pack_except_words(uint64_t len);
+int mk_pack_append(uint64_t *codes, uint64_t *except, uint64_t at, const char *chars, uint64_t n);
+
+/* Miekki::insert_sequences (Miekki.cpp:277-314) for packed sequences; pipelined like
+ * mk_index_append (the arrays may be reused when the call returns). */
+int mk_index_append_packed(mk_ctx *ctx, const mk_packed_seq *seqs, uint32_t n);
 
 /* Page-locked host memory for sequences handed to mk_index_append / mk_qset_upload:
  * from such buffers the copy to the GPU is a direct DMA (no staging copy on the

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "mk_internal.hpp"
 
@@ -82,6 +83,7 @@ struct ScopedTimer {
 };
 
 static int settle_build(mk_ctx *c);
+static int build_from_characters(mk_ctx *c);
 
 // Every entry point starts here: bind the device and, unless the caller is an append
 // that wants to overlap with it, fold the build batch still in flight into the index.
@@ -236,8 +238,9 @@ int ensure_bloom_summary(mk_ctx *c)
     return MK_OK;
 }
 
-// for_append = false: the long-query sketches borrow the tables / codes / slots only; the Bloom
+// for_append = false: the long-query sketches borrow the tables / slots only; the Bloom
 // first-writer keys (8 bytes per reachable cell: 512 MiB at -b 33) are build-only.
+// seq_bytes: characters the batch brings (0: it comes packed, or is generated on the device).
 static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool for_append = true)
 {
     if (!c->d_tables) {
@@ -254,7 +257,12 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
     if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
     if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
-    MK_TRY(ensure_codes(c, seq_bytes));
+    if (for_append)
+        for (int b = 0; b < 2; ++b) {
+            if (!c->d_pk_off[b]) MK_TRY(dev_alloc(&c->d_pk_off[b], kBuildBatch + 1));
+            if (!c->d_heads[b]) MK_TRY(dev_alloc(&c->d_heads[b], (uint64_t)kBuildBatch * 32));
+        }
+    if (!for_append) MK_TRY(ensure_codes(c, seq_bytes));
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
         const uint64_t old_cap = c->seq_cap[buf];
         dev_free(c->d_seq[buf]);
@@ -263,6 +271,31 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
         MK_TRY(dev_alloc(&c->d_seq[buf], cap + 64));
         c->seq_cap[buf] = cap;
     }
+    return MK_OK;
+}
+
+// Offsets of a batch's sequences in its packed form (mk_ctx::d_pk): 8 bytes of codes per 32 positions plus
+// 32 bytes of slack each (the kernels read whole words past a sequence's end), 16-byte aligned so that half an
+// offset -- the sequence's place among the exception bits -- is 8-byte aligned.  Returns the bytes of codes.
+static uint64_t packed_offsets(const uint64_t *h_off, uint32_t n, uint64_t *pk_off)
+{
+    pk_off[0] = 0;
+    for (uint32_t g = 0; g < n; ++g)
+        pk_off[g + 1] = (pk_off[g] + 8 * ((h_off[g + 1] - h_off[g] + 31) / 32) + 32 + 15) / 16 * 16;
+    return pk_off[n];
+}
+
+// room for a batch of `code_bytes` of codes (+ half as many bytes of exception bits) in packed buffer `buf`
+// (never the buffer of the batch in flight)
+static int ensure_packed(mk_ctx *c, int buf, uint64_t code_bytes)
+{
+    if (code_bytes <= c->pk_cap[buf]) return MK_OK;
+    const uint64_t old_cap = c->pk_cap[buf];
+    dev_free(c->d_pk[buf]);
+    c->pk_cap[buf] = 0;
+    const uint64_t cap = (std::max<uint64_t>(code_bytes, std::max(c->pk_cap[buf ^ 1], old_cap * 2)) + 255) / 256 * 256;
+    MK_TRY(dev_alloc(&c->d_pk[buf], cap + cap / 2 + 256));
+    c->pk_cap[buf] = cap;
     return MK_OK;
 }
 
@@ -277,37 +310,70 @@ static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t
     return (uint64_t)est;
 }
 
-// Kernels of one batch: sequences already on their way into c->d_seq[buf] at offsets
-// h_off[0..n] (the caller has ordered the stream behind that copy).  Nothing here waits
-// for the device; the results are read back into pinned memory and folded in by
-// settle_build.
-static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf)
+// Kernels of one batch.  Its sequences are already on their way to the device, in one of three forms:
+//   kChars    characters in c->d_seq[buf] at offsets h_off[0..n] (packed here, pack_kernel)
+//   kPacked   codes / exception bits in c->d_pk[buf] at pk_off, first characters in c->d_heads[buf], the
+//             "has exceptions" flags in h_dirty (mk_index_append_packed)
+//   kSynth    codes generated into c->d_pk[buf] (no exceptions anywhere)
+// -- the caller has ordered the stream behind the copy or the generator.  Nothing here waits for the
+// device; the results are read back into pinned memory and folded in by settle_build.
+enum BatchForm { kChars, kPacked, kSynth };
+
+static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, BatchForm form, const uint32_t *h_dirty = nullptr)
 {
     MK_TRY(ensure_capacity(c, c->G + n));
     mk_ctx::BuildInFlight &b = c->build;
     b.n = n; b.buf = buf; b.binned = false;
+    b.have_chars = form == kChars; b.have_heads = form == kPacked;
     memcpy(b.off, h_off, (size_t)(n + 1) * 8);
-    const char *d_seq = c->d_seq[buf];
     MK_HIP(hipMemcpyAsync(c->d_seq_off, b.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    MK_TRY(upload_code_offsets(c, b.off, n));
-    MK_TRY(launch_seed_valid(c, d_seq, c->d_seq_off, n, c->d_seed_valid));
+    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));      // overflow mark, exception flags, sums: one block
+    uint8_t *codes = c->d_pk[buf], *except = c->d_pk[buf] + c->pk_cap[buf];
+    if (form == kChars) {
+        uint64_t *pk_off = c->h_pk_off[buf];
+        MK_TRY(ensure_packed(c, buf, packed_offsets(b.off, n, pk_off)));
+        codes = c->d_pk[buf]; except = c->d_pk[buf] + c->pk_cap[buf];
+        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        MK_TRY(launch_pack(c, c->d_seq[buf], c->d_seq_off, b.off, n, codes, except, c->d_pk_off[buf]));
+    } else if (form == kPacked && h_dirty) {
+        MK_HIP(hipMemcpyAsync(c->d_dirty, h_dirty, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    // the k-1 seed digits of every sequence (str2numstrand / rcb), and the seeds' validity for the fallback
+    // (generated sequences are plain ACGT: neither characters nor heads, nothing to rewrite)
+    MK_TRY(launch_seed_fix(c, form == kChars ? c->d_seq[buf] : nullptr, c->d_seq_off, form == kPacked ? c->d_heads[buf] : nullptr, n,
+                           codes, except, c->d_pk_off[buf]));
     MK_TRY(ensure_bloom_summary(c));
     {
-        // binned form: scatter, then ONE kernel that reduces, emits fingerprints and sizes and runs
-        // Bloom pass A, the matrix rows, Bloom pass B
+        // scatter, then ONE kernel that reduces, emits fingerprints and sizes and runs Bloom pass A, the matrix
+        // rows, Bloom pass B
         ScopedTimer t(c, 3);
-        MK_TRY(launch_genome_build_binned(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->G, &b.binned));
+        MK_TRY(launch_build_packed(c, codes, except, c->d_pk_off[buf], c->d_seq_off, b.off, n, c->G, &b.binned));
     }
-    if (!b.binned) {                                             // shapes the bins do not fit: atomic kernel + separate passes
-        { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
-        ScopedTimer t(c, 4);
-        MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
-        MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, c->d_code_off));
-    }
+    if (!b.binned) MK_TRY(build_from_characters(c));             // shapes the bins do not fit
     // one copy back of the batch's counters (overflow mark, active counts, cardinality sums)
     MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
     b.on = true;
     return MK_OK;
+}
+
+// The batch in flight once more, through the atomic kernel + separate passes, which work from characters:
+// for shapes the bins do not fit and for batches whose overflow list ran over (very repetitive sequence).
+// A batch that arrived packed is turned back into characters that mean the same to those kernels.
+static int build_from_characters(mk_ctx *c)
+{
+    mk_ctx::BuildInFlight &b = c->build;
+    const uint32_t n = b.n;
+    if (!b.have_chars) {
+        MK_TRY(ensure_build_scratch(c, b.off[n], b.buf));
+        MK_TRY(launch_unpack(c, c->d_pk[b.buf], c->d_pk[b.buf] + c->pk_cap[b.buf], c->d_pk_off[b.buf],
+                             b.have_heads ? c->d_heads[b.buf] : nullptr, c->d_seq_off, b.off, n, c->d_seq[b.buf]));
+        b.have_chars = true;
+    }
+    const char *d_seq = c->d_seq[b.buf];
+    { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
+    ScopedTimer t(c, 4);
+    MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
+    return launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr);
 }
 
 // Wait for the batch in flight and fold it into the index (Miekki.cpp:303-311).
@@ -318,16 +384,10 @@ static int settle_build(mk_ctx *c)
     b.on = false;
     MK_HIP(hipStreamSynchronize(c->stream));
     const uint32_t n = b.n;
-    if (b.binned && binned_build_overflowed(c->h_back->ovf)) {
-        // the overflow list of the binned sketch ran over (very repetitive sequence): the
+    if (b.binned && build_overflowed(c->h_back->ovf)) {
+        // the overflow list of the binned build ran over (very repetitive sequence): the
         // batch's later kernels saw the same mark and did nothing; redo it with the atomic kernel
-        const char *d_seq = c->d_seq[b.buf];
-        { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
-        {
-            ScopedTimer t(c, 4);
-            MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
-            MK_TRY(launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr));
-        }
+        MK_TRY(build_from_characters(c));
         MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
         MK_HIP(hipStreamSynchronize(c->stream));
     }
@@ -806,6 +866,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_bloom = nullptr; c->d_bloom_order = nullptr; c->build_batch = 0; c->d_tables = nullptr;
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_counters = nullptr; c->h_sizes = nullptr; c->size_parity = 0;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
+    for (int b = 0; b < 2; ++b) { c->d_pk[b] = nullptr; c->pk_cap[b] = 0; c->d_pk_off[b] = nullptr; c->d_heads[b] = nullptr; }
     c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
     c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
@@ -856,6 +917,7 @@ void mk_destroy(mk_ctx *c)
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_counters); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
     dev_free(c->d_bloom_order); dev_free(c->d_tables);
+    for (int b = 0; b < 2; ++b) { dev_free(c->d_pk[b]); dev_free(c->d_pk_off[b]); dev_free(c->d_heads[b]); }
     dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
     dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_partials);
@@ -968,7 +1030,57 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(settle_build(c));
         MK_HIP(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-        MK_TRY(enqueue_batch(c, off, nb, buf));
+        MK_TRY(enqueue_batch(c, off, nb, buf, kChars));
+        c->seq_cur = buf;
+        MK_HIP(hipEventSynchronize(c->ev_copy));
+        g0 += nb;
+    }
+    return MK_OK;
+}
+
+// insert_sequences for sequences that arrive packed: a quarter of the bytes cross
+// PCIe -- 2 bits per base, plus 1 where a sequence has characters other than A, C, G, T -- and the
+// device skips its own packing pass.  Pipelined exactly like mk_index_append.
+int mk_index_append_packed(mk_ctx *c, const mk_packed_seq *seqs, uint32_t n)
+{
+    if (!c || (n && !seqs)) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c, false));
+    for (uint32_t g = 0; g < n; ++g) {
+        if (seqs[g].len < c->p.k) { set_error("sequence %u shorter than k", g); return MK_ERR_ARG; }
+        if (!seqs[g].codes) { set_error("sequence %u has no codes", g); return MK_ERR_ARG; }
+    }
+    MK_TRY(ensure_build_scratch(c, 0, c->seq_cur ^ 1));
+    for (uint32_t g0 = 0; g0 < n;) {
+        uint64_t off[kBuildBatch + 1];
+        off[0] = 0;
+        uint32_t nb = 0;
+        while (nb < c->build_batch && g0 + nb < n && (nb == 0 || off[nb] + seqs[g0 + nb].len <= (2ull << 30))) {
+            off[nb + 1] = off[nb] + seqs[g0 + nb].len;
+            ++nb;
+        }
+        const int buf = c->seq_cur ^ 1;
+        uint64_t *pk_off = c->h_pk_off[buf];
+        uint32_t *dirty = c->h_dirty[buf];
+        char *heads = c->h_heads[buf];
+        MK_TRY(ensure_packed(c, buf, packed_offsets(off, nb, pk_off)));
+        uint8_t *codes = c->d_pk[buf], *except = c->d_pk[buf] + c->pk_cap[buf];
+        // small per-batch arrays first, then one copy per array of codes / exception bits -- a DMA each when the
+        // caller's buffers are page-locked
+        for (uint32_t g = 0; g < nb; ++g) memcpy(heads + 32 * g, seqs[g0 + g].head, 32);
+        MK_HIP(hipMemcpyAsync(c->d_heads[buf], heads, (size_t)nb * 32, hipMemcpyHostToDevice, c->copy_stream));
+        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        for (uint32_t g = 0; g < nb; ++g) {
+            const mk_packed_seq &q = seqs[g0 + g];
+            MK_HIP(hipMemcpyAsync(codes + pk_off[g], q.codes, (size_t)((q.len + 31) / 32) * 8, hipMemcpyHostToDevice, c->copy_stream));
+            dirty[g] = q.except ? 1u : 0u;
+            if (q.except)
+                MK_HIP(hipMemcpyAsync(except + pk_off[g] / 2, q.except, (size_t)((q.len + 63) / 64) * 8, hipMemcpyHostToDevice,
+                                      c->copy_stream));
+        }
+        MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
+        MK_TRY(settle_build(c));
+        MK_HIP(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        MK_TRY(enqueue_batch(c, off, nb, buf, kPacked, dirty));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
@@ -1004,12 +1116,15 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         uint64_t off[kBuildBatch + 1];
         for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
         const int buf = c->seq_cur ^ 1;
-        MK_TRY(ensure_build_scratch(c, off[nb], buf));
-        // the generator fills the buffer the batch in flight does NOT read: queue it behind that batch's
-        // kernels before waiting for them, so that the device is never idle while the host settles
-        MK_TRY(launch_synth_genomes(c, first_id + g0, nb, length, c->d_seq[buf]));
+        uint64_t *pk_off = c->h_pk_off[buf];
+        MK_TRY(ensure_packed(c, buf, packed_offsets(off, nb, pk_off)));
+        // the generator fills the buffer the batch in flight does NOT read -- in packed form, which is what the
+        // build works from: queue it behind that batch's kernels before waiting for them, so that the device is
+        // never idle while the host settles
+        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        MK_TRY(launch_synth_packed(c, first_id + g0, nb, length, c->d_pk[buf], c->d_pk_off[buf]));
         MK_TRY(settle_build(c));
-        MK_TRY(enqueue_batch(c, off, nb, buf));
+        MK_TRY(enqueue_batch(c, off, nb, buf, kSynth));
         c->seq_cur = buf;
     }
     return MK_OK;
@@ -1429,26 +1544,72 @@ int mk_dev_download(mk_ctx *c, void *dst, const void *d_src, uint64_t bytes)
 // Device-to-device copy between two contexts' GPUs (a peer DMA over xGMI when they differ),
 // queued on the SOURCE context's stream -- so behind the kernels that produced d_src -- and
 // waited for before returning: afterwards d_dst is complete for any stream of dst.
+// Peer access is asked for and enabled once per ordered pair of GPUs; a pair without it (a
+// restricted container, say) copies through host memory instead, and every copy is counted by
+// the path it took (mk_stats of the source context), so that a staged exchange is visible as
+// such and not as a slow xGMI.  Reads nothing of dst but its device ordinal.
+}  // extern "C"
+
+namespace {
+std::mutex g_peer_mutex;
+int g_peer_state[64][64];                                        // [src][dst]: 0 not asked yet, 1 peer access on, 2 none
+
+bool peer_access(int src, int dst)
+{
+    if (src == dst) return true;
+    if (src < 0 || dst < 0 || src >= 64 || dst >= 64) return false;
+    std::lock_guard<std::mutex> g(g_peer_mutex);
+    if (g_peer_state[src][dst] == 0) {
+        int can = 0;
+        bool on = hipDeviceCanAccessPeer(&can, src, dst) == hipSuccess && can;
+        if (on) {                                                // (the caller has bound `src`: the access is enabled FROM the current device)
+            const hipError_t e = hipDeviceEnablePeerAccess(dst, 0);
+            on = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        }
+        (void)hipGetLastError();
+        g_peer_state[src][dst] = on ? 1 : 2;
+        if (getenv("MIEKKI_VERBOSE"))
+            fprintf(stderr, "[miekki] GPU %d -> GPU %d: %s\n", src, dst, on ? "peer access (xGMI)" : "NO peer access: copies go through host memory");
+    }
+    return g_peer_state[src][dst] == 1;
+}
+}  // namespace
+
+extern "C" {
+
 int mk_dev_copy(mk_ctx *dst, void *d_dst, mk_ctx *src, const void *d_src, uint64_t bytes)
 {
     if (!dst || !src || (bytes && (!d_dst || !d_src))) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(src, false));
-    if (bytes) {
-        if (dst->p.device == src->p.device) {
-            MK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, src->stream));
-        } else if (hipMemcpyPeerAsync(d_dst, dst->p.device, d_src, src->p.device, bytes, src->stream) != hipSuccess) {
-            // no peer path between the two GPUs (a restricted container, say): through host memory
+    if (!bytes) { MK_HIP(hipStreamSynchronize(src->stream)); return MK_OK; }
+    const int sd = src->p.device, dd = dst->p.device;
+    bool direct = peer_access(sd, dd);
+    if (direct) {
+        const hipError_t e = sd == dd ? hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, src->stream)
+                                      : hipMemcpyPeerAsync(d_dst, dd, d_src, sd, bytes, src->stream);
+        if (e != hipSuccess) {
             (void)hipGetLastError();
-            MK_HIP(hipStreamSynchronize(src->stream));
-            std::vector<uint8_t> tmp(bytes);
-            MK_HIP(hipMemcpy(tmp.data(), d_src, bytes, hipMemcpyDeviceToHost));
-            MK_HIP(hipSetDevice(dst->p.device));
-            MK_HIP(hipMemcpy(d_dst, tmp.data(), bytes, hipMemcpyHostToDevice));
-            MK_HIP(hipSetDevice(src->p.device));
-            return MK_OK;
+            if (sd == dd) { set_error("device copy failed: %s", hipGetErrorString(e)); return MK_ERR_DEVICE; }
+            { std::lock_guard<std::mutex> g(g_peer_mutex); g_peer_state[sd][dd] = 2; }     // the pair copies through the host from now on
+            direct = false;
         }
     }
+    if (direct) {
+        MK_HIP(hipStreamSynchronize(src->stream));
+        src->stats.peer_copies++; src->stats.peer_copy_bytes += bytes;
+        return MK_OK;
+    }
+    // no peer path between the two GPUs: through (page-locked) host memory
     MK_HIP(hipStreamSynchronize(src->stream));
+    void *tmp = nullptr;
+    MK_HIP(hipHostMalloc(&tmp, bytes, hipHostMallocDefault));
+    hipError_t e = hipMemcpy(tmp, d_src, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipSetDevice(dd);
+    if (e == hipSuccess) e = hipMemcpy(d_dst, tmp, bytes, hipMemcpyHostToDevice);
+    (void)hipSetDevice(sd);
+    (void)hipHostFree(tmp);
+    if (e != hipSuccess) { set_error("staged device copy failed: %s", hipGetErrorString(e)); return MK_ERR_DEVICE; }
+    src->stats.staged_copies++; src->stats.staged_copy_bytes += bytes;
     return MK_OK;
 }
 

@@ -1,0 +1,620 @@
+// The index build from PACKED sequences (gfx950 only): 2 bits per base + exception bits, the
+// form genomes arrive in through mk_index_append_packed, are generated in by the synthetic
+// source, and are brought into first when they arrive as characters (mk_index_append).
+//
+// Replaces Miekki::minhash_sketch_partition (Miekki.cpp:150-197) and the body of
+// insert_sequences (Miekki.cpp:287-311) for whole batches of genomes:
+//   pack_kernel        characters -> codes + exception bits + "has exceptions" flag    (A1)
+//   seed_fix_kernel    the k-1 seed digits as str2numstrand / rcb make them            (A2)
+//   build_scatter_kernel   rolling k-mers, revhash64, partition + fingerprint; every
+//                      (fingerprint, position, partition) item into the slot of its BIN
+//                      (the partition's high bits) -- sorted by bin in LDS first, so
+//                      that a bin's run leaves as 16-byte stores                       (A3-A6)
+//   build_reduce_kernel    one workgroup per (genome, bin): per-partition minimum of
+//                      (fingerprint, position) in LDS, then for the winners: fingerprint
+//                      bytes, sketch_size / cardinality sums, Bloom pass A              (A4, A7, A9)
+// followed by fp_transpose_kernel, bloom_kernel<true> and bloom_summary_kernel (sketch.hip).
+//
+// Selection rule: in every partition the k-mer with the smallest
+// fingerprint wins, the earliest position among equals; "empty" can never be stored.
+#include <cmath>
+#include <cstdlib>
+
+#include "codes.hpp"
+#include "mk_internal.hpp"
+
+namespace mk {
+
+namespace {
+
+constexpr uint32_t kSeg = 4096;            // k-mers per scatter workgroup
+constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
+constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
+constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
+constexpr uint32_t kOvfItems = 1u << 20;   // room in the overflow list
+constexpr uint32_t kOvfFold = 1u << 15;    // overflow items every reduce workgroup is willing to scan
+
+}  // namespace
+
+// ---------------------------------------------------------------- characters -> packed
+// One thread packs 32 positions: one 64-bit word of codes, 32 exception bits.  A character is
+// classified four at a time: (c >> 1) & 3 maps A C G T to 0 1 3 2, x ^ (x >> 1) to 0 1 2 3; a byte
+// permute looks "ACGT"[code] up again, and a character that is not what its code stands for is an
+// exception (code 0, reverse digit 0: nuc2int / nuc2intrc, utils.cpp:31-49, 107-125).
+__device__ __forceinline__ void classify4(uint32_t x, uint32_t &codes8, uint32_t &bad4)
+{
+    const uint32_t t = (x >> 1) & 0x03030303u;
+    uint32_t code = t ^ ((t >> 1) & 0x01010101u);
+    const uint32_t back = __builtin_amdgcn_perm(0u, 0x54474341u, code);          // 'A' 'C' 'G' 'T' by code
+    const uint32_t d = x ^ back;
+    const uint32_t nz = ((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & 0x01010101u;   // 1 per differing byte
+    code &= ~(nz * 3u);
+    codes8 = (code * 0x01041040u) >> 24;                                         // four 2-bit codes side by side
+    bad4 = ((nz * 0x01020408u) >> 24) & 0xfu;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off, uint32_t n,
+                                                   uint8_t *__restrict__ codes, uint8_t *__restrict__ except,
+                                                   const uint64_t *__restrict__ code_off, uint32_t *__restrict__ dirty)
+{
+    const uint32_t g = blockIdx.y;
+    const uint64_t len = off[g + 1] - off[g];
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w * 32 >= len) return;
+    const char *__restrict__ s = seq + off[g] + w * 32;
+    const uint32_t m = (uint32_t)min((uint64_t)32, len - w * 32);
+    // 32 characters from wherever the sequence starts: whole 8-byte words around them (the buffer
+    // starts 256-byte aligned and carries 64 bytes of slack, so the window stays inside it)
+    const uintptr_t a = reinterpret_cast<uintptr_t>(s);
+    const uint64_t *__restrict__ q = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
+    const uint32_t sh = (uint32_t)(a & 7u) * 8u;
+    uint64_t v[5];
+#pragma unroll
+    for (uint32_t j = 0; j < 5; ++j) v[j] = q[j];
+    uint64_t word = 0;
+    uint32_t bad = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t c8 = sh ? (v[j] >> sh) | (v[j + 1] << (64 - sh)) : v[j];
+        uint32_t c0, b0, c1, b1;
+        classify4((uint32_t)c8, c0, b0);
+        classify4((uint32_t)(c8 >> 32), c1, b1);
+        word |= (uint64_t)(c0 | (c1 << 8)) << (16 * j);
+        bad |= (b0 | (b1 << 4)) << (8 * j);
+    }
+    if (m < 32) {                                                   // past the end: code 0, no exception
+        word &= (1ULL << (2 * m)) - 1;
+        bad &= (1u << m) - 1u;
+    }
+    reinterpret_cast<uint64_t *>(codes + code_off[g])[w] = word;
+    reinterpret_cast<uint32_t *>(except + code_off[g] / 2)[w] = bad;
+    if (bad) atomicOr(&dirty[g], 1u);
+}
+
+// ---------------------------------------------------------------- the seed
+// The first k-1 characters of a sequence enter the rolling state through str2numstrand
+// (utils.cpp:252-272: case-insensitive; ANY other character makes the whole seed zero) and their
+// reverse digits through rcb (Miekki.cpp:66-76: always 3 - digit).  One thread per sequence
+// rewrites those positions of the packed form accordingly -- they lie in the first word -- and
+// records the seed's validity for the kernels that work from characters (the fallback path).
+// heads: the first 32 characters of every sequence, 32 bytes apart (packed input), or null:
+// then they are read from seq + off[g] (both null: nothing to do).
+__global__ void seed_fix_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off, const char *__restrict__ heads,
+                                uint32_t n, uint32_t k, uint8_t *__restrict__ codes, uint8_t *__restrict__ except,
+                                const uint64_t *__restrict__ code_off, uint32_t *__restrict__ valid)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    if (!heads && !seq) { valid[g] = 1; return; }                   // generated sequences: plain ACGT, the codes are the digits
+    const uint64_t len = off[g + 1] - off[g];
+    const char *__restrict__ s = heads ? heads + 32u * g : seq + off[g];
+    const uint32_t ns = (uint32_t)min((uint64_t)(k - 1), len);
+    uint32_t ok = 1;
+    uint64_t digits = 0;
+    for (uint32_t j = 0; j < ns; ++j) {
+        const uint32_t sc = seed_code((uint8_t)s[j]);
+        ok &= sc != 4u;
+        digits |= (uint64_t)(sc & 3u) << (2 * j);
+    }
+    if (!ok) digits = 0;
+    valid[g] = ok;
+    const uint64_t m2 = ns ? ((1ULL << (2 * ns)) - 1) : 0;
+    uint64_t *cw = reinterpret_cast<uint64_t *>(codes + code_off[g]);
+    cw[0] = (cw[0] & ~m2) | digits;
+    uint32_t *xw = reinterpret_cast<uint32_t *>(except + code_off[g] / 2);
+    xw[0] &= ~(uint32_t)((1ULL << ns) - 1);
+}
+
+// ---------------------------------------------------------------- synthetic genomes, packed
+// base i of genome g is the 2-bit field (62 - 2 * (i % 32)) of genome_word(g, i / 32),
+// i.e. the packed word is that word with the order of its digits reversed.
+__global__ void synth_packed_kernel(uint64_t first_id, uint32_t n, uint64_t len, uint8_t *__restrict__ codes,
+                                    const uint64_t *__restrict__ code_off)
+{
+    const uint64_t words = (len + 31) / 32;
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.y;
+    if (w >= words || g >= n) return;
+    uint64_t v = reverse_digits(genome_word(first_id + g, w));
+    const uint64_t m = len - w * 32;
+    if (m < 32) v &= (1ULL << (2 * m)) - 1;
+    reinterpret_cast<uint64_t *>(codes + code_off[g])[w] = v;
+}
+
+// packed -> characters with the same meaning to every kernel that works from characters: "ACGT"
+// by code, 'N' at an exception, and the head characters as they came (they decide the seed).
+__global__ void unpack_kernel(const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except,
+                              const uint64_t *__restrict__ code_off, const uint32_t *__restrict__ dirty,
+                              const char *__restrict__ heads, const uint64_t *__restrict__ off, char *__restrict__ seq)
+{
+    const uint32_t g = blockIdx.y;
+    const uint64_t len = off[g + 1] - off[g];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const uint64_t word = reinterpret_cast<const uint64_t *>(codes + code_off[g])[i >> 5];
+    char ch = "ACGT"[(word >> (2 * (i & 31u))) & 3u];
+    if (dirty[g] && ((reinterpret_cast<const uint32_t *>(except + code_off[g] / 2)[i >> 5] >> (i & 31u)) & 1u)) ch = 'N';
+    if (heads && i < 32) ch = heads[32u * g + i];
+    seq[off[g] + i] = ch;
+}
+
+// ---------------------------------------------------------------- scatter
+struct BuildShape {
+    uint32_t nbins, low_bits;      // low_bits = min(h, 12) partitions per bin (log2); nbins = P >> low_bits
+    uint32_t cap_words;            // words of one (genome, bin, workgroup) slot: word 0 = item count, then the items
+    uint32_t nwg;                  // scatter workgroups per genome
+    uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no slot reads
+};
+
+// Slot item: W == 1: fingerprint << 24 | position in segment << 12 | partition in bin  (32 bits);
+//            W == 2: fingerprint << 48 | position in segment << 12 | partition in bin  (64 bits).
+// The segment (= scatter workgroup) supplies the upper bits of the position.
+template <int W> struct ItemOf { using type = uint32_t; };
+template <> struct ItemOf<2> { using type = uint64_t; };
+
+// HyperMinHash fingerprint of anc's low 64 - h bits (Miekki::mantis, Miekki.cpp:91-113), for the
+// common case in one count-leading-zeros: v = the top 32 of those 64 - h bits.  When v >= 2^f the
+// leading one and the f bits below it all lie in v, the exponent max(prefix - 32 + h, 0) is v's own
+// bit index and the suffix the f bits below it.  (v < 2^f: one k-mer in 2^(32 - f); the general form.)
+__device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, uint32_t h, uint32_t f, uint32_t empty)
+{
+    const uint32_t v = __builtin_amdgcn_alignbit(ahi, alo, 32u - h);
+    if (__builtin_expect(v >> f, 1)) {
+        const uint32_t lz = (uint32_t)__clz((int)v);
+        const uint32_t top = v << lz;
+        return (((31u - lz) << f) | ((top << 1) >> (32u - f))) & empty;
+    }
+    return mantis_halves(ahi & ((1u << (32u - h)) - 1u), alo, h, f, empty);
+}
+
+// What bounds this kernel is instruction issue (round 3: ~122 vector instructions per k-mer in its
+// predecessor, most of them around the hash loop, not in it).  So: the positions arrive packed --
+// a thread's 16 + k-1 digits are three LDS words, no classification, no squeezing; the items of the
+// whole workgroup are sorted by bin through ONE 4096-entry stage (4-byte items: 16 KiB, eight
+// workgroups per CU), and a bin's run leaves with 16-byte stores, four items per lane, the lanes
+// of a bin side by side -- no per-item address arithmetic.
+template <int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
+    const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ slots,
+    uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count, SketchParams sp, BuildShape bs)
+{
+    using item_t = typename ItemOf<W>::type;
+    constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    item_t *stage = reinterpret_cast<item_t *>(smem);                 // kSeg + kIPV items
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
+    __shared__ uint32_t cw[kSeg / 16 + 4];                            // the workgroup's positions, 16 per word
+    __shared__ uint32_t xw[kSeg / 16 + 4];                            // their exception bits (low 16)
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
+    const uint64_t len = off[g + 1] - off[g];
+    const uint64_t nk = len > sp.k ? len - sp.k : 0;                  // Miekki.cpp:162: the last k-mer is skipped
+    const uint64_t seg0 = (uint64_t)wg * kSeg;
+    for (uint32_t b = tid; b <= bs.nbins; b += 256) bins[b] = 0;
+    const uint32_t cnt = seg0 < nk ? (uint32_t)min((uint64_t)kSeg, nk - seg0) : 0u;
+    const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
+    if (cnt) {
+        // positions [seg0, seg0 + cnt + k - 1): words seg0 / 16 .. of the sequence's codes (the arrays carry slack)
+        const uint32_t *__restrict__ c32 = reinterpret_cast<const uint32_t *>(codes + code_off[g]) + seg0 / 16;
+        const uint16_t *__restrict__ x16 = reinterpret_cast<const uint16_t *>(except + code_off[g] / 2) + seg0 / 16;
+        const uint64_t last_word = (len + 15) / 16;                   // words that hold positions of this sequence
+        for (uint32_t j = tid; j < kSeg / 16 + 2; j += 256) {
+            const bool in = seg0 / 16 + j < last_word;
+            cw[j] = in ? c32[j] : 0u;
+            xw[j] = in && has_x ? (uint32_t)x16[j] : 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t i0 = tid * kPer;
+    item_t it[kPer];
+    uint32_t key[kPer];                                               // bin << 12 | rank in bin; ~0: no item
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) key[u] = ~0u;
+    if (i0 < cnt) {
+        const uint32_t w0 = cw[tid], w1 = cw[tid + 1], w2 = cw[tid + 2];
+        // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
+        const uint64_t F = ((uint64_t)w1 << 32) | w0;
+        uint64_t R = ~F;
+        uint32_t R2 = ~w2;
+        if (has_x) {
+            R &= ~spread_pairs32(xw[tid] | (xw[tid + 1] << 16));
+            R2 &= ~spread_pairs16(xw[tid + 2]);
+        }
+        const uint32_t km1 = sp.k - 1;                                // 1..30 digits of seed
+        const uint64_t seedmask = (1ULL << (2 * km1)) - 1;
+        // state after k-1 digits, as the reference's loop leaves it (Miekki.cpp:158-164)
+        const uint64_t S0 = reverse_digits(F & seedmask) >> (64 - 2 * km1), RC0 = (R & seedmask) << 2;
+        // the sixteen digits that enter, one per k-mer
+        const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)w2 << (64 - 2 * km1)));
+        const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
+        // rolling state in 32-bit halves (a 64-bit shift / and is several issue slots, a funnel shift one)
+        uint32_t Slo = (uint32_t)S0, Shi = (uint32_t)(S0 >> 32), Rlo = (uint32_t)RC0, Rhi = (uint32_t)(RC0 >> 32);
+        const uint32_t mlo = (uint32_t)sp.kmask, mhi = (uint32_t)(sp.kmask >> 32);
+        const uint32_t topshift = 2 * sp.k - 2;                       // even: the entering reverse digit lies within ONE half
+        const bool top_hi = topshift >= 32;
+        const uint32_t tsh = top_hi ? topshift - 32 : topshift;
+        const uint32_t lowmask = (1u << bs.low_bits) - 1u;
+        const uint32_t cap_items = bs.cap_words - 1u;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;                  // update_kmer, Miekki.cpp:51-55
+            Slo = ((Slo << 2) | ((fnew >> (2 * u)) & 3u)) & mlo;
+            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);                         // update_kmer_RC, Miekki.cpp:59-62
+            Rhi >>= 2;
+            const uint32_t rd = ((rnew >> (2 * u)) & 3u) << tsh;
+            if (top_hi) Rhi |= rd; else Rlo |= rd;
+            const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
+            const uint64_t anc = revhash64(S < RC ? S : RC);                      // Miekki.cpp:167-168
+            const uint32_t ahi = (uint32_t)(anc >> 32);
+            const uint32_t bucket = ahi >> (32 - sp.h);                           // Miekki.cpp:169
+            const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
+            if (fp == sp.empty || i0 + u >= cnt) continue;           // (past the segment's end only in a sequence's last workgroup)
+            const uint32_t bin = bucket >> bs.low_bits;
+            const uint32_t rank = atomicAdd(&bins[bin], 1u);
+            if (rank < cap_items) {
+                it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(((i0 + u) << kBin) | (bucket & lowmask));
+                key[u] = (bin << 12) | rank;
+            } else {                                                  // slot full (very repetitive sequence): overflow list
+                const uint32_t o = atomicAdd(ovf_count, 1u);
+                if (o < kOvfItems) {
+                    ovf[2 * (uint64_t)o] = ((uint64_t)g << 32) | bucket;
+                    ovf[2 * (uint64_t)o + 1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of min(count, capacity)
+    {
+        const uint32_t cap_items = bs.cap_words - 1u;
+        uint32_t c4[4], sum = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t b = tid * 4 + e;
+            c4[e] = b < bs.nbins ? min(bins[b], cap_items) : 0u;
+            sum += c4[e];
+        }
+        uint32_t incl = sum;
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();                                              // (every count has been read: the starts may overwrite them)
+        uint32_t base = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t b = tid * 4 + e;
+            if (b < bs.nbins) bins[b] = base;
+            base += c4[e];
+            if (b + 1 == bs.nbins) bins[bs.nbins] = base;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u)
+        if (key[u] != ~0u) stage[bins[key[u] >> 12] + (key[u] & 4095u)] = it[u];
+    __syncthreads();
+    // ---- a bin's run -> its slot: word 0 = count, then the items; 16-byte stores, the lanes of a bin side by side
+    item_t *__restrict__ gslots = slots + ((uint64_t)g * bs.nbins * bs.nwg + wg) * bs.cap_words;
+    const uint64_t bin_stride = (uint64_t)bs.nwg * bs.cap_words;
+    constexpr uint32_t kLanes = 4;                                    // lanes per bin and pass
+    typedef item_t vec_t __attribute__((ext_vector_type(kIPV)));
+    for (uint32_t t = tid; t < bs.nbins * kLanes; t += 256) {
+        const uint32_t b = t / kLanes, q = t % kLanes;
+        const uint32_t lo = bins[b], n = bins[b + 1] - lo;
+        item_t *__restrict__ dst = gslots + b * bin_stride;
+        // slot word j (j >= 1) = stage[lo + j - 1]; lane q writes words [kIPV * q, kIPV * q + kIPV), then kLanes * kIPV further on
+        for (uint32_t j = q * kIPV; j <= n; j += kLanes * kIPV) {
+            vec_t v;
+#pragma unroll
+            for (uint32_t e = 0; e < kIPV; ++e) v[e] = j + e == 0 ? (item_t)n : stage[lo + j + e - 1];
+            *reinterpret_cast<vec_t *>(dst + j) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- reduce + fingerprints + sizes + Bloom pass A
+// One 1024-thread workgroup per (genome, bin).  The bin's slots (one per scatter workgroup) are
+// read with eight lanes per slot, 16 bytes per lane: a wave-instruction fetches the first 128
+// bytes of eight slots whether they are full or not -- the count sits in word 0 and decides
+// afterwards what is an item -- so a wave's share of the bin is in flight at once instead of
+// one dependent round per slot.  Minimum per partition with LDS atomics; KEY32 packs
+// (fingerprint, position) into 32 bits when the sequence is shorter than 2^23 (a 16 KiB table).
+template <int W, bool KEY32>
+__global__ __launch_bounds__(1024) void build_reduce_kernel(
+    const typename ItemOf<W>::type *__restrict__ slots, const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_count,
+    const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
+    const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
+    const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
+    uint8_t *__restrict__ posted_blk, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
+    SketchParams sp, BuildShape bs)
+{
+    using item_t = typename ItemOf<W>::type;
+    using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
+    using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
+    constexpr uint32_t kIPV = 16 / sizeof(item_t);
+    constexpr uint32_t kFpShift = sizeof(item_t) * 8 - 8 * W;
+    constexpr uint32_t kKeyPos = KEY32 ? 23 : 40;                    // key = fingerprint << kKeyPos | position
+    constexpr key_t kNoKey = (key_t)~(key_t)0;
+    constexpr uint32_t kWin = (1u << kBin) / 1024;                   // winners per thread
+    typedef item_t vec_t __attribute__((ext_vector_type(kIPV)));
+    __shared__ key_t table[1u << kBin];
+    __shared__ uint32_t blk_posted[(1u << kBin) / 256];
+    __shared__ uint32_t s_act;
+    __shared__ unsigned long long s_card;
+    const uint32_t n_ovf = *ovf_count;
+    if (n_ovf > kOvfFold) return;                                     // the host redoes the batch (build_overflowed)
+    const uint32_t bin = blockIdx.x, g = blockIdx.y;
+    const uint32_t R = 1u << bs.low_bits;
+    for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kNoKey;
+    if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    {
+        const item_t *__restrict__ base = slots + ((uint64_t)g * bs.nbins + bin) * bs.nwg * bs.cap_words;
+        const uint32_t sub = lane >> 3, piece = lane & 7u;            // slot within the wave's eight, 16-byte piece within the slot
+        const uint32_t nwg = (bs.tune & 2u) ? 0u : bs.nwg;
+        constexpr uint32_t NW = 16, UN = 5;
+        auto fold = [&](item_t item, uint32_t w) {
+            const uint64_t pos = (uint64_t)w * kSeg + ((uint32_t)(item >> kBin) & (kSeg - 1u));
+            const key_t key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)pos;
+            atomicMin(&table[(uint32_t)item & (R - 1u)], key);
+        };
+        for (uint32_t w0 = wave * 8; w0 < nwg; w0 += NW * 8 * UN) {
+            vec_t v[UN];
+            uint32_t cnt[UN];
+#pragma unroll
+            for (uint32_t u = 0; u < UN; ++u) {
+                const uint32_t w = w0 + u * NW * 8 + sub;
+                // (a slot is at least 32 bytes; pieces past its end belong to the next slot and are never looked at)
+                if (w < nwg && piece * kIPV < bs.cap_words) v[u] = *reinterpret_cast<const vec_t *>(base + (uint64_t)w * bs.cap_words + piece * kIPV);
+                else v[u] = (vec_t)(item_t)0;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UN; ++u) {
+                const uint32_t w = w0 + u * NW * 8 + sub;
+                // the slot's count is word 0 of its piece 0: lane (sub << 3) holds it
+                cnt[u] = (uint32_t)__shfl((uint32_t)v[u][0], (int)(lane & ~7u));
+                if (w >= nwg) cnt[u] = 0;
+#pragma unroll
+                for (uint32_t e = 0; e < kIPV; ++e) {
+                    const uint32_t j = piece * kIPV + e;              // slot word; items are words 1 .. count
+                    if (j >= 1 && j <= cnt[u]) fold(v[u][e], w);
+                }
+            }
+            // slots that hold more than the first 128 bytes show: the rest, eight lanes a slot again
+#pragma unroll
+            for (uint32_t u = 0; u < UN; ++u) {
+                const uint32_t w = w0 + u * NW * 8 + sub;
+                for (uint32_t j0 = 8 * kIPV; j0 <= cnt[u]; j0 += 8 * kIPV) {
+                    const uint32_t j = j0 + piece * kIPV;
+                    if (j > cnt[u]) continue;
+                    const vec_t x = *reinterpret_cast<const vec_t *>(base + (uint64_t)w * bs.cap_words + j);
+#pragma unroll
+                    for (uint32_t e = 0; e < kIPV; ++e)
+                        if (j + e <= cnt[u]) fold(x[e], w);
+                }
+            }
+        }
+    }
+    // items that found their slot full (repetitive sequence): the few there are join here
+    for (uint32_t i = threadIdx.x; i < n_ovf; i += 1024) {
+        const uint64_t where = ovf[2 * (uint64_t)i];
+        if ((uint32_t)(where >> 32) == g && ((uint32_t)where >> bs.low_bits) == bin) {
+            const uint64_t k64 = ovf[2 * (uint64_t)i + 1];           // fingerprint << 40 | position
+            const key_t key = KEY32 ? (key_t)(((k64 >> 40) << 23) | (k64 & ((1ULL << 23) - 1))) : (key_t)k64;
+            atomicMin(&table[(uint32_t)where & (R - 1u)], key);
+        }
+    }
+    __syncthreads();
+    const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
+    fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
+    uint64_t canon[kWin];
+    uint32_t posted_mask = 0, act = 0;
+    unsigned long long card = 0;
+    const uint64_t *__restrict__ gcodes = reinterpret_cast<const uint64_t *>(codes + code_off[g]);
+    const uint64_t *__restrict__ gexcept = reinterpret_cast<const uint64_t *>(except + code_off[g] / 2);
+    const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
+#pragma unroll
+    for (uint32_t j = 0; j < kWin; ++j) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        canon[j] = kEmptyKey;
+        if (i >= R) continue;
+        const key_t key = table[i];
+        const uint32_t fp = key == kNoKey ? sp.empty : (uint32_t)(key >> kKeyPos);
+        fpo[i] = (fp_t)fp;
+        if (key == kNoKey) continue;
+        ++act;
+        card += 1ull << (31u - (fp >> sp.f));                         // Miekki.cpp:293: sum of 2^-exp, in units of 2^-31
+        if (!bloom || (bs.tune & 1u)) continue;
+        // pass A of the Bloom insert for this winner (see bloom_kernel<false>, sketch.hip)
+        const uint64_t pos = (uint64_t)key & ((1ULL << kKeyPos) - 1);
+        const uint64_t cn = canon_from_packed(gcodes, gexcept, has_x, pos, sp.k);
+        canon[j] = cn;
+        const uint64_t anc = revhash64(cn);
+        const uint32_t p = bin * R + i;
+        uint64_t sum_idx = ~0ull;
+        uint32_t sum_word = 0;
+        for (uint32_t hi = 0; hi < kNumHash; ++hi) {
+            const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
+            const uint64_t cell = hsh >> 3;
+            if (cell >= bloom_dev_bytes) continue;
+            const uint64_t grp = cell >> 3;
+            if ((grp >> 5) != sum_idx) { sum_idx = grp >> 5; sum_word = full[sum_idx]; }
+            if ((sum_word >> (grp & 31u)) & 1u) continue;
+            if (bloom[cell] == 0) {
+                const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (hi << 4) | (uint32_t)(hsh & 7);
+                atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+                posted_mask |= 1u << j;
+            }
+        }
+        if ((posted_mask >> j) & 1u) blk_posted[i >> 8] = 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); card += __shfl_xor(card, o); }
+    if (lane == 0 && act) { atomicAdd(&s_act, act); atomicAdd(&s_card, card); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_act) { atomicAdd(&active[g], s_act); atomicAdd(&cardsum[g], s_card); }
+    // what pass B needs: the canonical k-mers of the blocks in which something was posted
+#pragma unroll
+    for (uint32_t j = 0; j < kWin; ++j) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        if (i < R && blk_posted[i >> 8]) tables[row0 + i] = ((posted_mask >> j) & 1u) ? canon[j] : kEmptyKey;
+    }
+    const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
+    if (threadIdx.x < nblk) posted_blk[(uint64_t)g * blk_per_genome + (uint64_t)bin * nblk + threadIdx.x] = (uint8_t)blk_posted[threadIdx.x];
+}
+
+// ---------------------------------------------------------------- host side
+// shape of the build for a batch, and its slot memory; *fits = false when the batch does not suit the
+// bins (the caller then takes the atomic kernel, from characters)
+static int build_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BuildShape &bs, bool *fits, bool *key32)
+{
+    *fits = false;
+    uint64_t max_nk = 0, max_len = 0;
+    for (uint32_t g = 0; g < n; ++g) {
+        const uint64_t len = h_off[g + 1] - h_off[g];
+        max_len = std::max(max_len, len);
+        if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
+    }
+    static const uint32_t tune = [] { const char *e = getenv("MIEKKI_TUNE_BUILD"); return e ? (uint32_t)atoi(e) : 0u; }();
+    bs.tune = tune;
+    bs.low_bits = std::min<uint32_t>(c->p.h, kBin);
+    bs.nbins = c->P >> bs.low_bits;
+    if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
+    bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);
+    // per (workgroup, bin) the item count is ~Poisson(mean): a slot holds mean + 5.5 sigma + 2 items behind its
+    // count word (a handful of items per batch of 64 x 5 Mb go to the overflow list), in whole 32-byte units
+    const double mean = (double)kSeg / bs.nbins;
+    const uint32_t items = bs.nbins == 1 ? kSeg : std::min<uint32_t>(kSeg, (uint32_t)(mean + 5.5 * std::sqrt(mean) + 2.0));
+    bs.cap_words = (items + 1 + 7) / 8 * 8;
+    *key32 = c->W == 1 && max_len < (1ULL << 23);
+    const uint64_t isz = c->W == 1 ? 4 : 8;
+    const uint64_t need = (uint64_t)bs.nbins * bs.nwg * bs.cap_words * n * isz;       // bytes
+    if (need > (12ull << 30)) return MK_OK;                          // slot memory budget
+    if (need > c->slots_cap * 8) {
+        if (c->d_slots) (void)hipFree(c->d_slots);
+        c->d_slots = nullptr; c->slots_cap = 0;
+        MK_HIP(hipMalloc((void **)&c->d_slots, (need + 7) / 8 * 8 + 64));
+        c->slots_cap = (need + 7) / 8;
+    }
+    if (!c->d_ovf) MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfItems * 16));
+    MK_TRY(ensure_build_counters(c));
+    *fits = true;
+    return MK_OK;
+}
+
+bool build_overflowed(uint32_t ovf_count) { return ovf_count > kOvfFold; }
+
+int launch_pack(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint8_t *d_codes,
+                uint8_t *d_except, const uint64_t *d_code_off)
+{
+    uint64_t max_len = 0;
+    for (uint32_t g = 0; g < n; ++g) max_len = std::max(max_len, h_off[g + 1] - h_off[g]);
+    if (!n || !max_len) return MK_OK;
+    const uint64_t words = (max_len + 31) / 32;
+    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->stream, d_seq, d_off, n, d_codes,
+                       d_except, d_code_off, c->d_dirty);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int launch_seed_fix(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const char *d_heads, uint32_t n, uint8_t *d_codes,
+                    uint8_t *d_except, const uint64_t *d_code_off)
+{
+    if (!n) return MK_OK;
+    hipLaunchKernelGGL(seed_fix_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_seq, d_off, d_heads, n, c->p.k, d_codes,
+                       d_except, d_code_off, c->d_seed_valid);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off)
+{
+    if (!n || !len) return MK_OK;
+    const uint64_t words = (len + 31) / 32;
+    hipLaunchKernelGGL(synth_packed_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->stream, first_id, n, len,
+                       d_codes, d_code_off);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+int launch_unpack(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
+                  const uint64_t *d_off, const uint64_t *h_off, uint32_t n, char *d_seq)
+{
+    uint64_t max_len = 0;
+    for (uint32_t g = 0; g < n; ++g) max_len = std::max(max_len, h_off[g + 1] - h_off[g]);
+    if (!n || !max_len) return MK_OK;
+    hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)((max_len + 255) / 256), n), dim3(256), 0, c->stream, d_codes, d_except,
+                       d_code_off, c->d_dirty, d_heads, d_off, d_seq);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// The whole build of a batch from its packed form: scatter, reduce + fingerprints + sizes + Bloom pass A,
+// the matrix rows, Bloom pass B over the blocks that need it.  *used = false: the shape does not suit the bins.
+int launch_build_packed(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const uint64_t *d_off,
+                        const uint64_t *h_off, uint32_t n, uint32_t g0, bool *used)
+{
+    *used = false;
+    if (!n) return MK_OK;
+    BuildShape bs;
+    bool fits = false, key32 = false;
+    MK_TRY(build_setup(c, h_off, n, bs, &fits, &key32));
+    if (!fits) return MK_OK;
+    const uint64_t fp_bytes = (uint64_t)c->build_batch * c->P * c->W;
+    if (!c->d_fpT) {
+        MK_HIP(hipMalloc((void **)&c->d_fpT, fp_bytes + 64));
+        MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
+    }
+    const SketchParams sp = make_sp(c);
+    const size_t isz = c->W == 1 ? 4 : 8;
+    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
+#define MK_SCATTER(Wv)                                                                                                         \
+    hipLaunchKernelGGL(build_scatter_kernel<Wv>, dim3(bs.nwg, n), dim3(256), lds, c->stream, d_codes, d_except, d_code_off,      \
+                       c->d_dirty, d_off, reinterpret_cast<typename ItemOf<Wv>::type *>(c->d_slots), c->d_ovf, c->d_ovf_count, sp, bs)
+#define MK_REDUCE(Wv, K32)                                                                                                      \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(1024), 0, c->stream,                              \
+                       reinterpret_cast<const typename ItemOf<Wv>::type *>(c->d_slots), c->d_ovf, c->d_ovf_count, d_codes,      \
+                       d_except, d_code_off, c->d_dirty, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full,  \
+                       c->d_fpT, c->d_tables, c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bs)
+    if (c->W == 1) {
+        MK_SCATTER(1);
+        if (key32) MK_REDUCE(1, true); else MK_REDUCE(1, false);
+    } else {
+        MK_SCATTER(2);
+        MK_REDUCE(2, false);
+    }
+#undef MK_SCATTER
+#undef MK_REDUCE
+    MK_HIP(hipGetLastError());
+    MK_TRY(launch_build_tail(c, n, g0));
+    *used = true;
+    return MK_OK;
+}
+
+}  // namespace mk

@@ -124,10 +124,25 @@ struct mk_ctx {
     // other than the appends settles it first (settle_build in api.hip).
     struct BuildInFlight {
         bool on, binned;
+        bool have_chars;           // the batch's characters are in d_seq[buf] (else only its packed form exists, in d_pk[buf])
+        bool have_heads;           // d_heads[buf] holds the sequences' first 32 characters (packed input)
         uint32_t n;
         int buf;
         uint64_t off[mk::kBuildBatch + 1];
     } build;
+    // The batch in packed form (build.hip): d_pk[b] = [codes: pk_cap[b] bytes][exception bits: pk_cap[b] / 2 bytes],
+    // sequence g at byte offset pk_off[g] (16-byte aligned) of the codes and pk_off[g] / 2 of the exception bits.
+    // Two of everything: the next batch is generated or copied into one while the kernels of the batch in flight
+    // read the other.
+    uint8_t *d_pk[2];
+    uint64_t pk_cap[2];
+    uint64_t *d_pk_off[2];         // kBuildBatch + 1 offsets
+    char *d_heads[2];              // kBuildBatch x 32 characters
+    // host images of the small per-batch arrays: they are copied asynchronously, and an append returns with its
+    // batch still in flight, so they live here and not on a caller's stack
+    uint64_t h_pk_off[2][mk::kBuildBatch + 1];
+    uint32_t h_dirty[2][mk::kBuildBatch];
+    char h_heads[2][mk::kBuildBatch * 32];
     // Per-batch counters of the build live in ONE device block (one memset before a batch, one copy
     // back after it): d_ovf_count, d_dirty, d_active, d_cardsum point into d_counters.  BuildCounters
     // is its layout, and that of the pinned read-back block.
@@ -225,6 +240,20 @@ inline MatRef mat_ref(const mk_ctx *c)
     return m;
 }
 
+// parameters every sketch kernel takes
+struct SketchParams {
+    uint32_t k, h, f, empty, bloom_log2, P;
+    uint64_t kmask;
+};
+inline SketchParams make_sp(const mk_ctx *c)
+{
+    SketchParams s;
+    s.k = c->p.k; s.h = c->p.h; s.f = c->f; s.empty = c->empty; s.bloom_log2 = c->p.bloom_log2;
+    s.P = c->P;
+    s.kmask = (c->p.k < 32) ? ((1ULL << (2 * c->p.k)) - 1) : ~0ULL;
+    return s;
+}
+
 // timing helpers (api.hip)
 int timer_begin(mk_ctx *c, int kind, Timer &t);
 int timer_end(mk_ctx *c, Timer &t);
@@ -251,6 +280,18 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
                         const uint64_t *d_code_off);
 int launch_bloom_summary(mk_ctx *c);
+int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0);     // matrix rows, Bloom pass B, summary (after a fused reduce kernel)
+// ---- build.hip: the index build from packed sequences (2-bit codes + exception bits)
+int launch_pack(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint8_t *d_codes,
+                uint8_t *d_except, const uint64_t *d_code_off);
+int launch_seed_fix(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const char *d_heads, uint32_t n, uint8_t *d_codes,
+                    uint8_t *d_except, const uint64_t *d_code_off);
+int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off);
+int launch_unpack(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
+                  const uint64_t *d_off, const uint64_t *h_off, uint32_t n, char *d_seq);
+int launch_build_packed(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const uint64_t *d_off,
+                        const uint64_t *h_off, uint32_t n, uint32_t g0, bool *used);
+bool build_overflowed(uint32_t ovf_count);
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes);

@@ -12,6 +12,7 @@
 // on any other character: they travel as characters (mk_packed_seq::head).
 #include <immintrin.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/miekki_hip.h"
@@ -57,7 +58,8 @@ __attribute__((target("avx2"))) inline Block pack32_avx2(const unsigned char *c)
 
 bool have_avx2()
 {
-    static const bool yes = __builtin_cpu_supports("avx2");
+    // MIEKKI_PACK_SCALAR=1 forces the portable form (tests cover both)
+    static const bool yes = __builtin_cpu_supports("avx2") && !(getenv("MIEKKI_PACK_SCALAR") && atoi(getenv("MIEKKI_PACK_SCALAR")));
     return yes;
 }
 

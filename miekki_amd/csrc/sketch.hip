@@ -24,19 +24,6 @@ constexpr uint32_t kSegKmers = 4096;   // k-mers per workgroup of the genome ske
 constexpr uint32_t kPerThread = 16;    // consecutive k-mers per thread (rolling update)
 constexpr int kPosBits = 40;           // key = fingerprint << 40 | position
 
-struct SketchParams {
-    uint32_t k, h, f, empty, bloom_log2, P;
-    uint64_t kmask;
-};
-
-static SketchParams make_sp(const mk_ctx *c)
-{
-    SketchParams s;
-    s.k = c->p.k; s.h = c->p.h; s.f = c->f; s.empty = c->empty; s.bloom_log2 = c->p.bloom_log2;
-    s.P = c->P;
-    s.kmask = (c->p.k < 32) ? ((1ULL << (2 * c->p.k)) - 1) : ~0ULL;
-    return s;
-}
 
 // canonical k-mer starting at sequence position i, read straight from the characters
 __device__ __forceinline__ uint64_t canon_at_bytes(const char *__restrict__ seq, uint64_t i, uint32_t k,
@@ -804,6 +791,17 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
                            c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
                            c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables,
                            c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
+    MK_HIP(hipGetLastError());
+    MK_TRY(launch_build_tail(c, n, g0));
+    *used = true;
+    return MK_OK;
+}
+
+// What follows the fused reduce kernel of a batch (this file's or build.hip's): the batch's fingerprints
+// (d_fpT, genome-major) into the matrix rows, Bloom pass B over the blocks that posted a key, the summary.
+int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
+{
+    const SketchParams sp = make_sp(c);
     const uint32_t rows = 1024 / c->W;
     if (c->W == 1)
         hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
@@ -812,14 +810,15 @@ int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_o
         hipLaunchKernelGGL(fp_transpose_kernel<2>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
-        hipLaunchKernelGGL(bloom_kernel<true>, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables, d_seq, d_off,
-                           d_valid, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_ovf_count, c->d_codes,
-                           c->d_code_off, c->d_bloom_full, c->d_posted_blk, kOvfScan, sp);
+        // (pass B works from the canonical k-mers pass A left in d_tables: no sequence, no codes)
+        hipLaunchKernelGGL(bloom_kernel<true>, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables, (const char *)nullptr,
+                           (const uint64_t *)nullptr, (const uint32_t *)nullptr, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order,
+                           c->d_ovf_count, (const uint8_t *)nullptr, (const uint64_t *)nullptr, c->d_bloom_full, c->d_posted_blk,
+                           kOvfScan, sp);
         MK_HIP(hipGetLastError());
         MK_TRY(launch_bloom_summary(c));
     }
     MK_HIP(hipGetLastError());
-    *used = true;
     return MK_OK;
 }
 

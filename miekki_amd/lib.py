@@ -30,7 +30,12 @@ class Stats(C.Structure):
                 ("scan_launches", C.c_uint64), ("comparisons", C.c_uint64), ("active_partitions", C.c_uint64),
                 ("scan_algo_bytes", C.c_uint64), ("build_sketch_ms", C.c_double),
                 ("build_finalize_ms", C.c_double), ("build_kmers", C.c_uint64), ("build_genomes", C.c_uint64),
-                ("scan_slab_launches", C.c_uint64)]
+                ("scan_slab_launches", C.c_uint64), ("peer_copies", C.c_uint64), ("staged_copies", C.c_uint64),
+                ("peer_copy_bytes", C.c_uint64), ("staged_copy_bytes", C.c_uint64)]
+
+
+class PackedSeq(C.Structure):
+    _fields_ = [("codes", C.c_void_p), ("except_", C.c_void_p), ("len", C.c_uint64), ("head", C.c_char * 32)]
 
 
 vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
@@ -50,6 +55,10 @@ SIGNATURES = {
     "mk_probe_stream_read": (i32, [vp, u32, PP(C.c_double), PP(u64)]),
     "mk_probe_synth_genomes": (i32, [vp, u64, u32, u64, vp]),
     "mk_index_append": (i32, [vp, vp, vp, u32]),
+    "mk_index_append_packed": (i32, [vp, vp, u32]),
+    "mk_pack_code_words": (u64, [u64]),
+    "mk_pack_except_words": (u64, [u64]),
+    "mk_pack_append": (i32, [vp, vp, u64, vp, u64]),
     "mk_host_alloc": (i32, [vp, u64, PP(vp)]),
     "mk_host_free": (None, [vp, vp]),
     "mk_index_append_synthetic": (i32, [vp, u64, u32, u64]),

@@ -8,6 +8,7 @@
 #include <omp.h>          // Miekki.h uses omp_lock_t without including it
 #include "Miekki.h"
 #include "synth.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -134,15 +135,17 @@ static int cmd_filter(int argc, char** argv)
     return 0;
 }
 
-// scanbench <h> <G> <nq> <threads>: time the reference's query_sequences
+// scanbench <h> <G> <batches per thread> <threads>: time the reference's query_sequences
 // (Miekki.cpp:344-372) on an index of G genomes whose columns hold the real
 // fingerprints of a few synthetic genomes, cyclically shifted, with a saturated
-// Bloom filter (the >=10^4-genome regime).  Prints one
-// JSON line: comparisons, seconds.
+// Bloom filter (the >=10^4-genome regime).  Two samples on
+// the same index: ONE thread over one batch of 201 queries (the per-core figure),
+// then `threads` threads over `batches per thread` batches each, the way query_file
+// hands batches to its OpenMP threads (Miekki.cpp:430-480).  Prints one JSON line.
 static int cmd_scanbench(int argc, char** argv)
 {
     if (argc < 6) return 2;
-    uint32_t h = atoi(argv[2]), G = atoi(argv[3]), nq = atoi(argv[4]), th = atoi(argv[5]);
+    uint32_t h = atoi(argv[2]), G = atoi(argv[3]), per = atoi(argv[4]), th = atoi(argv[5]);
     const uint64_t L = 5000000, QL = 1000;
     const uint32_t NSRC = 4, k = 31;
     Miekki ix(k, h, 8, 5, 0, "/dev/null", 33, 200, th);
@@ -154,40 +157,100 @@ static int cmd_scanbench(int argc, char** argv)
     }
     ix.insert_sequences(gs);
     uint32_t P = 1u << h;
-    for (uint32_t p = 0; p < P; ++p) {                 // pad every column to G genomes
-        string col(G, 0);
-        for (uint32_t g = 0; g < G; ++g) col[g] = ix.index[(p + g / NSRC) & (P - 1)][g % NSRC];
-        ix.index[p] = col;
+    {                                                  // pad every column to G genomes (setup, not timed)
+        vector<string> cols(P);
+        #pragma omp parallel for num_threads(th) schedule(static)
+        for (uint32_t p = 0; p < P; ++p) {
+            string col(G, 0);
+            for (uint32_t g = 0; g < G; ++g) col[g] = ix.index[(p + g / NSRC) & (P - 1)][g % NSRC];
+            cols[p].swap(col);
+        }
+        ix.index.swap(cols);
     }
     ix.sketch_size.resize(G, ix.sketch_size[0]); ix.genome_size.resize(G, L); ix.index_size = G;
     std::fill(ix.Bloom_Filter.begin(), ix.Bloom_Filter.end(), 1);   // saturated
-    vector<vector<pair<string, uint32_t>>> batches;
+    const uint32_t nb = per * th, nq = nb * 201;
+    vector<vector<pair<string, uint32_t>>> batches(nb);
     for (uint32_t q = 0; q < nq; ++q) {
         uint64_t g, off; mk_query_origin(q, NSRC, L, QL, &g, &off);
-        if (q % 201 == 0) batches.emplace_back();
-        batches.back().push_back({gs[g].first.substr(off, QL), 0});
+        batches[q / 201].push_back({gs[g].first.substr(off, QL), 0});
     }
     // comparisons = G * sum over queries of active partitions
+    vector<uint64_t> act(nb, 0);
+    #pragma omp parallel for num_threads(th) schedule(dynamic)
+    for (uint32_t b = 0; b < nb; ++b)
+        for (auto& q : batches[b]) { uint32_t a = 0; auto sk = ix.minhash_sketch_partition(q.first, a); act[b] += a; }
     uint64_t act_sum = 0;
-    for (auto& b : batches) for (auto& q : b) { uint32_t a = 0; auto sk = ix.minhash_sketch_partition(q.first, a); act_sum += a; }
-    auto t0 = chrono::steady_clock::now();
+    for (uint64_t a : act) act_sum += a;
     uint64_t chk = 0;
+    auto t1 = chrono::steady_clock::now();
+    {
+        auto m = ix.query_sequences(batches[0]);
+        for (int i = 0; i < int(batches[0].size()); ++i) chk += m(i, 0);
+    }
+    double s1 = chrono::duration<double>(chrono::steady_clock::now() - t1).count();
+    auto t0 = chrono::steady_clock::now();
     #pragma omp parallel for num_threads(th) schedule(dynamic) reduction(+:chk)
     for (size_t b = 0; b < batches.size(); ++b) {
         auto m = ix.query_sequences(batches[b]);
         for (int i = 0; i < int(batches[b].size()); ++i) chk += m(i, 0);
     }
     double s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
-    printf("\n{\"comparisons\": %llu, \"seconds\": %.6f, \"threads\": %u, \"h\": %u, \"G\": %u, \"queries\": %u, \"check\": %llu}\n",
-           (unsigned long long)(act_sum * G), s, th, h, G, nq, (unsigned long long)chk);
+    printf("\n{\"comparisons\": %llu, \"seconds\": %.6f, \"threads\": %u, \"h\": %u, \"G\": %u, \"queries\": %u, "
+           "\"one_thread_comparisons\": %llu, \"one_thread_seconds\": %.6f, \"check\": %llu}\n",
+           (unsigned long long)(act_sum * G), s, th, h, G, nq, (unsigned long long)(act[0] * G), s1, (unsigned long long)chk);
+    return 0;
+}
+
+// sketchbench <h> <genomes> <threads>: time the reference's index build on synthetic 5 Mb genomes
+// held in memory: `threads` OpenMP threads each take the next genomes of the list and call
+// insert_sequences with batches of eleven -- index_file_of_file's structure (Miekki.cpp:546-581)
+// without its file reading: sketching runs in parallel, the append to the index is the
+// reference's own global critical section (Miekki.cpp:285).  First one thread over a few genomes
+// (the per-core figure), then all threads.  Prints one JSON line.
+static int cmd_sketchbench(int argc, char** argv)
+{
+    if (argc < 5) return 2;
+    uint32_t h = atoi(argv[2]), n = atoi(argv[3]), th = atoi(argv[4]);
+    const uint64_t L = 5000000;
+    const uint32_t k = 31, n1 = 8;
+    vector<string> seqs(n);
+    #pragma omp parallel for num_threads(th) schedule(dynamic)
+    for (uint32_t g = 0; g < n; ++g) { seqs[g].assign(L, 'A'); mk_genome_fill(g, 0, L, &seqs[g][0]); }
+    auto run = [&](uint32_t count, uint32_t threads) {
+        Miekki ix(k, h, 8, 5, 0, "/dev/null", 33, 200, threads);
+        uint32_t next = 0;
+        auto t0 = chrono::steady_clock::now();
+        #pragma omp parallel num_threads(threads)
+        {
+            vector<pair<string, string>> batch;
+            for (;;) {
+                uint32_t g;
+                #pragma omp critical(fof)
+                { g = next++; }
+                if (g >= count) break;
+                batch.push_back({seqs[g], "g"});
+                if (batch.size() > 10) { ix.insert_sequences(batch); batch.clear(); }
+            }
+            ix.insert_sequences(batch);
+        }
+        double s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+        if (ix.index_size != count) { fprintf(stderr, "sketchbench: %u genomes indexed, %u expected\n", (unsigned)ix.index_size, count); exit(1); }
+        return s;
+    };
+    const double s1 = run(std::min(n1, n), 1);
+    const double s = run(n, th);
+    printf("\n{\"genomes\": %u, \"seconds\": %.6f, \"threads\": %u, \"h\": %u, \"one_thread_genomes\": %u, "
+           "\"one_thread_seconds\": %.6f}\n", n, s, th, h, std::min(n1, n), s1);
     return 0;
 }
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: ref_harness golden|filter|scanbench ...\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness golden|filter|scanbench|sketchbench ...\n"); return 2; }
     if (!strcmp(argv[1], "golden")) return cmd_golden(argc, argv);
     if (!strcmp(argv[1], "filter")) return cmd_filter(argc, argv);
     if (!strcmp(argv[1], "scanbench")) return cmd_scanbench(argc, argv);
+    if (!strcmp(argv[1], "sketchbench")) return cmd_sketchbench(argc, argv);
     return 2;
 }

@@ -1,0 +1,113 @@
+"""SURVEY 8f row N2, packed ingest: mk_index_append_packed (2 bits per base + exception bits + the
+first 32 characters) must build exactly the index mk_index_append builds from the characters --
+and both go through the same device pipeline (build.hip), so these cases pin that pipeline to the
+ORACLE: the asymmetric strand codes of anything that is not ACGT (utils.cpp:31-49, 107-125), the
+seed's own rules (utils.cpp:252-272: lower case accepted, any other character zeroes it), lengths
+around k and around the 32-base words, both fingerprint widths."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import miekki_amd
+    return miekki_amd
+
+
+def masked(raw):
+    raw = np.frombuffer(bytes(raw), np.uint8).copy()
+    raw[32] = 0                                                  # uninitialised jaccard_estimation byte
+    return hashlib.sha256(raw.tobytes()).hexdigest()
+
+
+def messy_genomes(k, rng):
+    base = [synth.genome_bases(700 + i, 0, n) for i, n in enumerate(
+        [k, k + 1, k + 2, 31, 32, 33, 63, 64, 65, 4095 + k, 4096 + k, 4097 + k, 8192 + k, 20_000, 60_001, 130_000])]
+    base = [b for b in base if len(b) >= k]
+    out = list(base)
+    g = bytearray(base[-3])
+    g[5] = ord("N")                                              # N inside the seed: the whole seed becomes zero
+    out.append(bytes(g))
+    g = bytearray(base[-3])
+    g[:20] = bytes(g[:20]).lower()                               # lower case inside the seed: accepted there
+    g[200:260] = bytes(g[200:260]).lower()                       # ... and an exception everywhere else
+    g[4090:4100] = b"NNNNNNNNNN"                                 # across a workgroup's segment boundary
+    g[9000] = ord("-"); g[9001] = 0; g[9002] = 255
+    out.append(bytes(g))
+    g = bytearray(base[-2])
+    g[-40:] = b"N" * 40                                          # exceptions up to the last position
+    g[k - 2] = ord("n"); g[k - 1] = ord("n")                     # last seed position invalid, first rolling position an exception
+    out.append(bytes(g))
+    junk = np.frombuffer(b"ACGTNacgtnRYKM-", np.uint8)
+    out.append(bytes(rng.choice(junk, 30_000)))                  # mostly exceptions
+    out.append(b"ACGT" * 9000)                                   # repetitive: bins overflow, the batch is redone from characters
+    return out
+
+
+@pytest.mark.parametrize("k,h,fpb", [(31, 14, 8), (21, 12, 16), (9, 8, 8), (15, 20, 8), (27, 17, 16)])
+def test_packed_ingest_against_oracle(hip, k, h, fpb):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(k * 31 + h)
+    seqs = messy_genomes(k, rng)
+    o = orc.OracleMiekki(k, h, fpb, 32, 10)
+    o.insert_sequences(seqs)
+    want = masked(o.serialize().tobytes())
+    from_chars = hip.Miekki(k, h, fpb, 32, 10)
+    from_packed = hip.Miekki(k, h, fpb, 32, 10)
+    mixed = hip.Miekki(k, h, fpb, 32, 10)
+    try:
+        from_chars.insert_sequences(seqs)
+        assert masked(b"".join(from_chars.serialize())) == want
+        for i in range(0, len(seqs), 7):                         # several batches, pipelined
+            from_packed.insert_sequences_packed(seqs[i:i + 7])
+        np.testing.assert_array_equal(from_packed.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(from_packed.genome_size, o.genome_size)
+        assert masked(b"".join(from_packed.serialize())) == want
+        third = len(seqs) // 3                                   # the two entry points taking turns on one index
+        mixed.insert_sequences_packed(seqs[:third])
+        mixed.insert_sequences(seqs[third:2 * third])
+        mixed.insert_sequences_packed(seqs[2 * third:])
+        assert masked(b"".join(mixed.serialize())) == want
+        qs = [seqs[-2][100:1400], seqs[-6][:900], seqs[-4][150:1150], seqs[10]]
+        np.testing.assert_array_equal(from_packed.query_sequences(qs), o.query_sequences(qs))
+    finally:
+        from_chars.close(); from_packed.close(); mixed.close()
+
+
+def test_packed_synthetic_and_character_builds_agree(hip):
+    """The device generator emits the packed form directly; the same genomes as characters through
+    mk_index_append and packed on the host through mk_index_append_packed give the same index, and
+    all three equal the oracle's.  5 Mb genomes at h = 20 take the 32-bit key path of the reduce
+    kernel, a 9 Mb one the 64-bit one."""
+    from oracle import oracle as orc
+    k, h = 31, 20
+    L_ = 1_200_000
+    ids = [3, 4, 5]
+    seqs = [synth.genome_bases(g, 0, L_) for g in ids]
+    o = orc.OracleMiekki(k, h, 8, 33, 200)
+    o.insert_sequences(seqs)
+    want = masked(o.serialize().tobytes())
+    a = hip.Miekki(k, h, 8, 33, 200); b = hip.Miekki(k, h, 8, 33, 200); c = hip.Miekki(k, h, 8, 33, 200)
+    try:
+        a.insert_synthetic(3, 3, L_)
+        b.insert_sequences(seqs)
+        c.insert_sequences_packed(seqs)
+        for ix in (a, b, c):
+            assert masked(b"".join(ix.serialize())) == want
+    finally:
+        a.close(); b.close(); c.close()
+    long_ = synth.genome_bases(77, 0, 9_000_000)                  # >= 2^23 positions: 64-bit keys
+    o2 = orc.OracleMiekki(k, 17, 8, 33, 200)
+    o2.insert_sequences([long_, seqs[0]])
+    d = hip.Miekki(k, 17, 8, 33, 200)
+    try:
+        d.insert_sequences_packed([long_, seqs[0]])
+        assert masked(b"".join(d.serialize())) == masked(o2.serialize().tobytes())
+    finally:
+        d.close()

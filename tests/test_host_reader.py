@@ -85,6 +85,18 @@ def test_reader_matches_getline_semantics(dumper, tmp_path):
                 assert ex == "0", i
             else:
                 assert (ex, int(ln), int(h, 16), failed) == ("1", len(w), fnv1a(w), "0"), (i, names[i], threads)
+    # packed items (the reader packs while it parses): same sequences with every non-ACGT character as an
+    # exception, the first 32 characters kept as they came, "dirty" exactly where there is an exception
+    out = subprocess.run([dumper, lst, "5", "16", "0", str(len(want)), "packed"], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
+    for i, w in enumerate(want):
+        f = out[i].split()
+        if w is None:
+            assert f[0] == "0", i
+            continue
+        norm = bytes(c if c in b"ACGT" else ord("?") for c in w)
+        assert (f[0], int(f[1]), int(f[2], 16), f[3]) == ("1", len(w), fnv1a(norm), "0"), (i, names[i], "packed")
+        assert f[4] == ("1" if norm != w else "0")
+        assert (f[5] if len(f) > 5 else "") == w[:32].hex()
     # an allocator that runs dry after 100 kB (the page-lock limit): later buffers come from malloc, same
     # sequences, and every allocator-owned buffer goes back through the allocator's release hook
     out = subprocess.run([dumper, lst, "4", "8", "100000"], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
