@@ -108,25 +108,35 @@ def cpu_baseline(h, host_cores):
     # G_cpu: the regime the metric is quoted in (>= 10^4 genomes: the per-genome compare dominates the
     # O(2^h x batch) sweep); two batches of 201 queries per thread, ~10-20 s on the box's cores
     G_cpu = 20_000 if h >= 19 else 10_000
-    per = 2
+    # One batch per thread.  query_file's batches hold 201 queries; at -h 20 one such batch costs a thread ~5 s alone
+    # and ~200 s when 256 threads run one each (measured, profiles/r3_cpu_baseline_scaling.txt: the O(2^h x batch)
+    # strided sweep of Miekki.cpp:355-360 saturates the memory system), so the all-thread sample uses batches of
+    # 32 -- the same work per query, a sample six times shorter.  The one-thread sample is a batch of 201.
+    per, batch = 1, (32 if h >= 19 and threads > 64 else 201)
     shape = (f"synthetic 1 kb queries vs {G_cpu} genomes (4 sketched 5 Mb genomes, columns padded cyclically), "
              f"-h {h}, saturated Bloom")
     if os.path.exists(harness):
         try:
-            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
-            out = subprocess.run([harness, "scanbench", str(h), str(G_cpu), str(per), str(threads)],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1500, env=env).stdout.decode()
+            # glibc serves the reference's 9 MB per-query vectors from its heaps instead of mmap (1.4x on 64 threads)
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", MALLOC_MMAP_THRESHOLD_="4294967296",
+                       MALLOC_TRIM_THRESHOLD_="17179869184", MALLOC_TOP_PAD_="268435456")
+            sys.stderr.write(f"[bench] cpu baseline: reference query_sequences on {threads} threads ...\n")
+            out = subprocess.run([harness, "scanbench", str(h), str(G_cpu), str(per), str(threads), str(batch)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode()
             r = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             res = {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
                    "host_cores": host_cores, "kind": "reference",
                    "all_core": r["comparisons"] / r["seconds"],
                    "per_core": r["one_thread_comparisons"] / r["one_thread_seconds"],
-                   "sample": f"reference query_sequences on {threads} threads, {r['queries']} {shape}; per_core = one thread, 201 queries",
+                   "sample": f"reference query_sequences on {threads} threads, one batch of {r['batch']} queries each, "
+                             f"{r['queries']} {shape}; per_core = one thread, one batch of 201 queries",
                    "sample_seconds": r["seconds"] + r["one_thread_seconds"]}
             try:
-                n_gen = max(64, min(threads, 192))
+                # (the append is one critical section, ~0.2 s per genome at -h 20 however many threads: ~96 genomes = ~20 s)
+                n_gen = max(16, min(threads, 96))
+                sys.stderr.write(f"[bench] cpu baseline: reference insert_sequences on {threads} threads ...\n")
                 out = subprocess.run([harness, "sketchbench", str(h), str(n_gen), str(threads)],
-                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1500, env=env).stdout.decode()
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode()
                 k = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
                 res["sketch"] = {"value": k["genomes"] / k["seconds"], "unit": "sketches/s", "cores": threads,
                                  "all_core": k["genomes"] / k["seconds"],

@@ -41,18 +41,18 @@ static void dev_free(T *&p)
 }
 
 // ---- device timers -----------------------------------------------------------
-int timer_begin(mk_ctx *c, int kind, Timer &t)
+int timer_begin(mk_ctx *c, int kind, Timer &t, hipStream_t stream)
 {
     if (!c->free_timers.empty()) { t = c->free_timers.back(); c->free_timers.pop_back(); }
     else { MK_HIP(hipEventCreate(&t.a)); MK_HIP(hipEventCreate(&t.b)); }
     t.kind = kind;
-    MK_HIP(hipEventRecord(t.a, c->stream));
+    MK_HIP(hipEventRecord(t.a, stream ? stream : c->stream));
     return MK_OK;
 }
 
-int timer_end(mk_ctx *c, Timer &t)
+int timer_end(mk_ctx *c, Timer &t, hipStream_t stream)
 {
-    MK_HIP(hipEventRecord(t.b, c->stream));
+    MK_HIP(hipEventRecord(t.b, stream ? stream : c->stream));
     c->pending.push_back(t);
     return MK_OK;
 }
@@ -77,9 +77,9 @@ int drain_timers(mk_ctx *c)
 }
 
 struct ScopedTimer {
-    mk_ctx *c; Timer t; bool on;
-    ScopedTimer(mk_ctx *ctx, int kind) : c(ctx), on(false) { on = timer_begin(c, kind, t) == MK_OK; }
-    ~ScopedTimer() { if (on) (void)timer_end(c, t); }
+    mk_ctx *c; Timer t; bool on; hipStream_t stream;
+    ScopedTimer(mk_ctx *ctx, int kind, hipStream_t st = nullptr) : c(ctx), on(false), stream(st) { on = timer_begin(c, kind, t, stream) == MK_OK; }
+    ~ScopedTimer() { if (on) (void)timer_end(c, t, stream); }
 };
 
 static int settle_build(mk_ctx *c);
@@ -182,15 +182,13 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
 }
 
 // ---- index build ---------------------------------------------------------------
+// the per-batch counters, offsets, overflow list ... of the build (mk_ctx::BuildSide); until a build has run the
+// aliases point at side 0
 int ensure_build_counters(mk_ctx *c)
 {
     if (c->d_counters) return MK_OK;
-    MK_TRY(dev_alloc(&c->d_counters, 1));
-    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));
-    c->d_ovf_count = &c->d_counters->ovf;
-    c->d_dirty = c->d_counters->dirty;
-    c->d_active = c->d_counters->act;
-    c->d_cardsum = c->d_counters->card;
+    MK_TRY(ensure_build_side(c, 0));
+    use_build_side(c, 0);
     return MK_OK;
 }
 
@@ -228,7 +226,9 @@ int ensure_bloom_summary(mk_ctx *c)
 {
     if (!c->d_bloom) return MK_OK;
     if (!c->d_bloom_full) {
-        MK_TRY(dev_alloc(&c->d_bloom_full, (c->bloom_dev_bytes / 8 + 31) / 32 + 1));
+        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1;
+        MK_TRY(dev_alloc(&c->d_bloom_full, nwords));
+        MK_TRY(dev_alloc(&c->d_bloom_full2, (nwords + 63) / 64 + 1));
         c->bloom_full_stale = true;
     }
     if (c->bloom_full_stale) {
@@ -247,18 +247,16 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
         const uint64_t budget = 1ull << 30;                       // table bytes per batch
         c->build_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kBuildBatch, budget / ((uint64_t)c->P * 8)));
         MK_TRY(dev_alloc(&c->d_tables, (uint64_t)c->build_batch * c->P));
-        MK_TRY(ensure_build_counters(c));
-        MK_TRY(dev_alloc(&c->d_seq_off, kBuildBatch + 1));
     }
+    MK_TRY(ensure_build_counters(c));
     if (for_append && c->d_bloom && !c->d_bloom_order) {
         MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
         MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
     }
-    if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-    if (!c->h_back) MK_HIP(hipHostMalloc((void **)&c->h_back, sizeof *c->h_back, hipHostMallocDefault));
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
     if (for_append)
         for (int b = 0; b < 2; ++b) {
+            MK_TRY(ensure_build_side(c, b));
             if (!c->d_pk_off[b]) MK_TRY(dev_alloc(&c->d_pk_off[b], kBuildBatch + 1));
             if (!c->d_heads[b]) MK_TRY(dev_alloc(&c->d_heads[b], (uint64_t)kBuildBatch * 32));
         }
@@ -310,48 +308,73 @@ static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t
     return (uint64_t)est;
 }
 
-// Kernels of one batch.  Its sequences are already on their way to the device, in one of three forms:
-//   kChars    characters in c->d_seq[buf] at offsets h_off[0..n] (packed here, pack_kernel)
+// One batch goes through two stages.  Its sequences are already on their way to the device, in one of three forms:
+//   kChars    characters in c->d_seq[buf] at offsets h_off[0..n] (packed by the front stage, pack_kernel)
 //   kPacked   codes / exception bits in c->d_pk[buf] at pk_off, first characters in c->d_heads[buf], the
 //             "has exceptions" flags in h_dirty (mk_index_append_packed)
-//   kSynth    codes generated into c->d_pk[buf] (no exceptions anywhere)
-// -- the caller has ordered the stream behind the copy or the generator.  Nothing here waits for the
-// device; the results are read back into pinned memory and folded in by settle_build.
+//   kSynth    codes generated into c->d_pk[buf] on the front stream (no exceptions anywhere)
+// FRONT (enqueue_front, on c->front_stream, behind `after` -- the copy): offsets, counters, packing, seed digits,
+// the scatter kernel into side `buf`.  It is queued while the batch before it is still in flight: its kernels are
+// bound by instruction issue, that batch's back stage by memory latency, and the two share the CUs.
+// BACK (enqueue_back, on c->stream, once that batch has been settled): reduce, matrix rows, Bloom passes, the
+// counters' copy back.  Nothing here waits for the device; settle_build folds the results in.
 enum BatchForm { kChars, kPacked, kSynth };
 
-static int enqueue_batch(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, BatchForm form, const uint32_t *h_dirty = nullptr)
+static int enqueue_front(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, BatchForm form, hipEvent_t after,
+                         const uint32_t *h_dirty = nullptr)
 {
-    MK_TRY(ensure_capacity(c, c->G + n));
-    mk_ctx::BuildInFlight &b = c->build;
-    b.n = n; b.buf = buf; b.binned = false;
-    b.have_chars = form == kChars; b.have_heads = form == kPacked;
-    memcpy(b.off, h_off, (size_t)(n + 1) * 8);
-    MK_HIP(hipMemcpyAsync(c->d_seq_off, b.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));      // overflow mark, exception flags, sums: one block
+    mk_ctx::BuildSide &sd = c->side[buf];
+    mk_ctx::BuildInFlight &f = c->front;
+    f.n = n; f.buf = buf; f.binned = false;
+    f.have_chars = form == kChars; f.have_heads = form == kPacked;
+    memcpy(f.off, h_off, (size_t)(n + 1) * 8);
+    hipStream_t fs = c->front_stream;
+    if (after) MK_HIP(hipStreamWaitEvent(fs, after, 0));
+    MK_HIP(hipMemcpyAsync(sd.d_seq_off, f.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, fs));
+    MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, fs));      // overflow marks, exception flags, sums: one block
     uint8_t *codes = c->d_pk[buf], *except = c->d_pk[buf] + c->pk_cap[buf];
     if (form == kChars) {
         uint64_t *pk_off = c->h_pk_off[buf];
-        MK_TRY(ensure_packed(c, buf, packed_offsets(b.off, n, pk_off)));
+        MK_TRY(ensure_packed(c, buf, packed_offsets(f.off, n, pk_off)));
         codes = c->d_pk[buf]; except = c->d_pk[buf] + c->pk_cap[buf];
-        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        MK_TRY(launch_pack(c, c->d_seq[buf], c->d_seq_off, b.off, n, codes, except, c->d_pk_off[buf]));
+        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, fs));
+        MK_TRY(launch_pack(c, buf, c->d_seq[buf], f.off, n, codes, except, c->d_pk_off[buf]));
     } else if (form == kPacked && h_dirty) {
-        MK_HIP(hipMemcpyAsync(c->d_dirty, h_dirty, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        MK_HIP(hipMemcpyAsync(sd.d_counters->dirty, h_dirty, (size_t)n * 4, hipMemcpyHostToDevice, fs));
     }
     // the k-1 seed digits of every sequence (str2numstrand / rcb), and the seeds' validity for the fallback
     // (generated sequences are plain ACGT: neither characters nor heads, nothing to rewrite)
-    MK_TRY(launch_seed_fix(c, form == kChars ? c->d_seq[buf] : nullptr, c->d_seq_off, form == kPacked ? c->d_heads[buf] : nullptr, n,
-                           codes, except, c->d_pk_off[buf]));
-    MK_TRY(ensure_bloom_summary(c));
+    MK_TRY(launch_seed_fix(c, buf, form == kChars ? c->d_seq[buf] : nullptr, form == kPacked ? c->d_heads[buf] : nullptr, n, codes,
+                           except, c->d_pk_off[buf]));
     {
-        // scatter, then ONE kernel that reduces, emits fingerprints and sizes and runs Bloom pass A, the matrix
-        // rows, Bloom pass B
-        ScopedTimer t(c, 3);
-        MK_TRY(launch_build_packed(c, codes, except, c->d_pk_off[buf], c->d_seq_off, b.off, n, c->G, &b.binned));
+        ScopedTimer t(c, 3, fs);
+        MK_TRY(launch_build_front(c, buf, codes, except, c->d_pk_off[buf], f.off, n, &f.binned));
     }
-    if (!b.binned) MK_TRY(build_from_characters(c));             // shapes the bins do not fit
+    MK_HIP(hipEventRecord(sd.ev_front, fs));
+    f.on = true;
+    return MK_OK;
+}
+
+static int enqueue_back(mk_ctx *c)
+{
+    mk_ctx::BuildInFlight &b = c->build;
+    b = c->front;                                                // the batch whose front stage was queued last
+    c->front.on = false;
+    const int buf = b.buf;
+    const uint32_t n = b.n;
+    mk_ctx::BuildSide &sd = c->side[buf];
+    use_build_side(c, buf);                                      // the aliases follow the batch in flight
+    MK_TRY(ensure_capacity(c, c->G + n));
+    MK_HIP(hipStreamWaitEvent(c->stream, sd.ev_front, 0));
+    MK_TRY(ensure_bloom_summary(c));
+    if (b.binned) {
+        ScopedTimer t(c, 4);
+        MK_TRY(launch_build_back(c, buf, c->d_pk[buf], c->d_pk[buf] + c->pk_cap[buf], c->d_pk_off[buf], n, c->G));
+    } else {
+        MK_TRY(build_from_characters(c));                        // shapes the bins do not fit
+    }
     // one copy back of the batch's counters (overflow mark, active counts, cardinality sums)
-    MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(sd.h_back, sd.d_counters, sizeof *sd.h_back, hipMemcpyDeviceToHost, c->stream));
     b.on = true;
     return MK_OK;
 }
@@ -365,8 +388,8 @@ static int build_from_characters(mk_ctx *c)
     const uint32_t n = b.n;
     if (!b.have_chars) {
         MK_TRY(ensure_build_scratch(c, b.off[n], b.buf));
-        MK_TRY(launch_unpack(c, c->d_pk[b.buf], c->d_pk[b.buf] + c->pk_cap[b.buf], c->d_pk_off[b.buf],
-                             b.have_heads ? c->d_heads[b.buf] : nullptr, c->d_seq_off, b.off, n, c->d_seq[b.buf]));
+        MK_TRY(launch_unpack(c, b.buf, c->d_pk[b.buf], c->d_pk[b.buf] + c->pk_cap[b.buf], c->d_pk_off[b.buf],
+                             b.have_heads ? c->d_heads[b.buf] : nullptr, b.off, n, c->d_seq[b.buf]));
         b.have_chars = true;
     }
     const char *d_seq = c->d_seq[b.buf];
@@ -617,7 +640,9 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
     // <= 255 entries by construction), i.e. no host round trip either.
     uint32_t small_below = 512;
     if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) small_below = (uint32_t)std::max(0L, atol(e));   // tests force the range-table path
-    if (qs->nq < small_below) {
+    // (with cold rows the ranges are cut by partition whatever the set's size: whole cold ranges are then staged
+    // through HBM once per chunk, where pieces cut by count would have every wave read its rows over PCIe)
+    if (qs->nq < small_below && !c->h_M) {
         const uint64_t waves = (uint64_t)ntiles_of(c) * qs->nq;
         // (up to eight pieces: that is what select_kernel sums with its words prefetched; more only
         // when the packed counters ask for it)
@@ -686,6 +711,56 @@ static int ensure_scores(mk_ctx *c, uint64_t rows)
     return MK_OK;
 }
 
+// two staging buffers in HBM for cold rows (the copy of one piece runs beside the scan of the previous one), each
+// `unit` rows or a multiple of it: as many as fit a sixteenth of the hot part, at least `unit`, at most the cold rows
+static int ensure_cold_stage(mk_ctx *c, uint64_t unit)
+{
+    unit = std::max<uint64_t>(unit, 1);
+    if (c->d_cold_stage && c->cold_stage_rows >= unit && c->cold_stage_rows % unit == 0) return MK_OK;
+    MK_HIP(hipStreamSynchronize(c->stream));
+    MK_HIP(hipStreamSynchronize(c->copy_stream));
+    dev_free(c->d_cold_stage);
+    c->cold_stage_rows = 0;
+    uint64_t rows = std::max<uint64_t>(unit, (uint64_t)c->P_hot / 16 / unit * unit);
+    rows = std::min<uint64_t>(rows, ((uint64_t)c->P - c->P_hot + unit - 1) / unit * unit + unit);
+    MK_TRY(dev_alloc(&c->d_cold_stage, 2 * rows * c->ld));
+    c->cold_stage_rows = rows;
+    for (int i = 0; i < 5; ++i)
+        if (!c->ev_cold[i]) MK_HIP(hipEventCreateWithFlags(&c->ev_cold[i], hipEventDisableTiming));
+    return MK_OK;
+}
+
+// Row windows of a matrix with cold rows, for the kernels that walk whole entry lists (plain schedule) or whole
+// row ranges (dense queries): first the rows in HBM, where they lie; then the cold rows, a staging buffer's
+// worth at a time -- copied from host memory on the copy stream beside the launch over the previous window, and
+// presented to the kernel as "the matrix" by a shifted base.  launch(M, Mc, P_hot, row_lo, row_hi, first).
+template <typename Launch>
+static int scan_windows(mk_ctx *c, Launch launch)
+{
+    if (!c->h_M) return launch(c->d_M, (const uint8_t *)nullptr, c->P, 0u, c->P, true);
+    MK_TRY(ensure_cold_stage(c, std::max<uint64_t>(1, c->P / 64)));
+    hipEvent_t ev_enter = c->ev_cold[4];
+    hipEvent_t *ev_copy = c->ev_cold, *ev_scan = c->ev_cold + 2;
+    MK_HIP(hipEventRecord(ev_enter, c->stream));
+    MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_enter, 0));
+    bool first = true;
+    if (c->P_hot) { MK_TRY(launch(c->d_M, (const uint8_t *)nullptr, c->P, 0u, c->P_hot, true)); first = false; }
+    uint32_t i = 0;
+    for (uint64_t r = c->P_hot; r < c->P; r += c->cold_stage_rows, ++i) {
+        const uint64_t nr = std::min<uint64_t>(c->cold_stage_rows, c->P - r);
+        const int b = (int)(i & 1u);
+        uint8_t *stage = c->d_cold_stage + (uint64_t)b * c->cold_stage_rows * c->ld;
+        if (i >= 2) MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_scan[b], 0));     // the launch that read this buffer last
+        MK_HIP(hipMemcpyAsync(stage, c->h_M + (r - c->P_hot) * c->ld, nr * c->ld, hipMemcpyHostToDevice, c->copy_stream));
+        MK_HIP(hipEventRecord(ev_copy[b], c->copy_stream));
+        MK_HIP(hipStreamWaitEvent(c->stream, ev_copy[b], 0));
+        MK_TRY(launch(stage - r * c->ld, (const uint8_t *)nullptr, c->P, (uint32_t)r, (uint32_t)(r + nr), first));
+        first = false;
+        MK_HIP(hipEventRecord(ev_scan[b], c->stream));
+    }
+    return MK_OK;
+}
+
 // scan queries [q0, q1) of the set into d_scores laid out as `lay` describes (the
 // tile-major layout is per call: its tile stride is (q1 - q0) * genomes per tile)
 static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores, const ScoreLayout &lay)
@@ -693,28 +768,36 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     if (q1 <= q0 || c->G == 0) return MK_OK;
     const uint32_t nt = ntiles_of(c);
     const uint32_t per_launch = std::max<uint32_t>(1, 0x7ffffff0u / nt);
-    for (uint32_t q = q0; q < q1; q += per_launch) {
-        const uint32_t n = std::min(per_launch, q1 - q);
-        ScanArgs a;
-        a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
-        a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_scan_n;
-        a.scores = d_scores + (uint64_t)(q - q0) * lay.q_stride;
-        a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
-        ScopedTimer t(c, 1);
-        MK_TRY(launch_scan(c, a));
-    }
+    const bool windowed = c->h_M != nullptr;                       // cold rows: one launch per window of rows
+    MK_TRY(scan_windows(c, [&](const uint8_t *M, const uint8_t *Mc, uint32_t P_hot, uint32_t row_lo, uint32_t row_hi, bool first) {
+        for (uint32_t q = q0; q < q1; q += per_launch) {
+            const uint32_t n = std::min(per_launch, q1 - q);
+            ScanArgs a;
+            a.M = M; a.Mc = Mc; a.P_hot = P_hot; a.ld = c->ld; a.G = c->G; a.ntiles = nt; a.nq = n; a.q_begin = q;
+            a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.nent = qs->d_scan_n;
+            a.scores = d_scores + (uint64_t)(q - q0) * lay.q_stride;
+            a.score_tile_stride = lay.tile_stride; a.score_q_stride = lay.q_stride; a.score_vec = lay.vec;
+            a.windowed = windowed ? 1u : 0u; a.row_lo = row_lo; a.row_hi = row_hi; a.accumulate = first ? 0u : 1u;
+            ScopedTimer t(c, 1);
+            MK_TRY(launch_scan(c, a));
+        }
+        return (int)MK_OK;
+    }));
     if (!qs->dense_q.empty()) {
         // the sparse kernel has just written zero rows for the dense queries (scan_n = 0);
         // the dense kernel adds their scores, up to eight queries per pass over the matrix
-        DenseArgs d;
-        d.M = c->d_M; d.Mc = mat_ref(c).cold_m; d.P_hot = c->P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
-        d.rows_per_item = std::min<uint32_t>(c->P, 8192);
-        d.nchunks = (c->P + d.rows_per_item - 1) / d.rows_per_item;
-        d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
-        d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
-        d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
-        ScopedTimer t(c, 1);
-        MK_TRY(launch_scan_dense(c, d));
+        MK_TRY(scan_windows(c, [&](const uint8_t *M, const uint8_t *Mc, uint32_t P_hot, uint32_t row_lo, uint32_t row_hi, bool) {
+            DenseArgs d;
+            d.M = M; d.Mc = Mc; d.P_hot = P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
+            d.row_lo = row_lo; d.row_hi = row_hi;
+            d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8192);
+            d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
+            d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
+            d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
+            d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
+            ScopedTimer t(c, 1);
+            return launch_scan_dense(c, d);
+        }));
     }
     return MK_OK;
 }
@@ -761,16 +844,9 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     // pieces over PCIe.  The range the hot / cold boundary falls into is staged as a whole (its hot
     // rows by a device copy, the rest from host memory).
     const uint32_t S_hot = c->P_hot / rows_per_range;               // ranges that lie in HBM completely
-    if (!c->d_cold_stage) {
-        // two staging buffers (the copy of one group of ranges runs beside the scan of the previous one),
-        // each as many ranges as fit a sixteenth of the hot part -- at least one range
-        uint64_t rows = std::max<uint64_t>(rows_per_range, (uint64_t)c->P_hot / 16 / rows_per_range * rows_per_range);
-        rows = std::min<uint64_t>(rows, (uint64_t)c->P - (uint64_t)S_hot * rows_per_range);
-        MK_TRY(dev_alloc(&c->d_cold_stage, 2 * rows * c->ld));
-        c->cold_stage_rows = rows;
-        for (int i = 0; i < 5; ++i)
-            if (!c->ev_cold[i]) MK_HIP(hipEventCreateWithFlags(&c->ev_cold[i], hipEventDisableTiming));
-    }
+    // two staging buffers (the copy of one group of ranges runs beside the scan of the previous one),
+    // each as many ranges as fit a sixteenth of the hot part -- at least one range
+    MK_TRY(ensure_cold_stage(c, rows_per_range));
     hipEvent_t ev_enter = c->ev_cold[4];
     hipEvent_t *ev_copy = c->ev_cold, *ev_scan = c->ev_cold + 2;
     // the copies may start as soon as everything queued so far (earlier scans out of the stage) is done
@@ -867,8 +943,10 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_counters = nullptr; c->h_sizes = nullptr; c->size_parity = 0;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
     for (int b = 0; b < 2; ++b) { c->d_pk[b] = nullptr; c->pk_cap[b] = 0; c->d_pk_off[b] = nullptr; c->d_heads[b] = nullptr; }
-    c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr;
-    c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->bloom_full_stale = true;
+    c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr; c->front_stream = nullptr;
+    memset(c->side, 0, sizeof c->side);
+    memset(&c->front, 0, sizeof c->front);
+    c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->d_bloom_full2 = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
@@ -886,6 +964,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
     MK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    MK_HIP(hipStreamCreateWithFlags(&c->front_stream, hipStreamNonBlocking));
     MK_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     c->bloom_bytes = p->bloom_log2 ? (1ull << p->bloom_log2) / 8 : 0;
     c->bloom_dev_bytes = 0;
@@ -906,6 +985,7 @@ void mk_destroy(mk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
+    if (c->front_stream) (void)hipStreamSynchronize(c->front_stream);
     (void)hipStreamSynchronize(c->stream);
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -915,20 +995,27 @@ void mk_destroy(mk_ctx *c)
     for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]);
     dev_free(c->d_hits); dev_free(c->d_nhits);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
-    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_counters); dev_free(c->d_code_off); dev_free(c->d_bloom_full);
+    for (int b = 0; b < 2; ++b) {                                  // (d_counters, h_back, d_seq_off, d_seed_valid, d_ovf alias one of these)
+        mk_ctx::BuildSide &sd = c->side[b];
+        dev_free(sd.d_counters); dev_free(sd.d_seq_off); dev_free(sd.d_seed_valid); dev_free(sd.d_ovf);
+        if (sd.d_slots) (void)hipFree(sd.d_slots);
+        if (sd.h_back) (void)hipHostFree(sd.h_back);
+        if (sd.ev_front) (void)hipEventDestroy(sd.ev_front);
+    }
+    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_code_off); dev_free(c->d_bloom_full); dev_free(c->d_bloom_full2);
     dev_free(c->d_bloom_order); dev_free(c->d_tables);
     for (int b = 0; b < 2; ++b) { dev_free(c->d_pk[b]); dev_free(c->d_pk_off[b]); dev_free(c->d_heads[b]); }
-    dev_free(c->d_seed_valid); dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_seq_off); dev_free(c->d_scores);
+    dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
-    dev_free(c->d_slot_counts); dev_free(c->d_ovf); dev_free(c->d_partials);
+    dev_free(c->d_slot_counts); dev_free(c->d_partials);
     dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_posted_blk);
     dev_free(c->d_qarena);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_res) (void)hipHostFree(c->h_res);
-    if (c->h_back) (void)hipHostFree(c->h_back);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->front_stream) (void)hipStreamDestroy(c->front_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1028,9 +1115,9 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
             MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice,
                                   c->copy_stream));
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
+        MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));
         MK_TRY(settle_build(c));
-        MK_HIP(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-        MK_TRY(enqueue_batch(c, off, nb, buf, kChars));
+        MK_TRY(enqueue_back(c));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
@@ -1078,9 +1165,9 @@ int mk_index_append_packed(mk_ctx *c, const mk_packed_seq *seqs, uint32_t n)
                                       c->copy_stream));
         }
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
+        MK_TRY(enqueue_front(c, off, nb, buf, kPacked, c->ev_copy, dirty));
         MK_TRY(settle_build(c));
-        MK_HIP(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-        MK_TRY(enqueue_batch(c, off, nb, buf, kPacked, dirty));
+        MK_TRY(enqueue_back(c));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
@@ -1119,12 +1206,13 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         uint64_t *pk_off = c->h_pk_off[buf];
         MK_TRY(ensure_packed(c, buf, packed_offsets(off, nb, pk_off)));
         // the generator fills the buffer the batch in flight does NOT read -- in packed form, which is what the
-        // build works from: queue it behind that batch's kernels before waiting for them, so that the device is
-        // never idle while the host settles
-        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        // build works from -- on the front stream, followed by this batch's front stage: the device is never idle
+        // while the host settles the batch before
+        MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->front_stream));
         MK_TRY(launch_synth_packed(c, first_id + g0, nb, length, c->d_pk[buf], c->d_pk_off[buf]));
+        MK_TRY(enqueue_front(c, off, nb, buf, kSynth, nullptr));
         MK_TRY(settle_build(c));
-        MK_TRY(enqueue_batch(c, off, nb, buf, kSynth));
+        MK_TRY(enqueue_back(c));
         c->seq_cur = buf;
     }
     return MK_OK;

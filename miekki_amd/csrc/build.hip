@@ -31,8 +31,8 @@ constexpr uint32_t kSeg = 4096;            // k-mers per scatter workgroup
 constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
-constexpr uint32_t kOvfItems = 1u << 20;   // room in the overflow list
-constexpr uint32_t kOvfFold = 1u << 15;    // overflow items every reduce workgroup is willing to scan
+constexpr uint32_t kOvfPerGenome = 1u << 14;   // room in a genome's overflow list (two 64-bit words per item)
+constexpr uint32_t kOvfFold = 1u << 15;        // batch-wide overflow mark above which the batch is redone from characters (= sketch.hip's kOvfScan)
 
 }  // namespace
 
@@ -197,7 +197,7 @@ template <int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ slots,
-    uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count, SketchParams sp, BuildShape bs)
+    uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_g, uint32_t *__restrict__ ovf_mark, SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
     constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
@@ -275,11 +275,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
             if (rank < cap_items) {
                 it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(((i0 + u) << kBin) | (bucket & lowmask));
                 key[u] = (bin << 12) | rank;
-            } else {                                                  // slot full (very repetitive sequence): overflow list
-                const uint32_t o = atomicAdd(ovf_count, 1u);
-                if (o < kOvfItems) {
-                    ovf[2 * (uint64_t)o] = ((uint64_t)g << 32) | bucket;
-                    ovf[2 * (uint64_t)o + 1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
+            } else {
+                // slot full: the genome's overflow list (a slot is sized for the common case, ~4 sigma: a few hundred
+                // items per 5 Mb genome land here; a list that runs over -- very repetitive sequence -- marks the batch)
+                const uint32_t o = atomicAdd(&ovf_g[g], 1u);
+                if (o < kOvfPerGenome) {
+                    uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + o) * 2;
+                    e[0] = bucket;
+                    e[1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
+                } else {
+                    atomicMax(ovf_mark, kOvfFold + 1u);
                 }
             }
         }
@@ -346,13 +351,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 // (fingerprint, position) into 32 bits when the sequence is shorter than 2^23 (a 16 KiB table).
 template <int W, bool KEY32>
 __global__ __launch_bounds__(1024) void build_reduce_kernel(
-    const typename ItemOf<W>::type *__restrict__ slots, const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_count,
+    const typename ItemOf<W>::type *__restrict__ slots, const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_g,
+    const uint32_t *__restrict__ ovf_mark,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
-    const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
+    const uint32_t *__restrict__ full, const uint64_t *__restrict__ full2, uint32_t full2_words,
+    uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
     uint8_t *__restrict__ posted_blk, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
     SketchParams sp, BuildShape bs)
 {
+    // second-level Bloom summary (one bit per 256 cells: all set), when it fits: full2_words 64-bit words, else none
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_full2[];
     using item_t = typename ItemOf<W>::type;
     using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
@@ -366,11 +375,14 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     __shared__ uint32_t blk_posted[(1u << kBin) / 256];
     __shared__ uint32_t s_act;
     __shared__ unsigned long long s_card;
-    const uint32_t n_ovf = *ovf_count;
-    if (n_ovf > kOvfFold) return;                                     // the host redoes the batch (build_overflowed)
+    if (*ovf_mark > kOvfFold) return;                                 // some genome's overflow list ran over: the host redoes the batch
     const uint32_t bin = blockIdx.x, g = blockIdx.y;
+    const uint32_t n_ovf = ovf_g[g];
     const uint32_t R = 1u << bs.low_bits;
     for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kNoKey;
+    // (a snapshot taken before the batch: cells never go back to zero, so "all set" stays true)
+    if (bloom && !(bs.tune & 1u))
+        for (uint32_t i = threadIdx.x; i < full2_words; i += 1024) s_full2[i] = full2[i];
     if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
     __syncthreads();
@@ -422,11 +434,12 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
             }
         }
     }
-    // items that found their slot full (repetitive sequence): the few there are join here
+    // items of this genome that found their slot full: the few there are join here
     for (uint32_t i = threadIdx.x; i < n_ovf; i += 1024) {
-        const uint64_t where = ovf[2 * (uint64_t)i];
-        if ((uint32_t)(where >> 32) == g && ((uint32_t)where >> bs.low_bits) == bin) {
-            const uint64_t k64 = ovf[2 * (uint64_t)i + 1];           // fingerprint << 40 | position
+        const uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + i) * 2;
+        const uint64_t where = e[0];
+        if (((uint32_t)where >> bs.low_bits) == bin) {
+            const uint64_t k64 = e[1];                               // fingerprint << 40 | position
             const key_t key = KEY32 ? (key_t)(((k64 >> 40) << 23) | (k64 & ((1ULL << 23) - 1))) : (key_t)k64;
             atomicMin(&table[(uint32_t)where & (R - 1u)], key);
         }
@@ -465,7 +478,13 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
             const uint64_t cell = hsh >> 3;
             if (cell >= bloom_dev_bytes) continue;
             const uint64_t grp = cell >> 3;
-            if ((grp >> 5) != sum_idx) { sum_idx = grp >> 5; sum_word = full[sum_idx]; }
+            if ((grp >> 5) != sum_idx) {
+                sum_idx = grp >> 5;
+                // the second level first (LDS): once the filter has filled up it answers nearly every probe, and the
+                // winner costs ONE request at the L2 -- its codes -- instead of two
+                if (full2_words && ((s_full2[sum_idx >> 6] >> (sum_idx & 63u)) & 1u)) sum_word = 0xffffffffu;
+                else sum_word = full[sum_idx];
+            }
             if ((sum_word >> (grp & 31u)) & 1u) continue;
             if (bloom[cell] == 0) {
                 const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (hi << 4) | (uint32_t)(hsh & 7);
@@ -490,9 +509,9 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
 }
 
 // ---------------------------------------------------------------- host side
-// shape of the build for a batch, and its slot memory; *fits = false when the batch does not suit the
+// shape of the build for a batch, and side b's slot memory; *fits = false when the batch does not suit the
 // bins (the caller then takes the atomic kernel, from characters)
-static int build_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BuildShape &bs, bool *fits, bool *key32)
+static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, BuildShape &bs, bool *fits, bool *key32)
 {
     *fits = false;
     uint64_t max_nk = 0, max_len = 0;
@@ -507,48 +526,76 @@ static int build_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BuildShape 
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
     bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);
-    // per (workgroup, bin) the item count is ~Poisson(mean): a slot holds mean + 5.5 sigma + 2 items behind its
-    // count word (a handful of items per batch of 64 x 5 Mb go to the overflow list), in whole 32-byte units
+    // per (workgroup, bin) the item count is ~Poisson(mean): a slot holds about mean + 4 sigma items behind its count
+    // word, in whole 32-byte units -- at h = 20 (mean 16) exactly one 128-byte line, which the reduce kernel fetches
+    // whole; the ~2 in 10,000 items that find their slot full (a few hundred per 5 Mb genome) go to the genome's
+    // overflow list.  (Round 3: 160-byte slots, mean + 5.5 sigma, read at 4.9 TB/s -- the slot bytes were the bound.)
     const double mean = (double)kSeg / bs.nbins;
-    const uint32_t items = bs.nbins == 1 ? kSeg : std::min<uint32_t>(kSeg, (uint32_t)(mean + 5.5 * std::sqrt(mean) + 2.0));
-    bs.cap_words = (items + 1 + 7) / 8 * 8;
+    const uint32_t words = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 1.0);
+    bs.cap_words = bs.nbins == 1 ? (kSeg + 1 + 7) / 8 * 8 : std::max<uint32_t>(8, (words + 4) / 8 * 8);
     *key32 = c->W == 1 && max_len < (1ULL << 23);
     const uint64_t isz = c->W == 1 ? 4 : 8;
     const uint64_t need = (uint64_t)bs.nbins * bs.nwg * bs.cap_words * n * isz;       // bytes
     if (need > (12ull << 30)) return MK_OK;                          // slot memory budget
-    if (need > c->slots_cap * 8) {
-        if (c->d_slots) (void)hipFree(c->d_slots);
-        c->d_slots = nullptr; c->slots_cap = 0;
-        MK_HIP(hipMalloc((void **)&c->d_slots, (need + 7) / 8 * 8 + 64));
-        c->slots_cap = (need + 7) / 8;
+    mk_ctx::BuildSide &sd = c->side[b];
+    if (need > sd.slots_bytes) {
+        if (sd.d_slots) (void)hipFree(sd.d_slots);
+        sd.d_slots = nullptr; sd.slots_bytes = 0;
+        MK_HIP(hipMalloc(&sd.d_slots, need + 64));
+        sd.slots_bytes = need;
     }
-    if (!c->d_ovf) MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfItems * 16));
-    MK_TRY(ensure_build_counters(c));
     *fits = true;
     return MK_OK;
 }
 
 bool build_overflowed(uint32_t ovf_count) { return ovf_count > kOvfFold; }
 
-int launch_pack(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint8_t *d_codes,
-                uint8_t *d_except, const uint64_t *d_code_off)
+// one side's own arrays (everything a front stage writes)
+int ensure_build_side(mk_ctx *c, int b)
+{
+    mk_ctx::BuildSide &sd = c->side[b];
+    if (!sd.d_counters) {
+        MK_HIP(hipMalloc((void **)&sd.d_counters, sizeof *sd.d_counters));
+        MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, c->stream));
+    }
+    if (!sd.h_back) MK_HIP(hipHostMalloc((void **)&sd.h_back, sizeof *sd.h_back, hipHostMallocDefault));
+    if (!sd.d_seq_off) MK_HIP(hipMalloc((void **)&sd.d_seq_off, (kBuildBatch + 1) * 8));
+    if (!sd.d_seed_valid) MK_HIP(hipMalloc((void **)&sd.d_seed_valid, kBuildBatch * 4));
+    if (!sd.d_ovf) MK_HIP(hipMalloc((void **)&sd.d_ovf, (uint64_t)kBuildBatch * kOvfPerGenome * 16));   // (= sketch.hip's 2^20 entries)
+    if (!sd.ev_front) MK_HIP(hipEventCreateWithFlags(&sd.ev_front, hipEventDisableTiming));
+    return MK_OK;
+}
+
+void use_build_side(mk_ctx *c, int b)
+{
+    mk_ctx::BuildSide &sd = c->side[b];
+    c->d_counters = sd.d_counters; c->h_back = sd.h_back; c->d_seq_off = sd.d_seq_off; c->d_seed_valid = sd.d_seed_valid;
+    c->d_ovf = sd.d_ovf;
+    c->d_ovf_count = &sd.d_counters->ovf;
+    c->d_dirty = sd.d_counters->dirty;
+    c->d_active = sd.d_counters->act;
+    c->d_cardsum = sd.d_counters->card;
+}
+
+int launch_pack(mk_ctx *c, int b, const char *d_seq, const uint64_t *h_off, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
+                const uint64_t *d_code_off)
 {
     uint64_t max_len = 0;
     for (uint32_t g = 0; g < n; ++g) max_len = std::max(max_len, h_off[g + 1] - h_off[g]);
     if (!n || !max_len) return MK_OK;
     const uint64_t words = (max_len + 31) / 32;
-    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->stream, d_seq, d_off, n, d_codes,
-                       d_except, d_code_off, c->d_dirty);
+    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->front_stream, d_seq, c->side[b].d_seq_off,
+                       n, d_codes, d_except, d_code_off, c->side[b].d_counters->dirty);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
-int launch_seed_fix(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const char *d_heads, uint32_t n, uint8_t *d_codes,
-                    uint8_t *d_except, const uint64_t *d_code_off)
+int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
+                    const uint64_t *d_code_off)
 {
     if (!n) return MK_OK;
-    hipLaunchKernelGGL(seed_fix_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_seq, d_off, d_heads, n, c->p.k, d_codes,
-                       d_except, d_code_off, c->d_seed_valid);
+    hipLaunchKernelGGL(seed_fix_kernel, dim3((n + 63) / 64), dim3(64), 0, c->front_stream, d_seq, c->side[b].d_seq_off, d_heads, n,
+                       c->p.k, d_codes, d_except, d_code_off, c->side[b].d_seed_valid);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
@@ -557,64 +604,93 @@ int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, 
 {
     if (!n || !len) return MK_OK;
     const uint64_t words = (len + 31) / 32;
-    hipLaunchKernelGGL(synth_packed_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->stream, first_id, n, len,
+    hipLaunchKernelGGL(synth_packed_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->front_stream, first_id, n, len,
                        d_codes, d_code_off);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
-int launch_unpack(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
-                  const uint64_t *d_off, const uint64_t *h_off, uint32_t n, char *d_seq)
+int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
+                  const uint64_t *h_off, uint32_t n, char *d_seq)
 {
     uint64_t max_len = 0;
     for (uint32_t g = 0; g < n; ++g) max_len = std::max(max_len, h_off[g + 1] - h_off[g]);
     if (!n || !max_len) return MK_OK;
     hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)((max_len + 255) / 256), n), dim3(256), 0, c->stream, d_codes, d_except,
-                       d_code_off, c->d_dirty, d_heads, d_off, d_seq);
+                       d_code_off, c->side[b].d_counters->dirty, d_heads, c->side[b].d_seq_off, d_seq);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
-// The whole build of a batch from its packed form: scatter, reduce + fingerprints + sizes + Bloom pass A,
-// the matrix rows, Bloom pass B over the blocks that need it.  *used = false: the shape does not suit the bins.
-int launch_build_packed(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const uint64_t *d_off,
-                        const uint64_t *h_off, uint32_t n, uint32_t g0, bool *used)
+static void shape_store(mk_ctx::BuildSide &sd, const BuildShape &bs)
+{
+    sd.shape[0] = bs.nbins; sd.shape[1] = bs.low_bits; sd.shape[2] = bs.cap_words; sd.shape[3] = bs.nwg; sd.shape[4] = bs.tune;
+}
+static BuildShape shape_load(const mk_ctx::BuildSide &sd)
+{
+    BuildShape bs;
+    bs.nbins = sd.shape[0]; bs.low_bits = sd.shape[1]; bs.cap_words = sd.shape[2]; bs.nwg = sd.shape[3]; bs.tune = sd.shape[4];
+    return bs;
+}
+
+// Front stage: the scatter kernel of a batch, on the front stream, into side b's slots.
+int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off,
+                       const uint64_t *h_off, uint32_t n, bool *used)
 {
     *used = false;
+    mk_ctx::BuildSide &sd = c->side[b];
+    sd.fits = false;
     if (!n) return MK_OK;
     BuildShape bs;
-    bool fits = false, key32 = false;
-    MK_TRY(build_setup(c, h_off, n, bs, &fits, &key32));
-    if (!fits) return MK_OK;
+    MK_TRY(build_setup(c, b, h_off, n, bs, &sd.fits, &sd.key32));
+    if (!sd.fits) return MK_OK;
+    shape_store(sd, bs);
+    const SketchParams sp = make_sp(c);
+    const size_t isz = c->W == 1 ? 4 : 8;
+    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
+#define MK_SCATTER(Wv)                                                                                                          \
+    hipLaunchKernelGGL(build_scatter_kernel<Wv>, dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except, d_code_off, \
+                       sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), sd.d_ovf, \
+                       sd.d_counters->ovf_g, &sd.d_counters->ovf, sp, bs)
+    if (c->W == 1) MK_SCATTER(1); else MK_SCATTER(2);
+#undef MK_SCATTER
+    MK_HIP(hipGetLastError());
+    *used = true;
+    return MK_OK;
+}
+
+// Back stage: reduce + fingerprints + sizes + Bloom pass A in one kernel, the matrix rows, Bloom pass B over the
+// blocks that need it, the summary -- on c->stream, from side b's slots.
+int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, uint32_t n,
+                      uint32_t g0)
+{
+    mk_ctx::BuildSide &sd = c->side[b];
+    if (!n || !sd.fits) return MK_OK;
+    const BuildShape bs = shape_load(sd);
     const uint64_t fp_bytes = (uint64_t)c->build_batch * c->P * c->W;
     if (!c->d_fpT) {
         MK_HIP(hipMalloc((void **)&c->d_fpT, fp_bytes + 64));
         MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
     const SketchParams sp = make_sp(c);
-    const size_t isz = c->W == 1 ? 4 : 8;
-    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
-#define MK_SCATTER(Wv)                                                                                                         \
-    hipLaunchKernelGGL(build_scatter_kernel<Wv>, dim3(bs.nwg, n), dim3(256), lds, c->stream, d_codes, d_except, d_code_off,      \
-                       c->d_dirty, d_off, reinterpret_cast<typename ItemOf<Wv>::type *>(c->d_slots), c->d_ovf, c->d_ovf_count, sp, bs)
-#define MK_REDUCE(Wv, K32)                                                                                                      \
-    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(1024), 0, c->stream,                              \
-                       reinterpret_cast<const typename ItemOf<Wv>::type *>(c->d_slots), c->d_ovf, c->d_ovf_count, d_codes,      \
-                       d_except, d_code_off, c->d_dirty, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full,  \
-                       c->d_fpT, c->d_tables, c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bs)
-    if (c->W == 1) {
-        MK_SCATTER(1);
-        if (key32) MK_REDUCE(1, true); else MK_REDUCE(1, false);
-    } else {
-        MK_SCATTER(2);
-        MK_REDUCE(2, false);
+    // the second-level Bloom summary rides in LDS beside the reduce table when it is at most 40 KiB (-b 33 at k = 31:
+    // 32 KiB and a word); a larger one is simply not consulted
+    uint32_t f2w = 0;
+    if (c->d_bloom) {
+        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, w2 = (nwords + 63) / 64;
+        if (w2 * 8 <= 40960) f2w = (uint32_t)w2;
     }
-#undef MK_SCATTER
+#define MK_REDUCE(Wv, K32)                                                                                                      \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(1024), (size_t)f2w * 8, c->stream,                 \
+                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), sd.d_ovf, sd.d_counters->ovf_g,         \
+                       &sd.d_counters->ovf, d_codes, d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes, \
+                       c->d_bloom_order, c->d_bloom_full, c->d_bloom_full2, f2w, c->d_fpT, c->d_tables, c->d_posted_blk,        \
+                       sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)
+    if (c->W == 1) { if (sd.key32) MK_REDUCE(1, true); else MK_REDUCE(1, false); }
+    else MK_REDUCE(2, false);
 #undef MK_REDUCE
     MK_HIP(hipGetLastError());
-    MK_TRY(launch_build_tail(c, n, g0));
-    *used = true;
-    return MK_OK;
+    return launch_build_tail(c, n, g0);
 }
 
 }  // namespace mk

@@ -116,6 +116,7 @@ struct mk_ctx {
     // 1 MiB for the 64 MiB of reachable cells at -b 33: L2-resident, and once the filter has
     // filled up it answers almost every probe of the build without touching the cells
     uint32_t *d_bloom_full;
+    uint64_t *d_bloom_full2;       // second level: one bit per word of d_bloom_full = all of its 256 cells are set
     bool bloom_full_stale;         // the cells were written behind the summary's back (import)
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
@@ -129,7 +130,7 @@ struct mk_ctx {
         uint32_t n;
         int buf;
         uint64_t off[mk::kBuildBatch + 1];
-    } build;
+    } build, front;                // build: the batch whose back stage is queued; front: the one whose front stage alone is
     // The batch in packed form (build.hip): d_pk[b] = [codes: pk_cap[b] bytes][exception bits: pk_cap[b] / 2 bytes],
     // sequence g at byte offset pk_off[g] (16-byte aligned) of the codes and pk_off[g] / 2 of the exception bits.
     // Two of everything: the next batch is generated or copied into one while the kernels of the batch in flight
@@ -147,13 +148,32 @@ struct mk_ctx {
     // back after it): d_ovf_count, d_dirty, d_active, d_cardsum point into d_counters.  BuildCounters
     // is its layout, and that of the pinned read-back block.
     struct BuildCounters {
-        uint32_t ovf, pad;
+        uint32_t ovf, pad;             // overflow mark of the batch (> the fold limit: the host redoes the batch)
+        uint32_t ovf_g[mk::kBuildBatch];   // build.hip: items per genome that found their slot full (the genome's overflow list)
         uint32_t dirty[mk::kBuildBatch];
         uint32_t act[mk::kBuildBatch];
         uint64_t card[mk::kBuildBatch];
     };
     BuildCounters *d_counters;
     BuildCounters *h_back;         // pinned, so that the copy back does not block the host
+    // The build runs as a two-stage pipeline over two SIDES (build.hip): the FRONT stage of a batch -- packing,
+    // seed digits, scatter: instruction-bound -- is queued on front_stream while the BACK stage of the batch before
+    // it -- reduce, matrix rows, Bloom passes: bound by memory latency -- still runs on `stream`; the two kinds of
+    // kernels share the CUs.  Everything a front stage writes is per side.  d_counters, h_back, d_seq_off,
+    // d_seed_valid, d_ovf (and d_ovf_count, d_dirty, d_active, d_cardsum) above alias the side whose back stage was
+    // queued last; the long-query sketches, which run only when no batch is in flight, borrow them.
+    struct BuildSide {
+        BuildCounters *d_counters, *h_back;
+        uint64_t *d_seq_off;
+        uint32_t *d_seed_valid;
+        uint64_t *d_ovf;
+        void *d_slots;
+        uint64_t slots_bytes;
+        hipEvent_t ev_front;       // front stage done
+        uint32_t shape[5];         // BuildShape of the batch (build.hip)
+        bool fits, key32;
+    } side[2];
+    hipStream_t front_stream;
     // sizes of the batch just settled on their way to the device (pinned, one per buffer parity: the copy
     // is queued, not waited for)
     struct SizeUpload { uint32_t ss[mk::kBuildBatch]; uint64_t gs[mk::kBuildBatch]; } *h_sizes;
@@ -255,8 +275,8 @@ inline SketchParams make_sp(const mk_ctx *c)
 }
 
 // timing helpers (api.hip)
-int timer_begin(mk_ctx *c, int kind, Timer &t);
-int timer_end(mk_ctx *c, Timer &t);
+int timer_begin(mk_ctx *c, int kind, Timer &t, hipStream_t stream = nullptr);
+int timer_end(mk_ctx *c, Timer &t, hipStream_t stream = nullptr);
 int drain_timers(mk_ctx *c);
 
 // ---- sketch.hip
@@ -270,11 +290,6 @@ int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_
 // d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 bool binned_overflowed(uint32_t ovf_count);
-bool binned_build_overflowed(uint32_t ovf_count);
-// the index build's own binned form: scatter, then reduce + fingerprints + sizes + Bloom pass A fused,
-// matrix rows, Bloom pass B (results in c->d_active / c->d_cardsum like launch_finalize)
-int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                               const uint32_t *d_valid, uint32_t n, uint32_t g0, bool *used);
 // d_codes != nullptr: the winners' k-mers are read from the packed code array of the batch
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
@@ -282,15 +297,23 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
 int launch_bloom_summary(mk_ctx *c);
 int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0);     // matrix rows, Bloom pass B, summary (after a fused reduce kernel)
 // ---- build.hip: the index build from packed sequences (2-bit codes + exception bits)
-int launch_pack(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint8_t *d_codes,
-                uint8_t *d_except, const uint64_t *d_code_off);
-int launch_seed_fix(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const char *d_heads, uint32_t n, uint8_t *d_codes,
-                    uint8_t *d_except, const uint64_t *d_code_off);
+// (these four run on c->front_stream, on side b's arrays; launch_unpack on c->stream)
+int launch_pack(mk_ctx *c, int b, const char *d_seq, const uint64_t *h_off, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
+                const uint64_t *d_code_off);
+int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
+                    const uint64_t *d_code_off);
 int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off);
-int launch_unpack(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
-                  const uint64_t *d_off, const uint64_t *h_off, uint32_t n, char *d_seq);
-int launch_build_packed(mk_ctx *c, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const uint64_t *d_off,
-                        const uint64_t *h_off, uint32_t n, uint32_t g0, bool *used);
+int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
+                  const uint64_t *h_off, uint32_t n, char *d_seq);
+// front stage of a batch on c->front_stream: the scatter kernel into side `b` (*used = false: the shape does not suit
+// the bins, nothing was launched); back stage on c->stream: reduce + fingerprints + sizes + Bloom pass A, matrix rows,
+// Bloom pass B, summary
+int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off,
+                       const uint64_t *h_off, uint32_t n, bool *used);
+int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, uint32_t n,
+                      uint32_t g0);
+int ensure_build_side(mk_ctx *c, int b);
+void use_build_side(mk_ctx *c, int b);       // point the aliases (d_counters, ...) at side b
 bool build_overflowed(uint32_t ovf_count);
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
@@ -326,6 +349,9 @@ struct ScanArgs {
     uint32_t *scores;              // see scan_kernel.hpp: two-stride addressing
     uint64_t score_tile_stride, score_q_stride;
     uint32_t score_vec;            // 16-byte stores allowed (strides and padding permit it)
+    // window launches (a matrix with cold rows, scan_windows in api.hip): only entries of partitions
+    // [row_lo, row_hi) count; accumulate: add to the scores instead of storing them
+    uint32_t windowed, row_lo, row_hi, accumulate;
 };
 int launch_scan(mk_ctx *c, const ScanArgs &a);
 // slab schedule (scan_kernel.hpp: scan_slab_kernel)
@@ -364,6 +390,7 @@ struct DenseArgs {
     uint32_t P_hot;
     uint64_t ld;
     uint32_t G, ntiles, P, rows_per_item, nchunks, ngroups;
+    uint32_t row_lo, row_hi;       // rows this launch walks (nchunks covers them in pieces of rows_per_item)
     const uint8_t *dense;          // [group][P][4] fingerprints (W bytes each), empty = inactive
     const uint32_t *dense_q;       // [group][4] set index of each slot or 0xffffffff
     uint32_t q0, q1;               // set range the score buffer covers

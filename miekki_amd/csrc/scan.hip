@@ -30,7 +30,8 @@ static int launch_scan_t(mk_ctx *c, const ScanArgs &a)
     if (work == 0) return MK_OK;
     if (work >= (1ull << 31)) { set_error("scan launch too large"); return MK_ERR_ARG; }
     const uint32_t blocks = (uint32_t)((work + 3) / 4);
-    hipLaunchKernelGGL((scan_kernel<W, 8, 1, false>), dim3(blocks), dim3(256), 0, c->stream, a);
+    if (a.windowed) hipLaunchKernelGGL((scan_kernel<W, 8, 1, false, true>), dim3(blocks), dim3(256), 0, c->stream, a);
+    else            hipLaunchKernelGGL((scan_kernel<W, 8, 1, false, false>), dim3(blocks), dim3(256), 0, c->stream, a);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

@@ -59,7 +59,12 @@ __device__ __forceinline__ const uint8_t *row_base(const uint8_t *hot, const uin
 }
 
 // One work item: query `ql` of the launch against row tile `tile`.
-template <int W, int UNROLL, bool NT>
+// WINDOW: only the entries whose partition lies in [a.row_lo, a.row_hi) count -- the launch covers one window
+// of rows (the part of the matrix in HBM, or a cold range staged there: api.hip, scan_windows) and ADDS its
+// share to the scores when a.accumulate is set.  The entries are wave-uniform, so a step of UNROLL entries
+// with none in the window is skipped by a scalar branch; a step with some loads the window's first row for
+// the others (cached) and masks them out.
+template <int W, int UNROLL, bool NT, bool WINDOW = false>
 __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32_t tile, uint32_t lane)
 {
     constexpr uint32_t NCNT = 16 / W;                    // genomes per lane
@@ -80,6 +85,8 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
     uint32_t ne32[NCNT];
 #pragma unroll
     for (uint32_t j = 0; j < NCNT; ++j) ne32[j] = 0;
+    uint32_t n_in = WINDOW ? 0u : n;                                 // entries that count (wave-uniform)
+    const uint32_t wlo = a.row_lo, wspan = a.row_hi - a.row_lo;
 
     for (uint32_t i0 = 0; i0 < n; i0 += CHUNK) {
         const uint32_t m = min(n - i0, CHUNK);
@@ -91,6 +98,28 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
             uint4 d[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) ev[u] = e[j + u];
+            if (WINDOW) {
+                uint32_t keep[UNROLL], any = 0;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    keep[u] = ((uint32_t)ev[u] - wlo) < wspan ? 0xffffffffu : 0u;
+                    any |= keep[u];
+                    n_in += keep[u] & 1u;
+                }
+                if (!__builtin_amdgcn_readfirstlane(any)) continue;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    d[u] = load_row16<NT>(row_base(base, cbase, P_hot, keep[u] ? (uint32_t)ev[u] : wlo, ld) + voff);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
+                    acc0 += ne_lanes<W>(d[u].x, b) & keep[u];
+                    acc1 += ne_lanes<W>(d[u].y, b) & keep[u];
+                    acc2 += ne_lanes<W>(d[u].z, b) & keep[u];
+                    acc3 += ne_lanes<W>(d[u].w, b) & keep[u];
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
                 d[u] = load_row16<NT>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
@@ -108,17 +137,25 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
             uint4 d[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) ev[u] = e[min(j + u, m - 1)];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                d[u] = load_row16<NT>(row_base(base, cbase, P_hot, (uint32_t)ev[u], ld) + voff);
+            uint32_t keep[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const uint32_t keep = j + u < m ? 0xffffffffu : 0u;
+                keep[u] = j + u < m ? 0xffffffffu : 0u;
+                if (WINDOW) {
+                    if (((uint32_t)ev[u] - wlo) >= wspan) keep[u] = 0u;
+                    n_in += keep[u] & 1u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                d[u] = load_row16<NT>(row_base(base, cbase, P_hot, (!WINDOW || keep[u]) ? (uint32_t)ev[u] : wlo, ld) + voff);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
                 const uint32_t b = bcast_fp<W>((uint32_t)(ev[u] >> 32));
-                acc0 += ne_lanes<W>(d[u].x, b) & keep;
-                acc1 += ne_lanes<W>(d[u].y, b) & keep;
-                acc2 += ne_lanes<W>(d[u].z, b) & keep;
-                acc3 += ne_lanes<W>(d[u].w, b) & keep;
+                acc0 += ne_lanes<W>(d[u].x, b) & keep[u];
+                acc1 += ne_lanes<W>(d[u].y, b) & keep[u];
+                acc2 += ne_lanes<W>(d[u].z, b) & keep[u];
+                acc3 += ne_lanes<W>(d[u].w, b) & keep[u];
             }
         }
         const uint32_t acc[4] = {acc0, acc1, acc2, acc3};
@@ -140,7 +177,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
     const uint32_t g0 = tile * (kTileBytes / W) + lane * NCNT;
     uint32_t score[NCNT];
 #pragma unroll
-    for (uint32_t j = 0; j < NCNT; ++j) score[j] = n - ne32[j];
+    for (uint32_t j = 0; j < NCNT; ++j) score[j] = n_in - ne32[j];
 
     // scores[tile * score_tile_stride + ql * score_q_stride + genome-in-tile]: row-major
     // ([query][genome], q_stride = row pitch, tile_stride = genomes per tile) for callers
@@ -153,6 +190,22 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
     }
     uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)ql * a.score_q_stride;
     const uint32_t i0 = lane * NCNT;                                   // genome index inside the tile
+    if (WINDOW && a.accumulate) {                                      // a later window of the same launch sequence: this
+        if (n_in == 0) return;                                         // wave owns the same words in every window, in stream order
+        if (a.score_vec) {
+#pragma unroll
+            for (uint32_t j = 0; j < NCNT; j += 4) {
+                uint4 v = *reinterpret_cast<uint4 *>(row + i0 + j);
+                v.x += score[j]; v.y += score[j + 1]; v.z += score[j + 2]; v.w += score[j + 3];
+                *reinterpret_cast<uint4 *>(row + i0 + j) = v;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < NCNT; ++j)
+                if (g0 + j < a.G) row[i0 + j] += score[j];
+        }
+        return;
+    }
     if (a.score_vec) {
 #pragma unroll
         for (uint32_t j = 0; j < NCNT; j += 4)
@@ -167,7 +220,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, uint32_t ql, uint32
 // ORDER 0: consecutive waves take adjacent tiles of one query (query-major);
 // ORDER 1: consecutive waves take the same tile of consecutive queries (tile-major).
 // NT: non-temporal row loads.
-template <int W, int UNROLL, int ORDER = 1, bool NT = false>
+template <int W, int UNROLL, int ORDER = 1, bool NT = false, bool WINDOW = false>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -177,7 +230,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanArgs a)
     uint32_t ql, tile;
     if (ORDER == 0) { ql = work / a.ntiles; tile = work - ql * a.ntiles; }
     else            { tile = work / a.nq;   ql = work - tile * a.nq; }
-    scan_item<W, UNROLL, NT>(a, ql, tile, lane);
+    scan_item<W, UNROLL, NT, WINDOW>(a, ql, tile, lane);
 }
 
 // ---------------------------------------------------------------- slab schedule
@@ -298,7 +351,8 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
         any |= grp_on[gb];
     }
     if (!any) return;
-    const uint32_t row0 = chunk * a.rows_per_item, row1 = min(a.P, row0 + a.rows_per_item);
+    // this launch walks rows [row_lo, row_hi) (the whole matrix, or one window of it: api.hip, scan_windows)
+    const uint32_t row0 = a.row_lo + chunk * a.rows_per_item, row1 = min(a.row_hi, row0 + a.rows_per_item);
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
     const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
     const uint32_t voff = lane * 16u;

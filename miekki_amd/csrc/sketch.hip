@@ -511,129 +511,7 @@ __global__ void bin_overflow_kernel(const uint64_t *__restrict__ ovf, const uint
     }
 }
 
-// ---------------------------------------------------------------- K1b+K2+K3a fused (index build)
-// For the index build the per-partition winners never need to exist as a table in HBM: the
-// workgroup that has just reduced a (genome, bin) in LDS -- 2^13 winners -- finishes them on the
-// spot.  It emits the fingerprints (1-2 bytes per partition, genome-major; fp_transpose_kernel
-// lays them into the matrix), adds up the genome's active count and cardinality sum
-// (Miekki.cpp:290-301), and runs pass A of the Bloom insert (bloom_kernel<false> below) for its
-// winners.  Only 256-partition blocks in which some k-mer actually posted a first-writer key get
-// their canonical k-mers written out for pass B, and pass B looks at the block flags first: once
-// the filter has filled up (~2,000 genomes) the 8-byte table -- 512 MB per batch, written once
-// and read three times by the unfused kernels -- is not touched at all.
-constexpr uint32_t kOvfScan = 1u << 15;           // overflow items every reduce workgroup is willing to scan
-
-template <int W>
-__global__ __launch_bounds__(1024) void bin_reduce_build_kernel(
-    const uint64_t *__restrict__ slots, const uint16_t *__restrict__ slot_counts, const uint64_t *__restrict__ ovf,
-    const uint32_t *__restrict__ ovf_count, const uint8_t *__restrict__ codes, const uint64_t *__restrict__ code_off,
-    const uint8_t *__restrict__ codes2, const uint32_t *__restrict__ dirty,
-    const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order, const uint32_t *__restrict__ full,
-    uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables, uint8_t *__restrict__ posted_blk,
-    uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum, SketchParams sp, BinParams bp)
-{
-    using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
-    constexpr uint32_t kPer = (1u << kBinBits) / 1024;             // winners per thread
-    __shared__ unsigned long long table[1u << kBinBits];
-    __shared__ uint32_t blk_posted[(1u << kBinBits) / 256];
-    __shared__ uint32_t s_act;
-    __shared__ unsigned long long s_card;
-    const uint32_t n_ovf = *ovf_count;
-    if (n_ovf > kOvfScan) return;                                    // the host redoes the batch (binned_overflowed)
-    const uint32_t bin = blockIdx.x, g = blockIdx.y;
-    const uint32_t R = 1u << bp.low_bits;
-    for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kEmptyKey;
-    if (threadIdx.x < (1u << kBinBits) / 256) blk_posted[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
-    __syncthreads();
-    const uint64_t *__restrict__ base = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)bin * bp.nwg * bp.cap;
-    const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    constexpr uint32_t NW = 16, UN = 8;
-    for (uint32_t w0 = wave; w0 < ((bp.tune & 2u) ? 0u : bp.nwg); w0 += NW * UN) {           // as bin_reduce_kernel
-        uint32_t cw[UN];
-        uint64_t item[UN];
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u) {
-            const uint32_t w = w0 + u * NW;
-            cw[u] = w < bp.nwg ? cnts[w] : 0u;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)
-            item[u] = lane < cw[u] ? base[(uint64_t)(w0 + u * NW) * bp.cap + lane] : kEmptyKey;
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)
-            if (item[u] != kEmptyKey) atomicMin(&table[item[u] & (R - 1u)], (unsigned long long)item[u]);
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)
-            for (uint32_t i = lane + 64; i < cw[u]; i += 64) {
-                const uint64_t it = base[(uint64_t)(w0 + u * NW) * bp.cap + i];
-                atomicMin(&table[it & (R - 1u)], (unsigned long long)it);
-            }
-    }
-    // items that found their slot full (repetitive sequence): the few there are join here
-    for (uint32_t i = threadIdx.x; i < n_ovf; i += 1024) {
-        const uint64_t where = ovf[2 * (uint64_t)i];
-        if ((uint32_t)(where >> 32) == g && ((uint32_t)where >> bp.low_bits) == bin)
-            atomicMin(&table[(uint32_t)where & (R - 1u)], (unsigned long long)ovf[2 * (uint64_t)i + 1]);
-    }
-    __syncthreads();
-    const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
-    fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
-    uint64_t canon[kPer];
-    uint32_t posted_mask = 0, act = 0;
-    unsigned long long card = 0;
-    const uint8_t *__restrict__ gcodes = codes + code_off[g];
-    const uint8_t *__restrict__ gcodes2 = codes2 + code_off[g] / 2;
-    const bool plain_acgt = dirty[g] == 0;                           // workgroup-uniform
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) {
-        const uint32_t i = threadIdx.x + 1024u * j;
-        canon[j] = kEmptyKey;
-        if (i >= R) continue;
-        const uint64_t it = table[i];
-        const uint32_t fp = it == kEmptyKey ? sp.empty : (uint32_t)(it >> 48);
-        fpo[i] = (fp_t)fp;
-        if (it == kEmptyKey) continue;
-        ++act;
-        card += 1ull << (31u - (fp >> sp.f));
-        if (!bloom || (bp.tune & 1u)) continue;
-        // pass A of the Bloom insert for this winner (see bloom_kernel<false>)
-        const uint64_t pos = (it >> kBinBits) & ((1ULL << kItemPosBits) - 1);
-        const uint64_t cn = plain_acgt ? canon_from_codes2(gcodes2, pos, sp.k) : canon_from_codes(gcodes, pos, sp.k);
-        canon[j] = cn;
-        const uint64_t anc = revhash64(cn);
-        const uint32_t p = bin * R + i;
-        uint64_t sum_idx = ~0ull;
-        uint32_t sum_word = 0;
-        for (uint32_t hi = 0; hi < kNumHash; ++hi) {
-            const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
-            const uint64_t cell = hsh >> 3;
-            if (cell >= bloom_dev_bytes) continue;
-            const uint64_t grp = cell >> 3;
-            if ((grp >> 5) != sum_idx) { sum_idx = grp >> 5; sum_word = full[sum_idx]; }
-            if ((sum_word >> (grp & 31u)) & 1u) continue;
-            if (bloom[cell] == 0) {
-                const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (hi << 4) | (uint32_t)(hsh & 7);
-                atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
-                posted_mask |= 1u << j;
-            }
-        }
-        if ((posted_mask >> j) & 1u) blk_posted[i >> 8] = 1;
-    }
-    for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); card += __shfl_xor(card, o); }
-    if (lane == 0 && act) { atomicAdd(&s_act, act); atomicAdd(&s_card, card); }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_act) { atomicAdd(&active[g], s_act); atomicAdd(&cardsum[g], s_card); }
-    // what pass B needs: the canonical k-mers of the blocks in which something was posted
-#pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) {
-        const uint32_t i = threadIdx.x + 1024u * j;
-        if (i < R && blk_posted[i >> 8]) tables[row0 + i] = ((posted_mask >> j) & 1u) ? canon[j] : kEmptyKey;
-    }
-    const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
-    if (threadIdx.x < nblk) posted_blk[(uint64_t)g * blk_per_genome + (uint64_t)bin * nblk + threadIdx.x] = (uint8_t)blk_posted[threadIdx.x];
-}
+constexpr uint32_t kOvfScan = 1u << 15;           // overflow items every reduce workgroup of the build folds in (build.hip: kOvfFold)
 
 // fp_out[n][P] (genome-major, W bytes) -> M[p][g0 .. g0+n): 16-byte loads of one genome's run of
 // partitions, transposed through LDS, 16-byte row pieces out (K2's layout work; its sums are done).
@@ -720,8 +598,7 @@ static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams 
         MK_HIP(hipMalloc((void **)&c->d_slot_counts, ncnt * 2));
         c->slot_counts_cap = ncnt;
     }
-    if (!c->d_ovf) MK_HIP(hipMalloc((void **)&c->d_ovf, (uint64_t)kOvfCap * 16));
-    MK_TRY(ensure_build_counters(c));
+    MK_TRY(ensure_build_counters(c));                              // counters and the overflow list (kOvfCap entries) of a build side
     *fits = true;
     return MK_OK;
 }
@@ -760,43 +637,6 @@ __global__ void bloom_kernel(uint64_t *__restrict__ tables, const char *__restri
                              const uint64_t *__restrict__ code_off, const uint32_t *__restrict__ full,
                              const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp);
 
-// The whole build of a batch in its binned form: scatter, then reduce + fingerprints + sizes +
-// Bloom pass A in one kernel, the matrix rows, Bloom pass B over the blocks that need it.
-int launch_genome_build_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                               const uint32_t *d_valid, uint32_t n, uint32_t g0, bool *used)
-{
-    *used = false;
-    if (!n) return MK_OK;
-    BinParams bp;
-    bool fits = false;
-    MK_TRY(binned_setup(c, h_off, n, bp, &fits));
-    if (!fits) return MK_OK;
-    const uint64_t fp_bytes = (uint64_t)c->build_batch * c->P * c->W;
-    if (!c->d_fpT) {
-        MK_HIP(hipMalloc((void **)&c->d_fpT, fp_bytes + 64));
-        MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
-    }
-    MK_HIP(hipMemsetAsync(c->d_counters, 0, sizeof *c->d_counters, c->stream));      // overflow mark, dirty flags, sums: one block
-    const SketchParams sp = make_sp(c);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
-                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
-                       sp, bp);
-    if (c->W == 1)
-        hipLaunchKernelGGL(bin_reduce_build_kernel<1>, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
-                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
-                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables,
-                           c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
-    else
-        hipLaunchKernelGGL(bin_reduce_build_kernel<2>, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
-                           c->d_slot_counts, c->d_ovf, c->d_ovf_count, c->d_codes, c->d_code_off, c->d_codes2, c->d_dirty,
-                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables,
-                           c->d_posted_blk, c->d_active, (unsigned long long *)c->d_cardsum, sp, bp);
-    MK_HIP(hipGetLastError());
-    MK_TRY(launch_build_tail(c, n, g0));
-    *used = true;
-    return MK_OK;
-}
-
 // What follows the fused reduce kernel of a batch (this file's or build.hip's): the batch's fingerprints
 // (d_fpT, genome-major) into the matrix rows, Bloom pass B over the blocks that posted a key, the summary.
 int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
@@ -823,7 +663,6 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
 }
 
 bool binned_overflowed(uint32_t ovf_count) { return ovf_count > kOvfCap; }
-bool binned_build_overflowed(uint32_t ovf_count) { return ovf_count > kOvfScan; }
 
 // ---------------------------------------------------------------- K2 finalize
 // tables[n][P] -> M[p][g0 .. g0+n) (transposed through LDS), plus per-genome
@@ -984,14 +823,16 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
 
 // full[grp] = all eight cells of group grp are non-zero.  Cells never go back to zero, so a
 // summary taken before a batch stays true during it; it is refreshed after every pass B.
-__global__ void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
-                                     uint32_t *__restrict__ full, uint64_t nwords)
+__global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                                            uint32_t *__restrict__ full, uint64_t nwords,
+                                                            unsigned long long *__restrict__ full2)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one summary word = 32 groups = 256 cells
-    if (w >= nwords) return;
     uint32_t bits = 0;
     const uint64_t base = w * 256;
-    if (base + 256 <= bloom_dev_bytes) {
+    if (w >= nwords) {
+        bits = 0;
+    } else if (base + 256 <= bloom_dev_bytes) {
         const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(bloom + base);
 #pragma unroll 4
         for (uint32_t i = 0; i < 16; ++i) {                                   // 16 bytes = 2 groups per load
@@ -1013,7 +854,11 @@ __global__ void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t
             bits |= (all ? 1u : 0u) << gI;
         }
     }
-    full[w] = bits;
+    if (w < nwords) full[w] = bits;
+    // second level: one bit per summary word = "all 256 cells set" -- 32 KiB for the 64 MiB of reachable cells at
+    // -b 33, small enough to sit in LDS beside a reduce workgroup's table (build.hip)
+    const unsigned long long m = __ballot(bits == 0xffffffffu);
+    if ((threadIdx.x & 63u) == 0 && (w >> 6) < (nwords + 63) / 64) full2[w >> 6] = m;
 }
 
 int launch_bloom_summary(mk_ctx *c)
@@ -1021,7 +866,7 @@ int launch_bloom_summary(mk_ctx *c)
     if (!c->d_bloom) return MK_OK;
     const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1;
     hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((nwords + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
-                       c->bloom_dev_bytes, c->d_bloom_full, nwords);
+                       c->bloom_dev_bytes, c->d_bloom_full, nwords, (unsigned long long *)c->d_bloom_full2);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

@@ -135,7 +135,7 @@ static int cmd_filter(int argc, char** argv)
     return 0;
 }
 
-// scanbench <h> <G> <batches per thread> <threads>: time the reference's query_sequences
+// scanbench <h> <G> <batches per thread> <threads> [queries per batch]: time the reference's query_sequences
 // (Miekki.cpp:344-372) on an index of G genomes whose columns hold the real
 // fingerprints of a few synthetic genomes, cyclically shifted, with a saturated
 // Bloom filter (the >=10^4-genome regime).  Two samples on
@@ -146,6 +146,7 @@ static int cmd_scanbench(int argc, char** argv)
 {
     if (argc < 6) return 2;
     uint32_t h = atoi(argv[2]), G = atoi(argv[3]), per = atoi(argv[4]), th = atoi(argv[5]);
+    const uint32_t B = argc > 6 ? atoi(argv[6]) : 201;      // queries per batch of the all-thread sample (query_file: 201)
     const uint64_t L = 5000000, QL = 1000;
     const uint32_t NSRC = 4, k = 31;
     Miekki ix(k, h, 8, 5, 0, "/dev/null", 33, 200, th);
@@ -169,11 +170,12 @@ static int cmd_scanbench(int argc, char** argv)
     }
     ix.sketch_size.resize(G, ix.sketch_size[0]); ix.genome_size.resize(G, L); ix.index_size = G;
     std::fill(ix.Bloom_Filter.begin(), ix.Bloom_Filter.end(), 1);   // saturated
-    const uint32_t nb = per * th, nq = nb * 201;
+    // batch 0 = the one-thread sample, always 201 queries; batches 1 .. per * th = the all-thread sample, B each
+    const uint32_t nb = 1 + per * th, nq = 201 + per * th * B;
     vector<vector<pair<string, uint32_t>>> batches(nb);
     for (uint32_t q = 0; q < nq; ++q) {
         uint64_t g, off; mk_query_origin(q, NSRC, L, QL, &g, &off);
-        batches[q / 201].push_back({gs[g].first.substr(off, QL), 0});
+        batches[q < 201 ? 0 : 1 + (q - 201) / B].push_back({gs[g].first.substr(off, QL), 0});
     }
     // comparisons = G * sum over queries of active partitions
     vector<uint64_t> act(nb, 0);
@@ -181,7 +183,7 @@ static int cmd_scanbench(int argc, char** argv)
     for (uint32_t b = 0; b < nb; ++b)
         for (auto& q : batches[b]) { uint32_t a = 0; auto sk = ix.minhash_sketch_partition(q.first, a); act[b] += a; }
     uint64_t act_sum = 0;
-    for (uint64_t a : act) act_sum += a;
+    for (uint32_t b = 1; b < nb; ++b) act_sum += act[b];
     uint64_t chk = 0;
     auto t1 = chrono::steady_clock::now();
     {
@@ -191,14 +193,14 @@ static int cmd_scanbench(int argc, char** argv)
     double s1 = chrono::duration<double>(chrono::steady_clock::now() - t1).count();
     auto t0 = chrono::steady_clock::now();
     #pragma omp parallel for num_threads(th) schedule(dynamic) reduction(+:chk)
-    for (size_t b = 0; b < batches.size(); ++b) {
+    for (size_t b = 1; b < batches.size(); ++b) {
         auto m = ix.query_sequences(batches[b]);
         for (int i = 0; i < int(batches[b].size()); ++i) chk += m(i, 0);
     }
     double s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
-    printf("\n{\"comparisons\": %llu, \"seconds\": %.6f, \"threads\": %u, \"h\": %u, \"G\": %u, \"queries\": %u, "
+    printf("\n{\"comparisons\": %llu, \"seconds\": %.6f, \"threads\": %u, \"h\": %u, \"G\": %u, \"queries\": %u, \"batch\": %u, "
            "\"one_thread_comparisons\": %llu, \"one_thread_seconds\": %.6f, \"check\": %llu}\n",
-           (unsigned long long)(act_sum * G), s, th, h, G, nq, (unsigned long long)(act[0] * G), s1, (unsigned long long)chk);
+           (unsigned long long)(act_sum * G), s, th, h, G, nq - 201, B, (unsigned long long)(act[0] * G), s1, (unsigned long long)chk);
     return 0;
 }
 

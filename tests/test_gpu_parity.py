@@ -313,6 +313,48 @@ def test_sharded_contexts_merge_equals_single_context(hip):
             ix.close()
 
 
+def oracle_sample_check(ix, k, h, fpb, G, L_, queries):
+    """Full-size collections cannot be rebuilt in the oracle, single genomes can: for eight genomes spread over
+    the id range, the column the HIP index holds (every partition, exported through mk_index_export_columns)
+    must be the oracle's sketch of the same synthetic genome, byte for byte; and the dense score rows of
+    `queries` restricted to those genomes must be what the oracle's query_sequences gives over exactly those
+    eight columns UNDER THE COLLECTION'S OWN BLOOM FILTER (exported from the index: the gate depends on all
+    genomes, the scores of a column only on the column and the gate)."""
+    import ctypes as C
+    import struct
+    from oracle import oracle as orc
+    from miekki_amd import lib as L
+    P, W = 1 << h, fpb // 8
+    sample = sorted({0, 1, G // 3, G // 2, G // 2 + 1, (2 * G) // 3, G - 2, G - 1})
+    o = orc.OracleMiekki(k, h, fpb, 33, 200)
+    want = np.empty((P, len(sample), W), np.uint8)
+    for j, g in enumerate(sample):
+        fp, _, _ = o.minhash_sketch_partition(synth.genome_bases(g, 0, L_))
+        if W == 1:
+            want[:, j, 0] = fp.astype(np.uint8)
+        else:                                                       # big-endian pairs, as add_index stores them (Miekki.cpp:230-231)
+            want[:, j, 0] = (fp >> 8).astype(np.uint8); want[:, j, 1] = (fp & 0xff).astype(np.uint8)
+    got = np.empty_like(want)
+    rows = max(1, min(P, (256 << 20) // (G * W)))
+    buf = np.empty(rows * G * W, np.uint8)
+    for p0 in range(0, P, rows):
+        r = min(rows, P - p0)
+        L.check(ix._lib.mk_index_export_columns(ix._h, p0, p0 + r, buf.ctypes.data))
+        got[p0:p0 + r] = buf[:r * G * W].reshape(r, G, W)[:, sample, :]
+    for j, g in enumerate(sample):
+        assert sha(got[:, j, :].tobytes()) == sha(want[:, j, :].tobytes()), f"column of genome {g}"
+    # an oracle index of just those columns + the collection's Bloom filter
+    ss, gs = ix.sketch_size[sample], ix.genome_size[sample]
+    nb = ix.bloom_size // 8
+    bloom = np.empty(nb, np.uint8)
+    L.check(ix._lib.mk_index_export_bloom(ix._h, 0, nb, bloom.ctypes.data))
+    hdr = struct.pack("<6IQBBIB", k, h, fpb, 5, len(sample), 33, ix.bloom_size, 0, 0, 200, 1)
+    stream = np.concatenate([np.frombuffer(hdr, np.uint8), want.reshape(-1), gs.astype(np.uint64).view(np.uint8), bloom,
+                             ss.astype(np.uint32).view(np.uint8)])
+    o8 = orc.OracleMiekki.deserialize(stream)
+    np.testing.assert_array_equal(ix.query_sequences(queries)[:, sample], o8.query_sequences(queries))
+
+
 def test_config3_shard_scale_properties(hip):
     """BASELINE-size check (config 3 shard: 12,500 synthetic 5 Mb genomes, -h 20)
     through size-independent properties: every query's source genome is its top
@@ -345,6 +387,8 @@ def test_config3_shard_scale_properties(hip):
             assert a.shape == b.shape and (b >= a).all()
         finally:
             small.close()
+        oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                            synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
     finally:
         ix.close()
 
@@ -374,6 +418,8 @@ def test_config2_full_size_properties(hip):
             want = ix.filter_results(scores[q], 10, 10, 0.0)            # all-equal intersections: pure tie order
             assert [(a.genome, a.matches) for a in loose[q]] == [(b.genome, b.matches) for b in want], q
         assert 100 < active.mean() < 969
+        oracle_sample_check(ix, 31, 17, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                            synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
     finally:
         ix.close()
 
@@ -398,6 +444,8 @@ def test_config4_full_size_properties(hip):
             assert np.delete(scores[q], src).max() <= 8                 # 16-bit fingerprints: chance matches ~ 900 / 2^11 / 3
             want = ix.filter_results(scores[q], 10, 10, 100.0)
             assert [(a.genome, a.matches) for a in hits[q]] == [(b.genome, b.matches) for b in want], q
+        oracle_sample_check(ix, 31, 20, 16, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                             synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
     finally:
         ix.close()
 

@@ -262,7 +262,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_ent, ent.data(), ent.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nent, nent.data(), Q * 4, hipMemcpyHostToDevice));
-    ScanArgs a;
+    ScanArgs a{};
     a.M = M; a.Mc = nullptr; a.P_hot = 0xffffffffu; a.ld = ld; a.G = G; a.ntiles = (uint32_t)(ld / kTileBytes); a.nq = Q; a.q_begin = 0;
     a.ntiles = (G + kTileBytes - 1) / kTileBytes;
     a.entries = d_ent; a.ent_off = d_off; a.nent = d_nent; a.scores = d_scores;
