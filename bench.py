@@ -167,6 +167,39 @@ def cpu_baseline(h, host_cores):
         return None
 
 
+def sketch_roofline(genomes, build_s, h, W):
+    """The index build is bound by vector-instruction issue, not by memory (SURVEY 8d asks for k-mers/s and
+    sketches/s with the HBM fraction as an informational number): instructions per k-mer of the two big
+    kernels from the committed SQ counter passes of this code (profiles/pmc_build.json), the issue time they
+    stand for at one wave-instruction per 4 cycles per SIMD, and that as a fraction of the measured build time."""
+    kmers = genomes * (GENOME_LEN - 31)
+    out = {"bound": "valu-issue", "kmers_per_s": kmers / build_s, "sketches_per_s": genomes / build_s}
+    # algorithmic HBM bytes per k-mer: 2-bit codes in, one 4-byte item (8 at 2 bytes) out and in again for the 15/16 of
+    # k-mers whose fingerprint is not "empty", W * 2^h fingerprint bytes per genome out, in and out again (transposer)
+    item = 4 if W == 1 else 8
+    bpk = 0.25 + 2 * item * 15 / 16 + 3.0 * W * (1 << h) / (GENOME_LEN - 31)
+    out["hbm_bytes_per_kmer_algorithmic"] = bpk
+    out["hbm_frac_informational"] = bpk * kmers / build_s / 1e9 / HBM_PEAK_GBS
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_build.json")))
+        per_batch_kmers = pm["batch_genomes"] * (pm["genome_len"] - 31)
+        valu = sum(k["valu_wave_instructions_per_batch"] for k in pm["kernels"].values())
+        simds, clock = 256 * 4, 2.4e9
+        issue_s_per_batch = valu * 4 / (simds * clock)
+        batch_s = build_s / max(genomes / pm["batch_genomes"], 1e-9)
+        out.update({"valu_instructions_per_kmer": valu * 64 / per_batch_kmers,
+                    "valu_instructions_per_kmer_by_kernel": {n: k["valu_wave_instructions_per_batch"] * 64 / per_batch_kmers
+                                                             for n, k in pm["kernels"].items()},
+                    "issue_ms_per_batch": issue_s_per_batch * 1e3, "ms_per_batch": batch_s * 1e3,
+                    "frac": issue_s_per_batch / batch_s,
+                    "note": "frac = vector-instruction issue time of scatter + reduce (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz)) "
+                            "over the measured time per 64-genome batch; the two kernels of consecutive batches overlap on the device",
+                    "counters_source": pm["source"]})
+    except Exception as e:
+        out["counters_source"] = f"profiles/pmc_build.json unavailable: {e}"
+    return out
+
+
 def host_fed_build_rate(lib, L, device, h, fp_bits, packed, n=64, rounds=6):
     """PCIe-inclusive build rate (DESIGN.md section 5 asks for it next to `value`, never as `value`): the same
     synthetic genomes, but handed over as HOST buffers (page-locked, mk_host_alloc) the way the `miekki`
@@ -408,13 +441,21 @@ def main(argv=None):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "hbm_floor_bytes": matrix_bytes,
                          "reuse_factor": algo_per_launch / matrix_bytes if matrix_bytes else None,
+                         "served_by": "Infinity Cache + L2 (repeat touches of a row piece) over HBM (first touch)",
+                         "hbm_side": {"bytes_per_launch_floor": matrix_bytes,
+                                      "gbs_floor": matrix_bytes / avg_launch_s / 1e9,
+                                      "frac_of_measured_stream_read": (matrix_bytes / avg_launch_s / 1e9 / stream_gbs) if stream_gbs else None,
+                                      "note": "the least HBM itself must deliver: the shard's matrix once per launch; the true HBM share "
+                                              "lies between this and `traffic` (no gfx950 counter isolates it: FETCH_SIZE counts "
+                                              "Infinity-Cache hits, rocprofv3 lists no MALL / UMC byte counters on this image)"},
                          "kernel": "scan_slab_kernel" if st["scan_slab_launches"] else "scan_kernel",
                          "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch,
                          "note": "achieved = algorithmic bytes (W per comparison + 4 per query x genome) / HIP-event launch time; "
                                  "hbm_floor_bytes = the shard's matrix once per launch, the least HBM can deliver; "
                                  "measured_stream_read_ceiling = mk_probe_stream_read over the resident matrix in this run"},
-            "sketch": {"query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
+            "sketch": {"roofline": sketch_roofline(G, build_s, args.h, W),
+                       "query_sketch_ms_per_step": st["sketch_ms"] / args.steps,
                        "index_build_s": build_s_max, "index_sketches_per_s": G_total / build_s_max,
                        "index_sketches_per_s_per_gpu": G / build_s,
                        "index_kmers_per_s": G_total * (GENOME_LEN - 31) / build_s_max,

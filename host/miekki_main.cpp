@@ -36,6 +36,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "fasta_reader.hpp"
@@ -107,12 +108,63 @@ bool nucleotide_start(const string &s)           // Miekki.cpp:736, 771
 
 using mkhost::OrderedFastaReader;
 
-void *pinned_alloc(void *ctx, size_t bytes)
-{
-    void *p = nullptr;
-    return mk_host_alloc((mk_ctx *)ctx, bytes, &p) == MK_OK ? p : nullptr;
-}
-void pinned_free(void *ctx, void *p) { mk_host_free((mk_ctx *)ctx, p); }
+// Page-locked memory for the reader pools, in slabs: page-locking is a slow, serialised driver call (a pool of a few
+// hundred 2 MB buffers locked one by one costs a visible part of a second at start-up), so buffers are carved out
+// of 256 MB slabs and handed back to a free list; the slabs go when the arena goes.  Requests of half a slab or
+// more are locked on their own.  Thread-safe (the readers allocate).
+class PinnedArena {
+public:
+    explicit PinnedArena(mk_ctx *ctx) : ctx_(ctx) {}
+    ~PinnedArena() { for (void *s : slabs_) mk_host_free(ctx_, s); }
+    void *alloc(size_t bytes)
+    {
+        bytes = (bytes + 4095) / 4096 * 4096;
+        if (bytes >= kSlab / 2) {
+            void *p = nullptr;
+            if (mk_host_alloc(ctx_, bytes, &p) != MK_OK) return nullptr;
+            std::lock_guard<std::mutex> g(m_);
+            big_.insert(p);
+            return p;
+        }
+        std::lock_guard<std::mutex> g(m_);
+        for (size_t i = 0; i < free_.size(); ++i)                    // first fit among the blocks handed back
+            if (free_[i].second >= bytes) {
+                void *p = free_[i].first;
+                sizes_[p] = free_[i].second;
+                free_.erase(free_.begin() + (long)i);
+                return p;
+            }
+        if (!cur_ || left_ < bytes) {
+            void *s = nullptr;
+            if (mk_host_alloc(ctx_, kSlab, &s) != MK_OK) return nullptr;
+            slabs_.push_back(s);
+            cur_ = (char *)s; left_ = kSlab;
+        }
+        void *p = cur_;
+        cur_ += bytes; left_ -= bytes;
+        sizes_[p] = bytes;
+        return p;
+    }
+    void release(void *p)
+    {
+        std::unique_lock<std::mutex> g(m_);
+        if (big_.erase(p)) { g.unlock(); mk_host_free(ctx_, p); return; }
+        auto it = sizes_.find(p);
+        if (it != sizes_.end()) { free_.emplace_back(p, it->second); sizes_.erase(it); }
+    }
+private:
+    static constexpr size_t kSlab = 256u << 20;
+    mk_ctx *ctx_;
+    std::mutex m_;
+    vector<void *> slabs_;
+    char *cur_ = nullptr;
+    size_t left_ = 0;
+    vector<std::pair<void *, size_t>> free_;
+    std::unordered_map<void *, size_t> sizes_;
+    std::unordered_set<void *> big_;
+};
+void *pinned_alloc(void *arena, size_t bytes) { return ((PinnedArena *)arena)->alloc(bytes); }
+void pinned_free(void *arena, void *p) { ((PinnedArena *)arena)->release(p); }
 
 struct Driver {
     mkhost::DeviceGroup group;                   // one context per GPU, genome shards in list order
@@ -138,7 +190,8 @@ struct Driver {
         // ... and pack as they parse (2 bits per base, mk_index_append_packed): a quarter of the bytes to buffer and
         // to move over PCIe, and the device skips its own packing pass.  MIEKKI_INGEST=chars keeps the characters.
         static const bool as_chars = [] { const char *e = getenv("MIEKKI_INGEST"); return e && string(e) == "chars"; }();
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx}, 3 * 64,
+        PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 3 * 64,
                                   as_chars ? nullptr : &mk_pack_append);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
@@ -407,7 +460,8 @@ struct Driver {
             if (fn.size() > 3) files.push_back(fn);
         // readers parse into pinned buffers, two batches ahead: the upload of a batch is a DMA
         // straight out of them
-        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, ctx0()}, 2 * 32);
+        PinnedArena arena(ctx0());
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 2 * 32);
         // whole files are queried in batches so that the dense kernel can take four per
         // pass over the matrix; output stays in list order
         vector<string> names;

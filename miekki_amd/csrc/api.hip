@@ -254,6 +254,7 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
         MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
     }
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
+    if (!c->h_img) MK_HIP(hipHostMalloc((void **)&c->h_img, sizeof *c->h_img, hipHostMallocDefault));
     if (for_append)
         for (int b = 0; b < 2; ++b) {
             MK_TRY(ensure_build_side(c, b));
@@ -328,13 +329,14 @@ static int enqueue_front(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, 
     f.n = n; f.buf = buf; f.binned = false;
     f.have_chars = form == kChars; f.have_heads = form == kPacked;
     memcpy(f.off, h_off, (size_t)(n + 1) * 8);
+    memcpy(c->h_img->off[buf], h_off, (size_t)(n + 1) * 8);
     hipStream_t fs = c->front_stream;
     if (after) MK_HIP(hipStreamWaitEvent(fs, after, 0));
-    MK_HIP(hipMemcpyAsync(sd.d_seq_off, f.off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, fs));
+    MK_HIP(hipMemcpyAsync(sd.d_seq_off, c->h_img->off[buf], (size_t)(n + 1) * 8, hipMemcpyHostToDevice, fs));
     MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, fs));      // overflow marks, exception flags, sums: one block
     uint8_t *codes = c->d_pk[buf], *except = c->d_pk[buf] + c->pk_cap[buf];
     if (form == kChars) {
-        uint64_t *pk_off = c->h_pk_off[buf];
+        uint64_t *pk_off = c->h_img->pk_off[buf];
         MK_TRY(ensure_packed(c, buf, packed_offsets(f.off, n, pk_off)));
         codes = c->d_pk[buf]; except = c->d_pk[buf] + c->pk_cap[buf];
         MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, fs));
@@ -769,7 +771,10 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     const uint32_t nt = ntiles_of(c);
     const uint32_t per_launch = std::max<uint32_t>(1, 0x7ffffff0u / nt);
     const bool windowed = c->h_M != nullptr;                       // cold rows: one launch per window of rows
-    MK_TRY(scan_windows(c, [&](const uint8_t *M, const uint8_t *Mc, uint32_t P_hot, uint32_t row_lo, uint32_t row_hi, bool first) {
+    // One pass over the row windows for both kernels (a cold window is copied to HBM once): the sparse kernel
+    // first -- in the first window it also writes the zero rows of the dense queries (scan_n = 0) -- then the dense
+    // kernel, which adds the whole-genome queries' scores, up to eight queries per pass over the rows.
+    return scan_windows(c, [&](const uint8_t *M, const uint8_t *Mc, uint32_t P_hot, uint32_t row_lo, uint32_t row_hi, bool first) {
         for (uint32_t q = q0; q < q1; q += per_launch) {
             const uint32_t n = std::min(per_launch, q1 - q);
             ScanArgs a;
@@ -781,25 +786,18 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
             ScopedTimer t(c, 1);
             MK_TRY(launch_scan(c, a));
         }
-        return (int)MK_OK;
-    }));
-    if (!qs->dense_q.empty()) {
-        // the sparse kernel has just written zero rows for the dense queries (scan_n = 0);
-        // the dense kernel adds their scores, up to eight queries per pass over the matrix
-        MK_TRY(scan_windows(c, [&](const uint8_t *M, const uint8_t *Mc, uint32_t P_hot, uint32_t row_lo, uint32_t row_hi, bool) {
-            DenseArgs d;
-            d.M = M; d.Mc = Mc; d.P_hot = P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
-            d.row_lo = row_lo; d.row_hi = row_hi;
-            d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8192);
-            d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
-            d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
-            d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
-            d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
-            ScopedTimer t(c, 1);
-            return launch_scan_dense(c, d);
-        }));
-    }
-    return MK_OK;
+        if (qs->dense_q.empty()) return (int)MK_OK;
+        DenseArgs d;
+        d.M = M; d.Mc = Mc; d.P_hot = P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
+        d.row_lo = row_lo; d.row_hi = row_hi;
+        d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8192);
+        d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
+        d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
+        d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
+        d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
+        ScopedTimer t(c, 1);
+        return launch_scan_dense(c, d);
+    });
 }
 
 // ---- slab schedule: per-range partial counts instead of a u32 score matrix
@@ -810,6 +808,11 @@ static uint32_t chunk_queries_slab(const mk_ctx *c, uint32_t nq, uint32_t S)
     const uint64_t budget = chunk_budget(16ull << 30, c->partials_cap);
     uint64_t per = std::max<uint64_t>(1, budget / std::max<uint64_t>(partial_bytes_per_query(c, S), 1));
     per = std::min<uint64_t>(per, 0x7ffffff0ull / std::max<uint64_t>((uint64_t)ntiles_of(c) * S, 1));   // one launch
+    // The waves in flight share one slab of the matrix AND the entry lists of the chunk's queries for that range
+    // (~0.9 KB each): with very many queries per launch those lists (90 MB for 100,000 queries) crowd the slab out
+    // of the Infinity Cache.  MIEKKI_SLAB_MAX_QUERIES bounds the chunk (tuning knob).
+    static const uint64_t max_q = [] { const char *e = getenv("MIEKKI_SLAB_MAX_QUERIES"); return e ? (uint64_t)std::max(1L, atol(e)) : (uint64_t)kSlabMaxQueries; }();
+    per = std::min<uint64_t>(per, max_q);
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), std::max<uint32_t>(nq, 1));
 }
 
@@ -945,6 +948,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     for (int b = 0; b < 2; ++b) { c->d_pk[b] = nullptr; c->pk_cap[b] = 0; c->d_pk_off[b] = nullptr; c->d_heads[b] = nullptr; }
     c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr; c->front_stream = nullptr;
     memset(c->side, 0, sizeof c->side);
+    c->h_img = nullptr;
     memset(&c->front, 0, sizeof c->front);
     c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->d_bloom_full2 = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
@@ -1013,6 +1017,7 @@ void mk_destroy(mk_ctx *c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
+    if (c->h_img) (void)hipHostFree(c->h_img);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->front_stream) (void)hipStreamDestroy(c->front_stream);
@@ -1146,9 +1151,9 @@ int mk_index_append_packed(mk_ctx *c, const mk_packed_seq *seqs, uint32_t n)
             ++nb;
         }
         const int buf = c->seq_cur ^ 1;
-        uint64_t *pk_off = c->h_pk_off[buf];
-        uint32_t *dirty = c->h_dirty[buf];
-        char *heads = c->h_heads[buf];
+        uint64_t *pk_off = c->h_img->pk_off[buf];
+        uint32_t *dirty = c->h_img->dirty[buf];
+        char *heads = c->h_img->heads[buf];
         MK_TRY(ensure_packed(c, buf, packed_offsets(off, nb, pk_off)));
         uint8_t *codes = c->d_pk[buf], *except = c->d_pk[buf] + c->pk_cap[buf];
         // small per-batch arrays first, then one copy per array of codes / exception bits -- a DMA each when the
@@ -1203,7 +1208,7 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         uint64_t off[kBuildBatch + 1];
         for (uint32_t g = 0; g <= nb; ++g) off[g] = (uint64_t)g * length;
         const int buf = c->seq_cur ^ 1;
-        uint64_t *pk_off = c->h_pk_off[buf];
+        uint64_t *pk_off = c->h_img->pk_off[buf];
         MK_TRY(ensure_packed(c, buf, packed_offsets(off, nb, pk_off)));
         // the generator fills the buffer the batch in flight does NOT read -- in packed form, which is what the
         // build works from -- on the front stream, followed by this batch's front stage: the device is never idle

@@ -180,20 +180,100 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
 {
     const uint32_t v = __builtin_amdgcn_alignbit(ahi, alo, 32u - h);
     if (__builtin_expect(v >> f, 1)) {
-        const uint32_t lz = (uint32_t)__clz((int)v);
+        uint32_t lz;
+        asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(v));               // v != 0 here: no clamp needed
         const uint32_t top = v << lz;
-        return (((31u - lz) << f) | ((top << 1) >> (32u - f))) & empty;
+        return ((31u - lz) << f) | ((top >> (31u - f)) & ((1u << f) - 1u));       // <= 31 << f | 2^f - 1 = empty
     }
     return mantis_halves(ahi & ((1u << (32u - h)) - 1u), alo, h, f, empty);
 }
 
+// The hash loop of one thread: sixteen consecutive k-mers rolled out of three words of packed digits (w0, w1, w2:
+// the thread's 48 positions; x*: their exception bits), each one's item and, from an LDS counter, its rank in its bin.
+// KBIG: k >= 17 -- the entering reverse digit then always lands in the state's high word and the forward state's low
+// word needs no mask; FULL: all sixteen k-mers exist (every workgroup but a sequence's last).  Both are the same for
+// the whole workgroup; they only take instructions out of a loop that is bound by instruction issue.
+template <int W, bool KBIG, bool FULL>
+__device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bool has_x, uint32_t x01, uint32_t x2, uint32_t i0,
+                                       uint32_t cnt, uint32_t g, uint64_t seg0, uint32_t *bins, typename ItemOf<W>::type (&it)[kPer],
+                                       uint32_t (&key)[kPer], uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_g,
+                                       uint32_t *__restrict__ ovf_mark, const SketchParams &sp, const BuildShape &bs)
+{
+    using item_t = typename ItemOf<W>::type;
+    // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
+    const uint64_t F = ((uint64_t)w1 << 32) | w0;
+    uint64_t R = ~F;
+    uint32_t R2 = ~w2;
+    if (has_x) {
+        R &= ~spread_pairs32(x01);
+        R2 &= ~spread_pairs16(x2);
+    }
+    const uint32_t km1 = sp.k - 1;                                // 1..30 digits of seed
+    const uint64_t seedmask = (1ULL << (2 * km1)) - 1;
+    // state after k-1 digits, as the reference's loop leaves it (Miekki.cpp:158-164)
+    const uint64_t S0 = reverse_digits(F & seedmask) >> (64 - 2 * km1), RC0 = (R & seedmask) << 2;
+    // the sixteen digits that enter, one per k-mer
+    const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)w2 << (64 - 2 * km1)));
+    const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
+    // rolling state in 32-bit halves (a 64-bit shift / and is several issue slots, a funnel shift one)
+    uint32_t Slo = (uint32_t)S0, Shi = (uint32_t)(S0 >> 32), Rlo = (uint32_t)RC0, Rhi = (uint32_t)(RC0 >> 32);
+    const uint32_t mlo = (uint32_t)sp.kmask, mhi = (uint32_t)(sp.kmask >> 32);
+    const uint32_t topshift = 2 * sp.k - 2;                       // even: the entering reverse digit lies within ONE half
+    const bool top_hi = KBIG || topshift >= 32;
+    const uint32_t tsh = top_hi ? topshift - 32 : topshift;
+    const uint32_t cap_items = bs.cap_words - 1u;
+    const uint32_t bshift = 32u - sp.h;                           // bucket = anc >> (64 - h)  (Miekki.cpp:169)
+    const uint32_t ibase = i0 << kBin;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t fd = (fnew >> (2 * u)) & 3u, rd = (rnew >> (2 * u)) & 3u;
+        if (KBIG) {
+            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;                  // update_kmer, Miekki.cpp:51-55
+            Slo = (Slo << 2) | fd;
+            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);                         // update_kmer_RC, Miekki.cpp:59-62
+            Rhi = (Rhi >> 2) | (rd << tsh);
+        } else {
+            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;
+            Slo = ((Slo << 2) | fd) & mlo;
+            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);
+            Rhi >>= 2;
+            if (top_hi) Rhi |= rd << tsh; else Rlo |= rd << tsh;
+        }
+        const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
+        const uint64_t anc = revhash64(S < RC ? S : RC);                          // Miekki.cpp:167-168
+        const uint32_t ahi = (uint32_t)(anc >> 32);
+        const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
+        if (fp == sp.empty || (!FULL && i0 + u >= cnt)) continue;    // (past the segment's end only in a sequence's last workgroup)
+        const uint32_t bucket = ahi >> bshift;
+        const uint32_t binoff = (bucket >> bs.low_bits) << 2;          // byte offset of the bin's counter
+        const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
+        const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
+        if (rank < cap_items) {
+            it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(part | ibase | (u << kBin));
+            key[u] = (binoff << 12) | rank;
+        } else {
+            // slot full: the genome's overflow list (a slot is sized for the common case, ~4 sigma: a few hundred
+            // items per 5 Mb genome land here; a list that runs over -- very repetitive sequence -- marks the batch)
+            const uint32_t o = atomicAdd(&ovf_g[g], 1u);
+            if (o < kOvfPerGenome) {
+                uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + o) * 2;
+                e[0] = bucket;
+                e[1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
+            } else {
+                atomicMax(ovf_mark, kOvfFold + 1u);
+            }
+        }
+    }
+}
+
 // What bounds this kernel is instruction issue (round 3: ~122 vector instructions per k-mer in its
-// predecessor, most of them around the hash loop, not in it).  So: the positions arrive packed --
-// a thread's 16 + k-1 digits are three LDS words, no classification, no squeezing; the items of the
-// whole workgroup are sorted by bin through ONE 4096-entry stage (4-byte items: 16 KiB, eight
-// workgroups per CU), and a bin's run leaves with 16-byte stores, four items per lane, the lanes
-// of a bin side by side -- no per-item address arithmetic.
-template <int W>
+// predecessor, most of them around the hash loop, not in it; 84 in the first version of this one, PMC).
+// So: the positions arrive packed -- a thread's 16 + k-1 digits are three LDS words, no
+// classification, no squeezing; the items of the whole workgroup are sorted by bin through ONE
+// 4096-entry stage (4-byte items: 16 KiB, eight workgroups per CU), and a bin's run leaves with
+// 16-byte stores, four items per lane, the lanes of a bin side by side -- no per-item address
+// arithmetic.
+template <int W, bool KBIG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ slots,
@@ -202,8 +282,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     using item_t = typename ItemOf<W>::type;
     constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    item_t *stage = reinterpret_cast<item_t *>(smem);                 // kSeg + kIPV items
-    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
+    item_t *stage = reinterpret_cast<item_t *>(smem);                 // 1 + kSeg + kIPV: the sorted items from stage[1] on
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (1 + kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
     __shared__ uint32_t cw[kSeg / 16 + 4];                            // the workgroup's positions, 16 per word
     __shared__ uint32_t xw[kSeg / 16 + 4];                            // their exception bits (low 16)
     __shared__ uint32_t wave_sum[4];
@@ -228,66 +308,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     __syncthreads();
     const uint32_t i0 = tid * kPer;
     item_t it[kPer];
-    uint32_t key[kPer];                                               // bin << 12 | rank in bin; ~0: no item
+    uint32_t key[kPer];                                               // byte offset of the bin's counter << 12 | rank in bin; ~0: no item
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) key[u] = ~0u;
     if (i0 < cnt) {
         const uint32_t w0 = cw[tid], w1 = cw[tid + 1], w2 = cw[tid + 2];
-        // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
-        const uint64_t F = ((uint64_t)w1 << 32) | w0;
-        uint64_t R = ~F;
-        uint32_t R2 = ~w2;
-        if (has_x) {
-            R &= ~spread_pairs32(xw[tid] | (xw[tid + 1] << 16));
-            R2 &= ~spread_pairs16(xw[tid + 2]);
-        }
-        const uint32_t km1 = sp.k - 1;                                // 1..30 digits of seed
-        const uint64_t seedmask = (1ULL << (2 * km1)) - 1;
-        // state after k-1 digits, as the reference's loop leaves it (Miekki.cpp:158-164)
-        const uint64_t S0 = reverse_digits(F & seedmask) >> (64 - 2 * km1), RC0 = (R & seedmask) << 2;
-        // the sixteen digits that enter, one per k-mer
-        const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)w2 << (64 - 2 * km1)));
-        const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
-        // rolling state in 32-bit halves (a 64-bit shift / and is several issue slots, a funnel shift one)
-        uint32_t Slo = (uint32_t)S0, Shi = (uint32_t)(S0 >> 32), Rlo = (uint32_t)RC0, Rhi = (uint32_t)(RC0 >> 32);
-        const uint32_t mlo = (uint32_t)sp.kmask, mhi = (uint32_t)(sp.kmask >> 32);
-        const uint32_t topshift = 2 * sp.k - 2;                       // even: the entering reverse digit lies within ONE half
-        const bool top_hi = topshift >= 32;
-        const uint32_t tsh = top_hi ? topshift - 32 : topshift;
-        const uint32_t lowmask = (1u << bs.low_bits) - 1u;
-        const uint32_t cap_items = bs.cap_words - 1u;
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;                  // update_kmer, Miekki.cpp:51-55
-            Slo = ((Slo << 2) | ((fnew >> (2 * u)) & 3u)) & mlo;
-            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);                         // update_kmer_RC, Miekki.cpp:59-62
-            Rhi >>= 2;
-            const uint32_t rd = ((rnew >> (2 * u)) & 3u) << tsh;
-            if (top_hi) Rhi |= rd; else Rlo |= rd;
-            const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
-            const uint64_t anc = revhash64(S < RC ? S : RC);                      // Miekki.cpp:167-168
-            const uint32_t ahi = (uint32_t)(anc >> 32);
-            const uint32_t bucket = ahi >> (32 - sp.h);                           // Miekki.cpp:169
-            const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
-            if (fp == sp.empty || i0 + u >= cnt) continue;           // (past the segment's end only in a sequence's last workgroup)
-            const uint32_t bin = bucket >> bs.low_bits;
-            const uint32_t rank = atomicAdd(&bins[bin], 1u);
-            if (rank < cap_items) {
-                it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(((i0 + u) << kBin) | (bucket & lowmask));
-                key[u] = (bin << 12) | rank;
-            } else {
-                // slot full: the genome's overflow list (a slot is sized for the common case, ~4 sigma: a few hundred
-                // items per 5 Mb genome land here; a list that runs over -- very repetitive sequence -- marks the batch)
-                const uint32_t o = atomicAdd(&ovf_g[g], 1u);
-                if (o < kOvfPerGenome) {
-                    uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + o) * 2;
-                    e[0] = bucket;
-                    e[1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
-                } else {
-                    atomicMax(ovf_mark, kOvfFold + 1u);
-                }
-            }
-        }
+        const uint32_t x01 = has_x ? xw[tid] | (xw[tid + 1] << 16) : 0u, x2 = has_x ? xw[tid + 2] : 0u;
+        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, g, seg0, bins, it, key, ovf, ovf_g, ovf_mark, sp, bs);
+        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, g, seg0, bins, it, key, ovf, ovf_g, ovf_mark, sp, bs);
     }
     __syncthreads();
     // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of min(count, capacity)
@@ -321,7 +349,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u)
-        if (key[u] != ~0u) stage[bins[key[u] >> 12] + (key[u] & 4095u)] = it[u];
+        if (key[u] != ~0u)
+            stage[1u + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u)] = it[u];
     __syncthreads();
     // ---- a bin's run -> its slot: word 0 = count, then the items; 16-byte stores, the lanes of a bin side by side
     item_t *__restrict__ gslots = slots + ((uint64_t)g * bs.nbins * bs.nwg + wg) * bs.cap_words;
@@ -332,11 +361,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
         const uint32_t b = t / kLanes, q = t % kLanes;
         const uint32_t lo = bins[b], n = bins[b + 1] - lo;
         item_t *__restrict__ dst = gslots + b * bin_stride;
-        // slot word j (j >= 1) = stage[lo + j - 1]; lane q writes words [kIPV * q, kIPV * q + kIPV), then kLanes * kIPV further on
+        // slot word j (j >= 1) = the run's item j - 1 = stage[lo + j]; lane q writes words [kIPV * q, kIPV * q + kIPV), then
+        // kLanes * kIPV further on
         for (uint32_t j = q * kIPV; j <= n; j += kLanes * kIPV) {
             vec_t v;
 #pragma unroll
-            for (uint32_t e = 0; e < kIPV; ++e) v[e] = j + e == 0 ? (item_t)n : stage[lo + j + e - 1];
+            for (uint32_t e = 0; e < kIPV; ++e) v[e] = stage[lo + j + e];
+            if (j == 0) v[0] = (item_t)n;
             *reinterpret_cast<vec_t *>(dst + j) = v;
         }
     }
@@ -469,27 +500,33 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
         const uint64_t pos = (uint64_t)key & ((1ULL << kKeyPos) - 1);
         const uint64_t cn = canon_from_packed(gcodes, gexcept, has_x, pos, sp.k);
         canon[j] = cn;
-        const uint64_t anc = revhash64(cn);
         const uint32_t p = bin * R + i;
-        uint64_t sum_idx = ~0ull;
-        uint32_t sum_word = 0;
-        for (uint32_t hi = 0; hi < kNumHash; ++hi) {
-            const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
-            const uint64_t cell = hsh >> 3;
-            if (cell >= bloom_dev_bytes) continue;
-            const uint64_t grp = cell >> 3;
-            if ((grp >> 5) != sum_idx) {
-                sum_idx = grp >> 5;
-                // the second level first (LDS): once the filter has filled up it answers nearly every probe, and the
-                // winner costs ONE request at the L2 -- its codes -- instead of two
-                if (full2_words && ((s_full2[sum_idx >> 6] >> (sum_idx & 63u)) & 1u)) sum_word = 0xffffffffu;
-                else sum_word = full[sum_idx];
-            }
-            if ((sum_word >> (grp & 31u)) & 1u) continue;
+        const uint32_t chi = (uint32_t)(cn >> 32);
+        // probe one Bloom position: the summaries first -- the second level in LDS, which once the filter has filled up
+        // answers nearly every probe, so that the winner costs ONE request at the L2 (its codes) -- then the cell
+        auto probe = [&](uint64_t cell, uint32_t tag) {
+            if (cell >= bloom_dev_bytes) return;
+            const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;
+            if (full2_words && ((s_full2[sidx >> 6] >> (sidx & 63u)) & 1u)) return;
+            if ((full[sidx] >> (grp & 31u)) & 1u) return;
             if (bloom[cell] == 0) {
-                const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (hi << 4) | (uint32_t)(hsh & 7);
+                const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | tag;
                 atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
                 posted_mask |= 1u << j;
+            }
+        };
+        if ((uint32_t)cn <= 0xFFFFFC00u) {
+            // The five positions are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32:
+            // when the low word cannot carry they are ONE position, and of the five first-writer keys only the smallest,
+            // hash index 0, can ever win the cell (pass B re-derives all five and finds the same).  All but one k-mer in
+            // four million: one probe, 32-bit arithmetic on the high word, no revhash.
+            const uint32_t sh = sp.bloom_log2 - 32u;
+            probe(chi >> (sh + 3u), (chi >> sh) & 7u);
+        } else {
+            const uint64_t anc = revhash64(cn);
+            for (uint32_t hi = 0; hi < kNumHash; ++hi) {
+                const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
+                probe(hsh >> 3, (hi << 4) | (uint32_t)(hsh & 7));
             }
         }
         if ((posted_mask >> j) & 1u) blk_posted[i >> 8] = 1;
@@ -647,12 +684,14 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     shape_store(sd, bs);
     const SketchParams sp = make_sp(c);
     const size_t isz = c->W == 1 ? 4 : 8;
-    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
-#define MK_SCATTER(Wv)                                                                                                          \
-    hipLaunchKernelGGL(build_scatter_kernel<Wv>, dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except, d_code_off, \
-                       sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), sd.d_ovf, \
-                       sd.d_counters->ovf_g, &sd.d_counters->ovf, sp, bs)
-    if (c->W == 1) MK_SCATTER(1); else MK_SCATTER(2);
+    const size_t lds = (1 + kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
+#define MK_SCATTER(Wv, KB)                                                                                                      \
+    hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except,     \
+                       d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), \
+                       sd.d_ovf, sd.d_counters->ovf_g, &sd.d_counters->ovf, sp, bs)
+    const bool kbig = c->p.k >= 17;
+    if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
+    else           { if (kbig) MK_SCATTER(2, true); else MK_SCATTER(2, false); }
 #undef MK_SCATTER
     MK_HIP(hipGetLastError());
     *used = true;

@@ -31,6 +31,7 @@ constexpr uint32_t kShortMax = 4096;     // k-mers a query may have for the in-L
 constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batch
 constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
 constexpr uint64_t kEmptyKey = ~0ULL;
+constexpr uint32_t kSlabMaxQueries = 1u << 30;   // queries per launch of the slab schedule (no bound by default; see chunk_queries_slab)
 
 // packed query-sketch entry: partition in the low word, fingerprint in the high word
 __host__ __device__ inline uint64_t make_entry(uint32_t p, uint32_t fp) { return (uint64_t)p | ((uint64_t)fp << 32); }
@@ -141,9 +142,14 @@ struct mk_ctx {
     char *d_heads[2];              // kBuildBatch x 32 characters
     // host images of the small per-batch arrays: they are copied asynchronously, and an append returns with its
     // batch still in flight, so they live here and not on a caller's stack
-    uint64_t h_pk_off[2][mk::kBuildBatch + 1];
-    uint32_t h_dirty[2][mk::kBuildBatch];
-    char h_heads[2][mk::kBuildBatch * 32];
+    // (page-locked: a copy from pageable memory makes the host wait until the stream has reached it -- for the
+    // front stream that is the end of the batch's PCIe copy)
+    struct HostImages {
+        uint64_t pk_off[2][mk::kBuildBatch + 1];
+        uint64_t off[2][mk::kBuildBatch + 1];
+        uint32_t dirty[2][mk::kBuildBatch];
+        char heads[2][mk::kBuildBatch * 32];
+    } *h_img;
     // Per-batch counters of the build live in ONE device block (one memset before a batch, one copy
     // back after it): d_ovf_count, d_dirty, d_active, d_cardsum point into d_counters.  BuildCounters
     // is its layout, and that of the pinned read-back block.

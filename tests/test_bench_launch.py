@@ -25,6 +25,26 @@ def test_default_multi_gpu_workload_is_config3_strong_scaling():
     assert plan("--gpus", "1")["shards"] == [[0, 100000]] and plan("--gpus", "1")["launcher"] is None
 
 
+def test_shard_tables_and_launcher_lines_for_2_4_8_gpus():
+    """What the driver will run at N = 2, 4, 8: the plan's shard table is shard_range's (contiguous, ordered, sizes
+    within one of each other, 100,000 genomes in total) and the launcher line is the documented one."""
+    sys.path.insert(0, ROOT)
+    from miekki_amd.shard import shard_range
+    for n in (2, 4, 8):
+        p = plan("--gpus", str(n), "--steps", "3", "--warmup", "1")
+        assert p["scaling"] == "strong" and len(p["shards"]) == n
+        assert p["shards"] == [list(shard_range(100_000, r, n)) for r in range(n)]
+        sizes = [b - a for a, b in p["shards"]]
+        assert sum(sizes) == 100_000 and max(sizes) - min(sizes) <= 1 and p["shards"][0][0] == 0
+        L = p["launcher"]
+        assert L[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in L and f"--nproc-per-node={n}" in L
+        assert L[L.index("--master-addr") + 1] == "127.0.0.1" and L[L.index("--master-port") + 1].isdigit()
+        tail = L[L.index(BENCH) + 1:] if BENCH in L else L[-6:]
+        assert tail == ["--gpus", str(n), "--steps", "3", "--warmup", "1"]            # the ranks get the same arguments
+    p = plan("--gpus", "8", "--genomes", "100003")                                     # a remainder goes to the first ranks
+    assert [b - a for a, b in p["shards"]] == [12501] * 3 + [12500] * 5
+
+
 def test_weak_scaling_is_opt_in():
     p = plan("--gpus", "4", "--weak", "--genomes-per-gpu", "100000")
     assert p["scaling"] == "weak" and p["shards"][-1] == [300000, 400000]
