@@ -92,6 +92,27 @@ def self_launch(args, argv):
     return subprocess.call(launcher_command(args, argv), env=env)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota (the GPU boxes hand a
+    job 16 CPUs' worth of a 256-thread host: more threads than that only take turns on them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                    # cgroup v2
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:                                                                        # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    usable = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return usable, n, quota
+
+
 def cpu_baseline(h, host_cores):
     """The reference's own code timed on ALL of this host's cores (and on one, for the per-core figure),
     on bounded samples of the same workload, by oracle/_ref/ref_harness (the unmodified reference,
@@ -104,7 +125,8 @@ def cpu_baseline(h, host_cores):
     When that build is absent: the oracle's scalar restatement of the scan on the same sample shape,
     one core (kind "port"), and no sketch leg."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    threads = max(1, host_cores)
+    usable, affinity, quota = usable_cpus()
+    threads = max(1, usable)                          # every CPU this job may use (host_cores says what the machine has)
     # G_cpu: the regime the metric is quoted in (>= 10^4 genomes: the per-genome compare dominates the
     # O(2^h x batch) sweep); two batches of 201 queries per thread, ~10-20 s on the box's cores
     G_cpu = 20_000 if h >= 19 else 10_000
@@ -112,7 +134,7 @@ def cpu_baseline(h, host_cores):
     # and ~200 s when 256 threads run one each (measured, profiles/r3_cpu_baseline_scaling.txt: the O(2^h x batch)
     # strided sweep of Miekki.cpp:355-360 saturates the memory system), so the all-thread sample uses batches of
     # 32 -- the same work per query, a sample six times shorter.  The one-thread sample is a batch of 201.
-    per, batch = 1, (32 if h >= 19 and threads > 64 else 201)
+    per, batch = (2, 201) if threads <= 64 else (1, 32 if h >= 19 else 201)
     shape = (f"synthetic 1 kb queries vs {G_cpu} genomes (4 sketched 5 Mb genomes, columns padded cyclically), "
              f"-h {h}, saturated Bloom")
     if os.path.exists(harness):
@@ -125,7 +147,7 @@ def cpu_baseline(h, host_cores):
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode()
             r = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             res = {"value": r["comparisons"] / r["seconds"], "unit": "comparisons/s", "cores": threads,
-                   "host_cores": host_cores, "kind": "reference",
+                   "host_cores": host_cores, "cpu_affinity": affinity, "cgroup_cpu_quota": quota, "kind": "reference",
                    "all_core": r["comparisons"] / r["seconds"],
                    "per_core": r["one_thread_comparisons"] / r["one_thread_seconds"],
                    "sample": f"reference query_sequences on {threads} threads, one batch of {r['batch']} queries each, "
@@ -133,7 +155,7 @@ def cpu_baseline(h, host_cores):
                    "sample_seconds": r["seconds"] + r["one_thread_seconds"]}
             try:
                 # (the append is one critical section, ~0.2 s per genome at -h 20 however many threads: ~96 genomes = ~20 s)
-                n_gen = max(16, min(threads, 96))
+                n_gen = max(16, min(4 * threads, 96))
                 sys.stderr.write(f"[bench] cpu baseline: reference insert_sequences on {threads} threads ...\n")
                 out = subprocess.run([harness, "sketchbench", str(h), str(n_gen), str(threads)],
                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env).stdout.decode()
@@ -446,8 +468,9 @@ def main(argv=None):
                                       "gbs_floor": matrix_bytes / avg_launch_s / 1e9,
                                       "frac_of_measured_stream_read": (matrix_bytes / avg_launch_s / 1e9 / stream_gbs) if stream_gbs else None,
                                       "note": "the least HBM itself must deliver: the shard's matrix once per launch; the true HBM share "
-                                              "lies between this and `traffic` (no gfx950 counter isolates it: FETCH_SIZE counts "
-                                              "Infinity-Cache hits, rocprofv3 lists no MALL / UMC byte counters on this image)"},
+                                              "lies between this and `traffic`; no counter on this image isolates it: FETCH_SIZE counts "
+                                              "Infinity-Cache hits, rocprofv3 -L lists no MALL / UMC byte counters, and TCC_EA0_RDREQ_DRAM_sum "
+                                              "equals TCC_EA0_RDREQ_sum on this kernel (profiles/r3_pmc_scan_dram_counter.txt)"},
                          "kernel": "scan_slab_kernel" if st["scan_slab_launches"] else "scan_kernel",
                          "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algo_bytes_per_launch": algo_per_launch,

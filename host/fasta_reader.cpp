@@ -1,6 +1,8 @@
 #include "fasta_reader.hpp"
 
 #include <fcntl.h>
+#include <immintrin.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -27,36 +29,121 @@ size_t strip_fasta(const char *text, size_t n, char *dst)
     return (size_t)(o - dst);
 }
 
-size_t pack_fasta(const char *text, size_t n, PackAppendFn pack, uint64_t *codes, uint64_t *except, char head[32], bool *dirty)
+namespace {
+
+// 32 characters -> 64 bits of codes (character j at bits 2j) and 32 exception bits (nuc2int / nuc2intrc,
+// utils.cpp:31-49, 107-125: anything but A, C, G, T is 0 on both strands)
+struct Block { uint64_t codes; uint32_t except; };
+
+inline Block pack32_scalar(const unsigned char *c)
 {
-    const char *p = text, *const end = text + n;
+    Block b{0, 0};
+    for (unsigned j = 0; j < 32; ++j) {
+        const unsigned ch = c[j], t = (ch >> 1) & 3u;              // A C G T -> 0 1 3 2
+        if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') b.codes |= (uint64_t)(t ^ (t >> 1)) << (2 * j);
+        else b.except |= 1u << j;
+    }
+    return b;
+}
+
+__attribute__((target("avx2"))) inline Block pack32_avx2(const unsigned char *c)
+{
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(c));
+    const __m256i ok = _mm256_or_si256(
+        _mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('C'))),
+        _mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('T'))));
+    const __m256i t = _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(3));
+    __m256i v = _mm256_xor_si256(t, _mm256_and_si256(_mm256_srli_epi16(t, 1), _mm256_set1_epi8(1)));
+    v = _mm256_and_si256(v, ok);
+    v = _mm256_and_si256(_mm256_or_si256(v, _mm256_srli_epi64(v, 6)), _mm256_set1_epi64x(0x000F000F000F000FLL));
+    v = _mm256_and_si256(_mm256_or_si256(v, _mm256_srli_epi64(v, 12)), _mm256_set1_epi64x(0x000000FF000000FFLL));
+    v = _mm256_or_si256(v, _mm256_srli_epi64(v, 24));
+    Block b;
+    b.codes = ((uint64_t)_mm256_extract_epi64(v, 0) & 0xffffu) | (((uint64_t)_mm256_extract_epi64(v, 1) & 0xffffu) << 16) |
+              (((uint64_t)_mm256_extract_epi64(v, 2) & 0xffffu) << 32) | (((uint64_t)_mm256_extract_epi64(v, 3) & 0xffffu) << 48);
+    b.except = ~(uint32_t)_mm256_movemask_epi8(ok);
+    return b;
+}
+
+// appends bit strings to an array of 64-bit words, least significant bit first
+struct BitWriter {
+    uint64_t *w;
+    uint64_t acc = 0;
+    unsigned fill = 0;                                             // bits waiting in acc, < 64
+    explicit BitWriter(uint64_t *dst) : w(dst) {}
+    inline void put(uint64_t v, unsigned nbits)                    // the low nbits (<= 64) of v; the rest of v is zero
+    {
+        acc |= v << fill;
+        if (fill + nbits >= 64) {
+            *w++ = acc;
+            acc = fill ? v >> (64 - fill) : 0;
+            fill = fill + nbits - 64;
+        } else {
+            fill += nbits;
+        }
+    }
+    inline void finish() { *w++ = acc; *w++ = 0; }                 // (the arrays carry two words of slack)
+};
+
+template <bool AVX2>
+size_t pack_fasta_t(const char *text, size_t n, uint64_t *codes, uint64_t *except, char head[32], bool *dirty)
+{
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(text), *const end = p + n;
+    BitWriter cw(codes), xw(except);
     size_t at = 0;
-    bool any = false;
-    codes[0] = 0; except[0] = 0;                                   // an empty sequence is all-zero words
+    uint32_t any = 0;
     memset(head, 0, 32);
-    while (p <= end) {                                             // the line rules of strip_fasta
-        const char *e = p < end ? (const char *)memchr(p, '\n', (size_t)(end - p)) : nullptr;
+    while (p <= end) {                                             // the line rules of strip_fasta (getline, Miekki.cpp:559-567)
+        const unsigned char *e = p < end ? (const unsigned char *)memchr(p, '\n', (size_t)(end - p)) : nullptr;
         if (!e) e = end;
         if (e > p && *p != '>') {
-            const size_t m = (size_t)(e - p);
+            size_t m = (size_t)(e - p);
             if (at < 32) memcpy(head + at, p, std::min<size_t>(m, 32 - at));
-            if (pack(codes, except, at, p, m) > 0) any = true;
             at += m;
+            const unsigned char *q = p;
+            for (; m >= 32; m -= 32, q += 32) {
+                const Block b = AVX2 ? pack32_avx2(q) : pack32_scalar(q);
+                cw.put(b.codes, 64);
+                xw.put(b.except, 32);
+                any |= b.except;
+            }
+            if (m) {
+                // the line's last m < 32 characters: a whole 32-byte load when the text reaches that far (what follows
+                // the line is masked away), a padded copy at the very end of the text
+                unsigned char tail[32];
+                const unsigned char *src = q;
+                if (q + 32 > end) { memset(tail, 'A', sizeof tail); memcpy(tail, q, m); src = tail; }
+                const Block b = AVX2 ? pack32_avx2(src) : pack32_scalar(src);
+                const uint32_t x = b.except & ((1u << m) - 1u);
+                cw.put(b.codes & ((1ull << (2 * m)) - 1), 2 * (unsigned)m);
+                xw.put(x, (unsigned)m);
+                any |= x;
+            }
         }
         p = e + 1;
     }
-    *dirty = any;
+    cw.finish(); xw.finish();
+    *dirty = any != 0;
     return at;
 }
 
-static bool gunzip_all(const std::vector<char> &in, std::vector<char> &out)
+}  // namespace
+
+size_t pack_fasta(const char *text, size_t n, uint64_t *codes, uint64_t *except, char head[32], bool *dirty)
+{
+    // MIEKKI_PACK_SCALAR=1 forces the portable form (tests cover both)
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !(getenv("MIEKKI_PACK_SCALAR") && atoi(getenv("MIEKKI_PACK_SCALAR")));
+    return avx2 ? pack_fasta_t<true>(text, n, codes, except, head, dirty) : pack_fasta_t<false>(text, n, codes, except, head, dirty);
+}
+
+static bool gunzip_all(const char *in, size_t in_size, std::vector<char> &out)
 {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;
-    out.resize(std::max<size_t>(in.size() * 4, 1 << 16));
-    zs.next_in = (Bytef *)in.data();
-    size_t in_left = in.size(), produced = 0;
+    out.resize(std::max<size_t>(in_size * 4, 1 << 16));
+    zs.next_in = (Bytef *)in;
+    size_t in_left = in_size, produced = 0;
     bool ok = true;
     for (;;) {
         if (produced == out.size()) out.resize(out.size() * 2);
@@ -107,14 +194,51 @@ bool read_file(const std::string &path, std::vector<char> &out, std::vector<char
     }
     close(fd);
     raw.resize(got);
-    if (got >= 2 && (unsigned char)raw[0] == 0x1f && (unsigned char)raw[1] == 0x8b) return gunzip_all(raw, out);
+    if (got >= 2 && (unsigned char)raw[0] == 0x1f && (unsigned char)raw[1] == 0x8b) return gunzip_all(raw.data(), raw.size(), out);
     out.swap(raw);
     return true;
 }
 
-OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window,
-                                       PackAppendFn pack)
-    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(pack)
+bool FileText::open(const std::string &path, std::vector<char> &store)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {              // a pipe, a directory, ...: the reading path decides
+        close(fd);
+        std::vector<char> scratch;
+        if (!read_file(path, store, scratch)) return false;
+        p = store.data(); n = store.size();
+        return true;
+    }
+    if (st.st_size == 0) { close(fd); p = ""; n = 0; return true; }
+    maplen_ = (size_t)st.st_size;
+    map_ = mmap(nullptr, maplen_, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    close(fd);
+    if (map_ == MAP_FAILED) {
+        map_ = nullptr;
+        std::vector<char> scratch;
+        if (!read_file(path, store, scratch)) return false;
+        p = store.data(); n = store.size();
+        return true;
+    }
+    const unsigned char *m = (const unsigned char *)map_;
+    if (maplen_ >= 2 && m[0] == 0x1f && m[1] == 0x8b) {             // gzip: inflate every member (zstr.hpp:186-190)
+        if (!gunzip_all((const char *)map_, maplen_, store)) return false;
+        p = store.data(); n = store.size();
+    } else {
+        p = (const char *)map_; n = maplen_;
+    }
+    return true;
+}
+
+FileText::~FileText()
+{
+    if (map_) munmap(map_, maplen_);
+}
+
+OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed)
+    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed)
 {
     for (auto &r : ready_) r.store(0);
     const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
@@ -211,23 +335,24 @@ void OrderedFastaReader::work()
         struct stat st;
         it.exists = stat(files_[i].c_str(), &st) == 0;
         if (it.exists) {
-            text.clear();
-            if (!read_file(files_[i], text, scratch)) it.failed = true;
-            if (pack_) {
-                // no more than text.size() bases: two arrays of that many positions, 8-byte aligned in one buffer
-                const size_t cw = packed_code_words(text.size()), xw = packed_except_words(text.size());
+            FileText ft;                                               // mapped, or inflated into `text`
+            if (!ft.open(files_[i], text)) {
+                it.failed = true;
+            } else if (pack_) {
+                // no more than ft.n bases: two arrays of that many positions, 8-byte aligned in one buffer
+                const size_t cw = packed_code_words(ft.n), xw = packed_except_words(ft.n);
                 it.data = pool_get((cw + xw) * 8, it.cap);
                 if (it.data) {
                     it.packed = true;
                     it.codes = reinterpret_cast<uint64_t *>(it.data);
                     it.except = it.codes + cw;
-                    it.len = pack_fasta(text.data(), text.size(), pack_, it.codes, it.except, it.head, &it.dirty);
+                    it.len = pack_fasta(ft.p, ft.n, it.codes, it.except, it.head, &it.dirty);
                 } else {
                     it.failed = true;
                 }
             } else {
-                it.data = pool_get(text.size() + 1, it.cap);
-                if (it.data) it.len = strip_fasta(text.data(), text.size(), it.data);
+                it.data = pool_get(ft.n + 1, it.cap);
+                if (it.data) it.len = strip_fasta(ft.p, ft.n, it.data);
                 else it.failed = true;
             }
         }

@@ -30,17 +30,30 @@ struct HostAllocator {
 // all non-'>' lines of text[0..n) concatenated into dst (room for n bytes); getline semantics
 size_t strip_fasta(const char *text, size_t n, char *dst);
 
-// The same sequence, packed line by line as it is parsed (include/miekki_hip.h, mk_packed_seq: 2 bits
-// per base, one exception bit per base, the first 32 characters).  `pack` is the library's
-// mk_pack_append; the reader takes it as a pointer so that it builds without the library (tests).
-typedef int (*PackAppendFn)(uint64_t *codes, uint64_t *except, uint64_t at, const char *chars, uint64_t n);
-inline size_t packed_code_words(size_t len) { return (len + 31) / 32 + 1; }
-inline size_t packed_except_words(size_t len) { return (len + 63) / 64 + 1; }
-// returns the sequence's length; *dirty = it holds characters other than A, C, G, T
-size_t pack_fasta(const char *text, size_t n, PackAppendFn pack, uint64_t *codes, uint64_t *except, char head[32], bool *dirty);
+// The same sequence, packed as it is parsed (include/miekki_hip.h, mk_packed_seq: 2 bits per base -- base i at
+// bits 2 * (i % 32) of word i / 32, A C G T = 0 1 2 3, anything else 0 -- one exception bit per base for anything
+// else, the first 32 characters as they came).  The reader has its own packer (32 characters per step, AVX2 when
+// the CPU has it, a bit writer that carries over line ends) rather than a call per FASTA line into the library's
+// mk_pack_append: at 60-80 characters a line the calls were half of a reader thread's time.
+inline size_t packed_code_words(size_t len) { return (len + 31) / 32 + 2; }
+inline size_t packed_except_words(size_t len) { return (len + 63) / 64 + 2; }
+// returns the sequence's length; *dirty = it holds characters other than A, C, G, T.  text[0..n) must be readable.
+size_t pack_fasta(const char *text, size_t n, uint64_t *codes, uint64_t *except, char head[32], bool *dirty);
 
 // whole file into `out`, gunzipped when it starts with the gzip magic (any number of members)
 bool read_file(const std::string &path, std::vector<char> &out, std::vector<char> &scratch);
+
+// A file's text for one pass over it: a plain file is mapped (no copy out of the page cache), a gzip'd one is
+// inflated into `store`.  Closed by the destructor.
+struct FileText {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool open(const std::string &path, std::vector<char> &store);
+    ~FileText();
+private:
+    void *map_ = nullptr;
+    size_t maplen_ = 0;
+};
 
 class OrderedFastaReader {
 public:
@@ -55,9 +68,8 @@ public:
         char head[32] = {0};
     };
     // window = how many files may be parsed ahead of the consumer (each holds one buffer);
-    // pack != nullptr: items come packed (a quarter of the bytes to buffer and to copy to the GPU)
-    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window,
-                       PackAppendFn pack = nullptr);
+    // packed: items come packed (a quarter of the bytes to buffer and to copy to the GPU)
+    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed = false);
     ~OrderedFastaReader();
     // blocks until file i (called with i = 0, 1, 2, ...) has been read
     Item take(size_t i);
@@ -77,7 +89,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     HostAllocator a_;
-    PackAppendFn pack_ = nullptr;
+    bool pack_ = false;
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
     std::unordered_set<char *> plain_;              // buffers that came from malloc although an allocator was given

@@ -192,7 +192,7 @@ struct Driver {
         static const bool as_chars = [] { const char *e = getenv("MIEKKI_INGEST"); return e && string(e) == "chars"; }();
         PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
         OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 3 * 64,
-                                  as_chars ? nullptr : &mk_pack_append);
+                                  !as_chars);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         auto flush = [&]() {

@@ -1,8 +1,7 @@
 // Test helper: run the host driver's OrderedFastaReader over a list of files and print,
 // per file in list order, "<exists> <length> <fnv1a64 of the sequence> <failed>".
 //   reader_dump <list> <threads> [window] [allocator budget in bytes, 0 = no allocator] [take only the first N] [packed]
-// With "packed" the reader packs while it parses (2-bit codes + exception bits through a plain packer of
-// this file's own, same contract as the library's mk_pack_append) and the line is
+// With "packed" the reader packs while it parses (2-bit codes + exception bits, unpacked again here) and the line is
 // "<exists> <length> <fnv1a64 of the sequence with every non-ACGT character as '?'> <failed> <dirty> <head as hex>".
 // With a budget the reader gets an allocator that hands out at most that many bytes and then
 // fails (the page-lock limit of pinned memory); with "take only N" the reader is destroyed
@@ -27,24 +26,6 @@ static void *budget_alloc(void *, size_t bytes)
 }
 static void budget_free(void *, void *p) { --g_live; free(p); }
 
-// contract of mk_pack_append (include/miekki_hip.h), stated plainly
-static int plain_pack(uint64_t *codes, uint64_t *except, uint64_t at, const char *chars, uint64_t n)
-{
-    int any = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t p = at + i;
-        const char c = chars[i];
-        const uint64_t code = c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
-        const bool bad = !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-        if (p % 32 == 0) codes[p / 32] = 0;
-        if (p % 64 == 0) except[p / 64] = 0;
-        codes[p / 32] = (codes[p / 32] & ((1ull << (2 * (p % 32))) - 1)) | (code << (2 * (p % 32)));
-        except[p / 64] = (except[p / 64] & ((1ull << (p % 64)) - 1)) | ((uint64_t)bad << (p % 64));
-        any |= bad;
-    }
-    return any;
-}
-
 int main(int argc, char **argv)
 {
     if (argc < 3) return 2;
@@ -59,7 +40,7 @@ int main(int argc, char **argv)
         if (budget > 0) a = mkhost::HostAllocator{budget_alloc, budget_free, nullptr};
         const bool packed = argc > 6 && std::string(argv[6]) == "packed";
         mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), a, argc > 3 ? (size_t)atoi(argv[3]) : 4,
-                                          packed ? &plain_pack : nullptr);
+                                          packed);
         for (size_t i = 0; i < files.size() && i < only; ++i) {
             mkhost::OrderedFastaReader::Item it = reader.take(i);
             uint64_t h = 1469598103934665603ull;

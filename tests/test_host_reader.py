@@ -97,6 +97,10 @@ def test_reader_matches_getline_semantics(dumper, tmp_path):
         assert (f[0], int(f[1]), int(f[2], 16), f[3]) == ("1", len(w), fnv1a(norm), "0"), (i, names[i], "packed")
         assert f[4] == ("1" if norm != w else "0")
         assert (f[5] if len(f) > 5 else "") == w[:32].hex()
+    # the portable (non-AVX2) packer gives the same
+    out2 = subprocess.run([dumper, lst, "2", "4", "0", str(len(want)), "packed"], check=True, stdout=subprocess.PIPE,
+                          env=dict(os.environ, MIEKKI_PACK_SCALAR="1")).stdout.decode().split("\n")
+    assert out2[:len(want)] == out[:len(want)]
     # an allocator that runs dry after 100 kB (the page-lock limit): later buffers come from malloc, same
     # sequences, and every allocator-owned buffer goes back through the allocator's release hook
     out = subprocess.run([dumper, lst, "4", "8", "100000"], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
