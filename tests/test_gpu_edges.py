@@ -310,3 +310,30 @@ def test_exact_mode_many_tiny_contigs_and_many_queries(hip):
         assert int(i2[10]) > 400                                          # really shared
     finally:
         ix.close()
+
+
+def test_dev_copy_counts_the_path_it_took(hip):
+    """mk_dev_copy between two contexts (here both on GPU 0: the same-device path counts as direct) is complete on
+    return and is counted in the SOURCE context's stats: a staged exchange must show up as such."""
+    import ctypes as C
+    from miekki_amd import lib as L
+    a = hip.Miekki(21, 10, 8, 32, 10); b = hip.Miekki(21, 10, 8, 32, 10)
+    lib = a._lib
+    try:
+        n = 1 << 20
+        src = np.arange(n, dtype=np.uint8)
+        da, db = C.c_void_p(), C.c_void_p()
+        L.check(lib.mk_dev_alloc(a._h, n, C.byref(da))); L.check(lib.mk_dev_alloc(b._h, n, C.byref(db)))
+        L.check(lib.mk_dev_upload(a._h, da, src.ctypes.data, n))
+        before = a.stats()
+        L.check(lib.mk_dev_copy(b._h, db, a._h, da, n))
+        back = np.zeros(n, np.uint8)
+        L.check(lib.mk_dev_download(b._h, back.ctypes.data, db, n))
+        np.testing.assert_array_equal(back, src)
+        after = a.stats()
+        assert after["peer_copies"] == before["peer_copies"] + 1 and after["peer_copy_bytes"] == before["peer_copy_bytes"] + n
+        assert after["staged_copies"] == before["staged_copies"] == 0
+        assert b.stats()["peer_copies"] == 0                      # counted where the copy was queued
+        lib.mk_dev_free(a._h, da); lib.mk_dev_free(b._h, db)
+    finally:
+        a.close(); b.close()
