@@ -560,6 +560,53 @@ __global__ __launch_bounds__(1024) void fp_transpose_kernel(const uint8_t *__res
     }
 }
 
+// The same without LDS, for the usual batch (first genome and count multiples of four): a thread loads 16 bytes of
+// 4 / W genomes' fingerprints (16 / W partitions each), transposes them in registers with byte permutes and stores one
+// 32-bit word -- 4 / W genomes side by side -- per partition; the lanes of a wave are laid out so that a row piece
+// leaves as 64 (128) contiguous bytes.  (The LDS form wrote single bytes at a pitch that put all 64 lanes on one
+// bank: 0.117 ms per batch for 128 MB of traffic; round 3.)
+template <int W>
+__global__ __launch_bounds__(256) void fp_transpose_reg_kernel(const uint8_t *__restrict__ fp_in, uint32_t n, uint32_t g0, MatRef M,
+                                                               uint64_t ld, const uint32_t *__restrict__ ovf_count, SketchParams sp)
+{
+    if (*ovf_count > kOvfScan) return;
+    constexpr uint32_t GPT = 4 / W, PPT = 16 / W;                  // genomes, partitions per thread
+    constexpr uint32_t NG = kBuildBatch / GPT, NPB = 64 / NG;      // genome groups, partition blocks per wave
+    const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t gq = lane % NG, pb = lane / NG;
+    const uint32_t p0 = (wave * NPB + pb) * PPT;                   // first partition of this thread
+    const uint32_t gfirst = gq * GPT;
+    if (p0 >= sp.P || gfirst >= n) return;
+    uint4 in[GPT];
+#pragma unroll
+    for (uint32_t e = 0; e < GPT; ++e)                             // (P is a multiple of PPT whenever P >= 16; smaller P: the LDS form)
+        in[e] = *reinterpret_cast<const uint4 *>(fp_in + ((uint64_t)(gfirst + e) * sp.P + p0) * W);
+    uint32_t out[PPT];
+    if constexpr (W == 1) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {                          // one 4 x 4 byte block per dword position
+            const uint32_t a = (&in[0].x)[q], b = (&in[1].x)[q], c = (&in[2].x)[q], d = (&in[3].x)[q];
+            const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(d, c, 0x05010400u), u1 = __builtin_amdgcn_perm(d, c, 0x07030602u);
+            out[4 * q + 0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+            out[4 * q + 1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+            out[4 * q + 2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+            out[4 * q + 3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {                          // two 16-bit values of each of the two genomes per dword
+            const uint32_t a = (&in[0].x)[q], b = (&in[1].x)[q];
+            out[2 * q + 0] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+            out[2 * q + 1] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+        }
+    }
+    const uint64_t col = ((uint64_t)g0 + gfirst) * W;
+#pragma unroll
+    for (uint32_t j = 0; j < PPT; ++j)
+        *reinterpret_cast<uint32_t *>(mat_row(M, p0 + j, ld) + col) = out[j];
+}
+
 // shape of the binned sketch for a batch, and its scratch; *fits = false when the batch does not
 // suit it (the caller then takes the atomic kernel)
 static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams &bp, bool *fits)
@@ -635,7 +682,7 @@ __global__ void bloom_kernel(uint64_t *__restrict__ tables, const char *__restri
                              const uint32_t *__restrict__ valid, uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
                              const uint32_t *__restrict__ ovf_count, const uint8_t *__restrict__ codes,
                              const uint64_t *__restrict__ code_off, const uint32_t *__restrict__ full,
-                             const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp);
+                             const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp, uint32_t span);
 
 // What follows the fused reduce kernel of a batch (this file's or build.hip's): the batch's fingerprints
 // (d_fpT, genome-major) into the matrix rows, Bloom pass B over the blocks that posted a key, the summary.
@@ -643,7 +690,17 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
 {
     const SketchParams sp = make_sp(c);
     const uint32_t rows = 1024 / c->W;
-    if (c->W == 1)
+    if (g0 % 4 == 0 && n % 4 == 0 && c->P >= 16) {
+        // register form: a wave covers 64 (W = 1) or 16 (W = 2) partitions of all the batch's genomes
+        const uint32_t per_wave = c->W == 1 ? 64 : 16;
+        const uint32_t waves = (c->P + per_wave - 1) / per_wave;
+        if (c->W == 1)
+            hipLaunchKernelGGL(fp_transpose_reg_kernel<1>, dim3((waves + 3) / 4), dim3(256), 0, c->stream, c->d_fpT, n, g0, mat_ref(c),
+                               c->ld, c->d_ovf_count, sp);
+        else
+            hipLaunchKernelGGL(fp_transpose_reg_kernel<2>, dim3((waves + 3) / 4), dim3(256), 0, c->stream, c->d_fpT, n, g0, mat_ref(c),
+                               c->ld, c->d_ovf_count, sp);
+    } else if (c->W == 1)
         hipLaunchKernelGGL(fp_transpose_kernel<1>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     else
@@ -651,10 +708,11 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
         // (pass B works from the canonical k-mers pass A left in d_tables: no sequence, no codes)
-        hipLaunchKernelGGL(bloom_kernel<true>, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables, (const char *)nullptr,
+        const uint32_t nblk = (c->P + 255) / 256, span = 16;
+        hipLaunchKernelGGL(bloom_kernel<true>, dim3((nblk + span - 1) / span, n), dim3(256), 0, c->stream, c->d_tables, (const char *)nullptr,
                            (const uint64_t *)nullptr, (const uint32_t *)nullptr, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order,
                            c->d_ovf_count, (const uint8_t *)nullptr, (const uint64_t *)nullptr, c->d_bloom_full, c->d_posted_blk,
-                           kOvfScan, sp);
+                           kOvfScan, sp, span);
         MK_HIP(hipGetLastError());
         MK_TRY(launch_bloom_summary(c));
     }
@@ -767,18 +825,22 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
                                                     const uint64_t *__restrict__ code_off,
                                                     const uint32_t *__restrict__ full,
                                                     const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit,
-                                                    SketchParams sp)
+                                                    SketchParams sp, uint32_t span)
 {
     if (ovf_count && *ovf_count > ovf_limit) return;    // see finalize_kernel
     const uint32_t g = blockIdx.y;
-    // after the fused build kernel: only the 256-partition blocks in which a key was posted hold anything
-    if (posted_blk && !posted_blk[(uint64_t)g * max(1u, sp.P >> 8) + blockIdx.x]) return;
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    // a workgroup walks `span` blocks of 256 partitions.  After the fused build kernel only the blocks in which a
+    // key was posted hold anything -- usually none once the filter has filled up -- so pass B looks at a run of
+    // flags per workgroup instead of launching one workgroup per flag
+  for (uint32_t blk = blockIdx.x * span; blk < (blockIdx.x + 1) * span; ++blk) {
+    if ((uint64_t)blk * 256 >= sp.P) return;
+    if (posted_blk && !posted_blk[(uint64_t)g * max(1u, sp.P >> 8) + blk]) continue;
+    const uint32_t p = blk * 256 + threadIdx.x;
     if (p >= sp.P) return;
     uint64_t *slot = tables + (uint64_t)g * sp.P + p;
     // the table streams through once: keep it from evicting the codes and the summary from L2
     const uint64_t key = __builtin_nontemporal_load(slot);
-    if (key == kEmptyKey) return;
+    if (key == kEmptyKey) continue;
     uint64_t canon;
     if (!WRITE) {
         // pass A: the (fingerprint, position) key has served finalize; replace it by
@@ -819,6 +881,7 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
     // has filled up) has nothing to do in pass B: blank its slot so that pass B stops
     // at the first test
     if (!WRITE) __builtin_nontemporal_store(posted ? canon : kEmptyKey, slot);
+  }
 }
 
 // full[grp] = all eight cells of group grp are non-zero.  Cells never go back to zero, so a
@@ -914,10 +977,10 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
     dim3 grid((c->P + 255) / 256, n);
     hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
                        c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
-                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c));
+                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
     hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
                        c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
-                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c));
+                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
     MK_HIP(hipGetLastError());
     return launch_bloom_summary(c);
 }
