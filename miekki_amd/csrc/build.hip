@@ -31,8 +31,8 @@ constexpr uint32_t kSeg = 4096;            // k-mers per scatter workgroup
 constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
-constexpr uint32_t kOvfPerGenome = 1u << 14;   // room in a genome's overflow list (two 64-bit words per item)
-constexpr uint32_t kOvfFold = 1u << 15;        // batch-wide overflow mark above which the batch is redone from characters (= sketch.hip's kOvfScan)
+constexpr uint32_t kOvfFold = 1u << 15;        // overflow mark of a batch above which it is redone from characters (= sketch.hip's kOvfScan;
+                                               // only the long-query path of sketch.hip, which borrows a side's counters, ever sets it)
 
 }  // namespace
 
@@ -161,14 +161,16 @@ __global__ void unpack_kernel(const uint8_t *__restrict__ codes, const uint8_t *
 // ---------------------------------------------------------------- scatter
 struct BuildShape {
     uint32_t nbins, low_bits;      // low_bits = min(h, 12) partitions per bin (log2); nbins = P >> low_bits
-    uint32_t cap_words;            // words of one (genome, bin, workgroup) slot: word 0 = item count, then the items
+    uint32_t lpr;                  // lanes of a reduce wave that share one run, 16 bytes of items each (a power of two)
     uint32_t nwg;                  // scatter workgroups per genome
-    uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no slot reads
+    uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no item reads
 };
 
-// Slot item: W == 1: fingerprint << 24 | position in segment << 12 | partition in bin  (32 bits);
-//            W == 2: fingerprint << 48 | position in segment << 12 | partition in bin  (64 bits).
-// The segment (= scatter workgroup) supplies the upper bits of the position.
+// Item: W == 1: fingerprint << 24 | position in segment << 12 | partition in bin  (32 bits);
+//       W == 2: fingerprint << 48 | position in segment << 12 | partition in bin  (64 bits).
+// The segment (= scatter workgroup) supplies the upper bits of the position.  A scatter workgroup leaves its items
+// SORTED BY BIN and dense -- items[(genome, workgroup)][0 .. total) in a region of kSeg -- plus one word per bin,
+// run start << 16 | run length (meta[(genome, workgroup)][bin]): no capacities, no padding, no overflow.
 template <int W> struct ItemOf { using type = uint32_t; };
 template <> struct ItemOf<2> { using type = uint64_t; };
 
@@ -195,9 +197,8 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
 // the whole workgroup; they only take instructions out of a loop that is bound by instruction issue.
 template <int W, bool KBIG, bool FULL>
 __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bool has_x, uint32_t x01, uint32_t x2, uint32_t i0,
-                                       uint32_t cnt, uint32_t g, uint64_t seg0, uint32_t *bins, typename ItemOf<W>::type (&it)[kPer],
-                                       uint32_t (&key)[kPer], uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_g,
-                                       uint32_t *__restrict__ ovf_mark, const SketchParams &sp, const BuildShape &bs)
+                                       uint32_t cnt, uint32_t *bins, typename ItemOf<W>::type (&it)[kPer], uint32_t (&key)[kPer],
+                                       const SketchParams &sp, const BuildShape &bs)
 {
     using item_t = typename ItemOf<W>::type;
     // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
@@ -221,7 +222,6 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     const uint32_t topshift = 2 * sp.k - 2;                       // even: the entering reverse digit lies within ONE half
     const bool top_hi = KBIG || topshift >= 32;
     const uint32_t tsh = top_hi ? topshift - 32 : topshift;
-    const uint32_t cap_items = bs.cap_words - 1u;
     const uint32_t bshift = 32u - sp.h;                           // bucket = anc >> (64 - h)  (Miekki.cpp:169)
     const uint32_t ibase = i0 << kBin;
 #pragma unroll
@@ -248,21 +248,8 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
         const uint32_t binoff = (bucket >> bs.low_bits) << 2;          // byte offset of the bin's counter
         const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
         const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
-        if (rank < cap_items) {
-            it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(part | ibase | (u << kBin));
-            key[u] = (binoff << 12) | rank;
-        } else {
-            // slot full: the genome's overflow list (a slot is sized for the common case, ~4 sigma: a few hundred
-            // items per 5 Mb genome land here; a list that runs over -- very repetitive sequence -- marks the batch)
-            const uint32_t o = atomicAdd(&ovf_g[g], 1u);
-            if (o < kOvfPerGenome) {
-                uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + o) * 2;
-                e[0] = bucket;
-                e[1] = ((uint64_t)fp << 40) | (seg0 + i0 + u);
-            } else {
-                atomicMax(ovf_mark, kOvfFold + 1u);
-            }
-        }
+        it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(part | ibase | (u << kBin));
+        key[u] = (binoff << 12) | rank;                              // rank < 4096
     }
 }
 
@@ -276,14 +263,14 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
 template <int W, bool KBIG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
-    const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ slots,
-    uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_g, uint32_t *__restrict__ ovf_mark, SketchParams sp, BuildShape bs)
+    const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ items,
+    uint32_t *__restrict__ meta, SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
     constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    item_t *stage = reinterpret_cast<item_t *>(smem);                 // 1 + kSeg + kIPV: the sorted items from stage[1] on
-    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (1 + kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
+    item_t *stage = reinterpret_cast<item_t *>(smem);                 // kSeg + kIPV: the workgroup's items, sorted by bin
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
     __shared__ uint32_t cw[kSeg / 16 + 4];                            // the workgroup's positions, 16 per word
     __shared__ uint32_t xw[kSeg / 16 + 4];                            // their exception bits (low 16)
     __shared__ uint32_t wave_sum[4];
@@ -314,18 +301,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     if (i0 < cnt) {
         const uint32_t w0 = cw[tid], w1 = cw[tid + 1], w2 = cw[tid + 2];
         const uint32_t x01 = has_x ? xw[tid] | (xw[tid + 1] << 16) : 0u, x2 = has_x ? xw[tid + 2] : 0u;
-        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, g, seg0, bins, it, key, ovf, ovf_g, ovf_mark, sp, bs);
-        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, g, seg0, bins, it, key, ovf, ovf_g, ovf_mark, sp, bs);
+        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, it, key, sp, bs);
+        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, it, key, sp, bs);
     }
     __syncthreads();
-    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of min(count, capacity)
+    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of the counts
+    uint32_t c4[4], start4[4];
     {
-        const uint32_t cap_items = bs.cap_words - 1u;
-        uint32_t c4[4], sum = 0;
+        uint32_t sum = 0;
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) {
             const uint32_t b = tid * 4 + e;
-            c4[e] = b < bs.nbins ? min(bins[b], cap_items) : 0u;
+            c4[e] = b < bs.nbins ? bins[b] : 0u;
             sum += c4[e];
         }
         uint32_t incl = sum;
@@ -341,49 +328,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) {
             const uint32_t b = tid * 4 + e;
+            start4[e] = base;
             if (b < bs.nbins) bins[b] = base;
             base += c4[e];
-            if (b + 1 == bs.nbins) bins[bs.nbins] = base;
         }
     }
     __syncthreads();
+    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u)
         if (key[u] != ~0u)
-            stage[1u + *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u)] = it[u];
+            stage[*reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u)] = it[u];
     __syncthreads();
-    // ---- a bin's run -> its slot: word 0 = count, then the items; 16-byte stores, the lanes of a bin side by side
-    item_t *__restrict__ gslots = slots + ((uint64_t)g * bs.nbins * bs.nwg + wg) * bs.cap_words;
-    const uint64_t bin_stride = (uint64_t)bs.nwg * bs.cap_words;
-    constexpr uint32_t kLanes = 4;                                    // lanes per bin and pass
+    // ---- out: the sorted items as they lie, 16 bytes per lane (a pure stream), and one word per bin
+    const uint64_t seg = (uint64_t)g * bs.nwg + wg;
     typedef item_t vec_t __attribute__((ext_vector_type(kIPV)));
-    for (uint32_t t = tid; t < bs.nbins * kLanes; t += 256) {
-        const uint32_t b = t / kLanes, q = t % kLanes;
-        const uint32_t lo = bins[b], n = bins[b + 1] - lo;
-        item_t *__restrict__ dst = gslots + b * bin_stride;
-        // slot word j (j >= 1) = the run's item j - 1 = stage[lo + j]; lane q writes words [kIPV * q, kIPV * q + kIPV), then
-        // kLanes * kIPV further on
-        for (uint32_t j = q * kIPV; j <= n; j += kLanes * kIPV) {
-            vec_t v;
+    vec_t *__restrict__ dst = reinterpret_cast<vec_t *>(items + seg * kSeg);
+    const vec_t *__restrict__ src = reinterpret_cast<const vec_t *>(stage);
+    for (uint32_t i = tid; i * kIPV < total; i += 256) dst[i] = src[i];
+    uint32_t *__restrict__ m = meta + seg * bs.nbins;
 #pragma unroll
-            for (uint32_t e = 0; e < kIPV; ++e) v[e] = stage[lo + j + e];
-            if (j == 0) v[0] = (item_t)n;
-            *reinterpret_cast<vec_t *>(dst + j) = v;
-        }
+    for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t b = tid * 4 + e;
+        if (b < bs.nbins) m[b] = (start4[e] << 16) | c4[e];          // start < 4096; length <= 4096
     }
 }
 
 // ---------------------------------------------------------------- reduce + fingerprints + sizes + Bloom pass A
-// One 1024-thread workgroup per (genome, bin).  The bin's slots (one per scatter workgroup) are
-// read with eight lanes per slot, 16 bytes per lane: a wave-instruction fetches the first 128
-// bytes of eight slots whether they are full or not -- the count sits in word 0 and decides
-// afterwards what is an item -- so a wave's share of the bin is in flight at once instead of
-// one dependent round per slot.  Minimum per partition with LDS atomics; KEY32 packs
-// (fingerprint, position) into 32 bits when the sequence is shorter than 2^23 (a 16 KiB table).
+// One 1024-thread workgroup per (genome, bin).  The bin's runs -- one per scatter workgroup, found through the
+// workgroup's meta word (run start, run length) -- are read with `lpr` lanes per run, one item per lane: a wave's
+// meta words come first (into LDS), then all its runs are in flight together.  The items of a genome are one dense
+// array that the 2^(h-12) reduce workgroups of the genome walk side by side (neighbouring bins on one XCD, so that a
+// line that holds the end of one run and the start of the next is fetched into one L2): HBM sees it once.
+// Minimum per partition with LDS atomics; KEY32 packs (fingerprint, position) into 32 bits when the sequence is
+// shorter than 2^23 (a 16 KiB table).
 template <int W, bool KEY32>
 __global__ __launch_bounds__(1024) void build_reduce_kernel(
-    const typename ItemOf<W>::type *__restrict__ slots, const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_g,
-    const uint32_t *__restrict__ ovf_mark,
+    const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
     const uint32_t *__restrict__ full, const uint64_t *__restrict__ full2, uint32_t full2_words,
@@ -396,19 +377,19 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     using item_t = typename ItemOf<W>::type;
     using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
-    constexpr uint32_t kIPV = 16 / sizeof(item_t);
     constexpr uint32_t kFpShift = sizeof(item_t) * 8 - 8 * W;
     constexpr uint32_t kKeyPos = KEY32 ? 23 : 40;                    // key = fingerprint << kKeyPos | position
     constexpr key_t kNoKey = (key_t)~(key_t)0;
     constexpr uint32_t kWin = (1u << kBin) / 1024;                   // winners per thread
-    typedef item_t vec_t __attribute__((ext_vector_type(kIPV)));
     __shared__ key_t table[1u << kBin];
     __shared__ uint32_t blk_posted[(1u << kBin) / 256];
     __shared__ uint32_t s_act;
     __shared__ unsigned long long s_card;
-    if (*ovf_mark > kOvfFold) return;                                 // some genome's overflow list ran over: the host redoes the batch
-    const uint32_t bin = blockIdx.x, g = blockIdx.y;
-    const uint32_t n_ovf = ovf_g[g];
+    constexpr uint32_t kMetaChunk = 2048;                             // scatter workgroups whose meta words sit in LDS at a time
+    __shared__ uint32_t s_meta[kMetaChunk];
+    // workgroups are dealt to the XCDs round robin: XCD x gets the bins x * nbins / 8 ... of a genome, i.e. neighbours
+    const uint32_t g = blockIdx.y;
+    const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
     const uint32_t R = 1u << bs.low_bits;
     for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kNoKey;
     // (a snapshot taken before the batch: cells never go back to zero, so "all set" stays true)
@@ -419,60 +400,52 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     {
-        const item_t *__restrict__ base = slots + ((uint64_t)g * bs.nbins + bin) * bs.nwg * bs.cap_words;
-        const uint32_t sub = lane >> 3, piece = lane & 7u;            // slot within the wave's eight, 16-byte piece within the slot
+        // lpr lanes per run, 16 bytes (kIPL items) per lane: runs start wherever the bin's items start in their
+        // workgroup's sorted array, so the loads are item-aligned, not 16-byte-aligned (the hardware takes that)
+        constexpr uint32_t kIPL = 16 / sizeof(item_t);
+        typedef item_t vec_t __attribute__((ext_vector_type(kIPL), aligned(sizeof(item_t))));
+        const uint32_t lpr = bs.lpr, per_wave = 64u / lpr;            // runs per wave-instruction
+        const uint32_t sub = lane / lpr, j0 = (lane % lpr) * kIPL;
         const uint32_t nwg = (bs.tune & 2u) ? 0u : bs.nwg;
-        constexpr uint32_t NW = 16, UN = 5;
-        auto fold = [&](item_t item, uint32_t w) {
-            const uint64_t pos = (uint64_t)w * kSeg + ((uint32_t)(item >> kBin) & (kSeg - 1u));
-            const key_t key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)pos;
-            atomicMin(&table[(uint32_t)item & (R - 1u)], key);
-        };
-        for (uint32_t w0 = wave * 8; w0 < nwg; w0 += NW * 8 * UN) {
-            vec_t v[UN];
-            uint32_t cnt[UN];
+        constexpr uint32_t NW = 16, UN = 4;
+        for (uint32_t c0 = 0; c0 < nwg; c0 += kMetaChunk) {
+            const uint32_t cn = min(kMetaChunk, nwg - c0);
+            if (c0) __syncthreads();                                  // the previous chunk's words have been used
+            for (uint32_t i = threadIdx.x; i < cn; i += 1024) s_meta[i] = meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin];
+            __syncthreads();
+            for (uint32_t r0 = wave * per_wave; r0 < cn; r0 += NW * per_wave * UN) {
+                vec_t v[UN];
+                uint32_t cnt[UN];
+                const item_t *src[UN];
 #pragma unroll
-            for (uint32_t u = 0; u < UN; ++u) {
-                const uint32_t w = w0 + u * NW * 8 + sub;
-                // (a slot is at least 32 bytes; pieces past its end belong to the next slot and are never looked at)
-                if (w < nwg && piece * kIPV < bs.cap_words) v[u] = *reinterpret_cast<const vec_t *>(base + (uint64_t)w * bs.cap_words + piece * kIPV);
-                else v[u] = (vec_t)(item_t)0;
-            }
+                for (uint32_t u = 0; u < UN; ++u) {
+                    const uint32_t r = r0 + u * NW * per_wave + sub;
+                    const uint32_t mw = r < cn ? s_meta[r] : 0u;
+                    cnt[u] = mw & 0xffffu;
+                    src[u] = items + ((uint64_t)g * bs.nwg + c0 + r) * kSeg + (mw >> 16);
+                    // (a load may reach up to kIPL - 1 items past the run: still inside the workgroup's kSeg + kIPL places)
+                    if (j0 < cnt[u]) v[u] = *reinterpret_cast<const vec_t *>(src[u] + j0);
+                    else v[u] = (vec_t)(item_t)0;
+                }
 #pragma unroll
-            for (uint32_t u = 0; u < UN; ++u) {
-                const uint32_t w = w0 + u * NW * 8 + sub;
-                // the slot's count is word 0 of its piece 0: lane (sub << 3) holds it
-                cnt[u] = (uint32_t)__shfl((uint32_t)v[u][0], (int)(lane & ~7u));
-                if (w >= nwg) cnt[u] = 0;
+                for (uint32_t u = 0; u < UN; ++u) {
+                    const uint32_t w = c0 + r0 + u * NW * per_wave + sub;
+                    auto fold = [&](item_t item) {
+                        const uint64_t pos = (uint64_t)w * kSeg + ((uint32_t)(item >> kBin) & (kSeg - 1u));
+                        const key_t key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)pos;
+                        atomicMin(&table[(uint32_t)item & (R - 1u)], key);
+                    };
 #pragma unroll
-                for (uint32_t e = 0; e < kIPV; ++e) {
-                    const uint32_t j = piece * kIPV + e;              // slot word; items are words 1 .. count
-                    if (j >= 1 && j <= cnt[u]) fold(v[u][e], w);
+                    for (uint32_t e = 0; e < kIPL; ++e)
+                        if (j0 + e < cnt[u]) fold(v[u][e]);
+                    for (uint32_t j = j0 + lpr * kIPL; j < cnt[u]; j += lpr * kIPL) {           // runs longer than their lanes reach
+                        const vec_t x = *reinterpret_cast<const vec_t *>(src[u] + j);
+#pragma unroll
+                        for (uint32_t e = 0; e < kIPL; ++e)
+                            if (j + e < cnt[u]) fold(x[e]);
+                    }
                 }
             }
-            // slots that hold more than the first 128 bytes show: the rest, eight lanes a slot again
-#pragma unroll
-            for (uint32_t u = 0; u < UN; ++u) {
-                const uint32_t w = w0 + u * NW * 8 + sub;
-                for (uint32_t j0 = 8 * kIPV; j0 <= cnt[u]; j0 += 8 * kIPV) {
-                    const uint32_t j = j0 + piece * kIPV;
-                    if (j > cnt[u]) continue;
-                    const vec_t x = *reinterpret_cast<const vec_t *>(base + (uint64_t)w * bs.cap_words + j);
-#pragma unroll
-                    for (uint32_t e = 0; e < kIPV; ++e)
-                        if (j + e <= cnt[u]) fold(x[e], w);
-                }
-            }
-        }
-    }
-    // items of this genome that found their slot full: the few there are join here
-    for (uint32_t i = threadIdx.x; i < n_ovf; i += 1024) {
-        const uint64_t *__restrict__ e = ovf + ((uint64_t)g * kOvfPerGenome + i) * 2;
-        const uint64_t where = e[0];
-        if (((uint32_t)where >> bs.low_bits) == bin) {
-            const uint64_t k64 = e[1];                               // fingerprint << 40 | position
-            const key_t key = KEY32 ? (key_t)(((k64 >> 40) << 23) | (k64 & ((1ULL << 23) - 1))) : (key_t)k64;
-            atomicMin(&table[(uint32_t)where & (R - 1u)], key);
         }
     }
     __syncthreads();
@@ -563,17 +536,19 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
     bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);
-    // per (workgroup, bin) the item count is ~Poisson(mean): a slot holds about mean + 4 sigma items behind its count
-    // word, in whole 32-byte units -- at h = 20 (mean 16) exactly one 128-byte line, which the reduce kernel fetches
-    // whole; the ~2 in 10,000 items that find their slot full (a few hundred per 5 Mb genome) go to the genome's
-    // overflow list.  (Round 3: 160-byte slots, mean + 5.5 sigma, read at 4.9 TB/s -- the slot bytes were the bound.)
-    const double mean = (double)kSeg / bs.nbins;
-    const uint32_t words = (uint32_t)(mean + 4.0 * std::sqrt(mean) + 1.0);
-    bs.cap_words = bs.nbins == 1 ? (kSeg + 1 + 7) / 8 * 8 : std::max<uint32_t>(8, (words + 4) / 8 * 8);
+    // a run (one workgroup's items of one bin) holds ~Poisson(kSeg / nbins * 15/16) items: the lanes of a reduce wave that share
+    // it, 16 bytes each, cover mean + 4 sigma, so that a second, dependent load per run is the exception (at h = 20: mean 15,
+    // eight lanes x four items; with a reach of 16 items nearly every wave-load had a run with a tail and paid its latency)
+    const double mean = (double)kSeg / bs.nbins * 15.0 / 16.0, reach = mean + 4.0 * std::sqrt(mean);
+    const uint32_t ipl = c->W == 1 ? 4 : 2;                          // items per lane (16 bytes)
+    bs.lpr = 1;
+    while (bs.lpr < 64 && bs.lpr * ipl < reach) bs.lpr <<= 1;
     *key32 = c->W == 1 && max_len < (1ULL << 23);
     const uint64_t isz = c->W == 1 ? 4 : 8;
-    const uint64_t need = (uint64_t)bs.nbins * bs.nwg * bs.cap_words * n * isz;       // bytes
-    if (need > (12ull << 30)) return MK_OK;                          // slot memory budget
+    // the dense item array (kSeg item places per scatter workgroup) and, behind it, one meta word per (workgroup, bin)
+    const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
+    const uint64_t need = item_bytes + (uint64_t)n * bs.nwg * bs.nbins * 4;
+    if (need > (12ull << 30)) return MK_OK;                          // scratch budget
     mk_ctx::BuildSide &sd = c->side[b];
     if (need > sd.slots_bytes) {
         if (sd.d_slots) (void)hipFree(sd.d_slots);
@@ -598,7 +573,7 @@ int ensure_build_side(mk_ctx *c, int b)
     if (!sd.h_back) MK_HIP(hipHostMalloc((void **)&sd.h_back, sizeof *sd.h_back, hipHostMallocDefault));
     if (!sd.d_seq_off) MK_HIP(hipMalloc((void **)&sd.d_seq_off, (kBuildBatch + 1) * 8));
     if (!sd.d_seed_valid) MK_HIP(hipMalloc((void **)&sd.d_seed_valid, kBuildBatch * 4));
-    if (!sd.d_ovf) MK_HIP(hipMalloc((void **)&sd.d_ovf, (uint64_t)kBuildBatch * kOvfPerGenome * 16));   // (= sketch.hip's 2^20 entries)
+    if (!sd.d_ovf) MK_HIP(hipMalloc((void **)&sd.d_ovf, (uint64_t)(1u << 20) * 16));   // sketch.hip's overflow list (long-query path), 2^20 entries
     if (!sd.ev_front) MK_HIP(hipEventCreateWithFlags(&sd.ev_front, hipEventDisableTiming));
     return MK_OK;
 }
@@ -661,13 +636,20 @@ int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_exc
 
 static void shape_store(mk_ctx::BuildSide &sd, const BuildShape &bs)
 {
-    sd.shape[0] = bs.nbins; sd.shape[1] = bs.low_bits; sd.shape[2] = bs.cap_words; sd.shape[3] = bs.nwg; sd.shape[4] = bs.tune;
+    sd.shape[0] = bs.nbins; sd.shape[1] = bs.low_bits; sd.shape[2] = bs.lpr; sd.shape[3] = bs.nwg; sd.shape[4] = bs.tune;
 }
 static BuildShape shape_load(const mk_ctx::BuildSide &sd)
 {
     BuildShape bs;
-    bs.nbins = sd.shape[0]; bs.low_bits = sd.shape[1]; bs.cap_words = sd.shape[2]; bs.nwg = sd.shape[3]; bs.tune = sd.shape[4];
+    bs.nbins = sd.shape[0]; bs.low_bits = sd.shape[1]; bs.lpr = sd.shape[2]; bs.nwg = sd.shape[3]; bs.tune = sd.shape[4];
     return bs;
+}
+// the meta words lie behind the side's item array (build_setup)
+static uint32_t *meta_of(const mk_ctx *c, const mk_ctx::BuildSide &sd, const BuildShape &bs, uint32_t n)
+{
+    const uint64_t isz = c->W == 1 ? 4 : 8;
+    const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
+    return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(sd.d_slots) + item_bytes);
 }
 
 // Front stage: the scatter kernel of a batch, on the front stream, into side b's slots.
@@ -684,11 +666,11 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     shape_store(sd, bs);
     const SketchParams sp = make_sp(c);
     const size_t isz = c->W == 1 ? 4 : 8;
-    const size_t lds = (1 + kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
+    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except,     \
                        d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), \
-                       sd.d_ovf, sd.d_counters->ovf_g, &sd.d_counters->ovf, sp, bs)
+                       meta_of(c, sd, bs, n), sp, bs)
     const bool kbig = c->p.k >= 17;
     if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
     else           { if (kbig) MK_SCATTER(2, true); else MK_SCATTER(2, false); }
@@ -721,8 +703,8 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
     }
 #define MK_REDUCE(Wv, K32)                                                                                                      \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(1024), (size_t)f2w * 8, c->stream,                 \
-                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), sd.d_ovf, sd.d_counters->ovf_g,         \
-                       &sd.d_counters->ovf, d_codes, d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes, \
+                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), d_codes,         \
+                       d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
                        c->d_bloom_order, c->d_bloom_full, c->d_bloom_full2, f2w, c->d_fpT, c->d_tables, c->d_posted_blk,        \
                        sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)
     if (c->W == 1) { if (sd.key32) MK_REDUCE(1, true); else MK_REDUCE(1, false); }

@@ -155,7 +155,6 @@ struct mk_ctx {
     // is its layout, and that of the pinned read-back block.
     struct BuildCounters {
         uint32_t ovf, pad;             // overflow mark of the batch (> the fold limit: the host redoes the batch)
-        uint32_t ovf_g[mk::kBuildBatch];   // build.hip: items per genome that found their slot full (the genome's overflow list)
         uint32_t dirty[mk::kBuildBatch];
         uint32_t act[mk::kBuildBatch];
         uint64_t card[mk::kBuildBatch];
