@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 }
 
 // ---------------------------------------------------------------- reduce + fingerprints + sizes + Bloom pass A
-// One 1024-thread workgroup per (genome, bin).  The bin's runs -- one per scatter workgroup, found through the
+// One 512-thread workgroup per (genome, bin) -- 37 KiB of LDS, so four of them share a CU: the kernel is a chain of
+// latencies (meta words, items, the winners' codes) and what hides them is other workgroups.  The bin's runs -- one per scatter workgroup, found through the
 // workgroup's meta word (run start, run length) -- are read with `lpr` lanes per run, one item per lane: a wave's
 // meta words come first (into LDS), then all its runs are in flight together.  The items of a genome are one dense
 // array that the 2^(h-12) reduce workgroups of the genome walk side by side (neighbouring bins on one XCD, so that a
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 // Minimum per partition with LDS atomics; KEY32 packs (fingerprint, position) into 32 bits when the sequence is
 // shorter than 2^23 (a 16 KiB table).
 template <int W, bool KEY32>
-__global__ __launch_bounds__(1024) void build_reduce_kernel(
+__global__ __launch_bounds__(512) void build_reduce_kernel(
     const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
@@ -380,21 +381,21 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     constexpr uint32_t kFpShift = sizeof(item_t) * 8 - 8 * W;
     constexpr uint32_t kKeyPos = KEY32 ? 23 : 40;                    // key = fingerprint << kKeyPos | position
     constexpr key_t kNoKey = (key_t)~(key_t)0;
-    constexpr uint32_t kWin = (1u << kBin) / 1024;                   // winners per thread
+    constexpr uint32_t kThreads = 512, kWin = (1u << kBin) / kThreads;   // winners per thread
     __shared__ key_t table[1u << kBin];
     __shared__ uint32_t blk_posted[(1u << kBin) / 256];
     __shared__ uint32_t s_act;
     __shared__ unsigned long long s_card;
-    constexpr uint32_t kMetaChunk = 2048;                             // scatter workgroups whose meta words sit in LDS at a time
+    constexpr uint32_t kMetaChunk = 1280;                             // scatter workgroups whose meta words sit in LDS at a time (5 Mb: 1,221)
     __shared__ uint32_t s_meta[kMetaChunk];
     // workgroups are dealt to the XCDs round robin: XCD x gets the bins x * nbins / 8 ... of a genome, i.e. neighbours
     const uint32_t g = blockIdx.y;
     const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
     const uint32_t R = 1u << bs.low_bits;
-    for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kNoKey;
+    for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
     // (a snapshot taken before the batch: cells never go back to zero, so "all set" stays true)
     if (bloom && !(bs.tune & 1u))
-        for (uint32_t i = threadIdx.x; i < full2_words; i += 1024) s_full2[i] = full2[i];
+        for (uint32_t i = threadIdx.x; i < full2_words; i += kThreads) s_full2[i] = full2[i];
     if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
     __syncthreads();
@@ -407,11 +408,11 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
         const uint32_t lpr = bs.lpr, per_wave = 64u / lpr;            // runs per wave-instruction
         const uint32_t sub = lane / lpr, j0 = (lane % lpr) * kIPL;
         const uint32_t nwg = (bs.tune & 2u) ? 0u : bs.nwg;
-        constexpr uint32_t NW = 16, UN = 4;
+        constexpr uint32_t NW = kThreads / 64, UN = 4;
         for (uint32_t c0 = 0; c0 < nwg; c0 += kMetaChunk) {
             const uint32_t cn = min(kMetaChunk, nwg - c0);
             if (c0) __syncthreads();                                  // the previous chunk's words have been used
-            for (uint32_t i = threadIdx.x; i < cn; i += 1024) s_meta[i] = meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin];
+            for (uint32_t i = threadIdx.x; i < cn; i += kThreads) s_meta[i] = meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin];
             __syncthreads();
             for (uint32_t r0 = wave * per_wave; r0 < cn; r0 += NW * per_wave * UN) {
                 vec_t v[UN];
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
 #pragma unroll
     for (uint32_t j = 0; j < kWin; ++j) {
-        const uint32_t i = threadIdx.x + 1024u * j;
+        const uint32_t i = threadIdx.x + kThreads * j;
         canon[j] = kEmptyKey;
         if (i >= R) continue;
         const key_t key = table[i];
@@ -479,8 +480,8 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
         // answers nearly every probe, so that the winner costs ONE request at the L2 (its codes) -- then the cell
         auto probe = [&](uint64_t cell, uint32_t tag) {
             if (cell >= bloom_dev_bytes) return;
-            const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;
-            if (full2_words && ((s_full2[sidx >> 6] >> (sidx & 63u)) & 1u)) return;
+            const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5, s2 = sidx >> 1;          // 8, 256, 512 cells
+            if (full2_words && ((s_full2[s2 >> 6] >> (s2 & 63u)) & 1u)) return;
             if ((full[sidx] >> (grp & 31u)) & 1u) return;
             if (bloom[cell] == 0) {
                 const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | tag;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(1024) void build_reduce_kernel(
     // what pass B needs: the canonical k-mers of the blocks in which something was posted
 #pragma unroll
     for (uint32_t j = 0; j < kWin; ++j) {
-        const uint32_t i = threadIdx.x + 1024u * j;
+        const uint32_t i = threadIdx.x + kThreads * j;
         if (i < R && blk_posted[i >> 8]) tables[row0 + i] = ((posted_mask >> j) & 1u) ? canon[j] : kEmptyKey;
     }
     const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
@@ -694,15 +695,15 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
         MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
     const SketchParams sp = make_sp(c);
-    // the second-level Bloom summary rides in LDS beside the reduce table when it is at most 40 KiB (-b 33 at k = 31:
-    // 32 KiB and a word); a larger one is simply not consulted
+    // the second-level Bloom summary (one bit per 512 cells) rides in LDS beside the reduce table when it is at most
+    // 20 KiB (-b 33 at k = 31: 16 KiB and a word); a larger one is simply not consulted
     uint32_t f2w = 0;
     if (c->d_bloom) {
-        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, w2 = (nwords + 63) / 64;
-        if (w2 * 8 <= 40960) f2w = (uint32_t)w2;
+        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, w2 = ((nwords + 1) / 2 + 63) / 64;
+        if (w2 * 8 <= 20480) f2w = (uint32_t)w2;
     }
 #define MK_REDUCE(Wv, K32)                                                                                                      \
-    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(1024), (size_t)f2w * 8, c->stream,                 \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), (size_t)f2w * 8, c->stream,                  \
                        reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
                        c->d_bloom_order, c->d_bloom_full, c->d_bloom_full2, f2w, c->d_fpT, c->d_tables, c->d_posted_blk,        \

@@ -890,45 +890,52 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
                                                             uint32_t *__restrict__ full, uint64_t nwords,
                                                             unsigned long long *__restrict__ full2)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one summary word = 32 groups = 256 cells
-    uint32_t bits = 0;
-    const uint64_t base = w * 256;
-    if (w >= nwords) {
-        bits = 0;
-    } else if (base + 256 <= bloom_dev_bytes) {
-        const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(bloom + base);
+    // a thread makes TWO summary words (each = 32 groups = 256 cells): words 2t and 2t + 1
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool both = true;
+    for (uint32_t half = 0; half < 2; ++half) {
+        const uint64_t w = 2 * t + half;
+        uint32_t bits = 0;
+        const uint64_t base = w * 256;
+        if (w >= nwords) {
+            bits = 0;
+        } else if (base + 256 <= bloom_dev_bytes) {
+            const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(bloom + base);
 #pragma unroll 4
-        for (uint32_t i = 0; i < 16; ++i) {                                   // 16 bytes = 2 groups per load
-            const uint4 v = p[i];
-            const uint64_t a = ((uint64_t)v.y << 32) | v.x, b = ((uint64_t)v.w << 32) | v.z;
-            // exact zero-byte test: high bit of each byte set iff the byte is zero
-            const uint64_t za = ~(((a & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | a | 0x7f7f7f7f7f7f7f7fULL);
-            const uint64_t zb = ~(((b & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | b | 0x7f7f7f7f7f7f7f7fULL);
-            bits |= (za == 0 ? 1u : 0u) << (2 * i);
-            bits |= (zb == 0 ? 1u : 0u) << (2 * i + 1);
-        }
-    } else {                                                                  // ragged end of the reachable region
-        for (uint32_t gI = 0; gI < 32; ++gI) {
-            bool all = true;
-            for (uint32_t j = 0; j < 8; ++j) {
-                const uint64_t cell = base + gI * 8 + j;
-                all = all && cell < bloom_dev_bytes && bloom[cell] != 0;
+            for (uint32_t i = 0; i < 16; ++i) {                               // 16 bytes = 2 groups per load
+                const uint4 v = p[i];
+                const uint64_t a = ((uint64_t)v.y << 32) | v.x, b = ((uint64_t)v.w << 32) | v.z;
+                // exact zero-byte test: high bit of each byte set iff the byte is zero
+                const uint64_t za = ~(((a & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | a | 0x7f7f7f7f7f7f7f7fULL);
+                const uint64_t zb = ~(((b & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | b | 0x7f7f7f7f7f7f7f7fULL);
+                bits |= (za == 0 ? 1u : 0u) << (2 * i);
+                bits |= (zb == 0 ? 1u : 0u) << (2 * i + 1);
             }
-            bits |= (all ? 1u : 0u) << gI;
+        } else {                                                              // ragged end of the reachable region
+            for (uint32_t gI = 0; gI < 32; ++gI) {
+                bool all = true;
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const uint64_t cell = base + gI * 8 + j;
+                    all = all && cell < bloom_dev_bytes && bloom[cell] != 0;
+                }
+                bits |= (all ? 1u : 0u) << gI;
+            }
         }
+        if (w < nwords) full[w] = bits;
+        both = both && bits == 0xffffffffu;
     }
-    if (w < nwords) full[w] = bits;
-    // second level: one bit per summary word = "all 256 cells set" -- 32 KiB for the 64 MiB of reachable cells at
-    // -b 33, small enough to sit in LDS beside a reduce workgroup's table (build.hip)
-    const unsigned long long m = __ballot(bits == 0xffffffffu);
-    if ((threadIdx.x & 63u) == 0 && (w >> 6) < (nwords + 63) / 64) full2[w >> 6] = m;
+    // second level: one bit per PAIR of summary words = "all 512 cells set" -- 16 KiB for the 64 MiB of reachable
+    // cells at -b 33, small enough to sit in LDS beside a reduce workgroup's table four times per CU (build.hip)
+    const unsigned long long m = __ballot(both);
+    const uint64_t n2 = ((nwords + 1) / 2 + 63) / 64;
+    if ((threadIdx.x & 63u) == 0 && (t >> 6) < n2) full2[t >> 6] = m;
 }
 
 int launch_bloom_summary(mk_ctx *c)
 {
     if (!c->d_bloom) return MK_OK;
-    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1;
-    hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((nwords + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
+    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, threads = (nwords + 1) / 2;
+    hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
                        c->bloom_dev_bytes, c->d_bloom_full, nwords, (unsigned long long *)c->d_bloom_full2);
     MK_HIP(hipGetLastError());
     return MK_OK;
