@@ -375,14 +375,14 @@ static int enqueue_back(mk_ctx *c)
     } else {
         MK_TRY(build_from_characters(c));                        // shapes the bins do not fit
     }
-    // one copy back of the batch's counters (overflow mark, active counts, cardinality sums)
+    // one copy back of the batch's counters (active counts, cardinality sums)
     MK_HIP(hipMemcpyAsync(sd.h_back, sd.d_counters, sizeof *sd.h_back, hipMemcpyDeviceToHost, c->stream));
     b.on = true;
     return MK_OK;
 }
 
 // The batch in flight once more, through the atomic kernel + separate passes, which work from characters:
-// for shapes the bins do not fit and for batches whose overflow list ran over (very repetitive sequence).
+// for shapes the bins do not fit.
 // A batch that arrived packed is turned back into characters that mean the same to those kernels.
 static int build_from_characters(mk_ctx *c)
 {
@@ -409,13 +409,7 @@ static int settle_build(mk_ctx *c)
     b.on = false;
     MK_HIP(hipStreamSynchronize(c->stream));
     const uint32_t n = b.n;
-    if (b.binned && build_overflowed(c->h_back->ovf)) {
-        // the overflow list of the binned build ran over (very repetitive sequence): the
-        // batch's later kernels saw the same mark and did nothing; redo it with the atomic kernel
-        MK_TRY(build_from_characters(c));
-        MK_HIP(hipMemcpyAsync(c->h_back, c->d_counters, sizeof *c->h_back, hipMemcpyDeviceToHost, c->stream));
-        MK_HIP(hipStreamSynchronize(c->stream));
-    }
+    // (the binned build cannot overflow: every scatter workgroup owns the places of its own 4096 k-mers)
     // the sizes go to the device from a pinned block of their own (two, alternating: the copies are queued
     // behind this batch and not waited for -- the next batch is enqueued meanwhile)
     mk_ctx::SizeUpload &up = c->h_sizes[c->size_parity ^= 1];

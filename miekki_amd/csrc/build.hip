@@ -31,9 +31,6 @@ constexpr uint32_t kSeg = 4096;            // k-mers per scatter workgroup
 constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
-constexpr uint32_t kOvfFold = 1u << 15;        // overflow mark of a batch above which it is redone from characters (= sketch.hip's kOvfScan;
-                                               // only the long-query path of sketch.hip, which borrows a side's counters, ever sets it)
-
 }  // namespace
 
 // ---------------------------------------------------------------- characters -> packed
@@ -166,8 +163,8 @@ struct BuildShape {
     uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no item reads
 };
 
-// Item: W == 1: fingerprint << 24 | position in segment << 12 | partition in bin  (32 bits);
-//       W == 2: fingerprint << 48 | position in segment << 12 | partition in bin  (64 bits).
+// Item: W == 1: fingerprint << 24 | partition in bin << 12 | position in segment  (32 bits);
+//       W == 2: fingerprint << 48 | partition in bin << 12 | position in segment  (64 bits).
 // The segment (= scatter workgroup) supplies the upper bits of the position.  A scatter workgroup leaves its items
 // SORTED BY BIN and dense -- items[(genome, workgroup)][0 .. total) in a region of kSeg -- plus one word per bin,
 // run start << 16 | run length (meta[(genome, workgroup)][bin]): no capacities, no padding, no overflow.
@@ -223,7 +220,6 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     const bool top_hi = KBIG || topshift >= 32;
     const uint32_t tsh = top_hi ? topshift - 32 : topshift;
     const uint32_t bshift = 32u - sp.h;                           // bucket = anc >> (64 - h)  (Miekki.cpp:169)
-    const uint32_t ibase = i0 << kBin;
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint32_t fd = (fnew >> (2 * u)) & 3u, rd = (rnew >> (2 * u)) & 3u;
@@ -248,7 +244,7 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
         const uint32_t binoff = (bucket >> bs.low_bits) << 2;          // byte offset of the bin's counter
         const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
         const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
-        it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)(part | ibase | (u << kBin));
+        it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)((part << kBin) | (i0 + u));
         key[u] = (binoff << 12) | rank;                              // rank < 4096
     }
 }
@@ -362,9 +358,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 // array that the 2^(h-12) reduce workgroups of the genome walk side by side (neighbouring bins on one XCD, so that a
 // line that holds the end of one run and the start of the next is fetched into one L2): HBM sees it once.
 // Minimum per partition with LDS atomics; KEY32 packs (fingerprint, position) into 32 bits when the sequence is
-// shorter than 2^23 (a 16 KiB table).
+// shorter than 2^24 (a 16 KiB table).
 template <int W, bool KEY32>
-__global__ __launch_bounds__(512) void build_reduce_kernel(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 4, 8))) void build_reduce_kernel(
     const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
@@ -379,7 +375,7 @@ __global__ __launch_bounds__(512) void build_reduce_kernel(
     using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
     constexpr uint32_t kFpShift = sizeof(item_t) * 8 - 8 * W;
-    constexpr uint32_t kKeyPos = KEY32 ? 23 : 40;                    // key = fingerprint << kKeyPos | position
+    constexpr uint32_t kKeyPos = KEY32 ? 24 : 40;                    // key = fingerprint << kKeyPos | position
     constexpr key_t kNoKey = (key_t)~(key_t)0;
     constexpr uint32_t kThreads = 512, kWin = (1u << kBin) / kThreads;   // winners per thread
     __shared__ key_t table[1u << kBin];
@@ -394,126 +390,217 @@ __global__ __launch_bounds__(512) void build_reduce_kernel(
     const uint32_t R = 1u << bs.low_bits;
     for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
     // (a snapshot taken before the batch: cells never go back to zero, so "all set" stays true)
-    if (bloom && !(bs.tune & 1u))
-        for (uint32_t i = threadIdx.x; i < full2_words; i += kThreads) s_full2[i] = full2[i];
+    if (bloom && !(bs.tune & 1u)) {
+        constexpr uint32_t kF2Per = 3;                                // 16-byte pieces per thread: up to 24 KiB (the host allows 20)
+        const uint4 *__restrict__ f2 = reinterpret_cast<const uint4 *>(full2);
+        uint4 piece[kF2Per];
+#pragma unroll
+        for (uint32_t u = 0; u < kF2Per; ++u) {
+            const uint32_t i = threadIdx.x + u * kThreads;
+            piece[u] = 2 * i < full2_words ? f2[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kF2Per; ++u) {
+            const uint32_t i = threadIdx.x + u * kThreads;
+            if (2 * i < full2_words) reinterpret_cast<uint4 *>(s_full2)[i] = piece[u];
+        }
+    }
     if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     {
-        // lpr lanes per run, 16 bytes (kIPL items) per lane: runs start wherever the bin's items start in their
-        // workgroup's sorted array, so the loads are item-aligned, not 16-byte-aligned (the hardware takes that)
+        // lpr lanes per run, 16 bytes (kIPL items) per lane.  A run starts wherever the bin's items start in their
+        // workgroup's sorted array; the lanes load from the 16-byte boundary below it and drop what lies before the run
         constexpr uint32_t kIPL = 16 / sizeof(item_t);
-        typedef item_t vec_t __attribute__((ext_vector_type(kIPL), aligned(sizeof(item_t))));
+        typedef item_t vec_t __attribute__((ext_vector_type(kIPL)));
         const uint32_t lpr = bs.lpr, per_wave = 64u / lpr;            // runs per wave-instruction
         const uint32_t sub = lane / lpr, j0 = (lane % lpr) * kIPL;
         const uint32_t nwg = (bs.tune & 2u) ? 0u : bs.nwg;
-        constexpr uint32_t NW = kThreads / 64, UN = 4;
+        constexpr uint32_t NW = kThreads / 64, UN = 2;
+        constexpr uint32_t kMetaPer = (kMetaChunk + kThreads - 1) / kThreads;
         for (uint32_t c0 = 0; c0 < nwg; c0 += kMetaChunk) {
             const uint32_t cn = min(kMetaChunk, nwg - c0);
             if (c0) __syncthreads();                                  // the previous chunk's words have been used
-            for (uint32_t i = threadIdx.x; i < cn; i += kThreads) s_meta[i] = meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin];
+            uint32_t mw[kMetaPer];
+#pragma unroll
+            for (uint32_t u = 0; u < kMetaPer; ++u) {                 // (all of a thread's words requested before the first is stored)
+                const uint32_t i = threadIdx.x + u * kThreads;
+                mw[u] = i < cn ? meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kMetaPer; ++u) {
+                const uint32_t i = threadIdx.x + u * kThreads;
+                if (i < kMetaChunk) s_meta[i] = mw[u];
+            }
             __syncthreads();
-            for (uint32_t r0 = wave * per_wave; r0 < cn; r0 += NW * per_wave * UN) {
-                vec_t v[UN];
-                uint32_t cnt[UN];
-                const item_t *src[UN];
+            // two stages of UN wave-loads each: the runs of the next stage are requested before the items of the
+            // current one go to the table, so that the LDS atomics of one stage drain under the loads of the next
+            struct Stage { uint32_t m[UN]; vec_t v[UN]; };
+            auto place = [&](uint32_t m, uint32_t &a0, uint32_t &first, uint32_t &end) {
+                first = m >> 16;
+                end = first + (m & 0xffffu);
+                a0 = first & ~(kIPL - 1u);
+            };
+            // (no branch around the loads: every lane requests its 16 bytes, needed or not -- they lie in lines the run's
+            // neighbours need anyway -- so that the loads of the two stages are plain straight-line code whose order the
+            // compiler's wait counts can follow; a lane without a run asks for the chunk's last run)
+            auto fetch = [&](uint32_t r0, Stage &q) {
 #pragma unroll
                 for (uint32_t u = 0; u < UN; ++u) {
                     const uint32_t r = r0 + u * NW * per_wave + sub;
-                    const uint32_t mw = r < cn ? s_meta[r] : 0u;
-                    cnt[u] = mw & 0xffffu;
-                    src[u] = items + ((uint64_t)g * bs.nwg + c0 + r) * kSeg + (mw >> 16);
-                    // (a load may reach up to kIPL - 1 items past the run: still inside the workgroup's kSeg + kIPL places)
-                    if (j0 < cnt[u]) v[u] = *reinterpret_cast<const vec_t *>(src[u] + j0);
-                    else v[u] = (vec_t)(item_t)0;
+                    q.m[u] = r < cn ? s_meta[r] : 0u;
+                    uint32_t a0, first, end;
+                    place(q.m[u], a0, first, end);
+                    // (a load may reach up to lpr * kIPL places past the run's start: inside the array, whose last workgroup
+                    // is followed by the meta words)
+                    q.v[u] = *reinterpret_cast<const vec_t *>(items + ((uint64_t)g * bs.nwg + c0 + min(r, cn - 1u)) * kSeg + a0 + j0);
                 }
+            };
+            auto consume = [&](uint32_t r0, const Stage &q) {
 #pragma unroll
                 for (uint32_t u = 0; u < UN; ++u) {
                     const uint32_t w = c0 + r0 + u * NW * per_wave + sub;
+                    uint32_t a0, first, end;
+                    place(q.m[u], a0, first, end);
                     auto fold = [&](item_t item) {
-                        const uint64_t pos = (uint64_t)w * kSeg + ((uint32_t)(item >> kBin) & (kSeg - 1u));
-                        const key_t key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)pos;
-                        atomicMin(&table[(uint32_t)item & (R - 1u)], key);
+                        key_t key;
+                        if (KEY32) key = (key_t)(((uint32_t)item & 0xff000fffu) | (w << 12));     // fingerprint << 24 | position
+                        else key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)((uint64_t)w * kSeg + ((uint32_t)item & (kSeg - 1u)));
+                        atomicMin(&table[((uint32_t)item >> 12) & (R - 1u)], key);
                     };
 #pragma unroll
-                    for (uint32_t e = 0; e < kIPL; ++e)
-                        if (j0 + e < cnt[u]) fold(v[u][e]);
-                    for (uint32_t j = j0 + lpr * kIPL; j < cnt[u]; j += lpr * kIPL) {           // runs longer than their lanes reach
-                        const vec_t x = *reinterpret_cast<const vec_t *>(src[u] + j);
+                    for (uint32_t e = 0; e < kIPL; ++e) {
+                        const uint32_t at = a0 + j0 + e;
+                        if (at >= first && at < end) fold(q.v[u][e]);
+                    }
+                    for (uint32_t j = a0 + j0 + lpr * kIPL; j < end; j += lpr * kIPL) {        // runs longer than their lanes reach
+                        const vec_t x = *reinterpret_cast<const vec_t *>(items + ((uint64_t)g * bs.nwg + w) * kSeg + j);
 #pragma unroll
                         for (uint32_t e = 0; e < kIPL; ++e)
-                            if (j + e < cnt[u]) fold(x[e]);
+                            if (j + e < end) fold(x[e]);
                     }
                 }
+            };
+            constexpr uint32_t kStep = NW * UN;                       // wave-loads a stage of the whole workgroup covers
+            const uint32_t step = kStep * per_wave;
+            Stage A, B;
+            uint32_t r0 = wave * per_wave;
+            fetch(r0, A);
+            for (; r0 < cn; r0 += 2 * step) {                         // (a stage past the chunk's end holds no items)
+                fetch(r0 + step, B);
+                consume(r0, A);
+                fetch(r0 + 2 * step, A);
+                consume(r0 + step, B);
             }
         }
     }
     __syncthreads();
     const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
     fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
-    uint64_t canon[kWin];
     uint32_t posted_mask = 0, act = 0;
     unsigned long long card = 0;
     const uint64_t *__restrict__ gcodes = reinterpret_cast<const uint64_t *>(codes + code_off[g]);
     const uint64_t *__restrict__ gexcept = reinterpret_cast<const uint64_t *>(except + code_off[g] / 2);
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
+    // Pass A of the Bloom insert (see bloom_kernel<false>, sketch.hip) in two steps.  FIRST, every winner against the
+    // second-level summary in LDS: its codes (requested four winners at a time), its canonical k-mer, its cell.  The five
+    // positions of a k-mer are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32: when the
+    // low word cannot carry they are ONE position -- all but one k-mer in four million -- found with 32-bit arithmetic on
+    // the high word, no revhash.  Once the filter has filled up the summary answers nearly every winner here, at ONE
+    // request at the L2 each and without a store or an atomic in this loop (nothing for its loads to wait behind).
+    const bool pass_a = bloom && !(bs.tune & 1u);
+    uint32_t undecided = 0;                                           // winners the summary did not answer
+    if (R == kThreads * kWin && pass_a && full2_words) {
+        // (straight-line code again, so that the winners' loads are in flight together: a partition without a k-mer asks
+        // for position 0 and its answer is dropped)
+        auto first_step = [&](auto with_exceptions) {
+            constexpr uint32_t kAhead = 4;                            // winners whose codes are requested together
+            static_assert(kWin % kAhead == 0, "winners per thread");
 #pragma unroll
-    for (uint32_t j = 0; j < kWin; ++j) {
-        const uint32_t i = threadIdx.x + kThreads * j;
-        canon[j] = kEmptyKey;
-        if (i >= R) continue;
-        const key_t key = table[i];
-        const uint32_t fp = key == kNoKey ? sp.empty : (uint32_t)(key >> kKeyPos);
-        fpo[i] = (fp_t)fp;
-        if (key == kNoKey) continue;
-        ++act;
-        card += 1ull << (31u - (fp >> sp.f));                         // Miekki.cpp:293: sum of 2^-exp, in units of 2^-31
-        if (!bloom || (bs.tune & 1u)) continue;
-        // pass A of the Bloom insert for this winner (see bloom_kernel<false>, sketch.hip)
-        const uint64_t pos = (uint64_t)key & ((1ULL << kKeyPos) - 1);
-        const uint64_t cn = canon_from_packed(gcodes, gexcept, has_x, pos, sp.k);
-        canon[j] = cn;
-        const uint32_t p = bin * R + i;
-        const uint32_t chi = (uint32_t)(cn >> 32);
-        // probe one Bloom position: the summaries first -- the second level in LDS, which once the filter has filled up
-        // answers nearly every probe, so that the winner costs ONE request at the L2 (its codes) -- then the cell
-        auto probe = [&](uint64_t cell, uint32_t tag) {
-            if (cell >= bloom_dev_bytes) return;
-            const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5, s2 = sidx >> 1;          // 8, 256, 512 cells
-            if (full2_words && ((s_full2[s2 >> 6] >> (s2 & 63u)) & 1u)) return;
-            if ((full[sidx] >> (grp & 31u)) & 1u) return;
-            if (bloom[cell] == 0) {
-                const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | tag;
-                atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
-                posted_mask |= 1u << j;
+            for (uint32_t jb = 0; jb < kWin; jb += kAhead) {
+                packed_pair raw[kAhead];
+                uint32_t pos[kAhead], has_mask = 0;                   // (a batch is at most 2 GiB: positions fit 32 bits)
+#pragma unroll
+                for (uint32_t u = 0; u < kAhead; ++u) {
+                    const uint32_t i = threadIdx.x + kThreads * (jb + u);
+                    const key_t key = table[i];
+                    const bool has = key != kNoKey;
+                    const uint32_t fp = has ? (uint32_t)(key >> kKeyPos) : sp.empty;
+                    fpo[i] = (fp_t)fp;
+                    act += has ? 1u : 0u;
+                    card += has ? (unsigned long long)(1u << (31u - (fp >> sp.f))) : 0ull;   // Miekki.cpp:293, in units of 2^-31
+                    const uint64_t at = has ? (uint64_t)key & ((1ULL << kKeyPos) - 1) : 0ull;
+                    pos[u] = (uint32_t)at;
+                    has_mask |= has ? 1u << u : 0u;
+                    raw[u] = load_packed_pair(gcodes, at);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kAhead; ++u) {
+                    const uint64_t cn = canon_from_pair(raw[u], gexcept, with_exceptions.value, pos[u], sp.k);
+                    const uint64_t cell = (uint32_t)(cn >> 32) >> (sp.bloom_log2 - 32u + 3u);
+                    const uint32_t s2 = (uint32_t)min(cell, bloom_dev_bytes - 1) >> 9;            // 512 cells per bit
+                    const bool answered = (uint32_t)cn <= 0xFFFFFC00u && (cell >= bloom_dev_bytes || ((s_full2[s2 >> 6] >> (s2 & 63u)) & 1u));
+                    undecided |= (((has_mask >> u) & 1u) && !answered) ? 1u << (jb + u) : 0u;
+                }
             }
         };
+        if (has_x) first_step(std::true_type{}); else first_step(std::false_type{});
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < kWin; ++j) {
+            const uint32_t i = threadIdx.x + kThreads * j;
+            if (i >= R) continue;
+            const key_t key = table[i];
+            const uint32_t fp = key == kNoKey ? sp.empty : (uint32_t)(key >> kKeyPos);
+            fpo[i] = (fp_t)fp;
+            if (key == kNoKey) continue;
+            ++act;
+            card += (unsigned long long)(1u << (31u - (fp >> sp.f)));
+            if (pass_a) undecided |= 1u << j;
+        }
+    }
+    // THEN the winners still undecided, one at a time (all of them while the filter is young): first-level summary, the
+    // cell itself, and a first-writer key for every cell still empty; of the five keys of a one-cell k-mer only the
+    // smallest, hash index 0, can ever win (pass B re-derives all five and finds the same)
+    auto probe = [&](uint64_t cell, uint32_t tag, uint32_t p) -> bool {
+        if (cell >= bloom_dev_bytes) return false;
+        const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;                              // 8, 256 cells
+        if ((full[sidx] >> (grp & 31u)) & 1u) return false;
+        if (bloom[cell] != 0) return false;
+        const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | tag;
+        atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+        return true;
+    };
+    while (undecided) {
+        const uint32_t j = (uint32_t)__builtin_ctz(undecided), i = threadIdx.x + kThreads * j;
+        undecided &= undecided - 1u;
+        const uint64_t pos = (uint64_t)table[i] & ((1ULL << kKeyPos) - 1);
+        const uint64_t cn = canon_from_packed(gcodes, gexcept, has_x, pos, sp.k);
+        const uint32_t p = bin * R + i, chi = (uint32_t)(cn >> 32);
+        bool posted = false;
         if ((uint32_t)cn <= 0xFFFFFC00u) {
-            // The five positions are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32:
-            // when the low word cannot carry they are ONE position, and of the five first-writer keys only the smallest,
-            // hash index 0, can ever win the cell (pass B re-derives all five and finds the same).  All but one k-mer in
-            // four million: one probe, 32-bit arithmetic on the high word, no revhash.
             const uint32_t sh = sp.bloom_log2 - 32u;
-            probe(chi >> (sh + 3u), (chi >> sh) & 7u);
+            posted = probe(chi >> (sh + 3u), (chi >> sh) & 7u, p);
         } else {
             const uint64_t anc = revhash64(cn);
             for (uint32_t hi = 0; hi < kNumHash; ++hi) {
                 const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
-                probe(hsh >> 3, (hi << 4) | (uint32_t)(hsh & 7));
+                posted |= probe(hsh >> 3, (hi << 4) | (uint32_t)(hsh & 7), p);
             }
         }
-        if ((posted_mask >> j) & 1u) blk_posted[i >> 8] = 1;
+        // what pass B needs: the canonical k-mers of the blocks in which something was posted
+        if (posted) { posted_mask |= 1u << j; blk_posted[i >> 8] = 1; tables[row0 + i] = cn; }
     }
     for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); card += __shfl_xor(card, o); }
     if (lane == 0 && act) { atomicAdd(&s_act, act); atomicAdd(&s_card, card); }
     __syncthreads();
     if (threadIdx.x == 0 && s_act) { atomicAdd(&active[g], s_act); atomicAdd(&cardsum[g], s_card); }
-    // what pass B needs: the canonical k-mers of the blocks in which something was posted
+    // (and no key in the other places of such a block)
 #pragma unroll
     for (uint32_t j = 0; j < kWin; ++j) {
         const uint32_t i = threadIdx.x + kThreads * j;
-        if (i < R && blk_posted[i >> 8]) tables[row0 + i] = ((posted_mask >> j) & 1u) ? canon[j] : kEmptyKey;
+        if (i < R && blk_posted[i >> 8] && !((posted_mask >> j) & 1u)) tables[row0 + i] = kEmptyKey;
     }
     const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
     if (threadIdx.x < nblk) posted_blk[(uint64_t)g * blk_per_genome + (uint64_t)bin * nblk + threadIdx.x] = (uint8_t)blk_posted[threadIdx.x];
@@ -544,7 +631,7 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     const uint32_t ipl = c->W == 1 ? 4 : 2;                          // items per lane (16 bytes)
     bs.lpr = 1;
     while (bs.lpr < 64 && bs.lpr * ipl < reach) bs.lpr <<= 1;
-    *key32 = c->W == 1 && max_len < (1ULL << 23);
+    *key32 = c->W == 1 && max_len < (1ULL << 24);              // (a stored fingerprint is below the all-ones byte: no key equals "none")
     const uint64_t isz = c->W == 1 ? 4 : 8;
     // the dense item array (kSeg item places per scatter workgroup) and, behind it, one meta word per (workgroup, bin)
     const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
@@ -561,7 +648,6 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     return MK_OK;
 }
 
-bool build_overflowed(uint32_t ovf_count) { return ovf_count > kOvfFold; }
 
 // one side's own arrays (everything a front stage writes)
 int ensure_build_side(mk_ctx *c, int b)
@@ -703,7 +789,7 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
         if (w2 * 8 <= 20480) f2w = (uint32_t)w2;
     }
 #define MK_REDUCE(Wv, K32)                                                                                                      \
-    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), (size_t)f2w * 8, c->stream,                  \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), (size_t)(f2w + 1) / 2 * 16, c->stream,                 \
                        reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
                        c->d_bloom_order, c->d_bloom_full, c->d_bloom_full2, f2w, c->d_fpT, c->d_tables, c->d_posted_blk,        \

@@ -36,23 +36,35 @@ __device__ __forceinline__ uint64_t reverse_digits(uint64_t x)
 // compares them, Miekki.cpp:167) that starts at position pos: ONE 16-byte load of codes from an
 // 8-byte boundary -- every lane-load is a request of its own at the L2, and the request rate is what
 // bounds the callers -- plus, for sequences with exceptions only, the same of the exception bits.
-__device__ __forceinline__ uint64_t canon_from_packed(const uint64_t *__restrict__ codes, const uint64_t *__restrict__ except,
-                                                      bool has_except, uint64_t pos, uint32_t k)
+typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) packed_pair;
+
+__device__ __forceinline__ packed_pair load_packed_pair(const uint64_t *__restrict__ codes, uint64_t pos)
 {
-    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
-    const u64x2_a8 x = *reinterpret_cast<const u64x2_a8 *>(codes + (pos >> 5));
+    return *reinterpret_cast<const packed_pair *>(codes + (pos >> 5));
+}
+
+// (the second half of canon_from_packed, for callers that request the codes of several positions before using the first)
+__device__ __forceinline__ uint64_t canon_from_pair(packed_pair x, const uint64_t *__restrict__ except, bool has_except,
+                                                    uint64_t pos, uint32_t k)
+{
     const uint32_t sh = (uint32_t)(pos & 31u) * 2u;
     const uint64_t kmask = (1ULL << (2 * k)) - 1;                                  // k <= 31
     const uint64_t F = (sh ? (x.x >> sh) | (x.y << (64 - sh)) : x.x) & kmask;      // digit j of the k-mer at bits 2j
     uint64_t RC = ~F & kmask;                                                      // 3 - digit: update_kmer_RC's state
     if (has_except) {
-        const u64x2_a8 e = *reinterpret_cast<const u64x2_a8 *>(except + (pos >> 6));
+        const packed_pair e = *reinterpret_cast<const packed_pair *>(except + (pos >> 6));
         const uint32_t es = (uint32_t)(pos & 63u);
         const uint32_t bits = (uint32_t)(es ? (e.x >> es) | (e.y << (64 - es)) : e.x);   // 32 >= k exception bits
         RC &= ~spread_pairs32(bits);
     }
     const uint64_t S = reverse_digits(F) >> (64 - 2 * k);                          // digit 0 on top
     return S < RC ? S : RC;
+}
+
+__device__ __forceinline__ uint64_t canon_from_packed(const uint64_t *__restrict__ codes, const uint64_t *__restrict__ except,
+                                                      bool has_except, uint64_t pos, uint32_t k)
+{
+    return canon_from_pair(load_packed_pair(codes, pos), except, has_except, pos, k);
 }
 
 }  // namespace mk

@@ -319,7 +319,6 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
                       uint32_t g0);
 int ensure_build_side(mk_ctx *c, int b);
 void use_build_side(mk_ctx *c, int b);       // point the aliases (d_counters, ...) at side b
-bool build_overflowed(uint32_t ovf_count);
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
 int ensure_codes(mk_ctx *c, uint64_t seq_bytes);

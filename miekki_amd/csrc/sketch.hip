@@ -511,7 +511,7 @@ __global__ void bin_overflow_kernel(const uint64_t *__restrict__ ovf, const uint
     }
 }
 
-constexpr uint32_t kOvfScan = 1u << 15;           // overflow items every reduce workgroup of the build folds in (build.hip: kOvfFold)
+constexpr uint32_t kOvfScan = 1u << 15;           // overflow items every reduce workgroup of the long-query sketch folds in
 
 // fp_out[n][P] (genome-major, W bytes) -> M[p][g0 .. g0+n): 16-byte loads of one genome's run of
 // partitions, transposed through LDS, 16-byte row pieces out (K2's layout work; its sums are done).

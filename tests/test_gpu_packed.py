@@ -84,7 +84,7 @@ def test_packed_synthetic_and_character_builds_agree(hip):
     """The device generator emits the packed form directly; the same genomes as characters through
     mk_index_append and packed on the host through mk_index_append_packed give the same index, and
     all three equal the oracle's.  5 Mb genomes at h = 20 take the 32-bit key path of the reduce
-    kernel, a 9 Mb one the 64-bit one."""
+    kernel, a 17 Mb one the 64-bit one, a 12 Mb one 32-bit keys with the top position bit in use."""
     from oracle import oracle as orc
     k, h = 31, 20
     L_ = 1_200_000
@@ -102,12 +102,14 @@ def test_packed_synthetic_and_character_builds_agree(hip):
             assert masked(b"".join(ix.serialize())) == want
     finally:
         a.close(); b.close(); c.close()
-    long_ = synth.genome_bases(77, 0, 9_000_000)                  # >= 2^23 positions: 64-bit keys
-    o2 = orc.OracleMiekki(k, 17, 8, 33, 200)
-    o2.insert_sequences([long_, seqs[0]])
-    d = hip.Miekki(k, 17, 8, 33, 200)
-    try:
-        d.insert_sequences_packed([long_, seqs[0]])
-        assert masked(b"".join(d.serialize())) == masked(o2.serialize().tobytes())
-    finally:
-        d.close()
+    long_ = synth.genome_bases(77, 0, 17_000_000)                 # >= 2^24 positions: 64-bit keys
+    mid_ = synth.genome_bases(78, 0, 12_000_000)                  # 32-bit keys whose position uses all 24 bits
+    for batch in ([long_, seqs[0]], [mid_, seqs[1]]):
+        o2 = orc.OracleMiekki(k, 17, 8, 33, 200)
+        o2.insert_sequences(batch)
+        d = hip.Miekki(k, 17, 8, 33, 200)
+        try:
+            d.insert_sequences_packed(batch)
+            assert masked(b"".join(d.serialize())) == masked(o2.serialize().tobytes())
+        finally:
+            d.close()

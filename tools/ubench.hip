@@ -66,8 +66,12 @@ __global__ __launch_bounds__(256) void hash_kernel(uint32_t *out, uint32_t seed)
     if (acc == 0x12345678u) out[0] = (uint32_t)acc;
 }
 
-// LDS atomics: 16 per thread per trip, addresses hashed into `range` entries
-template <int OP>
+// LDS operations on a table of `range` 32-bit entries (a power of two), 16 per thread per trip.  The sixteen indices of a
+// thread are drawn once, outside the loop, and only rotated by a wave-uniform amount per trip (one v_add + one v_and per
+// access: well below what the LDS takes), so that what is timed is the LDS and not the index arithmetic.
+// PATTERN 0: random indices (bank conflicts as they come); 1: lane l goes to entry (l + c) mod range -- no conflicts;
+// 2: every lane the same entry.
+template <int OP, int PATTERN>
 __global__ __launch_bounds__(256) void lds_kernel(uint32_t *out, uint32_t range, uint32_t seed)
 {
     __shared__ unsigned long long tab[8192];
@@ -75,17 +79,24 @@ __global__ __launch_bounds__(256) void lds_kernel(uint32_t *out, uint32_t range,
     __syncthreads();
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + seed, r = 0;
     uint32_t *t32 = reinterpret_cast<uint32_t *>(tab);
+    const uint32_t mask = range - 1u;
+    uint32_t base[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        x = x * 1664525u + 1013904223u;
+        base[i] = PATTERN == 0 ? (x >> 11) : PATTERN == 1 ? (threadIdx.x & 63u) + 97u * i : 5u * i;
+    }
     for (int it = 0; it < kIters / 16; ++it) {
+        const uint32_t rot = (uint32_t)it * 7u;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            x = x * 1664525u + 1013904223u;
-            const uint32_t idx = (x >> 11) % range;
+            const uint32_t idx = (base[i] + rot) & mask;
             if (OP == 0) r += atomicAdd(&t32[idx], 1u);                                   // ds_add_rtn_u32
             if (OP == 1) atomicAdd(&t32[idx], 1u);                                        // ds_add_u32 (no return)
             if (OP == 2) atomicMin(&tab[idx], ((unsigned long long)x << 32) | idx);       // ds_min_u64
-            if (OP == 3) atomicMin(&t32[idx], x);                                         // ds_min_u32
-            if (OP == 4) r += t32[idx];                                                   // ds_read_b32 random
-            if (OP == 5) t32[idx] = x;                                                    // ds_write_b32 random
+            if (OP == 3) atomicMin(&t32[idx], x ^ rot);                                   // ds_min_u32
+            if (OP == 4) r += t32[idx];                                                   // ds_read_b32
+            if (OP == 5) t32[idx] = x;                                                    // ds_write_b32
         }
     }
     __syncthreads();
@@ -113,7 +124,7 @@ static double time_ms(void (*launch)(int, uint32_t *), int blocks, uint32_t *d)
 template <int OP> static void launch_valu(int blocks, uint32_t *d) { hipLaunchKernelGGL(valu_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d, 1u); }
 static void launch_hash(int blocks, uint32_t *d) { hipLaunchKernelGGL(hash_kernel, dim3(blocks), dim3(256), 0, 0, d, 1u); }
 static uint32_t g_range = 128;
-template <int OP> static void launch_lds(int blocks, uint32_t *d) { hipLaunchKernelGGL(lds_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d, g_range, 1u); }
+template <int OP, int PATTERN> static void launch_lds(int blocks, uint32_t *d) { hipLaunchKernelGGL((lds_kernel<OP, PATTERN>), dim3(blocks), dim3(256), 0, 0, d, g_range, 1u); }
 
 int main()
 {
@@ -149,22 +160,27 @@ int main()
                ms * 1e-3 * clk / ((double)kIters * kChains * wps));
     }
     const char *lnames[] = {"ds_add_rtn_u32", "ds_add_u32", "ds_min_u64", "ds_min_u32", "ds_read_b32", "ds_write_b32"};
-    void (*lfn[])(int, uint32_t *) = {launch_lds<0>, launch_lds<1>, launch_lds<2>, launch_lds<3>, launch_lds<4>, launch_lds<5>};
-    for (uint32_t range : {128u, 256u, 1024u, 4096u, 8192u}) {
-        g_range = range;
-        printf("LDS, random index in [0, %u): cycles per wave-instruction per CU at 4, 8, 16, 32 waves per CU\n", range);
-        for (int op = 0; op < 6; ++op) {
-            if ((op == 2) && range > 8192) continue;
-            printf("  %-16s", lnames[op]);
-            for (int wpc = 4; wpc <= 32; wpc *= 2) {
-                const int blocks = cus * (wpc / 4);
-                const double ms = time_ms(lfn[op], blocks, d);
-                const double inst_per_cu = (double)kIters * wpc;
-                printf(" %10.2f", ms * 1e-3 * clk / inst_per_cu);
+    void (*lfn[3][6])(int, uint32_t *) = {
+        {launch_lds<0, 0>, launch_lds<1, 0>, launch_lds<2, 0>, launch_lds<3, 0>, launch_lds<4, 0>, launch_lds<5, 0>},
+        {launch_lds<0, 1>, launch_lds<1, 1>, launch_lds<2, 1>, launch_lds<3, 1>, launch_lds<4, 1>, launch_lds<5, 1>},
+        {launch_lds<0, 2>, launch_lds<1, 2>, launch_lds<2, 2>, launch_lds<3, 2>, launch_lds<4, 2>, launch_lds<5, 2>}};
+    const char *pnames[] = {"random index", "lane l -> entry l + c (no bank conflicts)", "one entry for all lanes"};
+    for (int pat = 0; pat < 3; ++pat)
+        for (uint32_t range : {128u, 4096u, 8192u}) {
+            if (pat && range != 4096u) continue;
+            g_range = range;
+            printf("LDS, %s in [0, %u): cycles per wave-instruction per CU at 4, 8, 16, 32 waves per CU\n", pnames[pat], range);
+            for (int op = 0; op < 6; ++op) {
+                printf("  %-16s", lnames[op]);
+                for (int wpc = 4; wpc <= 32; wpc *= 2) {
+                    const int blocks = cus * (wpc / 4);
+                    const double ms = time_ms(lfn[pat][op], blocks, d);
+                    const double inst_per_cu = (double)kIters * wpc;
+                    printf(" %10.2f", ms * 1e-3 * clk / inst_per_cu);
+                }
+                printf("\n");
             }
-            printf("\n");
         }
-    }
     CK(hipFree(d));
     return 0;
 }
