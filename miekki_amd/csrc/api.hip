@@ -940,7 +940,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_active = nullptr; c->d_cardsum = nullptr; c->d_seed_valid = nullptr; c->d_counters = nullptr; c->h_sizes = nullptr; c->size_parity = 0;
     c->d_seq[0] = c->d_seq[1] = nullptr; c->seq_cap[0] = c->seq_cap[1] = 0; c->seq_cur = 1;
     for (int b = 0; b < 2; ++b) { c->d_pk[b] = nullptr; c->pk_cap[b] = 0; c->d_pk_off[b] = nullptr; c->d_heads[b] = nullptr; }
-    c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr; c->front_stream = nullptr;
+    c->copy_stream = nullptr; c->ev_copy = nullptr; c->h_back = nullptr; c->front_stream = nullptr; c->n_copy_extra = 0;
     memset(c->side, 0, sizeof c->side);
     c->h_img = nullptr;
     memset(&c->front, 0, sizeof c->front);
@@ -964,6 +964,14 @@ int mk_create(const mk_params *p, mk_ctx **out)
     MK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     MK_HIP(hipStreamCreateWithFlags(&c->front_stream, hipStreamNonBlocking));
     MK_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    {
+        const char *e = getenv("MIEKKI_COPY_STREAMS");             // all copy streams of a packed append, this one included
+        c->n_copy_extra = std::max(0, std::min(mk_ctx::kCopyExtra, (e ? atoi(e) : kDefaultCopyStreams) - 1));
+        for (int i = 0; i < c->n_copy_extra; ++i) {
+            MK_HIP(hipStreamCreateWithFlags(&c->copy_extra[i], hipStreamNonBlocking));
+            MK_HIP(hipEventCreateWithFlags(&c->ev_extra[i], hipEventDisableTiming));
+        }
+    }
     c->bloom_bytes = p->bloom_log2 ? (1ull << p->bloom_log2) / 8 : 0;
     c->bloom_dev_bytes = 0;
     if (p->bloom_log2) {
@@ -1012,6 +1020,7 @@ void mk_destroy(mk_ctx *c)
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
     if (c->h_img) (void)hipHostFree(c->h_img);
+    for (int i = 0; i < c->n_copy_extra; ++i) { (void)hipEventDestroy(c->ev_extra[i]); (void)hipStreamDestroy(c->copy_extra[i]); }
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->front_stream) (void)hipStreamDestroy(c->front_stream);
@@ -1155,13 +1164,18 @@ int mk_index_append_packed(mk_ctx *c, const mk_packed_seq *seqs, uint32_t n)
         for (uint32_t g = 0; g < nb; ++g) memcpy(heads + 32 * g, seqs[g0 + g].head, 32);
         MK_HIP(hipMemcpyAsync(c->d_heads[buf], heads, (size_t)nb * 32, hipMemcpyHostToDevice, c->copy_stream));
         MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        const int ways = 1 + c->n_copy_extra;                        // the sequences take turns on the copy streams
         for (uint32_t g = 0; g < nb; ++g) {
             const mk_packed_seq &q = seqs[g0 + g];
-            MK_HIP(hipMemcpyAsync(codes + pk_off[g], q.codes, (size_t)((q.len + 31) / 32) * 8, hipMemcpyHostToDevice, c->copy_stream));
+            hipStream_t cs = g % ways ? c->copy_extra[g % ways - 1] : c->copy_stream;
+            MK_HIP(hipMemcpyAsync(codes + pk_off[g], q.codes, (size_t)((q.len + 31) / 32) * 8, hipMemcpyHostToDevice, cs));
             dirty[g] = q.except ? 1u : 0u;
             if (q.except)
-                MK_HIP(hipMemcpyAsync(except + pk_off[g] / 2, q.except, (size_t)((q.len + 63) / 64) * 8, hipMemcpyHostToDevice,
-                                      c->copy_stream));
+                MK_HIP(hipMemcpyAsync(except + pk_off[g] / 2, q.except, (size_t)((q.len + 63) / 64) * 8, hipMemcpyHostToDevice, cs));
+        }
+        for (int i = 0; i < c->n_copy_extra; ++i) {                  // one event stands for all of them
+            MK_HIP(hipEventRecord(c->ev_extra[i], c->copy_extra[i]));
+            MK_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_extra[i], 0));
         }
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kPacked, c->ev_copy, dirty));

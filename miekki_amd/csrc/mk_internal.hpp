@@ -31,6 +31,7 @@ constexpr uint32_t kShortMax = 4096;     // k-mers a query may have for the in-L
 constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batch
 constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
 constexpr uint64_t kEmptyKey = ~0ULL;
+constexpr int kDefaultCopyStreams = 2;            // copy streams of a packed append (MIEKKI_COPY_STREAMS; see mk_ctx::copy_extra)
 constexpr uint32_t kSlabMaxQueries = 1u << 30;   // queries per launch of the slab schedule (no bound by default; see chunk_queries_slab)
 
 // packed query-sketch entry: partition in the low word, fingerprint in the high word
@@ -121,6 +122,12 @@ struct mk_ctx {
     bool bloom_full_stale;         // the cells were written behind the summary's back (import)
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
+    // further copy streams for batches that arrive as many separate buffers (mk_index_append_packed: one per sequence,
+    // ~1 MB each): a DMA engine spends as long on starting such a copy as on moving it, several engines overlap that
+    static constexpr int kCopyExtra = 3;
+    hipStream_t copy_extra[kCopyExtra];
+    hipEvent_t ev_extra[kCopyExtra];
+    int n_copy_extra;
     // The batch whose kernels are enqueued but whose results (active counts, cardinality
     // sums, overflow mark) the host has not folded into the index yet.  Every entry point
     // other than the appends settles it first (settle_build in api.hip).

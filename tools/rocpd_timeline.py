@@ -14,8 +14,20 @@ sym_cols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_kernel_symbo
 name_col = "kernel_name" if "kernel_name" in sym_cols else ("display_name" if "display_name" in sym_cols else "name")
 rows = list(cur.execute(f"""select s.{name_col}, d.start, d.end from rocpd_kernel_dispatch d
                             join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start limit ? offset ?""", (count, first)))
+rows = [(re.search(r"(\w+_kernel|__amd_rocclr_\w+)", n).group(1) if re.search(r"(\w+_kernel|__amd_rocclr_\w+)", n) else n[:40], a, b)
+        for n, a, b in rows]
+# memory copies (rocprofv3 --memory-copy-trace), when the run recorded them: those inside the window of the kernels shown
+tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table', 'view') and name like '%memory_copy%'")]
+for t in tables:
+    cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
+    if "start" in cols and "end" in cols and rows:
+        size = "size" if "size" in cols else ("bytes" if "bytes" in cols else None)
+        lo, hi = rows[0][1], rows[-1][2]
+        q = f"select {size or 0}, start, end from {t} where end >= ? and start <= ? order by start"
+        rows += [(f"copy {sz} B", a, b) for sz, a, b in cur.execute(q, (lo, hi))]
+        break
+rows.sort(key=lambda r: r[1])
 if rows:
     t0 = rows[0][1]
     for name, a, b in rows:
-        m = re.search(r"(\w+_kernel|__amd_rocclr_\w+)", name)
-        print(f"{(a - t0) / 1e3:10.1f} {(b - t0) / 1e3:10.1f} {(b - a) / 1e3:9.1f}  {m.group(1) if m else name[:40]}")
+        print(f"{(a - t0) / 1e3:10.1f} {(b - t0) / 1e3:10.1f} {(b - a) / 1e3:9.1f}  {name}")
