@@ -221,16 +221,44 @@ int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n)
     return MK_OK;
 }
 
+// bytes of the coarse summary level: one bit per 2048 cells, written 16 bits per wave of bloom_summary_kernel
+uint64_t bloom_summary_bytes(const mk_ctx *c)
+{
+    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, threads = (nwords + 1) / 2;
+    return (threads + 63) / 64 * 2;
+}
+
+int ensure_bloom_summary_arrays(mk_ctx *c)
+{
+    if (!c->d_bloom || c->d_bloom_full) return MK_OK;
+    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, words2 = (bloom_summary_bytes(c) + 7) / 8 + 8;
+    MK_TRY(dev_alloc(&c->d_bloom_full, nwords));
+    MK_TRY(dev_alloc(&c->d_bloom_full2, words2));
+    MK_HIP(hipMemset(c->d_bloom_full, 0, nwords * 4));
+    MK_HIP(hipMemset(c->d_bloom_full2, 0, words2 * 8));
+    MK_HIP(hipStreamSynchronize(nullptr));                        // (the front stream does not wait for the null stream by itself)
+    c->bloom_full_stale = true;
+    return MK_OK;
+}
+
+// Cells are about to be replaced (an import): the summaries may not claim anything until they have been recomputed.  The
+// build's front stage reads the coarse level before the back stage refreshes it, so "stale" alone is not enough here.
+static int forget_bloom_summary(mk_ctx *c)
+{
+    c->bloom_full_stale = true;
+    if (!c->d_bloom_full) return MK_OK;
+    const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, words2 = (bloom_summary_bytes(c) + 7) / 8 + 8;
+    MK_HIP(hipMemsetAsync(c->d_bloom_full, 0, nwords * 4, c->stream));
+    MK_HIP(hipMemsetAsync(c->d_bloom_full2, 0, words2 * 8, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    return MK_OK;
+}
+
 // the "all eight cells set" summary of the Bloom filter, current
 int ensure_bloom_summary(mk_ctx *c)
 {
     if (!c->d_bloom) return MK_OK;
-    if (!c->d_bloom_full) {
-        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1;
-        MK_TRY(dev_alloc(&c->d_bloom_full, nwords));
-        MK_TRY(dev_alloc(&c->d_bloom_full2, (nwords + 63) / 64 + 1));
-        c->bloom_full_stale = true;
-    }
+    MK_TRY(ensure_bloom_summary_arrays(c));
     if (c->bloom_full_stale) {
         MK_TRY(launch_bloom_summary(c));
         c->bloom_full_stale = false;
@@ -1300,7 +1328,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
     c->has_empty_sketch = false;
     ++c->gen;
     if (c->d_bloom) MK_HIP(hipMemset(c->d_bloom, 0, c->bloom_dev_bytes));
-    c->bloom_full_stale = true;
+    MK_TRY(forget_bloom_summary(c));
     return MK_OK;
 }
 
@@ -1335,7 +1363,7 @@ int mk_index_import_bloom(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t
     MK_TRY(use_device(c));
     const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
     if (begin < dev_end) MK_HIP(hipMemcpy(c->d_bloom + begin, src, dev_end - begin, hipMemcpyHostToDevice));
-    c->bloom_full_stale = true;
+    MK_TRY(forget_bloom_summary(c));
     ++c->gen;
     return MK_OK;
 }
@@ -1742,7 +1770,7 @@ int mk_index_import_bloom_device(mk_ctx *c, uint64_t begin, uint64_t end, const 
     const uint64_t dev_end = std::min(end, c->bloom_dev_bytes);
     if (begin < dev_end) MK_HIP(hipMemcpyAsync(c->d_bloom + begin, d_src, dev_end - begin, hipMemcpyDeviceToDevice, c->stream));
     MK_HIP(hipStreamSynchronize(c->stream));
-    c->bloom_full_stale = true;
+    MK_TRY(forget_bloom_summary(c));
     ++c->gen;
     return MK_OK;
 }

@@ -31,6 +31,7 @@ constexpr uint32_t kSeg = 4096;            // k-mers per scatter workgroup
 constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
+constexpr uint32_t kAllFlagged = 127;      // meta word: the run's flagged count when it is >= this, i.e. "all of them"
 }  // namespace
 
 // ---------------------------------------------------------------- characters -> packed
@@ -161,13 +162,19 @@ struct BuildShape {
     uint32_t lpr;                  // lanes of a reduce wave that share one run, 16 bytes of items each (a power of two)
     uint32_t nwg;                  // scatter workgroups per genome
     uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no item reads
+    uint32_t sum_words;            // 64-bit words of the Bloom summary the scatter kernel consults (one bit per 2048 cells); 0: none
+    uint32_t bloom_on;             // the index has a Bloom filter (and pass A is not switched off): items get flagged
 };
 
 // Item: W == 1: fingerprint << 24 | partition in bin << 12 | position in segment  (32 bits);
 //       W == 2: fingerprint << 48 | partition in bin << 12 | position in segment  (64 bits).
 // The segment (= scatter workgroup) supplies the upper bits of the position.  A scatter workgroup leaves its items
 // SORTED BY BIN and dense -- items[(genome, workgroup)][0 .. total) in a region of kSeg -- plus one word per bin,
-// run start << 16 | run length (meta[(genome, workgroup)][bin]): no capacities, no padding, no overflow.
+// meta[(genome, workgroup)][bin] = run start << 20 | run length << 7 | flagged: no capacities, no padding, no overflow.
+// FLAGGED items are those whose k-mer may still have work to do in the Bloom filter (the scatter kernel has the canonical
+// k-mer at hand and asks a summary of the filter, below); they come first in their run, so that the item itself needs no
+// bit for it.  kAllFlagged stands for "every item of the run" (and is what a count that does not fit becomes: a flag
+// too many only costs the reduce kernel a look at the filter).
 template <int W> struct ItemOf { using type = uint32_t; };
 template <> struct ItemOf<2> { using type = uint64_t; };
 
@@ -194,8 +201,8 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
 // the whole workgroup; they only take instructions out of a loop that is bound by instruction issue.
 template <int W, bool KBIG, bool FULL>
 __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bool has_x, uint32_t x01, uint32_t x2, uint32_t i0,
-                                       uint32_t cnt, uint32_t *bins, typename ItemOf<W>::type (&it)[kPer], uint32_t (&key)[kPer],
-                                       const SketchParams &sp, const BuildShape &bs)
+                                       uint32_t cnt, uint32_t *bins, const uint32_t *sum32, typename ItemOf<W>::type (&it)[kPer],
+                                       uint32_t (&key)[kPer], const SketchParams &sp, const BuildShape &bs)
 {
     using item_t = typename ItemOf<W>::type;
     // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
@@ -220,6 +227,7 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     const bool top_hi = KBIG || topshift >= 32;
     const uint32_t tsh = top_hi ? topshift - 32 : topshift;
     const uint32_t bshift = 32u - sp.h;                           // bucket = anc >> (64 - h)  (Miekki.cpp:169)
+    const uint32_t sumshift = bs.sum_words ? sp.bloom_log2 - 32u + 3u + 11u : 31u;   // canon's high word -> group of 2048 cells
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint32_t fd = (fnew >> (2 * u)) & 3u, rd = (rnew >> (2 * u)) & 3u;
@@ -236,16 +244,26 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
             if (top_hi) Rhi |= rd << tsh; else Rlo |= rd << tsh;
         }
         const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
-        const uint64_t anc = revhash64(S < RC ? S : RC);                          // Miekki.cpp:167-168
+        const uint64_t canon = S < RC ? S : RC;
+        // Would inserting this k-mer into the Bloom filter still change anything (Miekki.cpp:121-131)?  Its five positions
+        // are (canon + t_i) >> b with t_i < 1024 and b >= 32 (universal_hash, utils.cpp:197-199): ONE cell unless the low
+        // word can carry, and the summary says whether every cell of that cell's group of 2048 is taken already.  Cells are
+        // never emptied, so a summary older than the filter only flags more.
+        // (asked before the hash so that the LDS read is under way while the hash is computed)
+        // (no branch here: without a summary the shift leaves group 0 and the one word there says "nothing is settled", or,
+        // for an index without a filter, "everything is")
+        const uint32_t s3 = (uint32_t)(canon >> 32) >> sumshift;                  // cell >> 11
+        const uint32_t settled = (sum32[s3 >> 5] >> (s3 & 31u)) & ((uint32_t)canon <= 0xFFFFFC00u ? 1u : 0u);
+        const uint64_t anc = revhash64(canon);                                    // Miekki.cpp:167-168
         const uint32_t ahi = (uint32_t)(anc >> 32);
         const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
         if (fp == sp.empty || (!FULL && i0 + u >= cnt)) continue;    // (past the segment's end only in a sequence's last workgroup)
         const uint32_t bucket = ahi >> bshift;
-        const uint32_t binoff = (bucket >> bs.low_bits) << 2;          // byte offset of the bin's counter
         const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
+        const uint32_t binoff = ((bucket >> bs.low_bits) << 3) | (settled << 2);   // byte offset of the bin's counter: flagged, settled
         const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
         it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)((part << kBin) | (i0 + u));
-        key[u] = (binoff << 12) | rank;                              // rank < 4096
+        key[u] = (binoff << 12) | rank;                              // rank < 4096 (among the bin's flagged / settled items)
     }
 }
 
@@ -260,13 +278,17 @@ template <int W, bool KBIG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ items,
-    uint32_t *__restrict__ meta, SketchParams sp, BuildShape bs)
+    uint32_t *__restrict__ meta, const uint32_t *summary, SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
     constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     item_t *stage = reinterpret_cast<item_t *>(smem);                 // kSeg + kIPV: the workgroup's items, sorted by bin
-    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));   // nbins + 1: counts, then run starts
+    // 2 * nbins + 1 counters (per bin: flagged items, then settled ones), later the places where their runs start
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));
+    // the Bloom summary (one bit per 2048 cells: all taken), when there is one: 4 KiB at -b 33 -- as a snapshot of whatever
+    // the array holds right now (the summary kernel of the batch before may be writing it: bits only ever get set)
+    uint32_t *sum32 = bins + ((2 * bs.nbins + 1 + 3) & ~3u);          // (at least one word)
     __shared__ uint32_t cw[kSeg / 16 + 4];                            // the workgroup's positions, 16 per word
     __shared__ uint32_t xw[kSeg / 16 + 4];                            // their exception bits (low 16)
     __shared__ uint32_t wave_sum[4];
@@ -274,7 +296,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     const uint64_t len = off[g + 1] - off[g];
     const uint64_t nk = len > sp.k ? len - sp.k : 0;                  // Miekki.cpp:162: the last k-mer is skipped
     const uint64_t seg0 = (uint64_t)wg * kSeg;
-    for (uint32_t b = tid; b <= bs.nbins; b += 256) bins[b] = 0;
+    for (uint32_t b = tid; b <= 2 * bs.nbins; b += 256) bins[b] = 0;
+    // (the summary: at most 8 KiB = two 16-byte pieces per thread, both requested before the first is stored -- the workgroup
+    // lives ~12 us, a chain of dependent loads at its start would be a third of that)
+    const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(summary);
+    const uint32_t pieces = (bs.sum_words + 1) / 2;                  // of 16 bytes (the array is padded)
+    uint4 sum_a = make_uint4(0, 0, 0, 0), sum_b = sum_a;
+    if (tid < pieces) sum_a = s4[tid];
+    if (tid + 256 < pieces) sum_b = s4[tid + 256];
     const uint32_t cnt = seg0 < nk ? (uint32_t)min((uint64_t)kSeg, nk - seg0) : 0u;
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
     if (cnt) {
@@ -288,6 +317,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
             xw[j] = in && has_x ? (uint32_t)x16[j] : 0u;
         }
     }
+    if (tid < pieces) reinterpret_cast<uint4 *>(sum32)[tid] = sum_a;
+    if (tid + 256 < pieces) reinterpret_cast<uint4 *>(sum32)[tid + 256] = sum_b;
+    if (!bs.sum_words && tid == 0) sum32[0] = bs.bloom_on ? 0u : 1u;
     __syncthreads();
     const uint32_t i0 = tid * kPer;
     item_t it[kPer];
@@ -297,19 +329,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     if (i0 < cnt) {
         const uint32_t w0 = cw[tid], w1 = cw[tid + 1], w2 = cw[tid + 2];
         const uint32_t x01 = has_x ? xw[tid] | (xw[tid + 1] << 16) : 0u, x2 = has_x ? xw[tid + 2] : 0u;
-        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, it, key, sp, bs);
-        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, it, key, sp, bs);
+        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, sum32, it, key, sp, bs);
+        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, sum32, it, key, sp, bs);
     }
     __syncthreads();
-    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of the counts
-    uint32_t c4[4], start4[4];
+    // ---- where each run starts among the workgroup's sorted items: exclusive prefix of the counts (a thread: four bins)
+    uint32_t c8[8], start4[4];
     {
         uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t b = tid * 4 + e;
-            c4[e] = b < bs.nbins ? bins[b] : 0u;
-            sum += c4[e];
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t b = tid * 8 + e;
+            c8[e] = b < 2 * bs.nbins ? bins[b] : 0u;
+            sum += c8[e];
         }
         uint32_t incl = sum;
         const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -322,11 +354,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
         uint32_t base = incl - sum;
         for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
 #pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t b = tid * 4 + e;
-            start4[e] = base;
-            if (b < bs.nbins) bins[b] = base;
-            base += c4[e];
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t b = tid * 8 + e;
+            if (!(e & 1u)) start4[e >> 1] = base;
+            if (b < 2 * bs.nbins) bins[b] = base;
+            base += c8[e];
         }
     }
     __syncthreads();
@@ -345,32 +377,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     uint32_t *__restrict__ m = meta + seg * bs.nbins;
 #pragma unroll
     for (uint32_t e = 0; e < 4; ++e) {
-        const uint32_t b = tid * 4 + e;
-        if (b < bs.nbins) m[b] = (start4[e] << 16) | c4[e];          // start < 4096; length <= 4096
+        const uint32_t b = tid * 4 + e, flagged = c8[2 * e], length = flagged + c8[2 * e + 1];      // length <= 4096
+        if (b < bs.nbins) m[b] = ((start4[e] & (kSeg - 1u)) << 20) | (length << 7) | min(flagged, kAllFlagged);
     }
 }
 
 // ---------------------------------------------------------------- reduce + fingerprints + sizes + Bloom pass A
-// One 512-thread workgroup per (genome, bin) -- 37 KiB of LDS, so four of them share a CU: the kernel is a chain of
-// latencies (meta words, items, the winners' codes) and what hides them is other workgroups.  The bin's runs -- one per scatter workgroup, found through the
-// workgroup's meta word (run start, run length) -- are read with `lpr` lanes per run, one item per lane: a wave's
-// meta words come first (into LDS), then all its runs are in flight together.  The items of a genome are one dense
-// array that the 2^(h-12) reduce workgroups of the genome walk side by side (neighbouring bins on one XCD, so that a
-// line that holds the end of one run and the start of the next is fetched into one L2): HBM sees it once.
-// Minimum per partition with LDS atomics; KEY32 packs (fingerprint, position) into 32 bits when the sequence is
-// shorter than 2^24 (a 16 KiB table).
+// One 512-thread workgroup per (genome, bin) -- 38 KiB of LDS, so four of them share a CU: the kernel is a chain of
+// latencies (meta words, then items) and what hides them is other workgroups.  The bin's runs -- one per scatter
+// workgroup, found through the workgroup's meta word (run start, run length, flagged items) -- are read with `lpr`
+// lanes per run, 16 bytes per lane.  The items of a genome are one dense array that the 2^(h-12) reduce workgroups of
+// the genome walk side by side (neighbouring bins on one XCD, so that a line that holds the end of one run and the
+// start of the next is fetched into one L2): HBM sees it once.  Minimum per partition with LDS atomics; KEY32 packs
+// (fingerprint, position) into 32 bits when the sequence is shorter than 2^24 (a 16 KiB table).
+// Bloom pass A works on FLAGGED winners only (the scatter kernel's flag: the k-mer's cell may still be empty): flagged
+// items are noted in an LDS list while they pass, and those that turn out to be their partition's minimum get the
+// filter looked at.  Once the filter has filled up nothing is flagged and a winner costs no memory request at all
+// (before: its codes, 16 bytes from a random place of the genome -- 67 M L2 requests per 64 x 5 Mb batch).
 template <int W, bool KEY32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 4, 8))) void build_reduce_kernel(
     const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
-    const uint32_t *__restrict__ full, const uint64_t *__restrict__ full2, uint32_t full2_words,
-    uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
+    const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
     uint8_t *__restrict__ posted_blk, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
     SketchParams sp, BuildShape bs)
 {
-    // second-level Bloom summary (one bit per 256 cells: all set), when it fits: full2_words 64-bit words, else none
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_full2[];
     using item_t = typename ItemOf<W>::type;
     using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
@@ -384,29 +416,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     __shared__ unsigned long long s_card;
     constexpr uint32_t kMetaChunk = 1280;                             // scatter workgroups whose meta words sit in LDS at a time (5 Mb: 1,221)
     __shared__ uint32_t s_meta[kMetaChunk];
+    // flagged items seen: partition in bin << 32 | position.  More than fit: every winner of the bin gets the filter
+    // looked at (that is the state of a young filter, where nearly everything is flagged anyway)
+    constexpr uint32_t kNoted = 2048;
+    __shared__ unsigned long long noted[kNoted];
+    __shared__ uint32_t n_noted;
+    __shared__ uint32_t to_check[(1u << kBin) / 32];                  // partitions whose winner is a flagged item
     // workgroups are dealt to the XCDs round robin: XCD x gets the bins x * nbins / 8 ... of a genome, i.e. neighbours
     const uint32_t g = blockIdx.y;
     const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
     const uint32_t R = 1u << bs.low_bits;
     for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
-    // (a snapshot taken before the batch: cells never go back to zero, so "all set" stays true)
-    if (bloom && !(bs.tune & 1u)) {
-        constexpr uint32_t kF2Per = 3;                                // 16-byte pieces per thread: up to 24 KiB (the host allows 20)
-        const uint4 *__restrict__ f2 = reinterpret_cast<const uint4 *>(full2);
-        uint4 piece[kF2Per];
-#pragma unroll
-        for (uint32_t u = 0; u < kF2Per; ++u) {
-            const uint32_t i = threadIdx.x + u * kThreads;
-            piece[u] = 2 * i < full2_words ? f2[i] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kF2Per; ++u) {
-            const uint32_t i = threadIdx.x + u * kThreads;
-            if (2 * i < full2_words) reinterpret_cast<uint4 *>(s_full2)[i] = piece[u];
-        }
-    }
     if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_act = 0; s_card = 0; }
+    if (threadIdx.x < (1u << kBin) / 32) to_check[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_act = 0; s_card = 0; n_noted = 0; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     {
@@ -426,20 +449,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
 #pragma unroll
             for (uint32_t u = 0; u < kMetaPer; ++u) {                 // (all of a thread's words requested before the first is stored)
                 const uint32_t i = threadIdx.x + u * kThreads;
-                mw[u] = i < cn ? meta[((uint64_t)g * bs.nwg + c0 + i) * bs.nbins + bin] : 0u;
+                mw[u] = meta[((uint64_t)g * bs.nwg + c0 + min(i, cn - 1u)) * bs.nbins + bin];   // (no branch: see the item loads below)
             }
 #pragma unroll
             for (uint32_t u = 0; u < kMetaPer; ++u) {
                 const uint32_t i = threadIdx.x + u * kThreads;
-                if (i < kMetaChunk) s_meta[i] = mw[u];
+                if (i < cn) s_meta[i] = mw[u];
             }
             __syncthreads();
             // two stages of UN wave-loads each: the runs of the next stage are requested before the items of the
             // current one go to the table, so that the LDS atomics of one stage drain under the loads of the next
             struct Stage { uint32_t m[UN]; vec_t v[UN]; };
             auto place = [&](uint32_t m, uint32_t &a0, uint32_t &first, uint32_t &end) {
-                first = m >> 16;
-                end = first + (m & 0xffffu);
+                first = m >> 20;
+                end = first + ((m >> 7) & 0x1fffu);
                 a0 = first & ~(kIPL - 1u);
             };
             // (no branch around the loads: every lane requests its 16 bytes, needed or not -- they lie in lines the run's
@@ -463,22 +486,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     const uint32_t w = c0 + r0 + u * NW * per_wave + sub;
                     uint32_t a0, first, end;
                     place(q.m[u], a0, first, end);
-                    auto fold = [&](item_t item) {
+                    // the flagged items are the first ones of their run (rare once the filter has filled up: none)
+                    const uint32_t nf = q.m[u] & 127u, fend = nf == kAllFlagged ? end : first + nf;
+                    auto fold = [&](item_t item, bool flagged) {
+                        const uint32_t part = ((uint32_t)item >> 12) & (R - 1u);
                         key_t key;
                         if (KEY32) key = (key_t)(((uint32_t)item & 0xff000fffu) | (w << 12));     // fingerprint << 24 | position
                         else key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)((uint64_t)w * kSeg + ((uint32_t)item & (kSeg - 1u)));
-                        atomicMin(&table[((uint32_t)item >> 12) & (R - 1u)], key);
+                        atomicMin(&table[part], key);
+                        if (flagged) {
+                            const uint32_t slot = atomicAdd(&n_noted, 1u);
+                            if (slot < kNoted)
+                                noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + ((uint32_t)item & (kSeg - 1u)));
+                        }
                     };
 #pragma unroll
                     for (uint32_t e = 0; e < kIPL; ++e) {
                         const uint32_t at = a0 + j0 + e;
-                        if (at >= first && at < end) fold(q.v[u][e]);
+                        if (at >= first && at < end) fold(q.v[u][e], at < fend);
                     }
                     for (uint32_t j = a0 + j0 + lpr * kIPL; j < end; j += lpr * kIPL) {        // runs longer than their lanes reach
                         const vec_t x = *reinterpret_cast<const vec_t *>(items + ((uint64_t)g * bs.nwg + w) * kSeg + j);
 #pragma unroll
                         for (uint32_t e = 0; e < kIPL; ++e)
-                            if (j + e < end) fold(x[e]);
+                            if (j + e < end) fold(x[e], j + e < fend);
                     }
                 }
             };
@@ -496,73 +527,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         }
     }
     __syncthreads();
+    // which winners are flagged items: a noted item whose position is its partition's minimum
+    const uint32_t n_seen = n_noted;
+    const bool check_all = n_seen > kNoted;
+    if (n_seen && !check_all) {
+        for (uint32_t e = threadIdx.x; e < n_seen; e += kThreads) {
+            const unsigned long long x = noted[e];
+            const uint32_t part = (uint32_t)(x >> 32);
+            if ((uint32_t)((uint64_t)table[part] & ((1ULL << kKeyPos) - 1)) == (uint32_t)x) atomicOr(&to_check[part >> 5], 1u << (part & 31u));
+        }
+        __syncthreads();
+    }
     const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
     fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
-    uint32_t posted_mask = 0, act = 0;
+    uint32_t posted_mask = 0, act = 0, undecided = 0;
     unsigned long long card = 0;
+    const bool pass_a = bloom && !(bs.tune & 1u);
+#pragma unroll
+    for (uint32_t j = 0; j < kWin; ++j) {
+        const uint32_t i = threadIdx.x + kThreads * j;
+        if (i >= R) continue;
+        const key_t key = table[i];
+        const bool has = key != kNoKey;
+        const uint32_t fp = has ? (uint32_t)(key >> kKeyPos) : sp.empty;
+        fpo[i] = (fp_t)fp;
+        act += has ? 1u : 0u;
+        card += has ? (unsigned long long)(1u << (31u - (fp >> sp.f))) : 0ull;   // Miekki.cpp:293: sum of 2^-exp, in units of 2^-31
+        if (has && pass_a && (check_all || ((to_check[i >> 5] >> (i & 31u)) & 1u))) undecided |= 1u << j;
+    }
+    // Pass A of the Bloom insert (see bloom_kernel<false>, sketch.hip) for those, one at a time: the canonical k-mer from
+    // the packed codes, first-level summary, the cell itself, and a first-writer key for every cell still empty.  The five
+    // positions of a k-mer are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32: when
+    // the low word cannot carry they are ONE position -- all but one k-mer in four million -- and of the five keys only
+    // the smallest, hash index 0, can ever win the cell (pass B re-derives all five and finds the same)
     const uint64_t *__restrict__ gcodes = reinterpret_cast<const uint64_t *>(codes + code_off[g]);
     const uint64_t *__restrict__ gexcept = reinterpret_cast<const uint64_t *>(except + code_off[g] / 2);
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
-    // Pass A of the Bloom insert (see bloom_kernel<false>, sketch.hip) in two steps.  FIRST, every winner against the
-    // second-level summary in LDS: its codes (requested four winners at a time), its canonical k-mer, its cell.  The five
-    // positions of a k-mer are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32: when the
-    // low word cannot carry they are ONE position -- all but one k-mer in four million -- found with 32-bit arithmetic on
-    // the high word, no revhash.  Once the filter has filled up the summary answers nearly every winner here, at ONE
-    // request at the L2 each and without a store or an atomic in this loop (nothing for its loads to wait behind).
-    const bool pass_a = bloom && !(bs.tune & 1u);
-    uint32_t undecided = 0;                                           // winners the summary did not answer
-    if (R == kThreads * kWin && pass_a && full2_words) {
-        // (straight-line code again, so that the winners' loads are in flight together: a partition without a k-mer asks
-        // for position 0 and its answer is dropped)
-        auto first_step = [&](auto with_exceptions) {
-            constexpr uint32_t kAhead = 4;                            // winners whose codes are requested together
-            static_assert(kWin % kAhead == 0, "winners per thread");
-#pragma unroll
-            for (uint32_t jb = 0; jb < kWin; jb += kAhead) {
-                packed_pair raw[kAhead];
-                uint32_t pos[kAhead], has_mask = 0;                   // (a batch is at most 2 GiB: positions fit 32 bits)
-#pragma unroll
-                for (uint32_t u = 0; u < kAhead; ++u) {
-                    const uint32_t i = threadIdx.x + kThreads * (jb + u);
-                    const key_t key = table[i];
-                    const bool has = key != kNoKey;
-                    const uint32_t fp = has ? (uint32_t)(key >> kKeyPos) : sp.empty;
-                    fpo[i] = (fp_t)fp;
-                    act += has ? 1u : 0u;
-                    card += has ? (unsigned long long)(1u << (31u - (fp >> sp.f))) : 0ull;   // Miekki.cpp:293, in units of 2^-31
-                    const uint64_t at = has ? (uint64_t)key & ((1ULL << kKeyPos) - 1) : 0ull;
-                    pos[u] = (uint32_t)at;
-                    has_mask |= has ? 1u << u : 0u;
-                    raw[u] = load_packed_pair(gcodes, at);
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kAhead; ++u) {
-                    const uint64_t cn = canon_from_pair(raw[u], gexcept, with_exceptions.value, pos[u], sp.k);
-                    const uint64_t cell = (uint32_t)(cn >> 32) >> (sp.bloom_log2 - 32u + 3u);
-                    const uint32_t s2 = (uint32_t)min(cell, bloom_dev_bytes - 1) >> 9;            // 512 cells per bit
-                    const bool answered = (uint32_t)cn <= 0xFFFFFC00u && (cell >= bloom_dev_bytes || ((s_full2[s2 >> 6] >> (s2 & 63u)) & 1u));
-                    undecided |= (((has_mask >> u) & 1u) && !answered) ? 1u << (jb + u) : 0u;
-                }
-            }
-        };
-        if (has_x) first_step(std::true_type{}); else first_step(std::false_type{});
-    } else {
-#pragma unroll
-        for (uint32_t j = 0; j < kWin; ++j) {
-            const uint32_t i = threadIdx.x + kThreads * j;
-            if (i >= R) continue;
-            const key_t key = table[i];
-            const uint32_t fp = key == kNoKey ? sp.empty : (uint32_t)(key >> kKeyPos);
-            fpo[i] = (fp_t)fp;
-            if (key == kNoKey) continue;
-            ++act;
-            card += (unsigned long long)(1u << (31u - (fp >> sp.f)));
-            if (pass_a) undecided |= 1u << j;
-        }
-    }
-    // THEN the winners still undecided, one at a time (all of them while the filter is young): first-level summary, the
-    // cell itself, and a first-writer key for every cell still empty; of the five keys of a one-cell k-mer only the
-    // smallest, hash index 0, can ever win (pass B re-derives all five and finds the same)
     auto probe = [&](uint64_t cell, uint32_t tag, uint32_t p) -> bool {
         if (cell >= bloom_dev_bytes) return false;
         const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;                              // 8, 256 cells
@@ -620,6 +620,12 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     }
     static const uint32_t tune = [] { const char *e = getenv("MIEKKI_TUNE_BUILD"); return e ? (uint32_t)atoi(e) : 0u; }();
     bs.tune = tune;
+    // the scatter kernel flags the k-mers that may still have work to do in the Bloom filter; it asks the filter's coarse
+    // summary (one bit per 2048 cells, bloom_summary_bytes: 4 KiB at -b 33), which rides in its LDS when it is at most 8 KiB
+    // -- a larger one is not consulted and every item counts as flagged
+    bs.bloom_on = c->d_bloom && !(tune & 1u) ? 1u : 0u;
+    bs.sum_words = 0;
+    if (bs.bloom_on && bloom_summary_bytes(c) <= 8192) bs.sum_words = (uint32_t)((bloom_summary_bytes(c) + 7) / 8);
     bs.low_bits = std::min<uint32_t>(c->p.h, kBin);
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
@@ -724,11 +730,13 @@ int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_exc
 static void shape_store(mk_ctx::BuildSide &sd, const BuildShape &bs)
 {
     sd.shape[0] = bs.nbins; sd.shape[1] = bs.low_bits; sd.shape[2] = bs.lpr; sd.shape[3] = bs.nwg; sd.shape[4] = bs.tune;
+    sd.shape[5] = bs.sum_words; sd.shape[6] = bs.bloom_on;
 }
 static BuildShape shape_load(const mk_ctx::BuildSide &sd)
 {
     BuildShape bs;
     bs.nbins = sd.shape[0]; bs.low_bits = sd.shape[1]; bs.lpr = sd.shape[2]; bs.nwg = sd.shape[3]; bs.tune = sd.shape[4];
+    bs.sum_words = sd.shape[5]; bs.bloom_on = sd.shape[6];
     return bs;
 }
 // the meta words lie behind the side's item array (build_setup)
@@ -753,11 +761,12 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     shape_store(sd, bs);
     const SketchParams sp = make_sp(c);
     const size_t isz = c->W == 1 ? 4 : 8;
-    const size_t lds = (kSeg + 16 / isz) * isz + ((size_t)bs.nbins + 1) * 4;
+    MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
+    const size_t lds = (kSeg + 16 / isz) * isz + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except,     \
                        d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), \
-                       meta_of(c, sd, bs, n), sp, bs)
+                       meta_of(c, sd, bs, n), reinterpret_cast<const uint32_t *>(c->d_bloom_full2), sp, bs)
     const bool kbig = c->p.k >= 17;
     if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
     else           { if (kbig) MK_SCATTER(2, true); else MK_SCATTER(2, false); }
@@ -781,18 +790,11 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
         MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
     const SketchParams sp = make_sp(c);
-    // the second-level Bloom summary (one bit per 512 cells) rides in LDS beside the reduce table when it is at most
-    // 20 KiB (-b 33 at k = 31: 16 KiB and a word); a larger one is simply not consulted
-    uint32_t f2w = 0;
-    if (c->d_bloom) {
-        const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, w2 = ((nwords + 1) / 2 + 63) / 64;
-        if (w2 * 8 <= 20480) f2w = (uint32_t)w2;
-    }
 #define MK_REDUCE(Wv, K32)                                                                                                      \
-    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), (size_t)(f2w + 1) / 2 * 16, c->stream,                 \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, c->stream,                              \
                        reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
-                       c->d_bloom_order, c->d_bloom_full, c->d_bloom_full2, f2w, c->d_fpT, c->d_tables, c->d_posted_blk,        \
+                       c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_posted_blk,                              \
                        sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)
     if (c->W == 1) { if (sd.key32) MK_REDUCE(1, true); else MK_REDUCE(1, false); }
     else MK_REDUCE(2, false);

@@ -118,7 +118,7 @@ struct mk_ctx {
     // 1 MiB for the 64 MiB of reachable cells at -b 33: L2-resident, and once the filter has
     // filled up it answers almost every probe of the build without touching the cells
     uint32_t *d_bloom_full;
-    uint64_t *d_bloom_full2;       // second level: one bit per word of d_bloom_full = all of its 256 cells are set
+    uint64_t *d_bloom_full2;       // coarse level: one bit per 2048 cells = all of them are taken (the build's scatter kernel asks it)
     bool bloom_full_stale;         // the cells were written behind the summary's back (import)
     hipStream_t copy_stream;
     hipEvent_t ev_copy;
@@ -182,7 +182,7 @@ struct mk_ctx {
         void *d_slots;
         uint64_t slots_bytes;
         hipEvent_t ev_front;       // front stage done
-        uint32_t shape[5];         // BuildShape of the batch (build.hip)
+        uint32_t shape[8];         // BuildShape of the batch (build.hip)
         bool fits, key32;
     } side[2];
     hipStream_t front_stream;
@@ -332,6 +332,8 @@ int ensure_codes(mk_ctx *c, uint64_t seq_bytes);
 int ensure_build_counters(mk_ctx *c);
 int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);
 int ensure_bloom_summary(mk_ctx *c);
+int ensure_bloom_summary_arrays(mk_ctx *c);           // allocated and zeroed ("nothing is full"), not computed
+uint64_t bloom_summary_bytes(const mk_ctx *c);         // of the coarse level: one bit per 2048 cells
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
 int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t n, bool *done);

@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
 // summary taken before a batch stays true during it; it is refreshed after every pass B.
 __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
                                                             uint32_t *__restrict__ full, uint64_t nwords,
-                                                            unsigned long long *__restrict__ full2)
+                                                            uint16_t *__restrict__ full2, uint64_t n16)
 {
     // a thread makes TWO summary words (each = 32 groups = 256 cells): words 2t and 2t + 1
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,11 +924,15 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
         if (w < nwords) full[w] = bits;
         both = both && bits == 0xffffffffu;
     }
-    // second level: one bit per PAIR of summary words = "all 512 cells set" -- 16 KiB for the 64 MiB of reachable
-    // cells at -b 33, small enough to sit in LDS beside a reduce workgroup's table four times per CU (build.hip)
-    const unsigned long long m = __ballot(both);
-    const uint64_t n2 = ((nwords + 1) / 2 + 63) / 64;
-    if ((threadIdx.x & 63u) == 0 && (t >> 6) < n2) full2[t >> 6] = m;
+    // coarse level: one bit per EIGHT summary words = "all 2048 cells taken" -- 4 KiB for the 64 MiB of reachable cells at
+    // -b 33, small enough to ride in the LDS of the build's scatter kernel (build.hip), which asks it for every k-mer.
+    // Four neighbouring threads hold those eight words; a wave writes its 16 bits.
+    unsigned long long m = __ballot(both);
+    m &= m >> 1; m &= m >> 2;                                                 // bit 4i: threads 4i .. 4i+3 all full
+    uint32_t packed = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) packed |= (uint32_t)((m >> (4 * i)) & 1ull) << i;
+    if ((threadIdx.x & 63u) == 0 && (t >> 6) < n16) full2[t >> 6] = (uint16_t)packed;
 }
 
 int launch_bloom_summary(mk_ctx *c)
@@ -936,7 +940,7 @@ int launch_bloom_summary(mk_ctx *c)
     if (!c->d_bloom) return MK_OK;
     const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, threads = (nwords + 1) / 2;
     hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
-                       c->bloom_dev_bytes, c->d_bloom_full, nwords, (unsigned long long *)c->d_bloom_full2);
+                       c->bloom_dev_bytes, c->d_bloom_full, nwords, (uint16_t *)c->d_bloom_full2, bloom_summary_bytes(c) / 2);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
