@@ -91,7 +91,7 @@ static int use_device(const mk_ctx *cc, bool settle = true)
 {
     MK_HIP(hipSetDevice(cc->p.device));
     mk_ctx *c = const_cast<mk_ctx *>(cc);
-    if (settle && c->build.on) MK_TRY(settle_build(c));
+    if (settle && (c->build.on || c->older.on)) MK_TRY(settle_build(c));
     return MK_OK;
 }
 
@@ -385,26 +385,40 @@ static int enqueue_front(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, 
     return MK_OK;
 }
 
+static int settle_one(mk_ctx *c, mk_ctx::BuildInFlight &b);
+
+// The back stage of the batch whose front stage was queued last goes onto c->stream right behind the back stage of the
+// batch before it -- the device starts it the moment that one ends, no host round trip in between -- and only then does
+// the host wait for that older batch and fold it in (the caller: settle_older).
 static int enqueue_back(mk_ctx *c)
 {
+    if (c->older.on) MK_TRY(settle_one(c, c->older));            // (at most two batches are not folded in at any time)
+    const uint32_t n = c->front.n;
+    if (c->G_back + n > c->capG) {
+        // the matrix has to grow: that re-lays it out with the columns of c->G genomes -- fold everything in first
+        if (c->build.on) MK_TRY(settle_one(c, c->build));
+        MK_TRY(ensure_capacity(c, c->G + n));
+    }
+    if (c->build.on) c->older = c->build;
     mk_ctx::BuildInFlight &b = c->build;
     b = c->front;                                                // the batch whose front stage was queued last
     c->front.on = false;
     const int buf = b.buf;
-    const uint32_t n = b.n;
+    b.g0 = c->G_back;
     mk_ctx::BuildSide &sd = c->side[buf];
-    use_build_side(c, buf);                                      // the aliases follow the batch in flight
-    MK_TRY(ensure_capacity(c, c->G + n));
+    use_build_side(c, buf);                                      // the aliases follow the batch whose kernels are being queued
     MK_HIP(hipStreamWaitEvent(c->stream, sd.ev_front, 0));
     MK_TRY(ensure_bloom_summary(c));
     if (b.binned) {
         ScopedTimer t(c, 4);
-        MK_TRY(launch_build_back(c, buf, c->d_pk[buf], c->d_pk[buf] + c->pk_cap[buf], c->d_pk_off[buf], n, c->G));
+        MK_TRY(launch_build_back(c, buf, c->d_pk[buf], c->d_pk[buf] + c->pk_cap[buf], c->d_pk_off[buf], n, b.g0));
     } else {
         MK_TRY(build_from_characters(c));                        // shapes the bins do not fit
     }
     // one copy back of the batch's counters (active counts, cardinality sums)
     MK_HIP(hipMemcpyAsync(sd.h_back, sd.d_counters, sizeof *sd.h_back, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipEventRecord(sd.ev_back, c->stream));
+    c->G_back += n;
     b.on = true;
     return MK_OK;
 }
@@ -425,36 +439,48 @@ static int build_from_characters(mk_ctx *c)
     const char *d_seq = c->d_seq[b.buf];
     { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
     ScopedTimer t(c, 4);
-    MK_TRY(launch_finalize(c, c->d_tables, n, c->G, nullptr));
+    MK_TRY(launch_finalize(c, c->d_tables, n, b.g0, nullptr));
     return launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr);
 }
 
-// Wait for the batch in flight and fold it into the index (Miekki.cpp:303-311).
-static int settle_build(mk_ctx *c)
+// Wait for one batch whose back stage is queued and fold it into the index (Miekki.cpp:303-311); oldest first.
+static int settle_one(mk_ctx *c, mk_ctx::BuildInFlight &b)
 {
-    mk_ctx::BuildInFlight &b = c->build;
     if (!b.on) return MK_OK;
     b.on = false;
-    MK_HIP(hipStreamSynchronize(c->stream));
+    mk_ctx::BuildSide &sd = c->side[b.buf];
+    MK_HIP(hipEventSynchronize(sd.ev_back));
     const uint32_t n = b.n;
     // (the binned build cannot overflow: every scatter workgroup owns the places of its own 4096 k-mers)
     // the sizes go to the device from a pinned block of their own (two, alternating: the copies are queued
-    // behind this batch and not waited for -- the next batch is enqueued meanwhile)
+    // behind the kernels already in the stream and not waited for)
     mk_ctx::SizeUpload &up = c->h_sizes[c->size_parity ^= 1];
     for (uint32_t g = 0; g < n; ++g) {
         const uint64_t len = b.off[g + 1] - b.off[g];
-        up.ss[g] = c->h_back->act[g];
-        up.gs[g] = estimate_genome_size(up.ss[g], c->h_back->card[g], len);
+        up.ss[g] = sd.h_back->act[g];
+        up.gs[g] = estimate_genome_size(up.ss[g], sd.h_back->card[g], len);
         c->h_sketch_size.push_back(up.ss[g]);
         c->h_genome_size.push_back(up.gs[g]);
         if (up.ss[g] == 0) c->has_empty_sketch = true;
         c->stats.build_kmers += len > c->p.k ? len - c->p.k : 0;
     }
-    MK_HIP(hipMemcpyAsync(c->d_sketch_size + c->G, up.ss, n * 4, hipMemcpyHostToDevice, c->stream));
-    MK_HIP(hipMemcpyAsync(c->d_genome_size + c->G, up.gs, n * 8, hipMemcpyHostToDevice, c->stream));
-    c->G += n;
+    MK_HIP(hipMemcpyAsync(c->d_sketch_size + b.g0, up.ss, n * 4, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipMemcpyAsync(c->d_genome_size + b.g0, up.gs, n * 8, hipMemcpyHostToDevice, c->stream));
+    c->G += n;                                                   // (== b.g0 + n: batches are folded in in order)
     ++c->gen;
     c->stats.build_genomes += n;
+    return MK_OK;
+}
+
+// after a back stage has been queued: the batch before it
+static int settle_older(mk_ctx *c) { return settle_one(c, c->older); }
+
+// everything in flight (every entry point other than the appends, and mk_sync)
+static int settle_build(mk_ctx *c)
+{
+    MK_TRY(settle_one(c, c->older));
+    MK_TRY(settle_one(c, c->build));
+    MK_HIP(hipStreamSynchronize(c->stream));                     // (the sizes' copies included)
     return MK_OK;
 }
 
@@ -974,6 +1000,8 @@ int mk_create(const mk_params *p, mk_ctx **out)
     memset(&c->front, 0, sizeof c->front);
     c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->d_bloom_full2 = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
+    memset(&c->older, 0, sizeof c->older);
+    c->G_back = 0;
     c->d_seq_off = nullptr; c->d_scores = nullptr; c->scores_cap = 0; c->d_count = nullptr; c->d_cand = nullptr;
     c->d_partials = nullptr; c->partials_cap = 0; c->d_flag = nullptr;
     c->d_hits = nullptr; c->d_nhits = nullptr; c->hits_cap = 0; c->nhits_cap = 0;
@@ -1035,6 +1063,7 @@ void mk_destroy(mk_ctx *c)
         if (sd.d_slots) (void)hipFree(sd.d_slots);
         if (sd.h_back) (void)hipHostFree(sd.h_back);
         if (sd.ev_front) (void)hipEventDestroy(sd.ev_front);
+        if (sd.ev_back) (void)hipEventDestroy(sd.ev_back);
     }
     dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_code_off); dev_free(c->d_bloom_full); dev_free(c->d_bloom_full2);
     dev_free(c->d_bloom_order); dev_free(c->d_tables);
@@ -1066,7 +1095,7 @@ int mk_reserve(mk_ctx *c, uint32_t n)
 uint32_t mk_index_size(const mk_ctx *c)
 {
     if (!c) return 0;
-    if (c->build.on) (void)use_device(c);                        // count the batch still in flight
+    if (c->build.on || c->older.on) (void)use_device(c);         // count the batches still in flight
     return c->G;
 }
 
@@ -1152,8 +1181,8 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
                                   c->copy_stream));
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));
-        MK_TRY(settle_build(c));
         MK_TRY(enqueue_back(c));
+        MK_TRY(settle_older(c));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
@@ -1207,8 +1236,8 @@ int mk_index_append_packed(mk_ctx *c, const mk_packed_seq *seqs, uint32_t n)
         }
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kPacked, c->ev_copy, dirty));
-        MK_TRY(settle_build(c));
         MK_TRY(enqueue_back(c));
+        MK_TRY(settle_older(c));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
         g0 += nb;
@@ -1252,8 +1281,8 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->front_stream));
         MK_TRY(launch_synth_packed(c, first_id + g0, nb, length, c->d_pk[buf], c->d_pk_off[buf]));
         MK_TRY(enqueue_front(c, off, nb, buf, kSynth, nullptr));
-        MK_TRY(settle_build(c));
         MK_TRY(enqueue_back(c));
+        MK_TRY(settle_older(c));
         c->seq_cur = buf;
     }
     return MK_OK;
@@ -1324,6 +1353,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
     c->h_sketch_size.clear(); c->h_genome_size.clear();
     MK_TRY(ensure_capacity(c, n));
     c->G = n;
+    c->G_back = n;
     c->h_sketch_size.assign(n, 0); c->h_genome_size.assign(n, 0);
     c->has_empty_sketch = false;
     ++c->gen;

@@ -668,6 +668,7 @@ int ensure_build_side(mk_ctx *c, int b)
     if (!sd.d_seed_valid) MK_HIP(hipMalloc((void **)&sd.d_seed_valid, kBuildBatch * 4));
     if (!sd.d_ovf) MK_HIP(hipMalloc((void **)&sd.d_ovf, (uint64_t)(1u << 20) * 16));   // sketch.hip's overflow list (long-query path), 2^20 entries
     if (!sd.ev_front) MK_HIP(hipEventCreateWithFlags(&sd.ev_front, hipEventDisableTiming));
+    if (!sd.ev_back) MK_HIP(hipEventCreateWithFlags(&sd.ev_back, hipEventDisableTiming));
     return MK_OK;
 }
 

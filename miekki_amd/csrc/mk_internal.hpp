@@ -136,9 +136,12 @@ struct mk_ctx {
         bool have_chars;           // the batch's characters are in d_seq[buf] (else only its packed form exists, in d_pk[buf])
         bool have_heads;           // d_heads[buf] holds the sequences' first 32 characters (packed input)
         uint32_t n;
+        uint32_t g0;               // its first column of the matrix (set when the back stage is queued)
         int buf;
         uint64_t off[mk::kBuildBatch + 1];
-    } build, front;                // build: the batch whose back stage is queued; front: the one whose front stage alone is
+    } build, older, front;         // build: the batch whose back stage was queued last; older: the one before it, not folded
+                                   // in yet (its back stage is running or done); front: front stage queued, back stage not
+    uint32_t G_back;               // genomes whose back stage has been queued: G + those of `older` and `build`
     // The batch in packed form (build.hip): d_pk[b] = [codes: pk_cap[b] bytes][exception bits: pk_cap[b] / 2 bytes],
     // sequence g at byte offset pk_off[g] (16-byte aligned) of the codes and pk_off[g] / 2 of the exception bits.
     // Two of everything: the next batch is generated or copied into one while the kernels of the batch in flight
@@ -179,6 +182,7 @@ struct mk_ctx {
         uint64_t *d_seq_off;
         uint32_t *d_seed_valid;
         uint64_t *d_ovf;
+        hipEvent_t ev_back;        // the batch's back stage (and its counters' copy back) is done
         void *d_slots;
         uint64_t slots_bytes;
         hipEvent_t ev_front;       // front stage done
