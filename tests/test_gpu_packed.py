@@ -113,3 +113,59 @@ def test_packed_synthetic_and_character_builds_agree(hip):
             assert masked(b"".join(d.serialize())) == masked(o2.serialize().tobytes())
         finally:
             d.close()
+
+
+def test_settled_cell_groups_and_an_import_into_a_filled_context(hip):
+    """The build's scatter kernel asks a coarse summary of the Bloom filter (one bit per 2048 cells: all taken) and
+    flags only the k-mers it does not settle.  With real k-mers the last cells of a group fill late (the canonical
+    k-mer is the smaller of two), so the settled regime is reached here by IMPORTING a filter whose 2049 reachable cells
+    (k = 23, -b 32) are all taken: the appends after it must leave the filter alone and still store the right
+    fingerprints.  Then the same context takes an import of a nearly empty filter -- the summary of the filled one must
+    be forgotten, or the next appends would skip k-mers that now have work to do.  Both against the oracle, which
+    deserialises the same streams and inserts the same genomes."""
+    from oracle import oracle as orc
+    from miekki_amd import lib as L
+    k, h, b = 23, 12, 32
+    P, hdr, nb = 1 << h, 39, (1 << b) // 8
+
+    def import_stream(ix, raw, G):
+        lib = ix._lib
+        L.check(lib.mk_index_import_begin(ix._h, G))
+        L.check(lib.mk_index_import_columns(ix._h, 0, P, raw[hdr:hdr + P * G]))
+        at = hdr + P * G
+        gs = np.frombuffer(raw[at:at + 8 * G], np.uint64).copy(); at += 8 * G
+        L.check(lib.mk_index_import_bloom(ix._h, 0, nb, raw[at:at + nb])); at += nb
+        ss = np.frombuffer(raw[at:at + 4 * G], np.uint32).copy()
+        L.check(lib.mk_index_import_sizes(ix._h, gs.ctypes.data, ss.ctypes.data))
+        ix.file_names = [f"g{i}" for i in range(G)]
+
+    seed = [synth.genome_bases(8800 + g, 0, 40_000) for g in range(3)]
+    o = orc.OracleMiekki(k, h, 8, b, 200)
+    o.insert_sequences(seed)
+    raw = np.frombuffer(o.serialize().tobytes(), np.uint8).copy()
+    cells0 = hdr + P * 3 + 8 * 3
+    raw[cells0:cells0 + 2049] = np.where(raw[cells0:cells0 + 2049] == 0, 1, raw[cells0:cells0 + 2049])   # every reachable cell taken
+    full = orc.OracleMiekki.deserialize(raw)
+    ix = hip.Miekki(k, h, 8, b, 200)
+    try:
+        import_stream(ix, raw.tobytes(), 3)
+        batches = [[synth.genome_bases(8820 + 10 * i + g, 0, 50_000 + 999 * g) for g in range(4)] for i in range(3)]
+        for batch in batches:                                    # the first one sees a forgotten summary, the others a full one
+            full.insert_sequences(batch)
+            ix.insert_sequences_packed(batch)
+        assert masked(b"".join(ix.serialize())) == masked(full.serialize().tobytes())
+        qs = [batches[2][1][100:1300], batches[0][3][:900], seed[1][5000:6000]]
+        np.testing.assert_array_equal(ix.query_sequences(qs), full.query_sequences(qs))
+        # now a nearly empty filter into the same context
+        small = [synth.genome_bases(8900 + g, 0, 30_000) for g in range(3)]
+        o2 = orc.OracleMiekki(k, h, 8, b, 200)
+        o2.insert_sequences(small)
+        import_stream(ix, o2.serialize().tobytes(), 3)
+        more = [synth.genome_bases(8950 + g, 0, 60_000) for g in range(5)]
+        o2.insert_sequences(more)
+        ix.insert_sequences_packed(more)
+        assert masked(b"".join(ix.serialize())) == masked(o2.serialize().tobytes())
+        np.testing.assert_array_equal(ix.query_sequences([more[2][:1000], small[0][:1000]]),
+                                      o2.query_sequences([more[2][:1000], small[0][:1000]]))
+    finally:
+        ix.close()
