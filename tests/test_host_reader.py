@@ -54,6 +54,14 @@ def test_reader_matches_getline_semantics(dumper, tmp_path):
             t += b"\n"                                                  # else: unterminated last line
         texts.append(t)
     texts += [b"", b"\n\n", b">only a header\n", b"ACGT", b">h\n\n\nAC\n\nGT\n"]
+    # line ends and headers at and around the packer's 32-character steps (and what a 64-byte-window form would meet), a '>' inside a line (a character, not a header), headers longer than a window, headers in a row,
+    # a header right behind an empty line, no newline at the end of a header
+    for n in (62, 63, 64, 65, 127, 128, 129):
+        texts.append(b">h\n" + bases(n) + b"\n" + bases(5) + b"\n")
+        texts.append(bases(n) + b"\n>" + b"x" * 70 + b"\n" + bases(n + 1))
+        texts.append(bases(n - 3) + b"A>C\n>second\n>third\n\n>fourth\n" + bases(9) + b"\n\n" + bases(n))
+    texts += [bases(40) + b"\n>unterminated header", b">" + b"y" * 200 + b"\n" + bases(64) + b"\n" + bases(64) + b"\n",
+              b"\n" * 70 + bases(3) + b"\n" * 64 + bases(2), bases(64) + b"\n>" , b">\n" + bases(1)]
     names, want = [], []
     for i, t in enumerate(texts):
         fn = str(tmp_path / f"f{i}.fa")
