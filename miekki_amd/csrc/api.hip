@@ -192,35 +192,6 @@ int ensure_build_counters(mk_ctx *c)
     return MK_OK;
 }
 
-// packed 4-bit codes of up to a build batch of sequences totalling seq_bytes characters
-int ensure_codes(mk_ctx *c, uint64_t seq_bytes)
-{
-    if (!c->d_code_off) MK_TRY(dev_alloc(&c->d_code_off, kBuildBatch + 1));
-    MK_TRY(ensure_build_counters(c));
-    const uint64_t code_bytes = seq_bytes / 2 + 32ull * (kBuildBatch + 1) + 64;
-    if (seq_bytes && code_bytes > c->codes_cap) {                  // only touched between settle and enqueue
-        MK_HIP(hipStreamSynchronize(c->stream));
-        dev_free(c->d_codes); dev_free(c->d_codes2);
-        c->codes_cap = 0;
-        MK_TRY(dev_alloc(&c->d_codes, code_bytes + code_bytes / 4));
-        MK_TRY(dev_alloc(&c->d_codes2, (code_bytes + code_bytes / 4) / 2 + 64));   // 2-bit forward codes, at half the offsets
-        c->codes_cap = code_bytes + code_bytes / 4;
-    }
-    return MK_OK;
-}
-
-// offsets of the sequences' code arrays inside d_codes: 16-byte aligned (so that half of one, the offset into
-// the 2-bit array d_codes2, is 8-byte aligned), at least 8 bytes of slack each
-int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n)
-{
-    uint64_t code_off[kBuildBatch + 1];
-    code_off[0] = 0;
-    for (uint32_t g = 0; g < n; ++g)
-        code_off[g + 1] = (code_off[g] + (h_off[g + 1] - h_off[g] + 1) / 2 + 16 + 15) / 16 * 16;
-    MK_HIP(hipMemcpyAsync(c->d_code_off, code_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    return MK_OK;
-}
-
 // bytes of the coarse summary level: one bit per 2048 cells, written 16 bits per wave of bloom_summary_kernel
 uint64_t bloom_summary_bytes(const mk_ctx *c)
 {
@@ -289,7 +260,6 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
             if (!c->d_pk_off[b]) MK_TRY(dev_alloc(&c->d_pk_off[b], kBuildBatch + 1));
             if (!c->d_heads[b]) MK_TRY(dev_alloc(&c->d_heads[b], (uint64_t)kBuildBatch * 32));
         }
-    if (!for_append) MK_TRY(ensure_codes(c, seq_bytes));
     if (seq_bytes > c->seq_cap[buf]) {                             // never the buffer of the batch in flight
         const uint64_t old_cap = c->seq_cap[buf];
         dev_free(c->d_seq[buf]);
@@ -304,7 +274,7 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
 // Offsets of a batch's sequences in its packed form (mk_ctx::d_pk): 8 bytes of codes per 32 positions plus
 // 32 bytes of slack each (the kernels read whole words past a sequence's end), 16-byte aligned so that half an
 // offset -- the sequence's place among the exception bits -- is 8-byte aligned.  Returns the bytes of codes.
-static uint64_t packed_offsets(const uint64_t *h_off, uint32_t n, uint64_t *pk_off)
+uint64_t packed_offsets(const uint64_t *h_off, uint32_t n, uint64_t *pk_off)
 {
     pk_off[0] = 0;
     for (uint32_t g = 0; g < n; ++g)
@@ -314,7 +284,7 @@ static uint64_t packed_offsets(const uint64_t *h_off, uint32_t n, uint64_t *pk_o
 
 // room for a batch of `code_bytes` of codes (+ half as many bytes of exception bits) in packed buffer `buf`
 // (never the buffer of the batch in flight)
-static int ensure_packed(mk_ctx *c, int buf, uint64_t code_bytes)
+int ensure_packed(mk_ctx *c, int buf, uint64_t code_bytes)
 {
     if (code_bytes <= c->pk_cap[buf]) return MK_OK;
     const uint64_t old_cap = c->pk_cap[buf];
@@ -440,7 +410,7 @@ static int build_from_characters(mk_ctx *c)
     { ScopedTimer t(c, 3); MK_TRY(launch_genome_sketch(c, d_seq, c->d_seq_off, b.off, c->d_seed_valid, n, c->d_tables)); }
     ScopedTimer t(c, 4);
     MK_TRY(launch_finalize(c, c->d_tables, n, b.g0, nullptr));
-    return launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr, nullptr, nullptr);
+    return launch_bloom_insert(c, c->d_tables, d_seq, c->d_seq_off, c->d_seed_valid, n, nullptr);
 }
 
 // Wait for one batch whose back stage is queued and fold it into the index (Miekki.cpp:303-311); oldest first.
@@ -998,7 +968,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     memset(c->side, 0, sizeof c->side);
     c->h_img = nullptr;
     memset(&c->front, 0, sizeof c->front);
-    c->d_codes = nullptr; c->d_codes2 = nullptr; c->d_dirty = nullptr; c->codes_cap = 0; c->d_code_off = nullptr; c->d_bloom_full = nullptr; c->d_bloom_full2 = nullptr; c->bloom_full_stale = true;
+    c->d_dirty = nullptr; c->d_bloom_full = nullptr; c->d_bloom_full2 = nullptr; c->bloom_full_stale = true;
     memset(&c->build, 0, sizeof c->build);
     memset(&c->older, 0, sizeof c->older);
     c->G_back = 0;
@@ -1011,8 +981,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->exact_have_B = false; c->exact_nB = 0; c->exact_log2B = 0;
     c->d_qarena = nullptr; c->qarena_cap = 0; c->qarena_busy = false;
     c->h_stage = nullptr; c->stage_cap = 0; c->h_res = nullptr; c->res_cap = 0;
-    c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_slots = nullptr; c->slots_cap = 0;
-    c->d_slot_counts = nullptr; c->slot_counts_cap = 0; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
+    c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
     c->d_fpT = nullptr; c->d_posted_blk = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
@@ -1065,12 +1034,11 @@ void mk_destroy(mk_ctx *c)
         if (sd.ev_front) (void)hipEventDestroy(sd.ev_front);
         if (sd.ev_back) (void)hipEventDestroy(sd.ev_back);
     }
-    dev_free(c->d_codes); dev_free(c->d_codes2); dev_free(c->d_code_off); dev_free(c->d_bloom_full); dev_free(c->d_bloom_full2);
+    dev_free(c->d_bloom_full); dev_free(c->d_bloom_full2);
     dev_free(c->d_bloom_order); dev_free(c->d_tables);
     for (int b = 0; b < 2; ++b) { dev_free(c->d_pk[b]); dev_free(c->d_pk_off[b]); dev_free(c->d_heads[b]); }
     dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_scores);
-    dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_slots);
-    dev_free(c->d_slot_counts); dev_free(c->d_partials);
+    dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_partials);
     dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_posted_blk);
     dev_free(c->d_qarena);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

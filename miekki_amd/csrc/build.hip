@@ -16,6 +16,7 @@
 //                      bytes, sketch_size / cardinality sums, Bloom pass A for the
 //                      flagged ones                                                     (A4, A7, A9)
 // followed by fp_transpose_kernel, bloom_kernel<true> and bloom_summary_kernel (sketch.hip).
+// Runs of long queries take the same kernels (launch_query_tables): no flags, the reduce kernel leaves the keys in a table.
 //
 // Selection rule: in every partition the k-mer with the smallest
 // fingerprint wins, the earliest position among equals; "empty" can never be stored.
@@ -166,6 +167,7 @@ struct BuildShape {
     uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no item reads
     uint32_t sum_words;            // 64-bit words of the Bloom summary the scatter kernel consults (one bit per 2048 cells); 0: none
     uint32_t bloom_on;             // the index has a Bloom filter (and pass A is not switched off): items get flagged
+    uint32_t tables_only;          // query sketches: the reduce kernel leaves the minimum keys in `tables` and nothing else
 };
 
 // Item: W == 1: fingerprint << 24 | partition in bin << 12 | position in segment  (32 bits);
@@ -528,6 +530,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         }
     }
     __syncthreads();
+    if (bs.tables_only) {
+        // a run of long queries: the minimum keys as the gating kernels of sketch.hip read them, nothing else
+#pragma unroll
+        for (uint32_t j = 0; j < kWin; ++j) {
+            const uint32_t i = threadIdx.x + kThreads * j;
+            if (i >= R) continue;
+            const key_t key = table[i];
+            tables[(uint64_t)g * sp.P + (uint64_t)bin * R + i] =
+                key == kNoKey ? kEmptyKey : ((uint64_t)(key >> kKeyPos) << kPosBits) | ((uint64_t)key & ((1ULL << kKeyPos) - 1));
+        }
+        return;
+    }
     // which winners are flagged items: a noted item whose position is its partition's minimum
     const uint32_t n_seen = n_noted;
     const bool check_all = n_seen > kNoted;
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
 // ---------------------------------------------------------------- host side
 // shape of the build for a batch, and side b's slot memory; *fits = false when the batch does not suit the
 // bins (the caller then takes the atomic kernel, from characters)
-static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, BuildShape &bs, bool *fits, bool *key32)
+static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, BuildShape &bs, bool *fits, bool *key32, bool for_queries)
 {
     *fits = false;
     uint64_t max_nk = 0, max_len = 0;
@@ -624,7 +638,8 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     // the scatter kernel flags the k-mers that may still have work to do in the Bloom filter; it asks the filter's coarse
     // summary (one bit per 2048 cells, bloom_summary_bytes: 4 KiB at -b 33), which rides in its LDS when it is at most 8 KiB
     // -- a larger one is not consulted and every item counts as flagged
-    bs.bloom_on = c->d_bloom && !(tune & 1u) ? 1u : 0u;
+    bs.tables_only = for_queries ? 1u : 0u;
+    bs.bloom_on = c->d_bloom && !(tune & 1u) && !for_queries ? 1u : 0u;   // (a query's k-mers are gated, not inserted)
     bs.sum_words = 0;
     if (bs.bloom_on && bloom_summary_bytes(c) <= 8192) bs.sum_words = (uint32_t)((bloom_summary_bytes(c) + 7) / 8);
     bs.low_bits = std::min<uint32_t>(c->p.h, kBin);
@@ -685,23 +700,23 @@ void use_build_side(mk_ctx *c, int b)
 }
 
 int launch_pack(mk_ctx *c, int b, const char *d_seq, const uint64_t *h_off, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
-                const uint64_t *d_code_off)
+                const uint64_t *d_code_off, hipStream_t st)
 {
     uint64_t max_len = 0;
     for (uint32_t g = 0; g < n; ++g) max_len = std::max(max_len, h_off[g + 1] - h_off[g]);
     if (!n || !max_len) return MK_OK;
     const uint64_t words = (max_len + 31) / 32;
-    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->front_stream, d_seq, c->side[b].d_seq_off,
+    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, st ? st : c->front_stream, d_seq, c->side[b].d_seq_off,
                        n, d_codes, d_except, d_code_off, c->side[b].d_counters->dirty);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
 int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
-                    const uint64_t *d_code_off)
+                    const uint64_t *d_code_off, hipStream_t st)
 {
     if (!n) return MK_OK;
-    hipLaunchKernelGGL(seed_fix_kernel, dim3((n + 63) / 64), dim3(64), 0, c->front_stream, d_seq, c->side[b].d_seq_off, d_heads, n,
+    hipLaunchKernelGGL(seed_fix_kernel, dim3((n + 63) / 64), dim3(64), 0, st ? st : c->front_stream, d_seq, c->side[b].d_seq_off, d_heads, n,
                        c->p.k, d_codes, d_except, d_code_off, c->side[b].d_seed_valid);
     MK_HIP(hipGetLastError());
     return MK_OK;
@@ -732,13 +747,13 @@ int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_exc
 static void shape_store(mk_ctx::BuildSide &sd, const BuildShape &bs)
 {
     sd.shape[0] = bs.nbins; sd.shape[1] = bs.low_bits; sd.shape[2] = bs.lpr; sd.shape[3] = bs.nwg; sd.shape[4] = bs.tune;
-    sd.shape[5] = bs.sum_words; sd.shape[6] = bs.bloom_on;
+    sd.shape[5] = bs.sum_words; sd.shape[6] = bs.bloom_on; sd.shape[7] = bs.tables_only;
 }
 static BuildShape shape_load(const mk_ctx::BuildSide &sd)
 {
     BuildShape bs;
     bs.nbins = sd.shape[0]; bs.low_bits = sd.shape[1]; bs.lpr = sd.shape[2]; bs.nwg = sd.shape[3]; bs.tune = sd.shape[4];
-    bs.sum_words = sd.shape[5]; bs.bloom_on = sd.shape[6];
+    bs.sum_words = sd.shape[5]; bs.bloom_on = sd.shape[6]; bs.tables_only = sd.shape[7];
     return bs;
 }
 // the meta words lie behind the side's item array (build_setup)
@@ -751,14 +766,14 @@ static uint32_t *meta_of(const mk_ctx *c, const mk_ctx::BuildSide &sd, const Bui
 
 // Front stage: the scatter kernel of a batch, on the front stream, into side b's slots.
 int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off,
-                       const uint64_t *h_off, uint32_t n, bool *used)
+                       const uint64_t *h_off, uint32_t n, bool *used, hipStream_t st, bool for_queries)
 {
     *used = false;
     mk_ctx::BuildSide &sd = c->side[b];
     sd.fits = false;
     if (!n) return MK_OK;
     BuildShape bs;
-    MK_TRY(build_setup(c, b, h_off, n, bs, &sd.fits, &sd.key32));
+    MK_TRY(build_setup(c, b, h_off, n, bs, &sd.fits, &sd.key32, for_queries));
     if (!sd.fits) return MK_OK;
     shape_store(sd, bs);
     const SketchParams sp = make_sp(c);
@@ -766,13 +781,51 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
     const size_t lds = (kSeg + 16 / isz) * isz + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
 #define MK_SCATTER(Wv, KB)                                                                                                      \
-    hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, c->front_stream, d_codes, d_except,     \
+    hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, st ? st : c->front_stream, d_codes,     \
+                       d_except,                                                                                                \
                        d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), \
                        meta_of(c, sd, bs, n), reinterpret_cast<const uint32_t *>(c->d_bloom_full2), sp, bs)
     const bool kbig = c->p.k >= 17;
     if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
     else           { if (kbig) MK_SCATTER(2, true); else MK_SCATTER(2, false); }
 #undef MK_SCATTER
+    MK_HIP(hipGetLastError());
+    *used = true;
+    return MK_OK;
+}
+
+int launch_query_tables(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint64_t *d_tables,
+                        bool *used)
+{
+    *used = false;
+    if (!n || n > c->build_batch) return MK_OK;
+    const int b = 0;
+    MK_TRY(ensure_build_side(c, b));
+    mk_ctx::BuildSide &sd = c->side[b];
+    if (!c->d_pk_off[b]) MK_HIP(hipMalloc((void **)&c->d_pk_off[b], (kBuildBatch + 1) * 8));
+    uint64_t pk_off[kBuildBatch + 1];
+    MK_TRY(ensure_packed(c, b, packed_offsets(h_off, n, pk_off)));
+    uint8_t *codes = c->d_pk[b], *except = c->d_pk[b] + c->pk_cap[b];
+    hipStream_t st = c->stream;
+    MK_HIP(hipMemcpyAsync(c->d_pk_off[b], pk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));   // (pageable: the call returns when it is on its way)
+    MK_HIP(hipMemcpyAsync(sd.d_seq_off, d_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, st));
+    MK_TRY(launch_pack(c, b, d_seq, h_off, n, codes, except, c->d_pk_off[b], st));
+    MK_TRY(launch_seed_fix(c, b, d_seq, nullptr, n, codes, except, c->d_pk_off[b], st));
+    bool fits = false;
+    MK_TRY(launch_build_front(c, b, codes, except, c->d_pk_off[b], h_off, n, &fits, st, true));
+    if (!fits) return MK_OK;
+    const BuildShape bs = shape_load(sd);
+    const SketchParams sp = make_sp(c);
+#define MK_QREDUCE(Wv, K32)                                                                                                     \
+    hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, st,                                     \
+                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), codes, except,   \
+                       c->d_pk_off[b], sd.d_counters->dirty, (const uint8_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr,         \
+                       (const uint32_t *)nullptr, (uint8_t *)nullptr, d_tables, (uint8_t *)nullptr, (uint32_t *)nullptr,        \
+                       (unsigned long long *)nullptr, sp, bs)
+    if (c->W == 1) { if (sd.key32) MK_QREDUCE(1, true); else MK_QREDUCE(1, false); }
+    else MK_QREDUCE(2, false);
+#undef MK_QREDUCE
     MK_HIP(hipGetLastError());
     *used = true;
     return MK_OK;

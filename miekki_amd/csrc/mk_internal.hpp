@@ -31,6 +31,7 @@ constexpr uint32_t kShortMax = 4096;     // k-mers a query may have for the in-L
 constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batch
 constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
 constexpr uint64_t kEmptyKey = ~0ULL;
+constexpr int kPosBits = 40;                      // a minimum key in a table: fingerprint << 40 | position
 constexpr int kDefaultCopyStreams = 2;            // copy streams of a packed append (MIEKKI_COPY_STREAMS; see mk_ctx::copy_extra)
 constexpr uint32_t kSlabMaxQueries = 1u << 30;   // queries per launch of the slab schedule (no bound by default; see chunk_queries_slab)
 
@@ -106,14 +107,7 @@ struct mk_ctx {
     uint64_t seq_cap[2];
     int seq_cur;                   // buffer of the batch enqueued last
     uint64_t *d_seq_off;           // kBuildBatch + 1
-    // the batch's sequences once more as 4-bit (forward, reverse) code pairs, written by the
-    // binned sketch for the Bloom pass: 2.5 MB per 5 Mb genome, which stays in one XCD's L2
-    // while that genome's winners are looked up (the characters, 5 MB, do not)
-    uint8_t *d_codes;
-    uint8_t *d_codes2;             // the same positions as 2-bit forward codes (enough for plain ACGT genomes), at half the offsets
-    uint32_t *d_dirty;             // per batch genome: some character is not A, C, G or T (the 4-bit codes are needed)
-    uint64_t codes_cap;            // bytes
-    uint64_t *d_code_off;          // kBuildBatch + 1 byte offsets (8-byte aligned)
+    uint32_t *d_dirty;             // per batch genome: some character is not A, C, G or T (alias of the side's counters)
     // one bit per 8 Bloom cells: all eight are non-zero (so none of them can change any more).
     // 1 MiB for the 64 MiB of reachable cells at -b 33: L2-resident, and once the filter has
     // filled up it answers almost every probe of the build without touching the cells
@@ -218,11 +212,6 @@ struct mk_ctx {
     uint8_t *h_res;                // pinned
     uint64_t res_cap;
     uint64_t *d_long_table;        // P keys, long-query path
-    // binned genome sketch (sketch.hip, K1): fixed-capacity (genome, bin, workgroup) slots
-    uint64_t *d_slots;
-    uint64_t slots_cap;            // entries
-    uint16_t *d_slot_counts;
-    uint64_t slot_counts_cap;
     uint8_t *d_fpT;                // build: fingerprints of the batch, genome-major [build_batch][P] (fused build kernel)
     uint8_t *d_posted_blk;         // build: per (genome, 256 partitions) "a Bloom first-writer key was posted here"
     uint64_t *d_ovf;               // (genome << 32 | bucket, item) pairs that missed their slot
@@ -296,28 +285,20 @@ int timer_end(mk_ctx *c, Timer &t, hipStream_t stream = nullptr);
 int drain_timers(mk_ctx *c);
 
 // ---- sketch.hip
-int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint32_t n, uint32_t *d_valid);
 int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
                          const uint32_t *d_valid, uint32_t n, uint64_t *d_tables);
-// same result through LDS-binned partitioning; *used = false when the shape does
-// not fit the binned path (the caller then takes the atomic kernel above)
-int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used, bool write_codes = true);
 // d_abort (may be null): the binned sketch's overflow counter; the kernels do nothing if it ran over
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
-bool binned_overflowed(uint32_t ovf_count);
-// d_codes != nullptr: the winners' k-mers are read from the packed code array of the batch
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
-                        const uint64_t *d_code_off);
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort);
 int launch_bloom_summary(mk_ctx *c);
 int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0);     // matrix rows, Bloom pass B, summary (after a fused reduce kernel)
 // ---- build.hip: the index build from packed sequences (2-bit codes + exception bits)
 // (these four run on c->front_stream, on side b's arrays; launch_unpack on c->stream)
 int launch_pack(mk_ctx *c, int b, const char *d_seq, const uint64_t *h_off, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
-                const uint64_t *d_code_off);
+                const uint64_t *d_code_off, hipStream_t st = nullptr);       // st: the front stream unless given
 int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
-                    const uint64_t *d_code_off);
+                    const uint64_t *d_code_off, hipStream_t st = nullptr);
 int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off);
 int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
                   const uint64_t *h_off, uint32_t n, char *d_seq);
@@ -325,16 +306,22 @@ int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_exc
 // the bins, nothing was launched); back stage on c->stream: reduce + fingerprints + sizes + Bloom pass A, matrix rows,
 // Bloom pass B, summary
 int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off,
-                       const uint64_t *h_off, uint32_t n, bool *used);
+                       const uint64_t *h_off, uint32_t n, bool *used, hipStream_t st = nullptr, bool for_queries = false);
+// K1 of a run of long queries through the build's packed kernels (side 0, c->stream; no build is in flight when a query
+// runs): d_tables[q][p] = fingerprint << kPosBits | position of partition p's minimum, kEmptyKey where there is none; the
+// queries' packed form stays in c->d_pk[0] (offsets c->d_pk_off[0], "has exceptions" flags in side 0's counters) for the
+// kernels that gate the winners.  *used = false: the shape does not fit the bins, nothing was written.
+int launch_query_tables(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n, uint64_t *d_tables,
+                        bool *used);
+uint64_t packed_offsets(const uint64_t *h_off, uint32_t n, uint64_t *pk_off);
+int ensure_packed(mk_ctx *c, int buf, uint64_t code_bytes);
 int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, uint32_t n,
                       uint32_t g0);
 int ensure_build_side(mk_ctx *c, int b);
 void use_build_side(mk_ctx *c, int b);       // point the aliases (d_counters, ...) at side b
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
 // api.hip: scratch shared by the build and the long-query sketches
-int ensure_codes(mk_ctx *c, uint64_t seq_bytes);
 int ensure_build_counters(mk_ctx *c);
-int upload_code_offsets(mk_ctx *c, const uint64_t *h_off, uint32_t n);
 int ensure_bloom_summary(mk_ctx *c);
 int ensure_bloom_summary_arrays(mk_ctx *c);           // allocated and zeroed ("nothing is full"), not computed
 uint64_t bloom_summary_bytes(const mk_ctx *c);         // of the coarse level: one bit per 2048 cells

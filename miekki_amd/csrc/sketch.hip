@@ -16,13 +16,13 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "codes.hpp"
 #include "mk_internal.hpp"
 
 namespace mk {
 
 constexpr uint32_t kSegKmers = 4096;   // k-mers per workgroup of the genome sketch
 constexpr uint32_t kPerThread = 16;    // consecutive k-mers per thread (rolling update)
-constexpr int kPosBits = 40;           // key = fingerprint << 40 | position
 
 
 // canonical k-mer starting at sequence position i, read straight from the characters
@@ -68,64 +68,6 @@ __device__ __forceinline__ uint64_t canon_at(const char *__restrict__ seq, uint6
     return S < RC ? S : RC;
 }
 
-// The same canonical k-mer from the packed 4-bit code array of a sequence: 31 nibbles
-// = 124 bits out of three aligned 64-bit words.  Seed positions need no special case,
-// the codes already are what the rolling state saw.  The two 2-bit streams are pulled
-// out of the nibbles 16 codes at a time (the Bloom pass is ALU-bound once its lookups
-// hit L2): `pairs` squeezes the low two bits of every nibble of x together.
-__device__ __forceinline__ uint32_t pairs(uint64_t x)
-{
-    x &= 0x3333333333333333ULL;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
-    return (uint32_t)(x | (x >> 16));
-}
-
-__device__ __forceinline__ uint64_t canon_from_codes(const uint8_t *__restrict__ codes, uint64_t pos, uint32_t k)
-{
-    const uint64_t byte = pos >> 1;
-    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(codes) + (byte >> 3);
-    const uint32_t sh = (uint32_t)(byte & 7u) * 8u + (uint32_t)(pos & 1u) * 4u;        // 0..60
-    // two loads, not three: every load of every lane is a request of its own at the L2, and
-    // the request rate of the L2 is what bounds this pass
-    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
-    const u64x2_a8 x01 = *reinterpret_cast<const u64x2_a8 *>(w);
-    const uint64_t x0 = x01.x, x1 = x01.y, x2 = w[2];
-    const uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;                      // codes 0..15
-    const uint64_t hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;                      // codes 16..31
-    const uint64_t kmask = (1ULL << (2 * k)) - 1;                                      // k <= 31
-    // digit j of the k-mer at bits 2j: that is RC as update_kmer_RC leaves it ...
-    const uint64_t F = (((uint64_t)pairs(hi) << 32) | pairs(lo)) & kmask;
-    const uint64_t RC = (((uint64_t)pairs(hi >> 2) << 32) | pairs(lo >> 2)) & kmask;
-    // ... and S has digit 0 on top: reverse the order of the 2-bit digits
-    uint64_t r = __builtin_bitreverse64(F);
-    r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
-    const uint64_t S = r >> (64 - 2 * k);
-    return S < RC ? S : RC;
-}
-
-// The build's Bloom pass is bound by the L2's request rate (one request per lane-load): for
-// sequences made of A, C, G, T only -- the reverse-strand code is then always 3 - forward code --
-// the forward codes alone, 2 bits per position, say it all, and a k-mer (62 bits) is ONE 16-byte
-// load from an 8-byte boundary instead of two loads from the 4-bit array.  The scatter kernel
-// writes this second array and flags every genome that has any other character (N, lower case:
-// those keep the 4-bit path).
-__device__ __forceinline__ uint64_t canon_from_codes2(const uint8_t *__restrict__ codes2, uint64_t pos, uint32_t k)
-{
-    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(codes2) + (pos >> 5);
-    const uint32_t sh = (uint32_t)(pos & 31u) * 2u;
-    typedef uint64_t __attribute__((ext_vector_type(2), aligned(8))) u64x2_a8;
-    const u64x2_a8 x = *reinterpret_cast<const u64x2_a8 *>(w);
-    const uint64_t kmask = (1ULL << (2 * k)) - 1;
-    const uint64_t F = (sh ? (x.x >> sh) | (x.y << (64 - sh)) : x.x) & kmask;      // digit j of the k-mer at bits 2j
-    const uint64_t RC = ~F & kmask;                                                // 3 - digit, as update_kmer_RC leaves it
-    uint64_t r = __builtin_bitreverse64(F);
-    r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
-    const uint64_t S = r >> (64 - 2 * k);
-    return S < RC ? S : RC;
-}
-
 // ---------------------------------------------------------------- seed validity
 __global__ void seed_valid_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
                                   uint32_t n, uint32_t k, uint32_t *__restrict__ valid)
@@ -137,15 +79,6 @@ __global__ void seed_valid_kernel(const char *__restrict__ seq, const uint64_t *
     uint32_t ok = 1;
     for (uint32_t j = 0; j + 1 < k && j < len; ++j) ok &= seed_code((uint8_t)s[j]) != 4u;
     valid[g] = ok;
-}
-
-int launch_seed_valid(mk_ctx *c, const char *d_seq, const uint64_t *d_off, uint32_t n, uint32_t *d_valid)
-{
-    if (!n) return MK_OK;
-    hipLaunchKernelGGL(seed_valid_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_seq, d_off, n,
-                       c->p.k, d_valid);
-    MK_HIP(hipGetLastError());
-    return MK_OK;
 }
 
 // ---------------------------------------------------------------- K1 genome sketch
@@ -217,300 +150,7 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
     return MK_OK;
 }
 
-// ---------------------------------------------------------------- K1 (binned)
-// The atomic kernel above is bound by the chip's scattered 64-bit atomic rate
-// (~4e10/s), two orders of magnitude below what the hashing itself costs.  The
-// binned form trades the atomics for two streaming passes:
-//   A  every workgroup hashes its 4096 k-mers and drops each (fingerprint,
-//      position, partition) item into the slot of its BIN -- the partition's high
-//      bits -- in a fixed-capacity (genome, bin, workgroup) slot array; the rank
-//      inside the slot comes from an LDS counter, no global atomics;
-//   B  one workgroup per (genome, bin) reads its slots, takes the minimum per
-//      partition with LDS atomics in a 2^13-entry table and streams the table out.
-// Items that find their slot full (possible only for very repetitive sequence) go
-// to an overflow list that pass C folds in with global atomics.  Result: exactly
-// the per-partition minimum of (fingerprint, position), as before.
-constexpr uint32_t kBinBits = 13;                 // partitions per bin = LDS table entries
-constexpr uint32_t kMaxBins = 1024;
-constexpr uint32_t kItemPosBits = 35;
-constexpr uint32_t kOvfCap = 1u << 20;
-
-struct BinParams {
-    uint32_t nbins, low_bits, cap, nwg;           // low_bits = min(h, 13); nwg = workgroups per genome
-    uint32_t tune;                                // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no slot reads
-    uint64_t slots_per_genome;                    // nbins * nwg * cap
-};
-
-// item = fingerprint << 48 | position << 13 | partition-within-bin
-__device__ __forceinline__ uint64_t item_to_key(uint64_t item)
-{
-    return ((item >> 48) << kPosBits) | ((item >> kBinBits) & ((1ULL << kItemPosBits) - 1));
-}
-
-// 16 bytes that hold one 4-bit code each -> one 64-bit word, code j at bits 4j
-__device__ __forceinline__ uint32_t squeeze8(uint64_t x)
-{
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
-    return (uint32_t)(x | (x >> 16));
-}
-
-// What bounds this kernel is not arithmetic but the number of write REQUESTS at the L2: an item
-// stored by each lane to "its" bin is one 8-byte request per k-mer (3.2e8 per 64-genome batch,
-// ~2e11/s -- the rate the Bloom pass ran into as well), and halving the instruction count alone
-// changed nothing (round 2).  So the workgroup sorts its 4096 items by bin in LDS first
-// -- a counting sort whose rank is the LDS atomic the slot position needs anyway -- and writes each
-// bin's run with consecutive lanes: ~32 items = 256 contiguous bytes, four 64-byte requests
-// instead of 32.  The items wait in registers (16 per thread) while the bin counts settle, and go
-// through a 1024-entry stage in four rounds, so that eight workgroups fit a CU.
-// Arithmetic: a character is classified by ONE look-up in a 256-entry LDS table (the compare
-// chains of nuc2int / nuc2intrc cost ~55 instructions per character), the codes are packed 16 per
-// 64-bit word, and a thread fetches its 16 + k-1 positions as three words: the k-1 seed digits and
-// the sixteen incoming digits come out of registers with a handful of shifts (`pairs`, one bit
-// reversal) instead of k-1 + 16 LDS reads and a 30-step seed loop per thread.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bin_scatter_kernel(const char *__restrict__ seq,
-                                                          const uint64_t *__restrict__ off,
-                                                          const uint32_t *__restrict__ valid,
-                                                          uint64_t *__restrict__ slots,
-                                                          uint16_t *__restrict__ slot_counts,
-                                                          uint64_t *__restrict__ ovf, uint32_t *__restrict__ ovf_count,
-                                                          uint8_t *__restrict__ packed, const uint64_t *__restrict__ code_off,
-                                                          uint8_t *__restrict__ packed2, uint32_t *__restrict__ dirty,
-                                                          SketchParams sp, BinParams bp)
-{
-    static_assert(kPerThread == 16 && kSegKmers == 256 * kPerThread, "one 64-bit word of 4-bit codes per thread");
-    constexpr uint32_t kWords = kSegKmers / 16 + 2;                  // words a workgroup's threads look at
-    // items per write-out round.  Measured (round 2, 64 x 5 Mb per batch): 4096 (one round, 3 workgroups
-    // per CU) 15.9k sketches/s, 2048 17.7k, 1024 with the registers held to 64 (8 workgroups per CU, the
-    // most the SIMDs take) 19.6k: the kernel lives on occupancy -- its LDS atomics and barriers are
-    // latency, not throughput -- and the extra rounds cost less than the waves they make room for
-    constexpr uint32_t kStage = 1024;
-    __shared__ __attribute__((aligned(16))) uint64_t stage[kStage];  // first the character codes, later the sorted items
-    __shared__ uint64_t pk[kWords + 2];
-    __shared__ uint32_t bin_count[kMaxBins];
-    __shared__ uint32_t bin_start[kMaxBins];
-    __shared__ uint32_t wave_sum[4];
-    __shared__ uint8_t lut[256];
-    uint8_t *codes = reinterpret_cast<uint8_t *>(stage);             // kWords * 16 bytes, dead once pk is built
-    static_assert(kWords * 16 <= kStage * 8, "codes fit the stage");
-    const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
-    const uint64_t len = off[g + 1] - off[g];
-    const uint64_t nk = len > sp.k ? len - sp.k : 0;
-    const uint64_t seg0 = (uint64_t)wg * kSegKmers;
-    lut[tid] = (uint8_t)(fwd_code((uint8_t)tid) | (rc_code((uint8_t)tid) << 2));   // nuc2int / nuc2intrc, once per character value
-    for (uint32_t b = tid; b < bp.nbins; b += 256) bin_count[b] = 0;
-    __syncthreads();
-    uint32_t cnt = 0, nchar = 0;
-    if (seg0 < nk) {
-        cnt = (uint32_t)min((uint64_t)kSegKmers, nk - seg0);
-        nchar = cnt + sp.k - 1;
-        const char *__restrict__ s = seq + off[g];
-        for (uint32_t j = tid; j < nchar; j += 256) codes[j] = lut[(uint8_t)s[seg0 + j]];
-        for (uint32_t j = nchar + tid; j < kWords * 16u; j += 256) codes[j] = 0;
-        // the k-1 characters of the sequence's seed go through str2numstrand / rcb instead
-        // (Miekki.cpp:158-164): only the first workgroup of a genome sees them
-        if (seg0 == 0 && tid + 1 < sp.k && tid < nchar) codes[tid] = (uint8_t)pos_codes((uint8_t)s[tid], tid, sp.k, valid[g] != 0);
-    }
-    __syncthreads();
-    if (cnt) {
-        auto pack_word = [&](uint32_t w) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(codes + 16u * w);
-            return (uint64_t)squeeze8(((uint64_t)v.y << 32) | v.x) | ((uint64_t)squeeze8(((uint64_t)v.w << 32) | v.z) << 32);
-        };
-        // this workgroup's own 4096 positions as 4-bit (forward, reverse) codes: what the Bloom
-        // pass reads back for the winners.  The k-1 characters past them belong to the next
-        // workgroup -- or to this one if it is the sequence's last.
-        uint64_t *__restrict__ dst = packed ? reinterpret_cast<uint64_t *>(packed + code_off[g] + seg0 / 2) : nullptr;
-        // ... and once more as 2-bit forward codes (canon_from_codes2), with the genome flagged as soon
-        // as one position is not plain A, C, G, T (reverse code != 3 - forward code)
-        uint32_t *__restrict__ dst2 = packed2 ? reinterpret_cast<uint32_t *>(packed2 + code_off[g] / 2 + seg0 / 4) : nullptr;
-        auto emit = [&](uint32_t w, uint64_t word) {
-            if (dst) dst[w] = word;
-            if (dst2) {
-                const uint32_t f2 = pairs(word), r2 = pairs(word >> 2);
-                dst2[w] = f2;
-                const uint32_t nd = min(16u, nchar - 16u * w);
-                const uint32_t m = nd == 16u ? 0xffffffffu : (1u << (2u * nd)) - 1u;
-                if (((f2 ^ r2) & m) != m) atomicOr(&dirty[g], 1u);
-            }
-        };
-        const uint64_t mine = pack_word(tid);
-        pk[tid] = mine;
-        if (16u * tid < nchar) emit(tid, mine);
-        if (tid < 2) {
-            const uint64_t extra = pack_word(256 + tid);
-            pk[256 + tid] = extra;
-            if (seg0 + cnt == nk && kSegKmers + 16u * tid < nchar) emit(256 + tid, extra);
-        }
-    }
-    __syncthreads();
-    // ---- hash: sixteen items per thread, kept in registers.  Register item:
-    //      fingerprint << 48 | rank in bin << 35 | bin << 25 | position in segment << 13 | partition in bin
-    const uint32_t i0 = tid * kPerThread;
-    uint64_t reg[kPerThread];
-#pragma unroll
-    for (uint32_t u = 0; u < kPerThread; ++u) reg[u] = ~0ULL;
-    if (i0 < cnt) {
-        const uint64_t w0 = pk[tid], w1 = pk[tid + 1], w2 = pk[tid + 2];
-        // digit j of the thread's 48 positions at bits 2j: forward codes (F) and reverse-strand codes (R)
-        const uint64_t F = ((uint64_t)pairs(w1) << 32) | pairs(w0), R = ((uint64_t)pairs(w1 >> 2) << 32) | pairs(w0 >> 2);
-        const uint32_t F2 = pairs(w2), R2 = pairs(w2 >> 2);
-        const uint32_t km1 = sp.k - 1;                            // 1..30 digits of seed
-        const uint64_t seedmask = (1ULL << (2 * km1)) - 1;
-        // state after the k-1 seed digits, as the reference's loop leaves it (Miekki.cpp:158-164)
-        uint64_t r = __builtin_bitreverse64(F & seedmask);
-        r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
-        const uint64_t S0 = r >> (64 - 2 * km1), RC0 = (R & seedmask) << 2;
-        // the sixteen digits that enter, one per k-mer
-        const uint32_t fnew = (uint32_t)((F >> (2 * km1)) | ((uint64_t)F2 << (64 - 2 * km1)));
-        const uint32_t rnew = (uint32_t)((R >> (2 * km1)) | ((uint64_t)R2 << (64 - 2 * km1)));
-        // The rolling state lives in 32-bit halves: a 64-bit shift / add / and is two to four issue
-        // slots on this hardware, a funnel shift (v_alignbit) is one, and the loop is issue-bound.
-        uint32_t Slo = (uint32_t)S0, Shi = (uint32_t)(S0 >> 32), Rlo = (uint32_t)RC0, Rhi = (uint32_t)(RC0 >> 32);
-        const uint32_t mlo = (uint32_t)sp.kmask, mhi = (uint32_t)(sp.kmask >> 32);
-        const uint32_t topshift = 2 * sp.k - 2;                   // even: the entering reverse digit lies within ONE half
-        const bool top_hi = topshift >= 32;
-        const uint32_t tsh = top_hi ? topshift - 32 : topshift;
-        const uint32_t lowmask = (1u << bp.low_bits) - 1u;
-        const uint32_t vmask_hi = (1u << (32 - sp.h)) - 1u;       // h <= 28: the fingerprint's operand is anc's low 64-h bits
-#pragma unroll
-        for (uint32_t u = 0; u < kPerThread; ++u) {
-            Shi = (funnel_shift(Shi, Slo, 30) ) & mhi;                          // update_kmer, Miekki.cpp:51-55
-            Slo = ((Slo << 2) | ((fnew >> (2 * u)) & 3u)) & mlo;
-            Rlo = funnel_shift(Rhi, Rlo, 2);                                    // update_kmer_RC, Miekki.cpp:59-62
-            Rhi >>= 2;
-            const uint32_t rd = ((rnew >> (2 * u)) & 3u) << tsh;
-            if (top_hi) Rhi |= rd; else Rlo |= rd;
-            const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
-            const uint64_t anc = revhash64(S < RC ? S : RC);
-            const uint32_t ahi = (uint32_t)(anc >> 32);
-            const uint32_t bucket = ahi >> (32 - sp.h);                         // Miekki.cpp:169
-            const uint32_t fp = mantis_halves(ahi & vmask_hi, (uint32_t)anc, sp.h, sp.f, sp.empty);
-            if (fp == sp.empty || i0 + u >= cnt) continue;          // (past the segment's end only in a sequence's last workgroup)
-            const uint32_t bin = bucket >> bp.low_bits;
-            const uint32_t rank = atomicAdd(&bin_count[bin], 1u);
-            if (rank < bp.cap) {
-                // two words built side by side: fingerprint << 16 | rank << 3 | bin >> 7   and   bin << 25 | position << 13 | partition
-                const uint32_t hi32 = (fp << 16) | (rank << 3) | (bin >> 7);
-                const uint32_t lo32 = (bin << 25) | ((i0 + u) << kBinBits) | (bucket & lowmask);
-                reg[u] = ((uint64_t)hi32 << 32) | lo32;
-            } else {                                                // slot full (very repetitive sequence): overflow list
-                const uint32_t o = atomicAdd(ovf_count, 1u);
-                if (o < kOvfCap) {
-                    ovf[2 * (uint64_t)o] = ((uint64_t)g << 32) | bucket;
-                    ovf[2 * (uint64_t)o + 1] = ((uint64_t)fp << 48) | ((seg0 + i0 + u) << kBinBits) | (bucket & lowmask);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- where each bin's run starts among the workgroup's sorted items: exclusive prefix of min(count, cap)
-    {
-        uint32_t c4[4], sum = 0;
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t b = tid * 4 + e;
-            c4[e] = b < bp.nbins ? min(bin_count[b], bp.cap) : 0u;
-            sum += c4[e];
-        }
-        uint32_t incl = sum;
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-        for (uint32_t o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        uint32_t base = incl - sum;
-        for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t b = tid * 4 + e;
-            if (b < bp.nbins) bin_start[b] = base;
-            base += c4[e];
-        }
-    }
-    __syncthreads();
-    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
-    uint64_t *__restrict__ gslots = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)wg * bp.cap;
-    const uint32_t bin_stride = bp.nwg * bp.cap;                  // < 2^24 (binned_setup checks)
-    for (uint32_t h0 = 0; h0 < total; h0 += kStage) {             // wave-uniform trip count
-#pragma unroll
-        for (uint32_t u = 0; u < kPerThread; ++u) {
-            if (reg[u] == ~0ULL) continue;
-            const uint32_t d = bin_start[(uint32_t)(reg[u] >> 25) & 1023u] + ((uint32_t)(reg[u] >> 35) & 4095u);
-            if (d - h0 < kStage) stage[d - h0] = reg[u];          // (d < h0 wraps around to a huge value)
-        }
-        __syncthreads();
-        const uint32_t m = min(kStage, total - h0);
-        for (uint32_t i = tid; i < m; i += 256) {
-            const uint64_t it = stage[i];
-            const uint32_t bin = (uint32_t)(it >> 25) & 1023u, rank = (uint32_t)(it >> 35) & 4095u;
-            const uint64_t pos = seg0 + ((uint32_t)(it >> kBinBits) & 4095u);
-            // consecutive i of one bin are consecutive ranks: consecutive lanes write consecutive words
-            gslots[__umul24(bin, bin_stride) + rank] = (it & 0xffff000000000000ULL) | (pos << kBinBits) | (it & ((1u << kBinBits) - 1u));
-        }
-        __syncthreads();
-    }
-    uint16_t *__restrict__ gc = slot_counts + (uint64_t)g * bp.nbins * bp.nwg;
-    for (uint32_t b = tid; b < bp.nbins; b += 256)
-        gc[(uint64_t)b * bp.nwg + wg] = (uint16_t)min(bin_count[b], bp.cap);
-}
-
-__global__ __launch_bounds__(1024) void bin_reduce_kernel(const uint64_t *__restrict__ slots,
-                                                          const uint16_t *__restrict__ slot_counts,
-                                                          uint64_t *__restrict__ tables, SketchParams sp, BinParams bp)
-{
-    __shared__ unsigned long long table[1u << kBinBits];
-    const uint32_t bin = blockIdx.x, g = blockIdx.y;
-    const uint32_t R = 1u << bp.low_bits;
-    for (uint32_t i = threadIdx.x; i < R; i += 1024) table[i] = kEmptyKey;
-    __syncthreads();
-    const uint64_t *__restrict__ base = slots + (uint64_t)g * bp.slots_per_genome + (uint64_t)bin * bp.nwg * bp.cap;
-    const uint16_t *__restrict__ cnts = slot_counts + ((uint64_t)g * bp.nbins + bin) * bp.nwg;
-    // one wave per slot, eight slots in flight per wave: the used prefix of a slot is a
-    // short contiguous run, and independent loads are what hides the HBM latency here
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    constexpr uint32_t NW = 16, UN = 8;
-    for (uint32_t w0 = wave; w0 < bp.nwg; w0 += NW * UN) {
-        uint32_t cw[UN];
-        uint64_t item[UN];
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u) {
-            const uint32_t w = w0 + u * NW;
-            cw[u] = w < bp.nwg ? cnts[w] : 0u;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)
-            item[u] = lane < cw[u] ? base[(uint64_t)(w0 + u * NW) * bp.cap + lane] : kEmptyKey;
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)
-            if (item[u] != kEmptyKey) atomicMin(&table[item[u] & (R - 1u)], (unsigned long long)item[u]);
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u)                           // slots longer than a wave (small h)
-            for (uint32_t i = lane + 64; i < cw[u]; i += 64) {
-                const uint64_t it = base[(uint64_t)(w0 + u * NW) * bp.cap + i];
-                atomicMin(&table[it & (R - 1u)], (unsigned long long)it);
-            }
-    }
-    __syncthreads();
-    uint64_t *__restrict__ out = tables + (uint64_t)g * sp.P + (uint64_t)bin * R;
-    for (uint32_t i = threadIdx.x; i < R; i += 1024) {
-        const uint64_t it = table[i];
-        out[i] = it == kEmptyKey ? kEmptyKey : item_to_key(it);
-    }
-}
-
-__global__ void bin_overflow_kernel(const uint64_t *__restrict__ ovf, const uint32_t *__restrict__ ovf_count,
-                                    uint64_t *__restrict__ tables, uint32_t P)
-{
-    const uint32_t n = min(*ovf_count, kOvfCap);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint64_t where = ovf[2 * (uint64_t)i], key = item_to_key(ovf[2 * (uint64_t)i + 1]);
-        atomicMin((unsigned long long *)&tables[(where >> 32) * P + (uint32_t)where], (unsigned long long)key);
-    }
-}
-
+constexpr uint32_t kOvfCap = 1u << 20;            // entries of a build side's scratch list (mk_ctx::BuildSide::d_ovf)
 constexpr uint32_t kOvfScan = 1u << 15;           // overflow items every reduce workgroup of the long-query sketch folds in
 
 // fp_out[n][P] (genome-major, W bytes) -> M[p][g0 .. g0+n): 16-byte loads of one genome's run of
@@ -607,81 +247,10 @@ __global__ __launch_bounds__(256) void fp_transpose_reg_kernel(const uint8_t *__
         *reinterpret_cast<uint32_t *>(mat_row(M, p0 + j, ld) + col) = out[j];
 }
 
-// shape of the binned sketch for a batch, and its scratch; *fits = false when the batch does not
-// suit it (the caller then takes the atomic kernel)
-static int binned_setup(mk_ctx *c, const uint64_t *h_off, uint32_t n, BinParams &bp, bool *fits)
-{
-    *fits = false;
-    uint64_t max_nk = 0, max_len = 0;
-    for (uint32_t g = 0; g < n; ++g) {
-        const uint64_t len = h_off[g + 1] - h_off[g];
-        max_len = std::max(max_len, len);
-        if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
-    }
-    bp.low_bits = std::min<uint32_t>(c->p.h, kBinBits);
-    static const uint32_t tune = [] { const char *e = getenv("MIEKKI_TUNE_BUILD"); return e ? (uint32_t)atoi(e) : 0u; }();
-    bp.tune = tune;
-    bp.nbins = c->P >> bp.low_bits;
-    if (bp.nbins > kMaxBins || max_len >= (1ULL << kItemPosBits) || max_nk == 0) return MK_OK;
-    bp.nwg = (uint32_t)((max_nk + kSegKmers - 1) / kSegKmers);
-    // per (workgroup, bin) the count is ~Poisson(mean): size the slot for mean + 6 sigma
-    const double mean = (double)kSegKmers / bp.nbins;
-    bp.cap = bp.nbins == 1 ? kSegKmers
-                           : std::min<uint32_t>(kSegKmers, (uint32_t)((mean + 6.0 * std::sqrt(mean) + 8.0 + 7.0) / 8.0) * 8u);
-    bp.slots_per_genome = (uint64_t)bp.nbins * bp.nwg * bp.cap;
-    if ((uint64_t)bp.nwg * bp.cap >= (1u << 24)) return MK_OK;     // the scatter kernel's 24-bit slot arithmetic
-    const uint64_t need = bp.slots_per_genome * n;
-    if (need * 8 > (12ull << 30)) return MK_OK;                    // slot memory budget
-    if (need > c->slots_cap) {
-        if (c->d_slots) (void)hipFree(c->d_slots);
-        c->d_slots = nullptr; c->slots_cap = 0;
-        MK_HIP(hipMalloc((void **)&c->d_slots, need * 8));
-        c->slots_cap = need;
-    }
-    const uint64_t ncnt = (uint64_t)n * bp.nbins * bp.nwg;
-    if (ncnt > c->slot_counts_cap) {
-        if (c->d_slot_counts) (void)hipFree(c->d_slot_counts);
-        c->d_slot_counts = nullptr; c->slot_counts_cap = 0;
-        MK_HIP(hipMalloc((void **)&c->d_slot_counts, ncnt * 2));
-        c->slot_counts_cap = ncnt;
-    }
-    MK_TRY(ensure_build_counters(c));                              // counters and the overflow list (kOvfCap entries) of a build side
-    *fits = true;
-    return MK_OK;
-}
-
-int launch_genome_sketch_binned(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
-                                const uint32_t *d_valid, uint32_t n, uint64_t *d_tables, bool *used, bool write_codes)
-{
-    *used = false;
-    if (!n) return MK_OK;
-    BinParams bp;
-    bool fits = false;
-    MK_TRY(binned_setup(c, h_off, n, bp, &fits));
-    if (!fits) return MK_OK;
-    MK_HIP(hipMemsetAsync(c->d_ovf_count, 0, 4, c->stream));
-    const SketchParams sp = make_sp(c);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(bp.nwg, n), dim3(256), 0, c->stream, d_seq, d_off, d_valid,
-                       c->d_slots, c->d_slot_counts, c->d_ovf, c->d_ovf_count, write_codes ? c->d_codes : nullptr,
-                       c->d_code_off, (uint8_t *)nullptr, (uint32_t *)nullptr, sp, bp);
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3(bp.nbins, n), dim3(1024), 0, c->stream, c->d_slots,
-                       c->d_slot_counts, d_tables, sp, bp);
-    hipLaunchKernelGGL(bin_overflow_kernel, dim3(64), dim3(256), 0, c->stream, c->d_ovf, c->d_ovf_count, d_tables,
-                       c->P);
-    MK_HIP(hipGetLastError());
-    // A full overflow list would lose items.  Nothing waits for that here: the later
-    // kernels of the batch look at *d_ovf_count themselves and do nothing if it ran over,
-    // and the host, which reads the count back with the batch's results, then redoes the
-    // batch with the atomic kernel (binned_overflowed).
-    *used = true;
-    return MK_OK;
-}
-
 template <bool WRITE>
 __global__ void bloom_kernel(uint64_t *__restrict__ tables, const char *__restrict__ seq, const uint64_t *__restrict__ off,
                              const uint32_t *__restrict__ valid, uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
-                             const uint32_t *__restrict__ ovf_count, const uint8_t *__restrict__ codes,
-                             const uint64_t *__restrict__ code_off, const uint32_t *__restrict__ full,
+                             const uint32_t *__restrict__ ovf_count, const uint32_t *__restrict__ full,
                              const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp, uint32_t span);
 
 // What follows the fused reduce kernel of a batch (this file's or build.hip's): the batch's fingerprints
@@ -711,7 +280,7 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
         const uint32_t nblk = (c->P + 255) / 256, span = 16;
         hipLaunchKernelGGL(bloom_kernel<true>, dim3((nblk + span - 1) / span, n), dim3(256), 0, c->stream, c->d_tables, (const char *)nullptr,
                            (const uint64_t *)nullptr, (const uint32_t *)nullptr, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order,
-                           c->d_ovf_count, (const uint8_t *)nullptr, (const uint64_t *)nullptr, c->d_bloom_full, c->d_posted_blk,
+                           c->d_ovf_count, c->d_bloom_full, c->d_posted_blk,
                            kOvfScan, sp, span);
         MK_HIP(hipGetLastError());
         MK_TRY(launch_bloom_summary(c));
@@ -719,8 +288,6 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
-
-bool binned_overflowed(uint32_t ovf_count) { return ovf_count > kOvfCap; }
 
 // ---------------------------------------------------------------- K2 finalize
 // tables[n][P] -> M[p][g0 .. g0+n) (transposed through LDS), plus per-genome
@@ -821,8 +388,6 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
                                                     const uint32_t *__restrict__ valid, uint8_t *bloom,
                                                     uint64_t bloom_dev_bytes, uint64_t *order,
                                                     const uint32_t *__restrict__ ovf_count,
-                                                    const uint8_t *__restrict__ codes,
-                                                    const uint64_t *__restrict__ code_off,
                                                     const uint32_t *__restrict__ full,
                                                     const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit,
                                                     SketchParams sp, uint32_t span)
@@ -846,8 +411,7 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
         // pass A: the (fingerprint, position) key has served finalize; replace it by
         // the winner's canonical k-mer so that pass B need not touch the sequence again
         const uint64_t pos = key & ((1ULL << kPosBits) - 1);
-        canon = codes ? canon_from_codes(codes + code_off[g], pos, sp.k)
-                      : canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
+        canon = canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
     } else {
         canon = key;
     }
@@ -981,16 +545,15 @@ int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d
 }
 
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
-                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort, const uint8_t *d_codes,
-                        const uint64_t *d_code_off)
+                        const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort)
 {
     if (!n || !c->d_bloom) return MK_OK;
     dim3 grid((c->P + 255) / 256, n);
     hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort,
                        c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
     hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort, d_codes, d_code_off,
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort,
                        c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
     MK_HIP(hipGetLastError());
     return launch_bloom_summary(c);
@@ -1270,7 +833,9 @@ int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q)
 constexpr uint32_t kCountStride = 32;             // u32 words between two queries' counters
 __global__ __launch_bounds__(256) void long_compact_batch_kernel(const uint64_t *__restrict__ tables,
                                                                  const uint8_t *__restrict__ codes,
+                                                                 const uint8_t *__restrict__ except,
                                                                  const uint64_t *__restrict__ code_off,
+                                                                 const uint32_t *__restrict__ dirty,
                                                                  const uint8_t *__restrict__ bloom,
                                                                  uint64_t bloom_dev_bytes,
                                                                  const uint32_t *__restrict__ full,
@@ -1288,7 +853,10 @@ __global__ __launch_bounds__(256) void long_compact_batch_kernel(const uint64_t 
         const uint64_t key = __builtin_nontemporal_load(tables + (uint64_t)g * sp.P + p);
         if (key != kEmptyKey) {
             fp = (uint32_t)(key >> kPosBits);
-            const uint64_t canon = canon_from_codes(codes + code_off[g], key & ((1ULL << kPosBits) - 1), sp.k);
+            // (the queries' packed form, as the build's kernels left it: launch_query_tables)
+            const uint64_t canon = canon_from_packed(reinterpret_cast<const uint64_t *>(codes + code_off[g]),
+                                                     reinterpret_cast<const uint64_t *>(except + code_off[g] / 2), dirty[g] != 0,
+                                                     key & ((1ULL << kPosBits) - 1), sp.k);
             keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2, full);
         }
     }
@@ -1315,22 +883,16 @@ __global__ void spread_counts_kernel(const uint32_t *__restrict__ counters, uint
 int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t n, bool *done)
 {
     *done = false;
-    MK_TRY(launch_seed_valid(c, qs->d_seq, qs->d_off + q0, n, c->d_seed_valid));
-    MK_TRY(ensure_codes(c, qs->h_off[q0 + n] - qs->h_off[q0]));
-    MK_TRY(upload_code_offsets(c, qs->h_off.data() + q0, n));
     bool used = false;
-    MK_TRY(launch_genome_sketch_binned(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, c->d_seed_valid, n,
-                                       c->d_tables, &used, true));
+    MK_TRY(launch_query_tables(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, n, c->d_tables, &used));
     if (!used) return MK_OK;
-    uint32_t novf = 0;
-    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
-    if (binned_overflowed(novf)) return MK_OK;
-    // the overflow list has been folded in (and found short enough): its buffer is free scratch
+    const uint8_t *pk_codes = c->d_pk[0], *pk_except = c->d_pk[0] + c->pk_cap[0];
+    const uint32_t *pk_dirty = c->side[0].d_counters->dirty;
+    // (no build is in flight: a side's overflow list is free scratch)
     uint32_t *counters = reinterpret_cast<uint32_t *>(c->d_ovf);
     MK_HIP(hipMemsetAsync(counters, 0, (size_t)n * kCountStride * 4, c->stream));
     hipLaunchKernelGGL(long_compact_batch_kernel, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, c->d_tables,
-                       c->d_codes, c->d_code_off, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_entries,
+                       pk_codes, pk_except, c->d_pk_off[0], pk_dirty, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_entries,
                        qs->d_ent_off + q0, counters, make_sp(c));
     hipLaunchKernelGGL(spread_counts_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, counters, n, qs->d_nent + q0);
     MK_HIP(hipGetLastError());
@@ -1395,7 +957,9 @@ int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot)
 template <int W>
 __global__ __launch_bounds__(256) void dense_batch_kernel(const uint64_t *__restrict__ tables,
                                                           const uint8_t *__restrict__ codes,
+                                                          const uint8_t *__restrict__ except,
                                                           const uint64_t *__restrict__ code_off,
+                                                          const uint32_t *__restrict__ dirty,
                                                           const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
                                                           const uint32_t *__restrict__ full,
                                                           uint8_t *__restrict__ dense, uint32_t slot0,
@@ -1410,7 +974,9 @@ __global__ __launch_bounds__(256) void dense_batch_kernel(const uint64_t *__rest
     if (p < sp.P) {
         const uint64_t key = __builtin_nontemporal_load(tables + (uint64_t)g * sp.P + p);
         if (key != kEmptyKey) {
-            const uint64_t canon = canon_from_codes(codes + code_off[g], key & ((1ULL << kPosBits) - 1), sp.k);
+            const uint64_t canon = canon_from_packed(reinterpret_cast<const uint64_t *>(codes + code_off[g]),
+                                                     reinterpret_cast<const uint64_t *>(except + code_off[g] / 2), dirty[g] != 0,
+                                                     key & ((1ULL << kPosBits) - 1), sp.k);
             keep = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, revhash64(canon), sp.bloom_log2, full);
             if (keep) fp = (uint32_t)(key >> kPosBits);
         }
@@ -1443,27 +1009,21 @@ int launch_query_sketch_dense_batch(mk_ctx *c, mk_qset *qs, uint32_t slot, uint3
 {
     *done = false;
     const uint32_t q0 = qs->dense_q[slot];
-    MK_TRY(launch_seed_valid(c, qs->d_seq, qs->d_off + q0, n, c->d_seed_valid));
-    MK_TRY(ensure_codes(c, qs->h_off[q0 + n] - qs->h_off[q0]));
-    MK_TRY(upload_code_offsets(c, qs->h_off.data() + q0, n));
     bool used = false;
-    MK_TRY(launch_genome_sketch_binned(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, c->d_seed_valid, n,
-                                       c->d_tables, &used, true));
+    MK_TRY(launch_query_tables(c, qs->d_seq, qs->d_off + q0, qs->h_off.data() + q0, n, c->d_tables, &used));
     if (!used) return MK_OK;
-    uint32_t novf = 0;
-    MK_HIP(hipMemcpyAsync(&novf, c->d_ovf_count, 4, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
-    if (binned_overflowed(novf)) return MK_OK;
+    const uint8_t *pk_codes = c->d_pk[0], *pk_except = c->d_pk[0] + c->pk_cap[0];
+    const uint32_t *pk_dirty = c->side[0].d_counters->dirty;
     const dim3 grid((c->P + 255) / 256, n);
-    // the overflow list has been folded in (and found short enough): its buffer is free scratch
+    // (no build is in flight: a side's overflow list is free scratch)
     uint32_t *partial = reinterpret_cast<uint32_t *>(c->d_ovf);
     if ((uint64_t)grid.x * n * 4 > (uint64_t)kOvfCap * 16) return MK_OK;
     if (c->W == 1)
-        hipLaunchKernelGGL(dense_batch_kernel<1>, grid, dim3(256), 0, c->stream, c->d_tables, c->d_codes, c->d_code_off,
-                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
+        hipLaunchKernelGGL(dense_batch_kernel<1>, grid, dim3(256), 0, c->stream, c->d_tables, pk_codes, pk_except, c->d_pk_off[0],
+                           pk_dirty, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
     else
-        hipLaunchKernelGGL(dense_batch_kernel<2>, grid, dim3(256), 0, c->stream, c->d_tables, c->d_codes, c->d_code_off,
-                           c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
+        hipLaunchKernelGGL(dense_batch_kernel<2>, grid, dim3(256), 0, c->stream, c->d_tables, pk_codes, pk_except, c->d_pk_off[0],
+                           pk_dirty, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, qs->d_dense, slot, partial, make_sp(c));
     hipLaunchKernelGGL(dense_count_kernel, dim3(n), dim3(256), 0, c->stream, partial, grid.x, qs->d_nent + q0);
     MK_HIP(hipGetLastError());
     *done = true;
