@@ -576,13 +576,14 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
     if (!qs->long_q.empty()) {
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-        // neighbours in the set share one binned K1 run and one gate-and-append launch
+        // neighbours in the set share one run of the build's packed kernels and one gate-and-append launch; shapes those
+        // kernels do not take (h > 22) go one by one through the atomic kernel
         MK_TRY(ensure_build_scratch(c, 0, 0, false));
         for (size_t i = 0; i < qs->long_q.size();) {
             uint32_t n = 1;
             while (i + n < qs->long_q.size() && n < c->build_batch && qs->long_q[i + n] == qs->long_q[i] + n) ++n;
             bool done = false;
-            if (n > 1) MK_TRY(launch_query_sketch_long_batch(c, qs, qs->long_q[i], n, &done));
+            MK_TRY(launch_query_sketch_long_batch(c, qs, qs->long_q[i], n, &done));     // (a loner too: a run of one)
             if (!done)
                 for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_long(c, qs, qs->long_q[i + j]));
             i += n;
@@ -591,15 +592,14 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
     if (!qs->dense_q.empty()) {
         if (!c->d_long_table) MK_TRY(dev_alloc(&c->d_long_table, (uint64_t)c->P));
         if (!c->d_seed_valid) MK_TRY(dev_alloc(&c->d_seed_valid, kBuildBatch));
-        // neighbours in the set go through the binned genome sketch together (K1), up to a
-        // build batch at a time; loners and shapes the bins do not fit go one by one
+        // the same for whole-genome (dense) queries, up to a build batch at a time
         MK_TRY(ensure_build_scratch(c, 0, 0, false));
         for (uint32_t slot = 0; slot < qs->dense_q.size();) {
             if (qs->dense_q[slot] == 0xffffffffu) { ++slot; continue; }
             uint32_t n = 1;
             while (slot + n < qs->dense_q.size() && n < c->build_batch && qs->dense_q[slot + n] == qs->dense_q[slot] + n) ++n;
             bool done = false;
-            if (n > 1) MK_TRY(launch_query_sketch_dense_batch(c, qs, slot, n, &done));
+            MK_TRY(launch_query_sketch_dense_batch(c, qs, slot, n, &done));
             if (!done)
                 for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_dense(c, qs, slot + j));
             slot += n;
