@@ -172,6 +172,11 @@ int mk_index_append_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64
 /* columns [p_begin, p_end): (p_end-p_begin) * G * (fp_bits/8) bytes, partition-
  * major, 16-bit values big-endian -- byte-for-byte what dump_disk writes. */
 int mk_index_export_columns(mk_ctx *ctx, uint32_t p_begin, uint32_t p_end, uint8_t *dst);
+/* The columns of n chosen genomes (ids as the context reports them), every partition: dst[p][j] = the
+ * fingerprint of genome ids[j] in partition p, 2^h * n * (fp_bits/8) bytes in dump_disk's byte order --
+ * what dump_disk (Miekki.cpp:665-668) would write as the column block of an index holding just those genomes.
+ * A sample of a 100,000-genome collection costs megabytes this way, not an export of the whole matrix. */
+int mk_index_export_genomes(mk_ctx *ctx, const uint32_t *ids, uint32_t n, uint8_t *dst);
 int mk_index_export_sizes(mk_ctx *ctx, uint64_t *genome_size, uint32_t *sketch_size);
 /* Bloom bytes [begin, end) of the 2^(b-3)-byte table */
 int mk_index_export_bloom(mk_ctx *ctx, uint64_t begin, uint64_t end, uint8_t *dst);

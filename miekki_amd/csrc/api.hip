@@ -1290,6 +1290,45 @@ int mk_index_export_columns(mk_ctx *c, uint32_t pb, uint32_t pe, uint8_t *dst)
     return staged_columns(c, false, pb, pe, dst);
 }
 
+int mk_index_export_genomes(mk_ctx *c, const uint32_t *ids, uint32_t n, uint8_t *dst)
+{
+    if (!c || (n && (!ids || !dst))) { set_error("null argument"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    for (uint32_t j = 0; j < n; ++j)
+        if (ids[j] < c->p.genome_id_base || ids[j] - c->p.genome_id_base >= c->G) { set_error("genome id %u is not in this index", ids[j]); return MK_ERR_ARG; }
+    if (!n) return MK_OK;
+    // in pieces of at most 64 genomes: 2^h x 64 x W bytes of staging (128 MiB at -h 20, 2-byte fingerprints)
+    uint32_t *d_ids = nullptr;
+    uint8_t *d_stage = nullptr;
+    const uint32_t per = std::min<uint32_t>(n, 64);
+    const uint64_t col = (uint64_t)c->P * c->W;
+    std::vector<uint32_t> local(per);
+    std::vector<uint8_t> piece;
+    int rc = dev_alloc(&d_ids, per);
+    if (rc == MK_OK) rc = dev_alloc(&d_stage, col * per);
+    for (uint32_t j0 = 0; j0 < n && rc == MK_OK; j0 += per) {
+        const uint32_t m = std::min(per, n - j0);
+        for (uint32_t j = 0; j < m; ++j) local[j] = ids[j0 + j] - c->p.genome_id_base;
+        if (hipMemcpyAsync(d_ids, local.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+        if (rc == MK_OK) rc = launch_export_genomes(c, d_ids, m, d_stage);
+        if (rc != MK_OK) break;
+        if (m == n) {                                                // one piece: it IS the result
+            if (hipMemcpyAsync(dst, d_stage, col * m, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+            if (rc == MK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+        } else {                                                     // dst[p][j0 .. j0 + m) of rows n genomes wide
+            piece.resize(col * m);
+            if (hipMemcpyAsync(piece.data(), d_stage, col * m, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+            if (rc == MK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
+            if (rc == MK_OK)
+                for (uint32_t p = 0; p < c->P; ++p)
+                    memcpy(dst + ((uint64_t)p * n + j0) * c->W, piece.data() + (uint64_t)p * m * c->W, (size_t)m * c->W);
+        }
+    }
+    if (rc == MK_ERR_DEVICE) set_error("genome column export failed: %s", hipGetErrorString(hipGetLastError()));
+    dev_free(d_ids); dev_free(d_stage);
+    return rc;
+}
+
 int mk_index_export_sizes(mk_ctx *c, uint64_t *genome_size, uint32_t *sketch_size)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }

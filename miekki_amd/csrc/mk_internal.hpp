@@ -338,6 +338,7 @@ int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len,
 int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
                          char *d_out);
 int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging);
+int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t *d_dst);   // d_dst[P][n] (W bytes each, dump byte order)
 inline MatRef mat_ref(const mk_ctx *c);
 
 // ---- scan.hip

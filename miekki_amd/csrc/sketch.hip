@@ -1188,4 +1188,34 @@ int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t
     return MK_OK;
 }
 
+// The columns of n chosen genomes, every partition: dst[p][j] = fingerprint of genome ids[j] in partition p, in the
+// byte order of dump_disk (16-bit values big-endian) -- i.e. the column block an index of just those genomes would
+// dump (Miekki.cpp:665-668).  A sample of a collection's columns then costs n x 2^h x W bytes instead of an
+// export of the whole matrix.
+template <int W>
+__global__ void export_genomes_kernel(MatRef M, uint64_t ld, uint32_t P, const uint32_t *__restrict__ ids, uint32_t n,
+                                      uint8_t *__restrict__ dst)
+{
+    const uint64_t total = (uint64_t)P * n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(idx / n), j = (uint32_t)(idx - (uint64_t)p * n);
+        const uint8_t *m = mat_row(M, p, ld) + (uint64_t)ids[j] * W;
+        uint8_t *d = dst + idx * W;
+        if (W == 1) d[0] = m[0];
+        else { d[0] = m[1]; d[1] = m[0]; }
+    }
+}
+
+int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t *d_dst)
+{
+    if (!n) return MK_OK;
+    const uint64_t total = (uint64_t)c->P * n;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 16384);
+    if (c->W == 1) hipLaunchKernelGGL((export_genomes_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, mat_ref(c), c->ld, c->P, d_ids, n, d_dst);
+    else hipLaunchKernelGGL((export_genomes_kernel<2>), dim3(blocks), dim3(256), 0, c->stream, mat_ref(c), c->ld, c->P, d_ids, n, d_dst);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+
 }  // namespace mk

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mk_host_free": (None, [vp, vp]),
     "mk_index_append_synthetic": (i32, [vp, u64, u32, u64]),
     "mk_index_export_columns": (i32, [vp, u32, u32, vp]),
+    "mk_index_export_genomes": (i32, [vp, vp, u32, vp]),
     "mk_index_export_sizes": (i32, [vp, vp, vp]),
     "mk_index_export_bloom": (i32, [vp, u64, u64, vp]),
     "mk_index_import_begin": (i32, [vp, u32]),

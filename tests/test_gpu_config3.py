@@ -1,0 +1,108 @@
+"""BASELINE config 3 at FULL size on one GPU: 100,000 synthetic 5 Mb genomes at -k 31 -h 20 (a 105 GB fingerprint
+matrix), queries through the slab path -- the configuration the metric is quoted on (it had no parity
+test, only its 12,500-genome shard).  The collection cannot be rebuilt in the oracle; single genomes can
+(gpu_checks.oracle_sample_check, through mk_index_export_genomes: megabytes instead of a 105 GB export), the rest
+are size-independent properties.  Then the same collection as TWO 50,000-genome shards in the one GPU through the
+`miekki` binary's multi-GPU driver (host/multi_gpu.cpp, DeviceGroup) -- the hits must be those of the single context,
+bit for bit, without a rerun (wide rows) or a dense replay at the driver's 96 entrant slots per shard.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+from gpu_checks import oracle_sample_check
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, L_, NQ = 100_000, 5_000_000, 2_400
+HIT = np.dtype([("genome", "<u4"), ("matches", "<u4"), ("jaccard", "<f8"), ("intersection", "<f8")])
+
+
+@pytest.fixture(scope="module")
+def helper(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("c3") / "group_synth")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-I", os.path.join(ROOT, "include"), "-o", out,
+                    os.path.join(ROOT, "tests", "helpers", "group_synth.cpp"), os.path.join(ROOT, "host", "multi_gpu.cpp"),
+                    "-L", os.path.join(ROOT, "miekki_amd"), "-lmiekki_hip", "-lpthread",
+                    "-Wl,-rpath," + os.path.join(ROOT, "miekki_amd")], check=True)
+    return out
+
+
+@pytest.fixture(scope="module")
+def single(tmp_path_factory):
+    """The single-context run: its checks happen here, its hits are kept for the sharded comparison, and the
+    context is closed before anything else wants the GPU's memory."""
+    import miekki_amd
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 150 << 30:
+        pytest.skip("needs a GPU with 150 GB free (the matrix alone is 105 GB)")
+    ix = miekki_amd.Miekki(31, 20, 8, 33, 200)
+    try:
+        ix.reserve(G)
+        for g0 in range(0, G, 4096):
+            ix.insert_synthetic(g0, min(4096, G - g0), L_)
+        assert ix.index_size == G
+        assert (ix.genome_size == L_).all()                             # capped at the sequence length (Miekki.cpp:307)
+        ss = ix.sketch_size
+        assert 1_030_000 < ss.min() and ss.max() < 1_043_000            # 2^20 x (1 - e^-4.47): 15/16 of 5e6 k-mers can be stored, over 2^20 partitions
+        qs = [synth.genome_bases(*synth.query_origin(q, G, L_, 1000), 1000) for q in range(NQ)]
+        ix.reset_stats()
+        hits, active = ix.query(qs, 10, 10, 100.0)                      # query_file's parameters; >= 512 queries: the slab schedule
+        st = ix.stats()
+        assert st["scan_slab_launches"] >= 1 and st["scan_launches"] == st["scan_slab_launches"]
+        assert all(h and h[0].genome == q % G for q, h in enumerate(hits))       # top hit = source genome
+        assert all(h[0].matches > 3 * h[1].matches for h in hits if len(h) > 1)  # ... by a wide margin over chance matches
+        assert 880 < active.mean() < 969
+        scores = ix.query_sequences(qs[:16])                            # plain kernel, dense rows
+        for q in range(16):
+            want = ix.filter_results(scores[q], 10, 10, 100.0)
+            assert [(a.genome, a.matches) for a in hits[q]] == [(b.genome, b.matches) for b in want], q
+            assert all(abs(a.intersection - b.intersection) <= 1e-6 * abs(b.intersection) for a, b in zip(hits[q], want))
+            assert scores[q, q % G] == hits[q][0].matches
+        # eight genomes' columns SHA-equal to the oracle's sketches, eight dense rows equal under the collection's own gate
+        sample = oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                                     synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
+        assert len(sample) == 8
+        flat = np.zeros((NQ, 10), HIT)
+        nh = np.zeros(NQ, np.uint32)
+        for q, h in enumerate(hits):
+            nh[q] = len(h)
+            for i, x in enumerate(h):
+                flat[q, i] = (x.genome, x.matches, x.jaccard, x.intersection)
+    finally:
+        ix.close()
+    return nh, flat
+
+
+def test_config3_full_size_properties(single):
+    nh, flat = single
+    assert (nh >= 1).all() and (nh <= 10).all()
+    inter = flat["intersection"]
+    for q in range(NQ):                                                 # filter_results' order: descending intersection
+        assert (np.diff(inter[q, :nh[q]]) <= 0).all()
+        assert (inter[q, :nh[q]] >= 100.0).all() and (flat["matches"][q, :nh[q]] >= 10).all()
+
+
+def test_config3_two_shards_in_one_gpu(single, helper, tmp_path):
+    nh, flat = single
+    out = str(tmp_path / "hits.bin")
+    env = dict(os.environ, MIEKKI_DEVICES="0,0")
+    env.pop("MIEKKI_SLAB_MIN_QUERIES", None)
+    r = subprocess.run([helper, str(G), str(L_), str(NQ), "1000", "31", "20", "8", "10", "10", "100.0", out],
+                       stdout=subprocess.PIPE, env=env, check=True, timeout=900)
+    words = r.stdout.decode().split()
+    info = dict(zip(words[0::2], (int(x) for x in words[1::2])))
+    assert info["shards"] == 2 and info["total"] == G
+    assert info["rerun"] == 0 and info["replayed"] == 0, info            # 96 entrant slots per shard suffice at this size
+    assert info["gather_bytes"] == NQ * 97 * 8                           # one exchange: the second shard's rows, 8 bytes per slot
+    raw = np.fromfile(out, np.uint8)
+    nh2 = raw[:NQ * 4].view(np.uint32)
+    flat2 = raw[NQ * 4:].view(HIT).reshape(NQ, 10)
+    np.testing.assert_array_equal(nh2, nh)
+    for q in range(NQ):
+        assert flat2[q, :nh[q]].tobytes() == flat[q, :nh[q]].tobytes(), q

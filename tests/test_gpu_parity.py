@@ -313,46 +313,24 @@ def test_sharded_contexts_merge_equals_single_context(hip):
             ix.close()
 
 
-def oracle_sample_check(ix, k, h, fpb, G, L_, queries):
-    """Full-size collections cannot be rebuilt in the oracle, single genomes can: for eight genomes spread over
-    the id range, the column the HIP index holds (every partition, exported through mk_index_export_columns)
-    must be the oracle's sketch of the same synthetic genome, byte for byte; and the dense score rows of
-    `queries` restricted to those genomes must be what the oracle's query_sequences gives over exactly those
-    eight columns UNDER THE COLLECTION'S OWN BLOOM FILTER (exported from the index: the gate depends on all
-    genomes, the scores of a column only on the column and the gate)."""
-    import ctypes as C
-    import struct
-    from oracle import oracle as orc
+from gpu_checks import oracle_sample_check  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["h20", "w16", "messy", "rnd4"])
+def test_export_genomes_is_a_slice_of_the_columns(built, name):
+    """mk_index_export_genomes (a gather of chosen genomes' columns) against mk_index_export_columns (the dump's
+    column block, pinned to the reference's index stream above): any id list, repeats and descending order included."""
+    from gpu_checks import export_genomes
     from miekki_amd import lib as L
-    P, W = 1 << h, fpb // 8
-    sample = sorted({0, 1, G // 3, G // 2, G // 2 + 1, (2 * G) // 3, G - 2, G - 1})
-    o = orc.OracleMiekki(k, h, fpb, 33, 200)
-    want = np.empty((P, len(sample), W), np.uint8)
-    for j, g in enumerate(sample):
-        fp, _, _ = o.minhash_sketch_partition(synth.genome_bases(g, 0, L_))
-        if W == 1:
-            want[:, j, 0] = fp.astype(np.uint8)
-        else:                                                       # big-endian pairs, as add_index stores them (Miekki.cpp:230-231)
-            want[:, j, 0] = (fp >> 8).astype(np.uint8); want[:, j, 1] = (fp & 0xff).astype(np.uint8)
-    got = np.empty_like(want)
-    rows = max(1, min(P, (256 << 20) // (G * W)))
-    buf = np.empty(rows * G * W, np.uint8)
-    for p0 in range(0, P, rows):
-        r = min(rows, P - p0)
-        L.check(ix._lib.mk_index_export_columns(ix._h, p0, p0 + r, buf.ctypes.data))
-        got[p0:p0 + r] = buf[:r * G * W].reshape(r, G, W)[:, sample, :]
-    for j, g in enumerate(sample):
-        assert sha(got[:, j, :].tobytes()) == sha(want[:, j, :].tobytes()), f"column of genome {g}"
-    # an oracle index of just those columns + the collection's Bloom filter
-    ss, gs = ix.sketch_size[sample], ix.genome_size[sample]
-    nb = ix.bloom_size // 8
-    bloom = np.empty(nb, np.uint8)
-    L.check(ix._lib.mk_index_export_bloom(ix._h, 0, nb, bloom.ctypes.data))
-    hdr = struct.pack("<6IQBBIB", k, h, fpb, 5, len(sample), 33, ix.bloom_size, 0, 0, 200, 1)
-    stream = np.concatenate([np.frombuffer(hdr, np.uint8), want.reshape(-1), gs.astype(np.uint64).view(np.uint8), bloom,
-                             ss.astype(np.uint32).view(np.uint8)])
-    o8 = orc.OracleMiekki.deserialize(stream)
-    np.testing.assert_array_equal(ix.query_sequences(queries)[:, sample], o8.query_sequences(queries))
+    case, gold, ix = built(name)
+    G, P, W = ix.index_size, ix.number_minimizer, ix.W
+    full = np.empty(P * G * W, np.uint8)
+    L.check(ix._lib.mk_index_export_columns(ix._h, 0, P, full.ctypes.data))
+    full = full.reshape(P, G, W)
+    for ids in ([0], [G - 1, 0], list(range(G)), [G // 2] * 3 + [0], list(range(G - 1, -1, -1)) * 9):
+        np.testing.assert_array_equal(export_genomes(ix, ids), full[:, ids, :])
+    bad = np.array([G], np.uint32)
+    assert ix._lib.mk_index_export_genomes(ix._h, bad.ctypes.data, 1, full.ctypes.data) == -1
 
 
 def test_config3_shard_scale_properties(hip):
