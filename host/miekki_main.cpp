@@ -16,7 +16,15 @@
 //   * where the reference scales with -t threads inside the one process, this one
 //     scales over the visible GPUs inside the one process (MIEKKI_DEVICES=0,1,..
 //     restricts them): genome shards in list order, one context per GPU
-//     (multi_gpu.hpp); ids, hits and files are those of one GPU.
+//     (multi_gpu.hpp); ids, hits and files are those of one GPU,
+//   * ... or over one PROCESS per GPU with RCCL between them, when a launcher says so:
+//         python -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+//             miekki -l genomes.txt -a queries.fa -o out.txt -h 20
+//     (RANK / WORLD_SIZE / LOCAL_RANK from the environment, or MIEKKI_RANK / MIEKKI_WORLD / MIEKKI_LOCAL_RANK): rank r
+//     indexes the r-th contiguous run of the list on its own GPU, the Bloom filters are folded by one all-reduce,
+//     every rank scans all queries against its shard and ONE ncclGather per batch carries the per-query heap
+//     entrants to rank 0, which merges them on its GPU and writes the files and the banners (the other ranks stay
+//     silent).  -l with -a / -A (and -e); -i and -d need the single-process form.
 #include <getopt.h>
 #include <unistd.h>
 
@@ -254,6 +262,7 @@ struct Driver {
             for (const string &fn : split_lines(text))
                 if (fn.size() > 3) files.push_back(fn);
         }
+        if (rank_world > 1 || forced_rank_mode) { index_file_of_file_ranked(list, have_list, files, devices, make_ctx); return; }
         // genome shards = contiguous runs of the list, one per GPU (never more shards than files)
         const size_t D = std::max<size_t>(1, std::min<size_t>(devices.size(), files.size()));
         vector<mk_ctx *> ctxs;
@@ -290,6 +299,75 @@ struct Driver {
             for (size_t d = 0; d < D; ++d)
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
                      << "s, in mk_index_append " << sb[d].t_append << "s" << endl;
+        finish_index(true);
+        cout << "Reference indexed: " << group.total() << endl;
+        mk_params p;
+        mk_get_params(ctx0(), &p);
+        if (p.bloom_log2) cout << "BF size:" << int_to_string(1ull << p.bloom_log2) << endl;
+    }
+
+    // ---- one process per GPU (RCCL): this process builds the rank_id-th contiguous run of the list
+    int rank_id = 0, rank_world = 1, rank_local = 0;
+    bool forced_rank_mode = false;                // a world of one was asked for explicitly (tests: RCCL on one GPU)
+    string comm_file;
+
+    // rank 0 draws the communicator's id and leaves it in a file the launcher's other children find
+    // (MIEKKI_COMM_FILE, or a name made of the launcher's pid and port): no network code in here
+    mk_comm *make_comm(mk_ctx *ctx)
+    {
+        uint8_t id[MK_COMM_ID_BYTES];
+        if (rank_id == 0) {
+            if (mk_comm_unique_id(id) != MK_OK) die("cannot start RCCL");
+            const string tmp = comm_file + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { cout << "cannot write " << tmp << endl; exit(1); }
+            fclose(f);
+            if (rename(tmp.c_str(), comm_file.c_str()) != 0) { cout << "cannot write " << comm_file << endl; exit(1); }
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 60000 && !got; ++tries) {      // up to ten minutes: rank 0 may still be starting
+                FILE *f = fopen(comm_file.c_str(), "rb");
+                if (f) { got = fread(id, 1, sizeof id, f) == sizeof id; fclose(f); }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            if (!got) { cerr << "rank " << rank_id << ": no communicator id in " << comm_file << endl; exit(1); }
+        }
+        mk_comm *comm = nullptr;
+        if (mk_comm_create(ctx, rank_id, rank_world, id, &comm) != MK_OK) die("cannot create the communicator");
+        if (mk_comm_barrier(comm) != MK_OK) die("communicator barrier failed");
+        if (rank_id == 0) remove(comm_file.c_str());                   // everybody has read it
+        return comm;
+    }
+
+    template <typename MakeCtx>
+    void index_file_of_file_ranked(const string &list, bool have_list, const vector<string> &files, const vector<int> &devices,
+                                   MakeCtx make_ctx)
+    {
+        // the GPU of this rank: the LOCAL_RANK-th of MIEKKI_DEVICES when given, else that ordinal
+        const int device = rank_local < (int)devices.size() ? devices[rank_local] : rank_local;
+        mk_ctx *ctx = make_ctx(device);
+        group.adopt({ctx});
+        group.set_comm(make_comm(ctx));
+        if (!have_list) { cout << "Missed file of file: " << list << endl; finish_index(true); return; }
+        uint64_t b, e;
+        mkhost::shard_range(files.size(), (uint32_t)rank_id, (uint32_t)rank_world, b, e);
+        const vector<string> part(files.begin() + b, files.begin() + e);
+        ShardBuild sb;
+        build_shard(ctx, part, std::max(1u, threads), false, sb);
+        // what the reference prints while it indexes, and the names of the genomes that were kept: every rank's, in
+        // rank order = list order (an error on any rank ends the run on all of them)
+        string err, names;
+        for (const string &n : sb.names) { names += n; names += '\n'; }
+        vector<string> logs, all_names, errors;
+        if (group.all_gather_text(sb.error, errors, err) || group.all_gather_text(sb.log, logs, err) ||
+            group.all_gather_text(names, all_names, err)) { cout << "multi-GPU setup failed: " << err << endl; exit(1); }
+        for (int r = 0; r < rank_world; ++r) {
+            cout << logs[r];
+            if (!errors[r].empty()) { cout << endl << errors[r] << endl; exit(1); }
+            for (const string &n : split_lines(all_names[r]))
+                if (!n.empty()) file_names.push_back(n);
+        }
+        cout << endl;
         finish_index(true);
         cout << "Reference indexed: " << group.total() << endl;
         mk_params p;
@@ -539,7 +617,7 @@ struct Driver {
     mk_ctx *exact_ctx(const vector<Pending> &v, size_t &shard)
     {
         // K7 runs on the GPU that owns the genome (any would do: the sets come from the file itself)
-        shard = v.empty() ? 0 : group.owner(v[0].genome);
+        shard = v.empty() || group.ranked() ? 0 : group.owner(v[0].genome);
         if (resident.size() != group.shards()) resident.assign(group.shards(), string());
         return group.ctx(shard);
     }
@@ -597,6 +675,7 @@ struct Driver {
         vector<mk_hit> hits;
         vector<uint32_t> nhits;
         run_query(seqs, nres, min_score, (double)threshold, hits, nhits);
+        if (!group.root()) return;                                   // (one process per GPU: rank 0 verifies and writes)
         // Same container, same insertion sequence and the same flush-at-100 rule as the
         // reference (Miekki.cpp:728-754, 779-785): with the same libstdc++ the lines of the
         // output file then come out in the reference's order, not just as the same set.
@@ -698,6 +777,13 @@ int main(int argc, char **argv)
         }
     }
     const vector<int> devices = mkhost::device_list();          // every visible GPU, or MIEKKI_DEVICES
+    // one process per GPU?  (a launcher's environment: torch.distributed.run --no-python sets RANK / WORLD_SIZE / LOCAL_RANK)
+    auto env_int = [](const char *a, const char *b, int dflt) { const char *e = getenv(a); if (!e) e = getenv(b); return e ? atoi(e) : dflt; };
+    const int rank_world = env_int("MIEKKI_WORLD", "WORLD_SIZE", 1), rank_id = env_int("MIEKKI_RANK", "RANK", 0);
+    const int rank_local = env_int("MIEKKI_LOCAL_RANK", "LOCAL_RANK", rank_id);
+    const bool rank_mode = rank_world > 1 || getenv("MIEKKI_WORLD") != nullptr;
+    if (rank_mode && (rank_id < 0 || rank_id >= rank_world)) { cout << "rank " << rank_id << " of " << rank_world << "?" << endl; return 1; }
+    if (rank_mode && rank_id != 0) cout.setstate(std::ios_base::badbit);      // rank 0 speaks for all
     const unsigned reader_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(core_number, 64));
     const uint32_t bit_per_min = (uint32_t)(5 + fingerprint_size);                              // main.cpp:184
     cout << "Using " << bit_per_min << " bits per minimizer, " << int_to_string(1ull << H) << " minimizers so "
@@ -705,6 +791,18 @@ int main(int argc, char **argv)
     auto start = chrono::system_clock::now();
     Driver drv;
     drv.threads = reader_threads;
+    if (rank_mode) {
+        if (!index_file.empty() || !index_dump.empty()) {
+            cout << "-i and -d are not available with one process per GPU: run them as a single process (it uses every visible GPU)" << endl;
+            return 1;
+        }
+        drv.rank_id = rank_id; drv.rank_world = rank_world; drv.rank_local = rank_local; drv.forced_rank_mode = true;
+        if (const char *e = getenv("MIEKKI_COMM_FILE")) drv.comm_file = e;
+        else {
+            const char *port = getenv("MASTER_PORT");
+            drv.comm_file = "/tmp/miekki_comm_" + to_string((long)getppid()) + "_" + (port ? port : "0");
+        }
+    }
     if (!index_file.empty()) {
         if (!mkhost::file_exists(index_file)) {
             cout << "File problem" << endl;
@@ -722,7 +820,7 @@ int main(int argc, char **argv)
         cout << "I output results in " << output_file << endl;
         cout << "Load sucessful" << endl;
     } else if (!list_file.empty()) {
-        drv.out.open(output_file.c_str());
+        if (!rank_mode || rank_id == 0) drv.out.open(output_file.c_str());
         cout << "I output results in " << output_file << endl;
         drv.k = (uint32_t)kmer_size; drv.threshold = (uint32_t)threshold;
         drv.index_file_of_file(list_file, devices, [&](int device) {
@@ -766,8 +864,8 @@ int main(int argc, char **argv)
     }
     auto end_query = chrono::system_clock::now();
     cout << "elapsed time: " << chrono::duration<double>(end_query - end_index).count() << "s\n";
-    if (getenv("MIEKKI_VERBOSE") && drv.group.shards() > 1)
-        cout << "[exchange] " << drv.group.shards() << " shards: " << drv.group.gather_bytes() << " bytes gathered, "
+    if (getenv("MIEKKI_VERBOSE") && (drv.group.shards() > 1 || drv.group.ranked()))
+        cout << "[exchange] " << (drv.group.ranked() ? (size_t)drv.group.world() : drv.group.shards()) << " shards: " << drv.group.gather_bytes() << " bytes gathered, "
              << drv.group.rerun_queries() << " queries rerun with wide rows, " << drv.group.replayed_queries()
              << " answered from dense score rows" << endl;
     cout << "The end" << endl;

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 3
+#define MK_ABI_VERSION 4
 
 typedef enum {
     MK_OK = 0,
@@ -224,6 +224,8 @@ int mk_merge_entrants(mk_ctx *ctx, const uint32_t *d_count, const mk_hit *d_cand
  * with world == 1, the context's own index is used.  Output as mk_merge_entrants. */
 int mk_merge_set_sizes(mk_ctx *ctx, const uint64_t *genome_size, const uint32_t *sketch_size,
                        uint32_t n_genomes, uint32_t id_base);
+/* the sizes mk_merge_set_sizes (or mk_comm_share_sizes) left on the context, back on the host (n = how many were set) */
+int mk_merge_get_sizes(mk_ctx *ctx, uint64_t *genome_size, uint32_t *sketch_size, uint32_t n);
 int mk_merge_compact(mk_ctx *ctx, const uint64_t *d_rows, uint32_t world, uint32_t nq, uint32_t cap,
                      uint32_t nresults, mk_hit *d_hits, uint32_t *d_nhits);
 
@@ -300,6 +302,49 @@ int mk_index_import_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, cons
 int mk_index_merge_bloom_device(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *d_later);
 /* bytes of the Bloom table a 2k-bit k-mer can reach (everything above stays zero) */
 uint64_t mk_bloom_reachable_bytes(const mk_ctx *ctx);
+
+/* ---- one process per GPU: the collectives of the genome-sharded index, on RCCL over xGMI --------------
+ * The reference scales inside one executable (-t threads, main.cpp:190-196; Miekki.cpp:546-581, 430-480) and has
+ * no distributed backend; SURVEY.md 8e defines the multi-GPU form: rank r owns a contiguous genome range, the
+ * Bloom filter is made global once after the build, and a query batch needs ONE exchange step -- ncclGather
+ * (rccl.h:745) of the per-query heap-entrant rows (mk_qset_run_compact) to the merging rank.  librccl is bound at
+ * run time (a process that already holds a copy, e.g. PyTorch's, keeps using it; MIEKKI_RCCL_LIB names one);
+ * single-GPU users never load it.  One communicator per context; every call below is COLLECTIVE: all ranks make
+ * it, in the same order.  Device pointers (d_*) are memory of the context's GPU; the collectives are queued on
+ * the context's stream like its kernels (mk_sync waits), so a gather needs no host wait after the scan. */
+typedef struct mk_comm mk_comm;
+#define MK_COMM_ID_BYTES 128
+/* rank 0 draws the id (ncclGetUniqueId) and hands it to the other ranks by any means (a file, the launcher's
+ * store, an environment variable); then every rank creates its communicator (ncclCommInitRank). */
+int mk_comm_unique_id(uint8_t *id /* MK_COMM_ID_BYTES */);
+int mk_comm_create(mk_ctx *ctx, int rank, int world, const uint8_t *id, mk_comm **out);
+void mk_comm_destroy(mk_comm *comm);
+int mk_comm_rank(const mk_comm *comm);
+int mk_comm_world(const mk_comm *comm);
+/* ncclGather / ncclAllGather / ncclBroadcast of plain bytes; d_recv holds world * bytes (gather: on root only). */
+int mk_comm_gather(mk_comm *comm, const void *d_send, uint64_t bytes, void *d_recv, int root);
+int mk_comm_allgather(mk_comm *comm, const void *d_send, uint64_t bytes, void *d_recv);
+int mk_comm_broadcast(mk_comm *comm, void *d_buf, uint64_t bytes, int root);
+int mk_comm_allreduce_max_f64(mk_comm *comm, double *d_values, uint32_t n);
+int mk_comm_barrier(mk_comm *comm);                                /* waits on the host, too */
+/* The single exchange step: every rank's exchange rows (`words` 64-bit words, what mk_qset_run_compact wrote) ->
+ * d_recv[world][words] on root, rank-major = shard order = genome order: the layout mk_merge_compact takes. */
+int mk_comm_gather_rows(mk_comm *comm, const uint64_t *d_rows, uint64_t words, uint64_t *d_recv, int root);
+/* Once after the build.  The reference has ONE Bloom filter and a cell keeps the byte of its first inserter in
+ * genome order (Miekki.cpp:125-129); with contiguous shards in rank order that is the lowest rank whose cell is
+ * non-zero: a MIN all-reduce over (rank << 8 | byte), in place on the context's filter, byte-exact. */
+int mk_comm_sync_bloom(mk_comm *comm);
+/* Once after the build: all-gathers how many genomes every rank holds and their sketch_size / genome_size, sets
+ * this context's genome id base to the genomes of the ranks before it (ids = those of a single-process run) and
+ * hands all sizes to the merge (mk_merge_set_sizes).  id_base / total may be NULL. */
+int mk_comm_share_sizes(mk_comm *comm, uint32_t *id_base, uint32_t *total);
+/* mk_qset_run_compact with its exchange step folded in: the rows of queries that are finished leave for `root` on
+ * the communicator's own stream WHILE the next chunk of queries is scanned (sets of >= 4096 queries go in four
+ * blocks, MIEKKI_EXCHANGE_BLOCKS; a smaller set is one ncclGather).  d_rows[nq][1 + cap] on every rank,
+ * d_recv[world][nq][1 + cap] on root (NULL elsewhere).  On return everything is queued and the context's stream
+ * waits for the exchange: mk_merge_compact(ctx, d_recv, world, ...) may follow at once. */
+int mk_qset_run_compact_gather(mk_ctx *ctx, mk_comm *comm, mk_qset *qs, uint32_t nresults, uint32_t min_score,
+                               double min_intersection, uint32_t cap, uint64_t *d_rows, uint64_t *d_recv, int root);
 
 /* ---- exact mode (ground_truth_batch, Miekki.cpp:792-859) ------------------- */
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 
@@ -214,7 +215,7 @@ int ensure_bloom_summary_arrays(mk_ctx *c)
 
 // Cells are about to be replaced (an import): the summaries may not claim anything until they have been recomputed.  The
 // build's front stage reads the coarse level before the back stage refreshes it, so "stale" alone is not enough here.
-static int forget_bloom_summary(mk_ctx *c)
+int forget_bloom_summary(mk_ctx *c)
 {
     c->bloom_full_stale = true;
     if (!c->d_bloom_full) return MK_OK;
@@ -1495,8 +1496,14 @@ void mk_qset_free(mk_ctx *c, mk_qset *qs)
 }
 
 // mk_qset_run / mk_qset_run_compact: the output is either (d_count, d_cand) or d_rows
-static int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
-                    uint32_t *d_count, mk_hit *d_cand, uint64_t *d_rows)
+// after_chunk (may be null): called once the scan + selection of queries [q0, q1) have been QUEUED on the context's
+// stream (comm.hip: the chunk's exchange rows go out on the communicator's stream while the next chunk scans);
+// min_chunks: cut the set into at least that many chunks (so that there is a next chunk to overlap with)
+}  // extern "C"
+namespace mk {
+int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
+             uint32_t *d_count, mk_hit *d_cand, uint64_t *d_rows, const std::function<int(uint32_t, uint32_t)> *after_chunk,
+             uint32_t min_chunks)
 {
     if (nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
@@ -1506,13 +1513,15 @@ static int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_scor
     }
     MK_TRY(qset_sketch(c, qs));
     const uint64_t rstride = (uint64_t)cap + 1;
-    if (c->G == 0) {
+    if (c->G == 0) {                                             // an empty shard still takes part in the exchange
         if (d_rows) MK_HIP(hipMemsetAsync(d_rows, 0, (size_t)qs->nq * rstride * 8, c->stream));
         else MK_HIP(hipMemsetAsync(d_count, 0, (size_t)qs->nq * 4, c->stream));
+        if (after_chunk) MK_TRY((*after_chunk)(0, qs->nq));
         return MK_OK;
     }
     const bool slab = qs->slab_ok;
-    const uint32_t per = slab ? chunk_queries_slab(c, qs->nq, qs->S) : chunk_queries(c, qs->nq);
+    uint32_t per = slab ? chunk_queries_slab(c, qs->nq, qs->S) : chunk_queries(c, qs->nq);
+    if (min_chunks > 1) per = std::max<uint32_t>(1, std::min<uint32_t>(per, (qs->nq + min_chunks - 1) / min_chunks));
     if (slab) MK_TRY(ensure_partials(c, (uint64_t)per * partial_bytes_per_query(c, qs->S)));
     else MK_TRY(ensure_scores(c, per));
     for (uint32_t q0 = 0; q0 < qs->nq; q0 += per) {
@@ -1529,22 +1538,25 @@ static int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_scor
             MK_TRY(qset_select(c, q1 - q0, c->d_scores, nullptr, 0, nullptr, nresults, min_score, min_inter, cap,
                                cnt, cand, rows));
         }
+        if (after_chunk) MK_TRY((*after_chunk)(q0, q1));
     }
     return MK_OK;
 }
+}  // namespace mk
+extern "C" {
 
 int mk_qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap,
                 uint32_t *d_count, mk_hit *d_cand)
 {
     if (!c || !qs || !d_count || !d_cand || !cap) { set_error("null argument"); return MK_ERR_ARG; }
-    return qset_run(c, qs, nresults, min_score, min_inter, cap, d_count, d_cand, nullptr);
+    return qset_run(c, qs, nresults, min_score, min_inter, cap, d_count, d_cand, nullptr, nullptr, 1);
 }
 
 int mk_qset_run_compact(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter,
                         uint32_t cap, uint64_t *d_rows)
 {
     if (!c || !qs || !d_rows || !cap) { set_error("null argument"); return MK_ERR_ARG; }
-    return qset_run(c, qs, nresults, min_score, min_inter, cap, nullptr, nullptr, d_rows);
+    return qset_run(c, qs, nresults, min_score, min_inter, cap, nullptr, nullptr, d_rows, nullptr, 1);
 }
 
 int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d_scores)
@@ -1648,6 +1660,17 @@ int mk_merge_set_sizes(mk_ctx *c, const uint64_t *genome_size, const uint32_t *s
     MK_HIP(hipMemcpy(c->d_all_ss, sketch_size, (size_t)n * 4, hipMemcpyHostToDevice));
     MK_HIP(hipMemcpy(c->d_all_gs, genome_size, (size_t)n * 8, hipMemcpyHostToDevice));
     c->all_n = n;
+    return MK_OK;
+}
+
+int mk_merge_get_sizes(mk_ctx *c, uint64_t *genome_size, uint32_t *sketch_size, uint32_t n)
+{
+    if (!c || (n && (!genome_size || !sketch_size))) { set_error("null argument"); return MK_ERR_ARG; }
+    if (n != c->all_n) { set_error("%u sizes were set (mk_merge_set_sizes), %u asked for", c->all_n, n); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    if (!n) return MK_OK;
+    MK_HIP(hipMemcpy(sketch_size, c->d_all_ss, (size_t)n * 4, hipMemcpyDeviceToHost));
+    MK_HIP(hipMemcpy(genome_size, c->d_all_gs, (size_t)n * 8, hipMemcpyDeviceToHost));
     return MK_OK;
 }
 

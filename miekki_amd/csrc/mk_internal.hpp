@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -320,6 +321,10 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
 int ensure_build_side(mk_ctx *c, int b);
 void use_build_side(mk_ctx *c, int b);       // point the aliases (d_counters, ...) at side b
 int launch_bloom_merge(mk_ctx *c, uint64_t begin, uint64_t end, const uint8_t *d_later);
+// api.hip: one pass of the hot path over a query set (mk_qset_run / mk_qset_run_compact; comm.hip hooks the chunks)
+int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, double min_inter, uint32_t cap, uint32_t *d_count,
+             mk_hit *d_cand, uint64_t *d_rows, const std::function<int(uint32_t, uint32_t)> *after_chunk, uint32_t min_chunks);
+int forget_bloom_summary(mk_ctx *c);         // the Bloom cells were replaced: the summaries may claim nothing until recomputed
 // api.hip: scratch shared by the build and the long-query sketches
 int ensure_build_counters(mk_ctx *c);
 int ensure_bloom_summary(mk_ctx *c);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mk_qset_run_compact": (i32, [vp, vp, u32, u32, C.c_double, u32, vp]),
     "mk_qset_invalidate": (i32, [vp, vp]),
     "mk_merge_set_sizes": (i32, [vp, vp, vp, u32, u32]),
+    "mk_merge_get_sizes": (i32, [vp, vp, vp, u32]),
     "mk_merge_compact": (i32, [vp, vp, u32, u32, u32, u32, vp, vp]),
     "mk_device_count": (i32, []),
     "mk_set_genome_id_base": (i32, [vp, u32]),
@@ -93,6 +94,20 @@ SIGNATURES = {
     "mk_index_import_bloom_device": (i32, [vp, u64, u64, vp]),
     "mk_index_merge_bloom_device": (i32, [vp, u64, u64, vp]),
     "mk_bloom_reachable_bytes": (u64, [vp]),
+    "mk_comm_unique_id": (i32, [vp]),
+    "mk_comm_create": (i32, [vp, i32, i32, vp, PP(vp)]),
+    "mk_comm_destroy": (None, [vp]),
+    "mk_comm_rank": (i32, [vp]),
+    "mk_comm_world": (i32, [vp]),
+    "mk_comm_gather": (i32, [vp, vp, u64, vp, i32]),
+    "mk_comm_allgather": (i32, [vp, vp, u64, vp]),
+    "mk_comm_broadcast": (i32, [vp, vp, u64, i32]),
+    "mk_comm_allreduce_max_f64": (i32, [vp, vp, u32]),
+    "mk_comm_barrier": (i32, [vp]),
+    "mk_comm_gather_rows": (i32, [vp, vp, u64, vp, i32]),
+    "mk_comm_sync_bloom": (i32, [vp]),
+    "mk_comm_share_sizes": (i32, [vp, PP(u32), PP(u32)]),
+    "mk_qset_run_compact_gather": (i32, [vp, vp, vp, u32, u32, C.c_double, u32, vp, vp, i32]),
     "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
     "mk_qset_active": (i32, [vp, vp, vp]),
     "mk_sync": (i32, [vp]),

@@ -114,6 +114,53 @@ def test_several_gpus_in_one_process_like_the_reference(workdirs, golden_dir, na
         assert (d / "exactA_m.txt").read_bytes() == open(exa, "rb").read()
 
 
+def run_ranked(args, cwd, extra_env=None):
+    """The binary in its one-process-per-GPU form, as a world of ONE rank (two ranks cannot share a GPU under RCCL):
+    communicator from an id file, Bloom all-reduce, size / log / name all-gathers, the entrant gather, the overflow
+    broadcast and the dense-row gather all execute, with rank 0 = the only rank."""
+    env = dict(os.environ, MIEKKI_DEVICES="0", MIEKKI_WORLD="1", MIEKKI_RANK="0", MIEKKI_COMM_FILE=str(cwd / "comm.id"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert not (cwd / "comm.id").exists()                        # rank 0 removes the id file once everybody has it
+    return r.stdout
+
+
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd1", "rnd4"])
+def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name):
+    """`miekki` with a communicator (RCCL called from the C++ host through the C ABI): -l with -a, -A, -e and -A -e must
+    give the reference's files and banners."""
+    case, d, base = workdirs(name)
+    so = run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_r.txt", *base], d)
+    assert (d / "out_r.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    want = open(os.path.join(golden_dir, f"{name}_stdout_l.txt"), "rb").read().replace(b"I write this index on the disk for later\n", b"")
+    assert norm(so).replace(b"out_r.txt", b"out.txt") == want
+    run_ranked(["-l", "genomes.lst", "-A", "qfiles.lst", "-o", "outA_r.txt", *base], d)
+    assert (d / "outA_r.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+    run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-e", "-o", "exact_r.txt", *base], d)
+    assert (d / "exact_r.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_exact.txt"), "rb").read()
+    exa = os.path.join(golden_dir, f"{name}_exactA.txt")
+    if os.path.exists(exa):
+        run_ranked(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA_r.txt", *base], d)
+        assert (d / "exactA_r.txt").read_bytes() == open(exa, "rb").read()
+    r = subprocess.run([CLI, "-i", "x.gz", "-a", "queries.fa"], cwd=d, stdout=subprocess.PIPE, env=dict(os.environ, MIEKKI_WORLD="1", MIEKKI_RANK="0"))
+    assert r.returncode == 1 and b"single process" in r.stdout
+
+
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_one_process_per_gpu_form_on_the_tie_heavy_collection(workdirs, golden_dir, wide):
+    """`dups` overflows every entrant row: the overflow list is broadcast, the rows run again 4,096 slots wide, and with
+    MIEKKI_SHARD_WIDE_ROWS=0 the answer comes from dense score rows gathered on rank 0 -- the reference's lines."""
+    case, d, base = workdirs("dups")
+    so = run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-o", f"out_r{wide}.txt", *base], d,
+                    {"MIEKKI_SHARD_WIDE_ROWS": wide, "MIEKKI_VERBOSE": "1"})
+    assert (d / f"out_r{wide}.txt").read_bytes() == open(os.path.join(golden_dir, "dups_out.txt"), "rb").read()
+    m = re.search(rb"\[exchange\] 1 shards: (\d+) bytes gathered, (\d+) queries rerun with wide rows, (\d+) answered from dense score rows", so)
+    assert m and (int(m.group(2)) > 0) == (wide == "1") and (int(m.group(3)) > 0) == (wide == "0"), so[-600:]
+
+
 def test_every_visible_gpu(workdirs, golden_dir):
     """The binary's default: one context per VISIBLE GPU, rows exchanged by peer DMA between distinct devices.
     Needs a box with at least two GPUs (the one-GPU boxes rehearse the path with repeated ordinals above)."""
