@@ -164,7 +164,7 @@ struct BuildShape {
     uint32_t nbins, low_bits;      // low_bits = min(h, 12) partitions per bin (log2); nbins = P >> low_bits
     uint32_t lpr;                  // lanes of a reduce wave that share one run, 16 bytes of items each (a power of two)
     uint32_t nwg;                  // scatter workgroups per genome
-    uint32_t tune;                 // timing experiments only (MIEKKI_TUNE_BUILD): 1 no Bloom pass A, 2 no item reads
+    uint32_t tune;                 // 0 in the shipped library; timing experiments of a -DMK_TUNE_BUILD build: 1 no Bloom pass A, 2 no item reads
     uint32_t sum_words;            // 64-bit words of the Bloom summary the scatter kernel consults (one bit per 2048 cells); 0: none
     uint32_t bloom_on;             // the index has a Bloom filter (and pass A is not switched off): items get flagged
     uint32_t tables_only;          // query sketches: the reduce kernel leaves the minimum keys in `tables` and nothing else
@@ -633,7 +633,13 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
         max_len = std::max(max_len, len);
         if (len > c->p.k) max_nk = std::max(max_nk, len - c->p.k);
     }
+    // timing experiments (1: no Bloom pass A, 2: no item reads -- both build a WRONG index) exist only in a library compiled
+    // with -DMK_TUNE_BUILD (tools/); the shipped one has no such switch
+#ifdef MK_TUNE_BUILD
     static const uint32_t tune = [] { const char *e = getenv("MIEKKI_TUNE_BUILD"); return e ? (uint32_t)atoi(e) : 0u; }();
+#else
+    constexpr uint32_t tune = 0;
+#endif
     bs.tune = tune;
     // the scatter kernel flags the k-mers that may still have work to do in the Bloom filter; it asks the filter's coarse
     // summary (one bit per 2048 cells, bloom_summary_bytes: 4 KiB at -b 33), which rides in its LDS when it is at most 8 KiB
@@ -663,7 +669,10 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     if (need > sd.slots_bytes) {
         if (sd.d_slots) (void)hipFree(sd.d_slots);
         sd.d_slots = nullptr; sd.slots_bytes = 0;
-        MK_HIP(hipMalloc(&sd.d_slots, need + 64));
+        // (+ 1 KiB: a reduce lane loads 16 bytes up to lpr * 16 bytes past its run's start without a bounds test; behind the
+        // last scatter workgroup's items that reaches into the meta words, and behind a very small meta array -- one short
+        // query -- it would leave the allocation)
+        MK_HIP(hipMalloc(&sd.d_slots, need + 1024 + 64));
         sd.slots_bytes = need;
     }
     *fits = true;

@@ -107,12 +107,15 @@ MK_HD void bucket_fp(uint64_t anc, uint32_t h, uint32_t f, uint32_t empty, uint3
     fp = mantis(anc & ((1ULL << (64 - h)) - 1), h, f, empty);
 }
 
-// i-th Bloom position of a selected k-mer (universal_hash, utils.cpp:197-199,
-// shifted as in Miekki.cpp:124/138).  unrevhash64(revhash64(c)) == c, so the
-// first term is the canonical k-mer itself.
+// i-th Bloom position of a selected k-mer: universal_hash(anc, i) >> b (utils.cpp:197-199, Miekki.cpp:124/138),
+// universal_hash(x, i) = unrevhash64(x) + (i * 69 * revhash64(x)) % 1024 called on x = anc = revhash64(canon).
+// The first term is the canonical k-mer itself; the multiplier of the second is revhash64(anc) -- the hash of the
+// HASH.  That term is below 1024 and b >= 32, so it changes the shifted value only when the low word of canon can
+// carry (one k-mer in four million): everybody else is spared the second hash.
 MK_HD uint64_t bloom_pos(uint64_t canon, uint64_t anc, uint32_t i, uint32_t bloom_log2)
 {
-    return (canon + (((uint64_t)(i * 69u) * anc) % 1024u)) >> bloom_log2;
+    if ((uint32_t)canon <= 0xFFFFFC00u) return canon >> bloom_log2;
+    return (canon + (((uint64_t)(i * 69u) * revhash64(anc)) % 1024u)) >> bloom_log2;
 }
 
 // splitmix64 and the synthetic genome generator of SURVEY.md 8d

@@ -337,3 +337,44 @@ def test_dev_copy_counts_the_path_it_took(hip):
         lib.mk_dev_free(a._h, da); lib.mk_dev_free(b._h, db)
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("b", [32, 33])
+def test_bloom_positions_when_the_low_word_carries(hip, b):
+    """universal_hash(anc, i) = canon + (i * 69 * revhash64(anc)) % 1024 (utils.cpp:197-199, called on the HASH): the
+    second term matters only when the low word of the canonical k-mer can carry (> 0xFFFFFC00, one k-mer in four million)
+    -- no seeded test ever meets one.  Constructed: k = 31, canonical k-mer A <14 free bases> T^15 G / T^15 A / T^15 C (low
+    word 0xFFFFFFFE / ...FC / ...FD; the other strand starts with C / T / G: larger), as the ONLY processed k-mer of a
+    32-base genome, so it is a partition's winner and goes into the filter.  Index stream (Bloom byte VALUES included) and
+    gated scores must be the oracle's; at -b 32 the carry changes the bit (hash % 8), at -b 33 only after a second one."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7 + b)
+    genomes = []
+    for tail in (b"T" * 15 + b"G", b"T" * 15 + b"A", b"T" * 15 + b"C"):   # (the other strand then starts with C, T, G: larger)
+        for _ in range(16):
+            mid = bytes(rng.choice(list(b"ACGT"), 14).tolist())
+            genomes.append(b"A" + mid + tail + b"A")                 # 32 bases: two k-mers, the last one is skipped (Miekki.cpp:162)
+    genomes += [synth.genome_bases(50 + i, 0, 3000) for i in range(3)]
+    o = orc.OracleMiekki(31, 12, 8, b, 0)
+    o.insert_sequences(genomes)
+    ix = hip.Miekki(31, 12, 8, b, 0)
+    try:
+        ix.insert_sequences(genomes[:20]); ix.insert_sequences_packed(genomes[20:])
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        assert (o.sketch_size[:48] == 1).sum() >= 40                # (a fingerprint of 255 cannot be stored: one k-mer in sixteen)
+        raw = np.frombuffer(stream_of(ix), np.uint8).copy()
+        want = o.serialize()
+        raw[32] = want[32] = 0
+        assert raw.size == want.size and raw.tobytes() == want.tobytes()
+        qs = genomes[:48] + [g[:31] + b"C" for g in genomes[:8]]
+        np.testing.assert_array_equal(ix.query_sequences(qs), o.query_sequences(qs))
+        fresh = hip.Miekki(31, 12, 8, b, 0)                          # the same k-mers as QUERIES against a filter that lacks them
+        try:
+            fresh.insert_sequences(genomes[48:])
+            o2 = orc.OracleMiekki(31, 12, 8, b, 0)
+            o2.insert_sequences(genomes[48:])
+            np.testing.assert_array_equal(fresh.query_sequences(qs), o2.query_sequences(qs))
+        finally:
+            fresh.close()
+    finally:
+        ix.close()
