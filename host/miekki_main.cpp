@@ -18,8 +18,8 @@
 //     restricts them): genome shards in list order, one context per GPU
 //     (multi_gpu.hpp); ids, hits and files are those of one GPU,
 //   * ... or over one PROCESS per GPU with RCCL between them, when a launcher says so:
-//         python -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-//             miekki -l genomes.txt -a queries.fa -o out.txt -h 20
+//         python -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+//             miekki -l genomes.txt -a queries.fa -o out.txt -h 20        (one command line)
 //     (RANK / WORLD_SIZE / LOCAL_RANK from the environment, or MIEKKI_RANK / MIEKKI_WORLD / MIEKKI_LOCAL_RANK): rank r
 //     indexes the r-th contiguous run of the list on its own GPU, the Bloom filters are folded by one all-reduce,
 //     every rank scans all queries against its shard and ONE ncclGather per batch carries the per-query heap

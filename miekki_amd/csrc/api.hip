@@ -218,6 +218,9 @@ int ensure_bloom_summary_arrays(mk_ctx *c)
 int forget_bloom_summary(mk_ctx *c)
 {
     c->bloom_full_stale = true;
+    // (the build's first-writer keys are never reset cell by cell -- a posted key means the cell was set in the same batch
+    // and is never looked at again -- but cells that are REPLACED may be empty again under an old key)
+    if (c->d_bloom_order) MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 4, c->stream));
     if (!c->d_bloom_full) return MK_OK;
     const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, words2 = (bloom_summary_bytes(c) + 7) / 8 + 8;
     MK_HIP(hipMemsetAsync(c->d_bloom_full, 0, nwords * 4, c->stream));
@@ -251,7 +254,7 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
     MK_TRY(ensure_build_counters(c));
     if (for_append && c->d_bloom && !c->d_bloom_order) {
         MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
-        MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 8, c->stream));
+        MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 4, c->stream));
     }
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
     if (!c->h_img) MK_HIP(hipHostMalloc((void **)&c->h_img, sizeof *c->h_img, hipHostMallocDefault));
@@ -580,13 +583,26 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
         // neighbours in the set share one run of the build's packed kernels and one gate-and-append launch; shapes those
         // kernels do not take (h > 22) go one by one through the atomic kernel
         MK_TRY(ensure_build_scratch(c, 0, 0, false));
-        for (size_t i = 0; i < qs->long_q.size();) {
+        // long reads and contigs (up to 2^18 k-mers): per-query hash tables, O(length) -- no 2^h table is touched
+        // (MIEKKI_MID_SKETCH=0 keeps them on the table path: tests compare the two)
+        static const bool mid_on = [] { const char *e = getenv("MIEKKI_MID_SKETCH"); return !e || atoi(e) != 0; }();
+        std::vector<uint32_t> mid, rest;
+        for (uint32_t q : qs->long_q) {
+            const uint64_t len = qs->h_off[q + 1] - qs->h_off[q];
+            (mid_on && query_is_mid_length(c, len - c->p.k) ? mid : rest).push_back(q);
+        }
+        // (MIEKKI_MID_SLOTS: fewer slots per round than the scratch holds -- the tests make small sets take several rounds)
+        static const uint64_t slot_cap = [] { const char *e = getenv("MIEKKI_MID_SLOTS"); return e ? (uint64_t)std::max(1L, atol(e)) : ~0ull; }();
+        MK_TRY(launch_query_sketch_mid(c, qs, mid, reinterpret_cast<unsigned long long *>(c->d_tables),
+                                       std::min<uint64_t>((uint64_t)c->build_batch * c->P, slot_cap)));
+        const std::vector<uint32_t> &long_q = rest;
+        for (size_t i = 0; i < long_q.size();) {
             uint32_t n = 1;
-            while (i + n < qs->long_q.size() && n < c->build_batch && qs->long_q[i + n] == qs->long_q[i] + n) ++n;
+            while (i + n < long_q.size() && n < c->build_batch && long_q[i + n] == long_q[i] + n) ++n;
             bool done = false;
-            MK_TRY(launch_query_sketch_long_batch(c, qs, qs->long_q[i], n, &done));     // (a loner too: a run of one)
+            MK_TRY(launch_query_sketch_long_batch(c, qs, long_q[i], n, &done));     // (a loner too: a run of one)
             if (!done)
-                for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_long(c, qs, qs->long_q[i + j]));
+                for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_long(c, qs, long_q[i + j]));
             i += n;
         }
     }

@@ -401,7 +401,7 @@ template <int W, bool KEY32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 4, 8))) void build_reduce_kernel(
     const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
-    const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
+    const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint32_t *order,
     const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
     uint8_t *__restrict__ posted_blk, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
     SketchParams sp, BuildShape bs)
@@ -578,13 +578,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     const uint64_t *__restrict__ gcodes = reinterpret_cast<const uint64_t *>(codes + code_off[g]);
     const uint64_t *__restrict__ gexcept = reinterpret_cast<const uint64_t *>(except + code_off[g] / 2);
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
-    auto probe = [&](uint64_t cell, uint32_t tag, uint32_t p) -> bool {
+    // (a young filter -- more flagged items than the list holds, check_all -- has no full groups to speak of: its winners
+    // skip the first-level summary and go to the cell, one L2 request less each)
+    auto probe = [&](uint64_t cell, uint32_t p) -> bool {
         if (cell >= bloom_dev_bytes) return false;
         const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;                              // 8, 256 cells
-        if ((full[sidx] >> (grp & 31u)) & 1u) return false;
+        if (!check_all && ((full[sidx] >> (grp & 31u)) & 1u)) return false;
         if (bloom[cell] != 0) return false;
-        const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | tag;
-        atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
+        atomicMin(&order[cell], (g << sp.h) | p);               // genome in batch, partition: pass B finds the hash index itself
         return true;
     };
     while (undecided) {
@@ -595,14 +596,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         const uint32_t p = bin * R + i, chi = (uint32_t)(cn >> 32);
         bool posted = false;
         if ((uint32_t)cn <= 0xFFFFFC00u) {
-            const uint32_t sh = sp.bloom_log2 - 32u;
-            posted = probe(chi >> (sh + 3u), (chi >> sh) & 7u, p);
+            posted = probe(chi >> (sp.bloom_log2 - 32u + 3u), p);
         } else {
             const uint64_t anc = revhash64(cn);
-            for (uint32_t hi = 0; hi < kNumHash; ++hi) {
-                const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
-                posted |= probe(hsh >> 3, (hi << 4) | (uint32_t)(hsh & 7), p);
-            }
+            for (uint32_t hi = 0; hi < kNumHash; ++hi) posted |= probe(bloom_pos(cn, anc, hi, sp.bloom_log2) >> 3, p);
         }
         // what pass B needs: the canonical k-mers of the blocks in which something was posted
         if (posted) { posted_mask |= 1u << j; blk_posted[i >> 8] = 1; tables[row0 + i] = cn; }
@@ -829,7 +826,7 @@ int launch_query_tables(mk_ctx *c, const char *d_seq, const uint64_t *d_off, con
 #define MK_QREDUCE(Wv, K32)                                                                                                     \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, st,                                     \
                        reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), codes, except,   \
-                       c->d_pk_off[b], sd.d_counters->dirty, (const uint8_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr,         \
+                       c->d_pk_off[b], sd.d_counters->dirty, (const uint8_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr,         \
                        (const uint32_t *)nullptr, (uint8_t *)nullptr, d_tables, (uint8_t *)nullptr, (uint32_t *)nullptr,        \
                        (unsigned long long *)nullptr, sp, bs)
     if (c->W == 1) { if (sd.key32) MK_QREDUCE(1, true); else MK_QREDUCE(1, false); }

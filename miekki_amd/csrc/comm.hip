@@ -11,6 +11,7 @@
 // Every collective is queued on a HIP stream of the context (its main stream, or the communicator's own for the
 // overlapped exchange) and ordered against the kernels with events: no host wait between a scan and its gather.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -141,7 +142,17 @@ int mk_comm_create(mk_ctx *c, int rank, int world, const uint8_t *id, mk_comm **
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     ncclComm_t nc = nullptr;
-    MK_NCCL(g_rccl.CommInitRank(&nc, world, u, rank));             // (collective: returns when every rank has called it)
+    // This RCCL build prints a version banner ("RCCL version : ...", five lines) on STDOUT from rank 0's first
+    // communicator -- into the middle of whatever the host program reports there (the `miekki` binary's banners are
+    // compared byte for byte with the reference's; bench.py's stdout is one JSON line).  It goes to stderr instead:
+    // descriptor 1 points at descriptor 2 while the communicator initialises.
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+    const ncclResult_t init = g_rccl.CommInitRank(&nc, world, u, rank);   // (collective: returns when every rank has called it)
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    MK_NCCL(init);
     mk_comm *m = new mk_comm();
     m->ctx = c; m->rank = rank; m->world = world; m->comm = nc; m->d_keys = nullptr; m->keys_cap = 0;
     m->stream = nullptr; m->ev_chunk = m->ev_done = m->ev_enter = nullptr;

@@ -95,7 +95,8 @@ struct mk_ctx {
     // Bloom filter: only the cells a 2k-bit k-mer can reach live on the device
     uint8_t *d_bloom;
     uint64_t bloom_dev_bytes, bloom_bytes;
-    uint64_t *d_bloom_order;       // first-writer arbitration keys (build only), lazily allocated
+    uint32_t *d_bloom_order;       // first-writer arbitration keys (build only), lazily allocated: one per reachable cell,
+                                   // genome in batch << h | partition of the first k-mer (in that order) that found the cell empty
     // build scratch (lazily allocated)
     uint32_t build_batch;          // genomes per build batch (<= kBuildBatch, bounded by table memory)
     uint64_t *d_tables;            // build_batch x P min-keys
@@ -333,6 +334,9 @@ uint64_t bloom_summary_bytes(const mk_ctx *c);         // of the coarse level: o
 int launch_query_sketch_short(mk_ctx *c, mk_qset *qs);
 int launch_query_sketch_long(mk_ctx *c, mk_qset *qs, uint32_t q);
 int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t n, bool *done);
+// O(length) sketches of long reads / contigs (per-query hash tables in d_scratch), see sketch.hip
+bool query_is_mid_length(const mk_ctx *c, uint64_t nk);
+int launch_query_sketch_mid(mk_ctx *c, mk_qset *qs, const std::vector<uint32_t> &which, unsigned long long *d_scratch, uint64_t scratch_slots);
 int launch_query_sketch_dense(mk_ctx *c, mk_qset *qs, uint32_t slot);   // slot = index into qs->dense_q
 int launch_query_sketch_dense_batch(mk_ctx *c, mk_qset *qs, uint32_t slot, uint32_t n, bool *done);
 int launch_scan_counts(mk_ctx *c, mk_qset *qs);                          // fills qs->d_scan_n

@@ -17,6 +17,8 @@
 #include <cstdlib>
 
 #include "codes.hpp"
+#include <cstring>
+
 #include "mk_internal.hpp"
 
 namespace mk {
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void fp_transpose_reg_kernel(const uint8_t *__
 
 template <bool WRITE>
 __global__ void bloom_kernel(uint64_t *__restrict__ tables, const char *__restrict__ seq, const uint64_t *__restrict__ off,
-                             const uint32_t *__restrict__ valid, uint8_t *bloom, uint64_t bloom_dev_bytes, uint64_t *order,
+                             const uint32_t *__restrict__ valid, uint8_t *bloom, uint64_t bloom_dev_bytes, uint32_t *order,
                              const uint32_t *__restrict__ ovf_count, const uint32_t *__restrict__ full,
                              const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp, uint32_t span);
 
@@ -377,16 +379,19 @@ int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0
 
 // ---------------------------------------------------------------- K3 Bloom insert
 // insert_bloom (Miekki.cpp:121-131) sets a zero cell to 1 << (hash % 8) of its FIRST
-// inserter in (genome, partition, hash index) order.  Pass A posts that order as a
-// 64-bit key per still-zero cell with an atomic minimum; pass B lets the winner
-// write the byte and reset the key.  Cells already non-zero are never touched.
+// inserter in (genome, partition, hash index) order.  Pass A posts (genome in batch << h | partition) as a
+// 32-bit key per still-zero cell with an atomic minimum (at most 27 bits: a batch holds at most 2^30 / (8 x 2^h)
+// genomes); pass B lets the k-mer that holds a cell's key write the byte -- for the lowest of its hash indices that
+// names the cell, which is what the reference's loop over the indices does.  Keys are never reset: a cell with a
+// key was set in that very batch and nobody asks for its key again (cells that are replaced wholesale -- an import
+// -- take fresh keys with them, forget_bloom_summary).  Cells already non-zero are never touched.
 // The table is consumed: after pass A it holds canonical k-mers, not keys.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ tables,
                                                     const char *__restrict__ seq,
                                                     const uint64_t *__restrict__ off,
                                                     const uint32_t *__restrict__ valid, uint8_t *bloom,
-                                                    uint64_t bloom_dev_bytes, uint64_t *order,
+                                                    uint64_t bloom_dev_bytes, uint32_t *order,
                                                     const uint32_t *__restrict__ ovf_count,
                                                     const uint32_t *__restrict__ full,
                                                     const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit,
@@ -415,29 +420,42 @@ __global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ table
     } else {
         canon = key;
     }
-    const uint64_t anc = revhash64(canon);
+    const uint32_t okey = (g << sp.h) | p;
     bool posted = false;
-    uint64_t sum_idx = ~0ull;
-    uint32_t sum_word = 0;
-    for (uint32_t i = 0; i < kNumHash; ++i) {
-        const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
-        const uint64_t cell = hsh >> 3;
-        if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
-        const uint64_t okey = ((uint64_t)g << 40) | ((uint64_t)p << 8) | (i << 4) | (uint32_t)(hsh & 7);
-        if (!WRITE) {
-            // the summary first (one bit per 8 cells, L2-resident): a full group has no zero cell.
-            // The five positions of a k-mer differ by less than 1024 >> b: nearly always one word
-            const uint64_t grp = cell >> 3;
-            if ((grp >> 5) != sum_idx) { sum_idx = grp >> 5; sum_word = full[sum_idx]; }
-            if ((sum_word >> (grp & 31u)) & 1u) continue;
-            if (bloom[cell] == 0) {
-                atomicMin((unsigned long long *)&order[cell], (unsigned long long)okey);
-                posted = true;
-            }
-        } else {
-            if (order[cell] == okey) {
+    if (__builtin_expect((uint32_t)canon <= 0xFFFFFC00u, 1)) {
+        // the five positions are ONE (the low word cannot carry, mk_device.hpp: bloom_pos): hash index 0 speaks for all
+        const uint64_t hsh = canon >> sp.bloom_log2, cell = hsh >> 3;
+        if (cell < bloom_dev_bytes) {
+            if (!WRITE) {
+                // the summary first (one bit per 8 cells, L2-resident): a full group has no zero cell
+                const uint64_t grp = cell >> 3;
+                if (!((full[grp >> 5] >> (grp & 31u)) & 1u) && bloom[cell] == 0) {
+                    atomicMin(&order[cell], okey);
+                    posted = true;
+                }
+            } else if (order[cell] == okey) {
                 bloom[cell] = (uint8_t)(1u << (hsh & 7));
-                order[cell] = kEmptyKey;
+            }
+        }
+    } else {
+        const uint64_t anc = revhash64(canon);
+        uint64_t wrote[2] = {~0ull, ~0ull};                      // (the positions name at most two cells)
+        for (uint32_t i = 0; i < kNumHash; ++i) {
+            const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
+            const uint64_t cell = hsh >> 3;
+            if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
+            if (!WRITE) {
+                const uint64_t grp = cell >> 3;
+                if ((full[grp >> 5] >> (grp & 31u)) & 1u) continue;
+                if (bloom[cell] == 0) {
+                    atomicMin(&order[cell], okey);
+                    posted = true;
+                }
+            } else if (cell != wrote[0] && cell != wrote[1] && order[cell] == okey && bloom[cell] == 0) {
+                // the reference's loop (Miekki.cpp:122-130): the FIRST index that finds the cell empty sets it
+                // (a cell that was taken before this batch may still hold an old key that happens to equal this one)
+                bloom[cell] = (uint8_t)(1u << (hsh & 7));
+                wrote[wrote[0] == ~0ull ? 0 : 1] = cell;
             }
         }
     }
@@ -898,6 +916,179 @@ int launch_query_sketch_long_batch(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t
     MK_HIP(hipGetLastError());
     *done = true;
     return MK_OK;
+}
+
+// ---------------------------------------------------------------- K4' query sketch (mid-length): O(length)
+// Long reads and contigs -- more k-mers than the in-LDS sketch takes (kShortMax), fewer than a quarter of the 2^h
+// partitions -- cost the table path O(2^h) each whatever their length: a 2^h-entry table filled by the build's kernels and
+// swept by the gate-and-append launch (13 us per 20 kb read at -h 20; the reference's sketch loop is O(length),
+// Miekki.cpp:162-183, and its O(2^h) gate, 214-224, is the defect SURVEY.md row A8 names).  Here a query gets an
+// open-addressing HASH TABLE of 2 x (its k-mers) 64-bit slots in device memory instead: a workgroup rolls 4096 k-mers of
+// one query out of LDS, asks the Bloom gate while the k-mer is at hand (as the short kernel does: the answer rides in the
+// key's lowest bit, below the position) and puts  partition << 35 | fingerprint << 19 | position << 1 | gate  into the
+// partition's slot -- claimed with a compare-and-swap, lowered with an atomic minimum: the smallest fingerprint, the
+// earliest position among equals (Miekki.cpp:172), whatever the order the k-mers arrive in.  A second launch sweeps the
+// slots (2 per k-mer, not 2^h per query) and appends the winners that pass the gate.  Entry order within a query is that
+// of the slots: such queries take the plain scan schedule, which does not need sorted lists.
+constexpr uint32_t kMidSeg = 4096;                 // k-mers per workgroup
+constexpr uint32_t kMidPer = kMidSeg / 256;
+constexpr uint32_t kMidPosBits = 18;               // positions a key can hold: queries up to 2^18 k-mers
+struct MidWork { uint32_t q_local, chunk; };
+
+__device__ __forceinline__ uint32_t mid_home(uint32_t bucket, uint32_t nslots)
+{
+    return (uint32_t)(((uint64_t)(bucket * 0x9E3779B1u) * nslots) >> 32);
+}
+
+__global__ __launch_bounds__(256) void mid_insert_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                         const uint32_t *__restrict__ qidx, const uint64_t *__restrict__ tab_off,
+                                                         const MidWork *__restrict__ work, unsigned long long *__restrict__ table,
+                                                         const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                                         const uint32_t *__restrict__ bloom_full, SketchParams sp)
+{
+    __shared__ uint8_t codes[kMidSeg + 32];
+    __shared__ uint32_t s_seed_bad;
+    const MidWork w = work[blockIdx.x];
+    const uint32_t q = qidx[w.q_local];
+    const uint64_t len = off[q + 1] - off[q];
+    const uint32_t nk = (uint32_t)(len - sp.k);                        // (the host only sends queries with kShortMax < nk <= 2^18)
+    const uint32_t i_begin = w.chunk * kMidSeg;
+    const uint32_t cnt = min(kMidSeg, nk - i_begin);
+    const char *__restrict__ s = seq + off[q];
+    if (threadIdx.x == 0) s_seed_bad = 0;
+    __syncthreads();
+    if (threadIdx.x + 1 < sp.k && seed_code((uint8_t)s[threadIdx.x]) == 4u) atomicOr(&s_seed_bad, 1u);
+    __syncthreads();
+    const bool sv = s_seed_bad == 0;
+    const uint32_t nchar = cnt + sp.k - 1;
+    for (uint32_t j = threadIdx.x; j < nchar; j += 256) codes[j] = (uint8_t)pos_codes((uint8_t)s[i_begin + j], (uint64_t)i_begin + j, sp.k, sv);
+    __syncthreads();
+    const uint32_t i0 = threadIdx.x * kMidPer;
+    if (i0 >= cnt) return;
+    unsigned long long *__restrict__ tab = table + tab_off[w.q_local];
+    const uint32_t nslots = (uint32_t)(tab_off[w.q_local + 1] - tab_off[w.q_local]);
+    uint64_t S = 0, RC = 0;
+    for (uint32_t j = 0; j + 1 < sp.k; ++j) {                         // first k-1 digits of k-mer i0
+        const uint32_t cd = codes[i0 + j];
+        S = (S << 2) | (cd & 3u);
+        RC |= (uint64_t)(cd >> 2) << (2 * (j + 1));
+    }
+    const uint32_t topshift = 2 * sp.k - 2;
+    for (uint32_t e = 0; e < kMidPer && i0 + e < cnt; ++e) {
+        const uint32_t cd = codes[i0 + e + sp.k - 1];
+        S = ((S << 2) | (cd & 3u)) & sp.kmask;
+        RC = (RC >> 2) | ((uint64_t)(cd >> 2) << topshift);
+        const uint64_t canon = S < RC ? S : RC;
+        const uint64_t anc = revhash64(canon);
+        uint32_t bucket, fp;
+        bucket_fp(anc, sp.h, sp.f, sp.empty, bucket, fp);
+        if (fp == sp.empty) continue;
+        const uint32_t pass = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, anc, sp.bloom_log2, bloom_full);
+        const unsigned long long key = ((unsigned long long)bucket << (kMidPosBits + 17)) | ((unsigned long long)fp << (kMidPosBits + 1)) |
+                                       ((unsigned long long)(i_begin + i0 + e) << 1) | pass;
+        uint32_t at = mid_home(bucket, nslots);
+        for (;;) {                                                    // fewer distinct partitions than slots: the walk ends
+            const unsigned long long old = atomicCAS(&tab[at], (unsigned long long)kEmptyKey, key);
+            if (old == kEmptyKey) break;
+            if ((uint32_t)(old >> (kMidPosBits + 17)) == bucket) { atomicMin(&tab[at], key); break; }
+            if (++at == nslots) at = 0;
+        }
+    }
+}
+
+// 256 slots of one query per workgroup (a query's slots are a multiple of 256): winners that pass the gate -> entries
+__global__ __launch_bounds__(256) void mid_compact_kernel(const unsigned long long *__restrict__ table, const uint64_t *__restrict__ tab_off,
+                                                          uint32_t n, const uint32_t *__restrict__ qidx, uint64_t *__restrict__ entries,
+                                                          const uint64_t *__restrict__ ent_off, uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_base, s_q;
+    const uint64_t slot0 = (uint64_t)blockIdx.x * 256;
+    if (threadIdx.x == 0) {                                           // the query whose slots these are
+        uint32_t lo = 0, hi = n;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tab_off[mid] <= slot0) lo = mid; else hi = mid; }
+        s_q = lo;
+    }
+    __syncthreads();
+    const uint32_t ql = s_q, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long key = __builtin_nontemporal_load(table + slot0 + threadIdx.x);
+    const bool keep = key != kEmptyKey && (key & 1ull);
+    const uint64_t mask = __ballot(keep);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (total == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(counters + (uint64_t)ql * kCountStride, total);
+    __syncthreads();
+    if (!keep) return;
+    uint32_t at = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w];
+    entries[ent_off[qidx[ql]] + at] = make_entry((uint32_t)(key >> (kMidPosBits + 17)), (uint32_t)(key >> (kMidPosBits + 1)) & 0xffffu);
+}
+
+__global__ void mid_counts_kernel(const uint32_t *__restrict__ counters, uint32_t n, const uint32_t *__restrict__ qidx, uint32_t *__restrict__ nent)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) nent[qidx[g]] = counters[(uint64_t)g * kCountStride];
+}
+
+bool query_is_mid_length(const mk_ctx *c, uint64_t nk) { return nk > kShortMax && nk <= (1ull << kMidPosBits) && nk < c->P / 4; }
+
+// the mid-length queries `which` (set indices): hash tables carved out of `d_scratch` (scratch_slots 64-bit slots), as many
+// queries per round as fit
+int launch_query_sketch_mid(mk_ctx *c, mk_qset *qs, const std::vector<uint32_t> &which, unsigned long long *d_scratch, uint64_t scratch_slots)
+{
+    if (which.empty()) return MK_OK;
+    const SketchParams sp = make_sp(c);
+    // per round: qidx[n] u32 | tab_off[n + 1] u64 | work[...] -- one upload
+    std::vector<uint32_t> qidx;
+    std::vector<uint64_t> tab_off;
+    std::vector<MidWork> work;
+    uint8_t *d_meta = nullptr;
+    uint64_t meta_cap = 0;
+    int rc = MK_OK;
+    size_t i = 0;
+    while (i < which.size() && rc == MK_OK) {
+        qidx.clear(); work.clear(); tab_off.assign(1, 0);
+        while (i < which.size() && qidx.size() < kOvfCap / kCountStride) {
+            const uint32_t q = which[i];
+            const uint64_t nk = qs->h_off[q + 1] - qs->h_off[q] - c->p.k;
+            const uint64_t slots = (2 * nk + 255) / 256 * 256;
+            if (tab_off.back() + slots > scratch_slots) break;
+            for (uint32_t ch = 0; ch * (uint64_t)kMidSeg < nk; ++ch) work.push_back(MidWork{(uint32_t)qidx.size(), ch});
+            qidx.push_back(q);
+            tab_off.push_back(tab_off.back() + slots);
+            ++i;
+        }
+        const uint32_t n = (uint32_t)qidx.size();
+        if (!n) { set_error("a mid-length query does not fit the sketch scratch"); rc = MK_ERR_NOMEM; break; }
+        const uint64_t o_tab = ((uint64_t)n * 4 + 7) / 8 * 8, o_work = o_tab + (uint64_t)(n + 1) * 8, bytes = o_work + work.size() * sizeof(MidWork);
+        if (bytes > meta_cap) {
+            if (d_meta) { (void)hipStreamSynchronize(c->stream); (void)hipFree(d_meta); d_meta = nullptr; }
+            meta_cap = bytes + bytes / 2;
+            if (hipMalloc((void **)&d_meta, meta_cap) != hipSuccess) { set_error("out of device memory"); rc = MK_ERR_NOMEM; break; }
+        }
+        std::vector<uint8_t> img(bytes);
+        memcpy(img.data(), qidx.data(), (size_t)n * 4);
+        memcpy(img.data() + o_tab, tab_off.data(), (size_t)(n + 1) * 8);
+        memcpy(img.data() + o_work, work.data(), work.size() * sizeof(MidWork));
+        bool ok = hipMemcpyAsync(d_meta, img.data(), bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;              // (img is pageable and about to go)
+        uint32_t *counters = reinterpret_cast<uint32_t *>(c->d_ovf);         // (no build is in flight: a side's list is free scratch)
+        ok = ok && hipMemsetAsync(counters, 0, (size_t)n * kCountStride * 4, c->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(d_scratch, 0xFF, tab_off.back() * 8, c->stream) == hipSuccess;
+        if (!ok) { set_error("mid-length sketch setup failed: %s", hipGetErrorString(hipGetLastError())); rc = MK_ERR_DEVICE; break; }
+        const uint32_t *d_qidx = reinterpret_cast<const uint32_t *>(d_meta);
+        const uint64_t *d_tab_off = reinterpret_cast<const uint64_t *>(d_meta + o_tab);
+        hipLaunchKernelGGL(mid_insert_kernel, dim3((uint32_t)work.size()), dim3(256), 0, c->stream, qs->d_seq, qs->d_off, d_qidx, d_tab_off,
+                           reinterpret_cast<const MidWork *>(d_meta + o_work), d_scratch, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_full, sp);
+        hipLaunchKernelGGL(mid_compact_kernel, dim3((uint32_t)(tab_off.back() / 256)), dim3(256), 0, c->stream, d_scratch, d_tab_off, n, d_qidx,
+                           qs->d_entries, qs->d_ent_off, counters);
+        hipLaunchKernelGGL(mid_counts_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, counters, n, d_qidx, qs->d_nent);
+        if (hipGetLastError() != hipSuccess) { set_error("mid-length sketch launch failed"); rc = MK_ERR_DEVICE; }
+    }
+    if (d_meta) { (void)hipStreamSynchronize(c->stream); (void)hipFree(d_meta); }
+    return rc;
 }
 
 // ---------------------------------------------------------------- K4'' query sketch (dense)

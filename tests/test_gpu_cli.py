@@ -122,10 +122,10 @@ def run_ranked(args, cwd, extra_env=None):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     env.update(extra_env or {})
-    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
-    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    r = subprocess.run([CLI, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr).decode(errors="replace")
     assert not (cwd / "comm.id").exists()                        # rank 0 removes the id file once everybody has it
-    return r.stdout
+    return r.stdout                                              # (RCCL's version banner goes to stderr: mk_comm_create)
 
 
 @pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd1", "rnd4"])

@@ -703,6 +703,58 @@ def test_runs_of_long_queries_against_oracle(hip):
         ix.close()
 
 
+@pytest.mark.parametrize("h,fpb,slots", [(20, 8, None), (18, 16, None), (18, 16, "300000"), (22, 8, None)])
+def test_mid_length_queries_against_oracle(hip, h, fpb, slots):
+    """Long reads and contigs (more than 4,096 k-mers, fewer than 2^h / 4 and at most 2^18) are sketched through per-query
+    hash tables in O(length) -- no 2^h table (sketch.hip: mid_insert_kernel / mid_compact_kernel): scores, active counts
+    and hits against the oracle for lengths around every boundary, N and lower case inside and outside the seed, an
+    invalid seed, a tandem repeat (every k-mer of a chunk in a few partitions: long probe-free chains of atomic minima),
+    a query cut at a chunk boundary, mixed with short ones; once with so few slots per round (MIEKKI_MID_SLOTS, in a
+    child process: the knob is read once) that the set takes many rounds."""
+    if slots:
+        import subprocess
+        import sys
+        env = dict(os.environ, MIEKKI_MID_SLOTS=slots, MK_MID_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", f"test_mid_length_queries_against_oracle and {h}-{fpb}-None"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        return
+    from oracle import oracle as orc
+    k = 31
+    rng = np.random.default_rng(h * 7 + fpb)
+    seqs = [synth.genome_bases(900 + i, 0, 400_000) for i in range(6)]
+    o = orc.OracleMiekki(k, h, fpb, 33, 10)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, fpb, 33, 10)
+    try:
+        ix.insert_sequences(seqs)
+        top = min((1 << h) // 4 - 1, 1 << 18)                           # most k-mers the path takes
+        lens = [4096 + k + 1, 4096 + k + 2, 8192 + k, 8192 + k + 1, 12_345, 20_000, 20_000, 50_001, top + k, top + k - 1, 30_000]
+        qs = []
+        for j, n in enumerate(lens):
+            g = j % 6
+            o0 = int(rng.integers(0, 400_000 - n)) if n < 400_000 else 0
+            qs.append(bytearray(seqs[g][o0:o0 + n]))
+        qs[4][5] = ord("N")                                             # an invalid seed (N among the first k-1 characters)
+        qs[5][10:14] = b"acgt"                                          # lower case inside the seed: valid there, code 0 outside
+        qs[6][5000:5003] = b"NNN"; qs[6][9000] = ord("t")               # N / lower case outside the seed, in later chunks
+        qs[7][4096 + k - 2:4096 + k + 2] = b"nNxN"                      # exceptions across a chunk boundary
+        qs.append(bytearray((b"ACGTTGCAAC" * 3000)[:24_000]))           # tandem repeat
+        qs.append(bytearray(b"A" * 9000))                               # one k-mer, 8,969 times
+        qs += [bytearray(seqs[1][100:1100]), bytearray(seqs[2][7:8000]), bytearray(seqs[3][:500])]
+        qs = [bytes(q) for q in qs]
+        assert top + k <= 400_000
+        want = o.query_sequences(qs)
+        np.testing.assert_array_equal(ix.query_sequences(qs), want)
+        hits, act = ix.query(qs, 10, 5, 1.0)
+        for q in range(len(qs)):
+            assert int(act[q]) == o.query_sequence(qs[q])[1], q
+            w = o.filter_results(want[q], 10, 5, 1.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(y[0], y[1]) for y in w], q
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("MK_FUZZ_SEEDS", "12")))))   # MK_FUZZ_SEEDS=N for a soak run
 def test_randomised_cases_against_oracle(hip, seed):
     """Seeded random corners: parameters, genome shapes (N, lower case, repeats, tiny), several
