@@ -1,6 +1,7 @@
 #include "fasta_reader.hpp"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -8,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -199,6 +201,28 @@ bool read_file(const std::string &path, std::vector<char> &out, std::vector<char
     return true;
 }
 
+unsigned usable_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+    double quota = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        double period = 0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / period;
+        fclose(f);
+    } else {
+        double q = 0, period = 0;                                               // cgroup v1
+        if (FILE *a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%lf", &q) != 1) q = 0; fclose(a); }
+        if (FILE *b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%lf", &period) != 1) period = 0; fclose(b); }
+        if (q > 0 && period > 0) quota = q / period;
+    }
+    if (quota > 0) n = std::max(1u, std::min(n, (unsigned)(quota + 0.5)));
+    return n;
+}
+
 bool FileText::open(const std::string &path, std::vector<char> &store)
 {
     const int fd = ::open(path.c_str(), O_RDONLY);
@@ -213,8 +237,12 @@ bool FileText::open(const std::string &path, std::vector<char> &store)
     }
     if (st.st_size == 0) { close(fd); p = ""; n = 0; return true; }
     maplen_ = (size_t)st.st_size;
-    map_ = mmap(nullptr, maplen_, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    // (no MAP_POPULATE: it would fault a whole multi-gigabyte file in before the first character is parsed, in every reader
+    // thread at once, against the bounded read-ahead window; the kernel's sequential read-ahead is asked for instead.
+    // Inputs must not be truncated or rewritten while they are being read: a mapped file that shrinks is a bus error.)
+    map_ = mmap(nullptr, maplen_, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
+    if (map_ != MAP_FAILED) (void)madvise(map_, maplen_, MADV_SEQUENTIAL);
     if (map_ == MAP_FAILED) {
         map_ = nullptr;
         std::vector<char> scratch;

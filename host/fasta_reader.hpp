@@ -21,6 +21,10 @@
 
 namespace mkhost {
 
+// CPUs this process may use: the affinity mask, capped by the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota) --
+// std::thread::hardware_concurrency() knows neither (a 256-thread host that grants a job 16 CPUs reports 256)
+unsigned usable_cpus();
+
 struct HostAllocator {
     void *(*alloc)(void *user, size_t bytes);     // nullptr: malloc / free
     void (*release)(void *user, void *p);

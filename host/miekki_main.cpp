@@ -178,6 +178,7 @@ struct Driver {
     mkhost::DeviceGroup group;                   // one context per GPU, genome shards in list order
     mk_ctx *ctx0() const { return group.ctx(0); }
     unsigned threads = 8;                        // -t: host reader threads
+    bool threads_given = false;                  // -t was on the command line: never start more readers than that in total
     uint32_t k = 31, threshold = 200;
     vector<string> file_names;                   // Miekki.h:59, never persisted
     ofstream out;
@@ -279,9 +280,11 @@ struct Driver {
         // reader threads per shard: -t as given for one GPU; with several, -t divided by the shards would leave each
         // with a reader or two (the default -t 8 on 8 GPUs: one), far below what a GPU sketches -- so at least eight
         // per shard, as far as the host's cores go
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned per = D == 1 ? std::max(1u, threads)
-                                    : std::max(1u, std::max(threads / (unsigned)D, std::min(8u, hw / (unsigned)D)));
+        // ... the CPUs this process may actually use (affinity mask, cgroup quota -- not hardware_concurrency(), which on a
+        // 256-thread host with a 16-CPU quota would start 64 readers for 8 shards); an explicit -t is never exceeded in total
+        const unsigned hw = mkhost::usable_cpus();
+        const unsigned floor_per = threads_given ? 1u : std::min(8u, std::max(1u, hw / (unsigned)D));
+        const unsigned per = D == 1 ? std::max(1u, threads) : std::max(1u, std::max(threads / (unsigned)D, floor_per));
         if (D == 1) {
             build_shard(ctxs[0], part[0], per, true, sb[0]);
         } else {                                                   // the shards build side by side
@@ -757,7 +760,7 @@ int main(int argc, char **argv)
     string index_file, list_file, query_lines, query_list, output_file("out.txt"), index_dump;
     uint64_t H = 17, core_number = 8, kmer_size = 31, bloom_size = 33, fingerprint_size = 3;   // main.cpp:131
     double threshold = 200;
-    bool exact_mode = false;
+    bool exact_mode = false, threads_given = false;
     int c;
     while ((c = getopt(argc, argv, "i:l:a:h:t:f:k:s:b:o:ed:A:")) != -1) {
         switch (c) {
@@ -767,7 +770,7 @@ int main(int argc, char **argv)
         case 'A': query_list = optarg; break;
         case 'o': output_file = optarg; break;
         case 'h': H = stoi(optarg); break;
-        case 't': core_number = stoi(optarg); break;
+        case 't': core_number = stoi(optarg); threads_given = true; break;
         case 'k': kmer_size = stoi(optarg); break;
         case 's': threshold = stof(optarg); break;
         case 'f': fingerprint_size = stoi(optarg); break;
@@ -791,6 +794,7 @@ int main(int argc, char **argv)
     auto start = chrono::system_clock::now();
     Driver drv;
     drv.threads = reader_threads;
+    drv.threads_given = threads_given;
     if (rank_mode) {
         if (!index_file.empty() || !index_dump.empty()) {
             cout << "-i and -d are not available with one process per GPU: run them as a single process (it uses every visible GPU)" << endl;

@@ -35,6 +35,7 @@ constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
 constexpr uint32_t kAllFlagged = 127;      // meta word: the run's flagged count when it is >= this, i.e. "all of them"
+constexpr uint32_t kScatterLdsFloor = 0;   // bytes of LDS a scatter workgroup asks for at least (0: what it needs), see launch_build_front
 }  // namespace
 
 // ---------------------------------------------------------------- characters -> packed
@@ -171,7 +172,11 @@ struct BuildShape {
 };
 
 // Item: W == 1: fingerprint << 24 | partition in bin << 12 | position in segment  (32 bits);
-//       W == 2: fingerprint << 48 | partition in bin << 12 | position in segment  (64 bits).
+//       W == 2: 40 bits of information, FIVE bytes in two arrays (round 3 stored a 64-bit word: twice the bytes of the
+//               one-byte build both ways, twice the LDS stage, half the scatter kernel's occupancy):
+//                   main  u32  fingerprint << 16 | partition in bin << 4 | position >> 8
+//                   low   u8   position & 255
+//               items[(genome, workgroup)][i] and low[(genome, workgroup)][i] belong together.
 // The segment (= scatter workgroup) supplies the upper bits of the position.  A scatter workgroup leaves its items
 // SORTED BY BIN and dense -- items[(genome, workgroup)][0 .. total) in a region of kSeg -- plus one word per bin,
 // meta[(genome, workgroup)][bin] = run start << 20 | run length << 7 | flagged: no capacities, no padding, no overflow.
@@ -179,8 +184,7 @@ struct BuildShape {
 // k-mer at hand and asks a summary of the filter, below); they come first in their run, so that the item itself needs no
 // bit for it.  kAllFlagged stands for "every item of the run" (and is what a count that does not fit becomes: a flag
 // too many only costs the reduce kernel a look at the filter).
-template <int W> struct ItemOf { using type = uint32_t; };
-template <> struct ItemOf<2> { using type = uint64_t; };
+template <int W> struct ItemOf { using type = uint32_t; };          // the main word in memory, either width
 
 // HyperMinHash fingerprint of anc's low 64 - h bits (Miekki::mantis, Miekki.cpp:91-113), for the
 // common case in one count-leading-zeros: v = the top 32 of those 64 - h bits.  When v >= 2^f the
@@ -208,7 +212,6 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
                                        uint32_t cnt, uint32_t *bins, const uint32_t *sum32, typename ItemOf<W>::type (&it)[kPer],
                                        uint32_t (&key)[kPer], const SketchParams &sp, const BuildShape &bs)
 {
-    using item_t = typename ItemOf<W>::type;
     // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
     const uint64_t F = ((uint64_t)w1 << 32) | w0;
     uint64_t R = ~F;
@@ -266,7 +269,8 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
         const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
         const uint32_t binoff = ((bucket >> bs.low_bits) << 3) | (settled << 2);   // byte offset of the bin's counter: flagged, settled
         const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
-        it[u] = ((item_t)fp << (sizeof(item_t) * 8 - 8 * W)) | (item_t)((part << kBin) | (i0 + u));
+        // (W == 2: the low eight position bits are (i0 + u) & 255, known to whoever stores the item: they are not kept here)
+        it[u] = W == 1 ? (fp << 24) | (part << kBin) | (i0 + u) : (fp << 16) | (part << 4) | ((i0 + u) >> 8);
         key[u] = (binoff << 12) | rank;                              // rank < 4096 (among the bin's flagged / settled items)
     }
 }
@@ -278,17 +282,19 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
 // settled) through ONE 4096-entry stage (4-byte items: 16 KiB; with the Bloom summary six
 // workgroups per CU) and leave as they lie, 16 bytes per lane -- no per-item address arithmetic.
 template <int W, bool KBIG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 : 4, 8))) void build_scatter_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
-    const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, typename ItemOf<W>::type *__restrict__ items,
+    const uint32_t *__restrict__ dirty, const uint64_t *__restrict__ off, uint32_t *__restrict__ items, uint8_t *__restrict__ low,
     uint32_t *__restrict__ meta, const uint32_t *summary, SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
-    constexpr uint32_t kIPV = 16 / sizeof(item_t);                   // items per 16-byte store
+    constexpr uint32_t kIPV = 4;                                      // items per 16-byte store of the main array
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    item_t *stage = reinterpret_cast<item_t *>(smem);                 // kSeg + kIPV: the workgroup's items, sorted by bin
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem);             // kSeg + kIPV: the workgroup's items (main words), sorted by bin
+    uint8_t *stage_low = smem + (kSeg + kIPV) * 4;                    // W == 2: their low position bytes, kSeg + 16
+    constexpr uint32_t kStageBytes = (kSeg + kIPV) * 4 + (W == 2 ? kSeg + 16 : 0);
     // 2 * nbins + 1 counters (per bin: flagged items, then settled ones), later the places where their runs start
-    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + (kSeg + kIPV) * sizeof(item_t));
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + kStageBytes);
     // the Bloom summary (one bit per 2048 cells: all taken), when there is one: 4 KiB at -b 33 -- as a snapshot of whatever
     // the array holds right now (the summary kernel of the batch before may be writing it: bits only ever get set)
     uint32_t *sum32 = bins + ((2 * bs.nbins + 1 + 3) & ~3u);          // (at least one word)
@@ -368,15 +374,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
     const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u)
-        if (key[u] != ~0u)
-            stage[*reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u)] = it[u];
+        if (key[u] != ~0u) {
+            const uint32_t at = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u);
+            stage[at] = it[u];
+            if (W == 2) stage_low[at] = (uint8_t)(i0 + u);
+        }
     __syncthreads();
     // ---- out: the sorted items as they lie, 16 bytes per lane (a pure stream), and one word per bin
     const uint64_t seg = (uint64_t)g * bs.nwg + wg;
-    typedef item_t vec_t __attribute__((ext_vector_type(kIPV)));
-    vec_t *__restrict__ dst = reinterpret_cast<vec_t *>(items + seg * kSeg);
-    const vec_t *__restrict__ src = reinterpret_cast<const vec_t *>(stage);
+    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(items + seg * kSeg);
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(stage);
     for (uint32_t i = tid; i * kIPV < total; i += 256) dst[i] = src[i];
+    if (W == 2) {
+        uint4 *__restrict__ dl = reinterpret_cast<uint4 *>(low + seg * kSeg);
+        const uint4 *__restrict__ sl = reinterpret_cast<const uint4 *>(stage_low);
+        for (uint32_t i = tid; i * 16 < total; i += 256) dl[i] = sl[i];
+    }
     uint32_t *__restrict__ m = meta + seg * bs.nbins;
 #pragma unroll
     for (uint32_t e = 0; e < 4; ++e) {
@@ -398,8 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 1 ? 8 
 // filter looked at.  Once the filter has filled up nothing is flagged and a winner costs no memory request at all
 // (before: its codes, 16 bytes from a random place of the genome -- 67 M L2 requests per 64 x 5 Mb batch).
 template <int W, bool KEY32>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 4, 8))) void build_reduce_kernel(
-    const typename ItemOf<W>::type *__restrict__ items, const uint32_t *__restrict__ meta,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 6, 8))) void build_reduce_kernel(
+    const typename ItemOf<W>::type *__restrict__ items, const uint8_t *__restrict__ low, const uint32_t *__restrict__ meta,
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint32_t *order,
     const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
@@ -409,7 +422,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     using item_t = typename ItemOf<W>::type;
     using key_t = typename std::conditional<KEY32, uint32_t, unsigned long long>::type;
     using fp_t = typename std::conditional<W == 1, uint8_t, uint16_t>::type;
-    constexpr uint32_t kFpShift = sizeof(item_t) * 8 - 8 * W;
     constexpr uint32_t kKeyPos = KEY32 ? 24 : 40;                    // key = fingerprint << kKeyPos | position
     constexpr key_t kNoKey = (key_t)~(key_t)0;
     constexpr uint32_t kThreads = 512, kWin = (1u << kBin) / kThreads;   // winners per thread
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     __shared__ uint32_t s_meta[kMetaChunk];
     // flagged items seen: partition in bin << 32 | position.  More than fit: every winner of the bin gets the filter
     // looked at (that is the state of a young filter, where nearly everything is flagged anyway)
-    constexpr uint32_t kNoted = 2048;
+    constexpr uint32_t kNoted = KEY32 ? 2048 : 1024;                  // (64-bit keys: a 32 KiB table -- 46 KiB in all, three workgroups per CU)
     __shared__ unsigned long long noted[kNoted];
     __shared__ uint32_t n_noted;
     __shared__ uint32_t to_check[(1u << kBin) / 32];                  // partitions whose winner is a flagged item
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
             __syncthreads();
             // two stages of UN wave-loads each: the runs of the next stage are requested before the items of the
             // current one go to the table, so that the LDS atomics of one stage drain under the loads of the next
-            struct Stage { uint32_t m[UN]; vec_t v[UN]; };
+            struct Stage { uint32_t m[UN]; vec_t v[UN]; uint32_t lo[W == 2 ? UN : 1]; };   // (lo: W == 2, the items' low position bytes)
             auto place = [&](uint32_t m, uint32_t &a0, uint32_t &first, uint32_t &end) {
                 first = m >> 20;
                 end = first + ((m >> 7) & 0x1fffu);
@@ -480,7 +492,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     place(q.m[u], a0, first, end);
                     // (a load may reach up to lpr * kIPL places past the run's start: inside the array, whose last workgroup
                     // is followed by the meta words)
-                    q.v[u] = *reinterpret_cast<const vec_t *>(items + ((uint64_t)g * bs.nwg + c0 + min(r, cn - 1u)) * kSeg + a0 + j0);
+                    const uint64_t at = ((uint64_t)g * bs.nwg + c0 + min(r, cn - 1u)) * kSeg + a0 + j0;
+                    q.v[u] = *reinterpret_cast<const vec_t *>(items + at);
+                    if (W == 2) q.lo[u] = *reinterpret_cast<const uint32_t *>(low + at);         // (a0 + j0 is a multiple of four)
                 }
             };
             auto consume = [&](uint32_t r0, const Stage &q) {
@@ -491,28 +505,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     place(q.m[u], a0, first, end);
                     // the flagged items are the first ones of their run (rare once the filter has filled up: none)
                     const uint32_t nf = q.m[u] & 127u, fend = nf == kAllFlagged ? end : first + nf;
-                    auto fold = [&](item_t item, bool flagged) {
-                        const uint32_t part = ((uint32_t)item >> 12) & (R - 1u);
+                    // (lob: the item's low position byte, W == 2 only)
+                    auto fold = [&](item_t item, uint32_t lob, bool flagged) {
+                        const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
+                        const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
                         key_t key;
-                        if (KEY32) key = (key_t)(((uint32_t)item & 0xff000fffu) | (w << 12));     // fingerprint << 24 | position
-                        else key = ((key_t)(item >> kFpShift) << kKeyPos) | (key_t)((uint64_t)w * kSeg + ((uint32_t)item & (kSeg - 1u)));
+                        if (KEY32) key = (key_t)((item & 0xff000fffu) | (w << 12));                // fingerprint << 24 | position
+                        else key = ((key_t)(item >> (W == 1 ? 24 : 16)) << kKeyPos) | (key_t)((uint64_t)w * kSeg + pos);
                         atomicMin(&table[part], key);
                         if (flagged) {
                             const uint32_t slot = atomicAdd(&n_noted, 1u);
-                            if (slot < kNoted)
-                                noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + ((uint32_t)item & (kSeg - 1u)));
+                            if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
                         }
                     };
 #pragma unroll
                     for (uint32_t e = 0; e < kIPL; ++e) {
                         const uint32_t at = a0 + j0 + e;
-                        if (at >= first && at < end) fold(q.v[u][e], at < fend);
+                        if (at >= first && at < end) fold(q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend);
                     }
                     for (uint32_t j = a0 + j0 + lpr * kIPL; j < end; j += lpr * kIPL) {        // runs longer than their lanes reach
-                        const vec_t x = *reinterpret_cast<const vec_t *>(items + ((uint64_t)g * bs.nwg + w) * kSeg + j);
+                        const uint64_t at = ((uint64_t)g * bs.nwg + w) * kSeg + j;
+                        const vec_t x = *reinterpret_cast<const vec_t *>(items + at);
+                        const uint32_t xl = W == 2 ? *reinterpret_cast<const uint32_t *>(low + at) : 0u;
 #pragma unroll
                         for (uint32_t e = 0; e < kIPL; ++e)
-                            if (j + e < end) fold(x[e], j + e < fend);
+                            if (j + e < end) fold(x[e], (xl >> (8 * e)) & 0xffu, j + e < fend);
                     }
                 }
             };
@@ -653,11 +670,11 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     // it, 16 bytes each, cover mean + 4 sigma, so that a second, dependent load per run is the exception (at h = 20: mean 15,
     // eight lanes x four items; with a reach of 16 items nearly every wave-load had a run with a tail and paid its latency)
     const double mean = (double)kSeg / bs.nbins * 15.0 / 16.0, reach = mean + 4.0 * std::sqrt(mean);
-    const uint32_t ipl = c->W == 1 ? 4 : 2;                          // items per lane (16 bytes)
+    const uint32_t ipl = 4;                                          // items per lane (16 bytes of main words, either width)
     bs.lpr = 1;
     while (bs.lpr < 64 && bs.lpr * ipl < reach) bs.lpr <<= 1;
     *key32 = c->W == 1 && max_len < (1ULL << 24);              // (a stored fingerprint is below the all-ones byte: no key equals "none")
-    const uint64_t isz = c->W == 1 ? 4 : 8;
+    const uint64_t isz = c->W == 1 ? 4 : 5;                          // (W == 2: the main words, then the low position bytes)
     // the dense item array (kSeg item places per scatter workgroup) and, behind it, one meta word per (workgroup, bin)
     const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
     const uint64_t need = item_bytes + (uint64_t)n * bs.nwg * bs.nbins * 4;
@@ -765,9 +782,14 @@ static BuildShape shape_load(const mk_ctx::BuildSide &sd)
 // the meta words lie behind the side's item array (build_setup)
 static uint32_t *meta_of(const mk_ctx *c, const mk_ctx::BuildSide &sd, const BuildShape &bs, uint32_t n)
 {
-    const uint64_t isz = c->W == 1 ? 4 : 8;
+    const uint64_t isz = c->W == 1 ? 4 : 5;
     const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
     return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(sd.d_slots) + item_bytes);
+}
+// W == 2: the items' low position bytes lie behind the main words
+static uint8_t *low_of(const mk_ctx::BuildSide &sd, const BuildShape &bs, uint32_t n)
+{
+    return static_cast<uint8_t *>(sd.d_slots) + (uint64_t)n * bs.nwg * kSeg * 4;
 }
 
 // Front stage: the scatter kernel of a batch, on the front stream, into side b's slots.
@@ -783,13 +805,18 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     if (!sd.fits) return MK_OK;
     shape_store(sd, bs);
     const SketchParams sp = make_sp(c);
-    const size_t isz = c->W == 1 ? 4 : 8;
     MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
-    const size_t lds = (kSeg + 16 / isz) * isz + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
+    const size_t stage_bytes = (kSeg + 4) * 4 + (c->W == 2 ? kSeg + 16 : 0);
+    size_t lds = stage_bytes + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
+    // How many scatter workgroups a CU takes decides whether the reduce kernel of the batch before (the other stream) finds
+    // room beside them: by itself the scatter kernel fills every CU with its small workgroups and the two kernels take
+    // turns.  A larger LDS request per workgroup leaves LDS -- and wave slots -- for reduce workgroups.
+    static const size_t lds_floor = [] { const char *e = getenv("MIEKKI_SCATTER_LDS_KIB"); return e ? (size_t)std::max(0, atoi(e)) << 10 : (size_t)kScatterLdsFloor; }();
+    if (!for_queries) lds = std::max(lds, std::min<size_t>(lds_floor, 64u << 10));
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, st ? st : c->front_stream, d_codes,     \
                        d_except,                                                                                                \
-                       d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<typename ItemOf<Wv>::type *>(sd.d_slots), \
+                       d_code_off, sd.d_counters->dirty, sd.d_seq_off, reinterpret_cast<uint32_t *>(sd.d_slots), low_of(sd, bs, n),  \
                        meta_of(c, sd, bs, n), reinterpret_cast<const uint32_t *>(c->d_bloom_full2), sp, bs)
     const bool kbig = c->p.k >= 17;
     if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
@@ -825,7 +852,7 @@ int launch_query_tables(mk_ctx *c, const char *d_seq, const uint64_t *d_off, con
     const SketchParams sp = make_sp(c);
 #define MK_QREDUCE(Wv, K32)                                                                                                     \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, st,                                     \
-                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), codes, except,   \
+                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), meta_of(c, sd, bs, n), codes, except,   \
                        c->d_pk_off[b], sd.d_counters->dirty, (const uint8_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr,         \
                        (const uint32_t *)nullptr, (uint8_t *)nullptr, d_tables, (uint8_t *)nullptr, (uint32_t *)nullptr,        \
                        (unsigned long long *)nullptr, sp, bs)
@@ -853,7 +880,7 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
     const SketchParams sp = make_sp(c);
 #define MK_REDUCE(Wv, K32)                                                                                                      \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, c->stream,                              \
-                       reinterpret_cast<const typename ItemOf<Wv>::type *>(sd.d_slots), meta_of(c, sd, bs, n), d_codes,         \
+                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), meta_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
                        c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_posted_blk,                              \
                        sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)

@@ -58,6 +58,38 @@ def mutate(seq: bytes, q: int, rate: float) -> bytes:
     return bytes(s)
 
 
+def strain(species: int, strain_id: int, length: int, rate: float) -> bytes:
+    """Strain `strain_id` of synthetic species `species`: the species' genome (genome_bases(species, 0, length)) with
+    round(rate * length) substitutions at seeded positions (strain 0 = the species genome itself).  Strains of one
+    species are independent descendants of it: two of them differ in about twice as many places.  A collection of
+    related strains is what the reference's README has in mind for its column compression (README.md:136-138)."""
+    seq = np.frombuffer(genome_bases(species, 0, length), np.uint8).copy()
+    n = int(round(rate * length)) if strain_id else 0
+    if n:
+        rng = np.random.default_rng((species << 20) ^ (strain_id << 1) ^ 0x5eed)
+        pos = rng.integers(0, length, n)
+        code = (np.searchsorted(_ACGT, seq[pos]) + rng.integers(1, 4, n)) & 3      # always a different base
+        seq[pos] = _ACGT[code]
+    return seq.tobytes()
+
+
+def tandem_rich(g: int, length: int, share: float, unit_lo: int = 2, unit_hi: int = 60) -> bytes:
+    """Genome g with about `share` of its length in tandem repeats and homopolymer runs (seeded): runs of 200-5,000
+    bases made of a 1-60 base unit, between stretches of the usual random sequence.  Repeat-rich input is what makes
+    many k-mers of one stretch fall into one partition (the build's reduce kernel: many lanes on one LDS entry)."""
+    rng = np.random.default_rng(0xBEEF ^ (g << 8))
+    out = bytearray(genome_bases(g, 0, length))
+    filled = 0
+    while filled < share * length:
+        n = int(rng.integers(200, 5000))
+        at = int(rng.integers(0, length - n))
+        unit = 1 if rng.random() < 0.3 else int(rng.integers(unit_lo, unit_hi + 1))
+        u = bytes(rng.choice(list(b"ACGT"), unit).tolist())
+        out[at:at + n] = (u * (n // unit + 1))[:n]
+        filled += n
+    return bytes(out)
+
+
 def fasta(name: str, seq: bytes, width: int = 80) -> bytes:
     lines = [b">" + name.encode()]
     lines += [seq[i:i + width] for i in range(0, len(seq), width)]
