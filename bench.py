@@ -197,40 +197,59 @@ def cpu_baseline(h, host_cores):
 
 
 def sketch_roofline(genomes, build_s, h, W):
-    """The index build is bound by vector-instruction issue, not by memory (SURVEY 8d asks for k-mers/s and
-    sketches/s with the HBM fraction as an informational number): instructions per k-mer of the two big
-    kernels from the committed SQ counter passes of this code (profiles/pmc_build.json), the issue time they
-    stand for at the measured cost of this instruction mix (3.6 cycles per wave-instruction and SIMD: the scatter kernel
-    alone on the chip; simple integer instructions issue in 3, shifts and multiplies in 4.2-5.4, profiles/r3_ubench.txt),
-    and that as a fraction of the measured build time."""
+    """The index build is bound by vector-instruction issue, not by memory (SURVEY 8d asks for k-mers/s and sketches/s with
+    the HBM fraction as an informational number).  The issue ceiling comes from RECORDED evidence, and only when it belongs to
+    this run: dynamic SQ_INSTS_VALU counts of the two big kernels (profiles/pmc_build.json, tools/pmc_build.py: one entry per
+    (k, h, fingerprint width), stamped with the SHA-256 of build.hip) x the price of their instruction mix (profiles/isa_mix.json,
+    tools/isa_mix.py: the kernels' opcodes from their ISA x per-opcode costs measured by tools/ubench -- NOT the kernel's own
+    run time) / (1024 SIMDs x 2.4 GHz).  Per kernel: issue time over the kernel's time alone on the chip; for the batch: the sum
+    of both over the measured time per 64-genome batch; beside it the same at the guide's peak of 2 cycles per wave-instruction."""
+    import hashlib
     kmers = genomes * (GENOME_LEN - 31)
     out = {"bound": "valu-issue", "kmers_per_s": kmers / build_s, "sketches_per_s": genomes / build_s}
-    # algorithmic HBM bytes per k-mer: 2-bit codes in, one 4-byte item (8 at 2 bytes) out and in again for the 15/16 of
-    # k-mers whose fingerprint is not "empty", W * 2^h fingerprint bytes per genome out, in and out again (transposer)
-    item = 4 if W == 1 else 8
+    # algorithmic HBM bytes per k-mer: 2-bit codes in, one item (4 bytes; 5 at 2-byte fingerprints) out and in again for the 15/16
+    # of k-mers whose fingerprint is not "empty", W * 2^h fingerprint bytes per genome out, in and out again (transposer)
+    item = 4 if W == 1 else 5
     bpk = 0.25 + 2 * item * 15 / 16 + 3.0 * W * (1 << h) / (GENOME_LEN - 31)
     out["hbm_bytes_per_kmer_algorithmic"] = bpk
     out["hbm_frac_informational"] = bpk * kmers / build_s / 1e9 / HBM_PEAK_GBS
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_build.json")))
-        per_batch_kmers = pm["batch_genomes"] * (pm["genome_len"] - 31)
-        valu = sum(k["valu_wave_instructions_per_batch"] for k in pm["kernels"].values())
+        sha = hashlib.sha256(open(os.path.join(ROOT, "miekki_amd", "csrc", "build.hip"), "rb").read()).hexdigest()
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_build.json")))["entries"].get(f"k31_h{h}_fp{8 * W}")
+        mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+        if pm is None:
+            raise ValueError(f"no recorded counters for -k 31 -h {h}, {8 * W}-bit fingerprints")
+        if pm["build_hip_sha256"] != sha:
+            raise ValueError("the recorded counters belong to another generation of build.hip")
+        if mix["build_hip_sha256"] != sha:
+            raise ValueError("the recorded instruction mix belongs to another generation of build.hip")
         simds, clock = 256 * 4, 2.4e9
-        cpi = float(pm.get("cycles_per_valu_wave_instruction", 4.0))
-        issue_s_per_batch = valu * cpi / (simds * clock)
+        per_batch_kmers = pm["batch_genomes"] * (pm["genome_len"] - 31)
         batch_s = build_s / max(genomes / pm["batch_genomes"], 1e-9)
-        out.update({"valu_instructions_per_kmer": valu * 64 / per_batch_kmers,
-                    "valu_instructions_per_kmer_by_kernel": {n: k["valu_wave_instructions_per_batch"] * 64 / per_batch_kmers
-                                                             for n, k in pm["kernels"].items()},
-                    "issue_ms_per_batch": issue_s_per_batch * 1e3, "ms_per_batch": batch_s * 1e3,
-                    "frac": issue_s_per_batch / batch_s,
-                    "cycles_per_valu_wave_instruction": cpi,
-                    "note": f"frac = vector-instruction issue time of scatter + reduce (SQ_INSTS_VALU x {cpi} cycles / (1024 SIMDs x 2.4 GHz)) "
-                            "over the measured time per 64-genome batch; the scatter kernel alone sits at that ceiling, the reduce "
-                            "kernel is bound by L2 requests, and the two take turns on the CUs rather than share them (DESIGN.md 4)",
+        per_kernel, issue_total, issue_peak_total = {}, 0.0, 0.0
+        for name, kd in pm["kernels"].items():
+            mk = next((v for k, v in mix["kernels"].items() if k.startswith(name.replace(">", ","))), None)
+            if mk is None or not kd.get("valu_wave_instructions_per_batch"):
+                raise ValueError(f"no instruction mix for {name}")
+            valu, cpi = kd["valu_wave_instructions_per_batch"], mk["weighted_cycles_per_valu"]
+            issue_s, issue_peak_s = valu * cpi / (simds * clock), valu * 2.0 / (simds * clock)
+            issue_total += issue_s; issue_peak_total += issue_peak_s
+            per_kernel[name] = {"valu_instructions_per_kmer": valu * 64 / per_batch_kmers, "cycles_per_valu_from_isa_mix": cpi,
+                                "issue_ms_per_batch": issue_s * 1e3, "alone_ms_per_batch": kd.get("alone_ms"),
+                                "frac_alone": (issue_s * 1e3 / kd["alone_ms"]) if kd.get("alone_ms") else None,
+                                "frac_alone_at_2_cycle_peak": (issue_peak_s * 1e3 / kd["alone_ms"]) if kd.get("alone_ms") else None}
+        out.update({"per_kernel": per_kernel, "issue_ms_per_batch": issue_total * 1e3, "ms_per_batch": batch_s * 1e3,
+                    "frac": issue_total / batch_s, "frac_at_2_cycle_peak": issue_peak_total / batch_s,
+                    "derived_from": "recorded counters (profiles/pmc_build.json) and the kernels' ISA (profiles/isa_mix.json), both stamped with "
+                                    "this build.hip; ms_per_batch is this run's",
+                    "note": "frac = (SQ_INSTS_VALU of scatter + reduce per 64-genome batch x the cost of their instruction mix: opcode counts "
+                            "from the ISA x per-opcode cycles measured by tools/ubench) / (1024 SIMDs x 2.4 GHz) over this run's time per batch; "
+                            "frac_at_2_cycle_peak prices every vector instruction at the guide's 2 cycles; the two kernels run on two streams "
+                            "and share the CUs zero-sum (DESIGN.md 4)",
                     "counters_source": pm["source"]})
     except Exception as e:
-        out["counters_source"] = f"profiles/pmc_build.json unavailable: {e}"
+        out["frac"] = None
+        out["frac_left_out_because"] = str(e)
     return out
 
 

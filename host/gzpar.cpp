@@ -53,7 +53,7 @@ void ParallelGzipWriter::deflate_block(Job *j)
 {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->bad = true; return; }   // raw deflate
+    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
     const size_t bound = deflateBound(&zs, (uLong)j->in.size()) + 64;
     j->out.resize(kHeader + bound + 8);
     zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
@@ -79,17 +79,41 @@ void ParallelGzipWriter::submit()
     std::unique_ptr<Job> j(new Job());
     j->in.swap(cur_);
     cur_.reserve(kBlock);
+    j->strategy = strategy_;
     Job *raw = j.get();
     j->th = std::thread(deflate_block, raw);
     jobs_.push_back(std::move(j));
     while (jobs_.size() >= nthreads_) drain_one();
 }
 
+void ParallelGzipWriter::write_zeros(size_t n)
+{
+    static const std::vector<uint8_t> zeros(1u << 20, 0);
+    // up to the next block boundary (and whatever is less than a block at the end) as ordinary bytes
+    while (n && !cur_.empty()) { const size_t take = std::min({n, zeros.size(), kBlock - cur_.size()}); write(zeros.data(), take); n -= take; }
+    if (n >= kBlock && zero_member_.empty()) {
+        Job j;
+        j.in.assign(kBlock, 0);
+        deflate_block(&j);
+        if (j.bad) failed_ = true; else zero_member_.swap(j.out);
+    }
+    while (n >= kBlock && !failed_) {                             // whole blocks: the ready-made member, in order
+        wrote_any_ = true;
+        std::unique_ptr<Job> j(new Job());
+        j->out = zero_member_;
+        j->ready = true;
+        jobs_.push_back(std::move(j));
+        while (jobs_.size() >= nthreads_) drain_one();
+        n -= kBlock;
+    }
+    while (n) { const size_t take = std::min(n, zeros.size()); write(zeros.data(), take); n -= take; }
+}
+
 void ParallelGzipWriter::drain_one()
 {
     std::unique_ptr<Job> j = std::move(jobs_.front());
     jobs_.pop_front();
-    j->th.join();
+    if (!j->ready) j->th.join();
     if (j->bad || !f_ || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
 }
 

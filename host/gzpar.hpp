@@ -29,10 +29,18 @@ public:
     ~ParallelGzipWriter();
     bool ok() const { return f_ && !failed_; }
     void write(const void *p, size_t n);
+    // n zero bytes.  Whole blocks of zeros -- the reference's index always carries its full 2^(b-3)-byte Bloom filter,
+    // of which a 2k-bit k-mer reaches only the first part: 960 MiB of zeros at k = 31, b = 33 -- are not deflated again
+    // and again: the member of an all-zero block is made once and written as often as needed.  Same stream, same format.
+    void write_zeros(size_t n);
+    // deflate strategy of the blocks submitted from now on (zlib: Z_DEFAULT_STRATEGY, Z_HUFFMAN_ONLY, ...).  Fingerprint
+    // columns have no repeats for LZ77 to find (profiles/r3_column_entropy.txt: level 1 gets 1.35:1, an order-0 entropy
+    // coder 1.39:1): Huffman-only codes them as small, several times faster.  Any inflater reads either.
+    void set_strategy(int strategy) { strategy_ = strategy; }
     bool finish();                       // flushes, closes; false on any error
     static constexpr size_t kBlock = 32u << 20;
 private:
-    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; };
+    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; int strategy = 0; bool ready = false; };
     static void deflate_block(Job *j);
     void submit();
     void drain_one();
@@ -41,6 +49,8 @@ private:
     std::vector<uint8_t> cur_;
     std::deque<std::unique_ptr<Job>> jobs_;
     bool failed_ = false, wrote_any_ = false;
+    int strategy_ = 0;                   // Z_DEFAULT_STRATEGY
+    std::vector<uint8_t> zero_member_;   // the gzip member of kBlock zero bytes, made on first use
 };
 
 class ParallelGzipReader {

@@ -71,6 +71,7 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
     std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1)), part;
+    w.set_strategy(Z_HUFFMAN_ONLY);                                // fingerprints: nothing for LZ77 to find (gzpar.hpp)
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
         if (D == 1) {
@@ -92,14 +93,18 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     std::vector<uint32_t> ss(G);
     for (size_t d = 0; ok && d < D; ++d)
         if (mk_index_export_sizes(ctxs[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) { err = mk_last_error(); ok = false; }
+    w.set_strategy(Z_DEFAULT_STRATEGY);
     if (ok) w.write(gs.data(), (size_t)G * 8);
-    const uint64_t nb = hd.bloom_bits / 8;
-    buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(nb, 1)));
-    for (uint64_t o = 0; ok && o < nb; o += kChunk) {              // every shard holds the global filter
-        const uint64_t e = std::min(nb, o + kChunk);
+    // the filter: the cells a 2k-bit k-mer can reach come from the device (every shard holds the global filter), the rest
+    // of the reference's 2^(b-3) bytes -- 960 MiB of the 1 GiB at k = 31, b = 33 -- are zeros by construction
+    const uint64_t nb = hd.bloom_bits / 8, reach = std::min<uint64_t>(nb, mk_bloom_reachable_bytes(ctxs[0]));
+    buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(reach, 1)));
+    for (uint64_t o = 0; ok && o < reach; o += kChunk) {
+        const uint64_t e = std::min(reach, o + kChunk);
         if (mk_index_export_bloom(ctxs[0], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
         w.write(buf.data(), (size_t)(e - o));
     }
+    if (ok) w.write_zeros((size_t)(nb - reach));
     if (ok) w.write(ss.data(), (size_t)G * 4);
     if (!w.finish()) ok = false;
     if (!ok && err.empty()) err = "write error on " + path;

@@ -303,6 +303,7 @@ struct Driver {
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
                      << "s, in mk_index_append " << sb[d].t_append << "s" << endl;
         finish_index(true);
+        compress_cold();
         cout << "Reference indexed: " << group.total() << endl;
         mk_params p;
         mk_get_params(ctx0(), &p);
@@ -372,10 +373,23 @@ struct Driver {
         }
         cout << endl;
         finish_index(true);
+        compress_cold();
         cout << "Reference indexed: " << group.total() << endl;
         mk_params p;
         mk_get_params(ctx0(), &p);
         if (p.bloom_log2) cout << "BF size:" << int_to_string(1ull << p.bloom_log2) << endl;
+    }
+
+    // INDEX->compress_index(1) of main.cpp:198, for the rows that live in host memory (a collection beyond the GPUs' memory):
+    // packed where related genomes sit next to each other in the list, left alone where nothing is to be gained
+    void compress_cold()
+    {
+        for (size_t d = 0; d < group.shards(); ++d) {
+            uint64_t raw = 0, packed = 0;
+            if (mk_index_compress(group.ctx(d), &raw, &packed) != MK_OK) { cout << "index compression failed: " << mk_last_error() << endl; exit(1); }
+            if (raw && getenv("MIEKKI_VERBOSE"))
+                cout << "[cold rows] shard " << d << ": " << raw << " bytes in host memory, " << packed << " after packing" << endl;
+        }
     }
 
     // id bases, the global Bloom filter and the sizes of all genomes on the merging GPU

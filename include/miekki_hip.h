@@ -97,6 +97,15 @@ void mk_destroy(mk_ctx *ctx);
  * Miekki.cpp:863-877, were for in the reference: a collection beyond fast memory.) */
 int mk_reserve(mk_ctx *ctx, uint32_t n_genomes);
 
+/* Miekki::compress_index / decompress_index (Miekki.cpp:863-877; main.cpp:198 compresses after -l) for the rows that live
+ * in host memory because the matrix exceeds its HBM budget (mk_reserve): per piece of 1,024 genomes of a row, one bit per
+ * genome "differs from the genome before" + the differing fingerprints -- what related strains next to each other in the
+ * list leave of a column (README.md:136-138); a row that would not shrink is kept as it is, and a collection that does
+ * not shrink by 5 % is left alone.  Queries then move the PACKED bytes of a cold range over PCIe and expand them in HBM;
+ * appends, exports and imports unpack first by themselves (the reference's dump decompresses first too, 662-664).
+ * raw_bytes / packed_bytes (may be NULL): the cold rows before and after (equal: nothing was packed). */
+int mk_index_compress(mk_ctx *ctx, uint64_t *raw_bytes, uint64_t *packed_bytes);
+int mk_index_decompress(mk_ctx *ctx);
 uint32_t mk_index_size(const mk_ctx *ctx);                 /* Miekki::index_size */
 int mk_get_params(const mk_ctx *ctx, mk_params *out);
 int mk_get_stats(const mk_ctx *ctx, mk_stats *out);
@@ -164,6 +173,12 @@ void mk_host_free(mk_ctx *ctx, void *p);
 /* mk_index_append for the synthetic genomes of SURVEY.md 8d, generated on the device
  * (ids first_id .. first_id+n-1, `length` bases each): no PCIe traffic. */
 int mk_index_append_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length);
+/* The same for a collection of RELATED genomes (measurement aid for the column codec, mk_index_compress): genome g is
+ * strain g % strains of species g / strains; strain 0 is the synthetic genome `species` of SURVEY.md 8d itself, the
+ * others are independent descendants of it with about rate_ppm substitutions per million bases (tests/synth.py:
+ * strain_device is the same generator on the host). */
+int mk_index_append_synthetic_strains(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains,
+                                      uint32_t rate_ppm);
 
 /* ---- persistence: the payload of dump_disk / the loading constructor
  * (Miekki.cpp:649-719), streamed in ranges so that the host never

@@ -110,6 +110,7 @@ static uint32_t hot_rows_for(const mk_ctx *c, uint64_t ld, uint64_t budget)
 static int ensure_capacity(mk_ctx *c, uint32_t need)
 {
     if (need <= c->capG) return MK_OK;
+    MK_TRY(need_raw_cold(c));                                      // (the re-layout copies rows as they are)
     uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(256, (uint64_t)c->capG * 2));
     cap = std::min<uint64_t>(cap, 0xffffff00ull);
     uint64_t ld = (cap * c->W + kTileBytes - 1) / kTileBytes * kTileBytes;
@@ -255,6 +256,9 @@ static int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool
     if (for_append && c->d_bloom && !c->d_bloom_order) {
         MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
         MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 4, c->stream));
+        const uint64_t regions = (c->bloom_dev_bytes >> kBloomRegionLog2) + 1;
+        MK_TRY(dev_alloc(&c->d_bloom_touched, regions));
+        MK_HIP(hipMemsetAsync(c->d_bloom_touched, 0, regions, c->stream));
     }
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
     if (!c->h_img) MK_HIP(hipHostMalloc((void **)&c->h_img, sizeof *c->h_img, hipHostMallocDefault));
@@ -367,6 +371,7 @@ static int settle_one(mk_ctx *c, mk_ctx::BuildInFlight &b);
 static int enqueue_back(mk_ctx *c)
 {
     if (c->older.on) MK_TRY(settle_one(c, c->older));            // (at most two batches are not folded in at any time)
+    MK_TRY(need_raw_cold(c));                                    // new columns are written into the rows as they are
     const uint32_t n = c->front.n;
     if (c->G_back + n > c->capG) {
         // the matrix has to grow: that re-lays it out with the columns of c->G genomes -- fold everything in first
@@ -679,7 +684,7 @@ static int qset_prepare_slab(mk_ctx *c, mk_qset *qs)
     if (const char *e = getenv("MIEKKI_SLAB_MIN_QUERIES")) small_below = (uint32_t)std::max(0L, atol(e));   // tests force the range-table path
     // (with cold rows the ranges are cut by partition whatever the set's size: whole cold ranges are then staged
     // through HBM once per chunk, where pieces cut by count would have every wave read its rows over PCIe)
-    if (qs->nq < small_below && !c->h_M) {
+    if (qs->nq < small_below && !has_cold(c)) {
         const uint64_t waves = (uint64_t)ntiles_of(c) * qs->nq;
         // (up to eight pieces: that is what select_kernel sums with its words prefetched; more only
         // when the packed counters ask for it)
@@ -774,8 +779,9 @@ static int ensure_cold_stage(mk_ctx *c, uint64_t unit)
 template <typename Launch>
 static int scan_windows(mk_ctx *c, Launch launch)
 {
-    if (!c->h_M) return launch(c->d_M, (const uint8_t *)nullptr, c->P, 0u, c->P, true);
+    if (!has_cold(c)) return launch(c->d_M, (const uint8_t *)nullptr, c->P, 0u, c->P, true);
     MK_TRY(ensure_cold_stage(c, std::max<uint64_t>(1, c->P / 64)));
+    MK_TRY(ensure_zstage(c, c->cold_stage_rows));
     hipEvent_t ev_enter = c->ev_cold[4];
     hipEvent_t *ev_copy = c->ev_cold, *ev_scan = c->ev_cold + 2;
     MK_HIP(hipEventRecord(ev_enter, c->stream));
@@ -788,7 +794,7 @@ static int scan_windows(mk_ctx *c, Launch launch)
         const int b = (int)(i & 1u);
         uint8_t *stage = c->d_cold_stage + (uint64_t)b * c->cold_stage_rows * c->ld;
         if (i >= 2) MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_scan[b], 0));     // the launch that read this buffer last
-        MK_HIP(hipMemcpyAsync(stage, c->h_M + (r - c->P_hot) * c->ld, nr * c->ld, hipMemcpyHostToDevice, c->copy_stream));
+        MK_TRY(stage_cold_rows(c, r, r + nr, stage, b, c->copy_stream));      // (packed rows: their packed bytes cross PCIe, cold.hip)
         MK_HIP(hipEventRecord(ev_copy[b], c->copy_stream));
         MK_HIP(hipStreamWaitEvent(c->stream, ev_copy[b], 0));
         MK_TRY(launch(stage - r * c->ld, (const uint8_t *)nullptr, c->P, (uint32_t)r, (uint32_t)(r + nr), first));
@@ -805,7 +811,7 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
     if (q1 <= q0 || c->G == 0) return MK_OK;
     const uint32_t nt = ntiles_of(c);
     const uint32_t per_launch = std::max<uint32_t>(1, 0x7ffffff0u / nt);
-    const bool windowed = c->h_M != nullptr;                       // cold rows: one launch per window of rows
+    const bool windowed = has_cold(c);                             // cold rows: one launch per window of rows
     // One pass over the row windows for both kernels (a cold window is copied to HBM once): the sparse kernel
     // first -- in the first window it also writes the zero rows of the dense queries (scan_n = 0) -- then the dense
     // kernel, which adds the whole-genome queries' scores, up to eight queries per pass over the rows.
@@ -871,7 +877,8 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     a.chunk = qs->chunk; a.nent = qs->d_scan_n;
     c->stats.scan_slab_launches++;
     const uint32_t rows_per_range = qs->S ? c->P / qs->S : c->P;
-    if (!c->h_M || qs->chunk || qs->S < 2 || rows_per_range == 0) {
+    if (has_cold(c) && (qs->chunk || qs->S < 2 || rows_per_range == 0)) MK_TRY(need_raw_cold(c));   // (read in place below)
+    if (!has_cold(c) || qs->chunk || qs->S < 2 || rows_per_range == 0) {
         // everything in HBM -- or ranges cut by count (small sets), which do not map to partition
         // ranges: cold rows, if any, are then read in place over PCIe
         ScopedTimer t(c, 1);
@@ -885,6 +892,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
     // two staging buffers (the copy of one group of ranges runs beside the scan of the previous one),
     // each as many ranges as fit a sixteenth of the hot part -- at least one range
     MK_TRY(ensure_cold_stage(c, rows_per_range));
+    MK_TRY(ensure_zstage(c, c->cold_stage_rows));
     hipEvent_t ev_enter = c->ev_cold[4];
     hipEvent_t *ev_copy = c->ev_cold, *ev_scan = c->ev_cold + 2;
     // the copies may start as soon as everything queued so far (earlier scans out of the stage) is done
@@ -901,6 +909,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
         const uint32_t nr = std::min(per, qs->S - r);
         const uint64_t first = (uint64_t)r * rows_per_range;
         if ((uint64_t)nr * rows_per_range > c->cold_stage_rows) {   // a range larger than a stage (a set with few, huge ranges): in place
+            MK_TRY(need_raw_cold(c));
             a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot;
         } else {
             const int b = (int)(i & 1u);
@@ -910,9 +919,7 @@ static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
             if (i >= 2) MK_HIP(hipStreamWaitEvent(c->copy_stream, ev_scan[b], 0));   // the scan that read this buffer last
             if (hot_rows)
                 MK_HIP(hipMemcpyAsync(stage, c->d_M + first * c->ld, hot_rows * c->ld, hipMemcpyDeviceToDevice, c->copy_stream));
-            if (first + hot_rows < last)
-                MK_HIP(hipMemcpyAsync(stage + hot_rows * c->ld, c->h_M + (first + hot_rows - c->P_hot) * c->ld,
-                                      (last - first - hot_rows) * c->ld, hipMemcpyHostToDevice, c->copy_stream));
+            if (first + hot_rows < last) MK_TRY(stage_cold_rows(c, first + hot_rows, last, stage + hot_rows * c->ld, b, c->copy_stream));
             MK_HIP(hipEventRecord(ev_copy[b], c->copy_stream));
             MK_HIP(hipStreamWaitEvent(c->stream, ev_copy[b], 0));
             // row p of these ranges now lives at stage + (p - first) * ld: present the stage as "the matrix"
@@ -974,6 +981,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->P = 1u << p->h; c->W = p->fp_bits / 8; c->f = p->fp_bits - kMantisBits;
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
+    c->h_Z = nullptr; c->z_bytes = 0; c->d_zoff = nullptr; c->d_zstage[0] = c->d_zstage[1] = nullptr; c->zstage_cap = 0;
     c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
     for (int i = 0; i < 5; ++i) c->ev_cold[i] = nullptr;
     if (const char *e = getenv("MIEKKI_HBM_MATRIX_MIB")) { const long v = atol(e); if (v > 0) c->hbm_matrix_budget = (uint64_t)v << 20; }
@@ -999,7 +1007,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->d_qarena = nullptr; c->qarena_cap = 0; c->qarena_busy = false;
     c->h_stage = nullptr; c->stage_cap = 0; c->h_res = nullptr; c->res_cap = 0;
     c->cand_cap_q = 0; c->d_long_table = nullptr; c->d_ovf = nullptr; c->d_ovf_count = nullptr;
-    c->d_fpT = nullptr; c->d_posted_blk = nullptr;
+    c->d_fpT = nullptr; c->d_bloom_touched = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     MK_HIP(hipSetDevice(p->device));
     MK_HIP(hipStreamCreate(&c->stream));
@@ -1039,6 +1047,8 @@ void mk_destroy(mk_ctx *c)
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
     if (c->h_M) (void)hipHostFree(c->h_M);
+    if (c->h_Z) (void)hipHostFree(c->h_Z);
+    dev_free(c->d_zoff); dev_free(c->d_zstage[0]); dev_free(c->d_zstage[1]);
     dev_free(c->d_cold_stage);
     for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]);
     dev_free(c->d_hits); dev_free(c->d_nhits);
@@ -1056,7 +1066,7 @@ void mk_destroy(mk_ctx *c)
     for (int b = 0; b < 2; ++b) { dev_free(c->d_pk[b]); dev_free(c->d_pk_off[b]); dev_free(c->d_heads[b]); }
     dev_free(c->d_seq[0]); dev_free(c->d_seq[1]); dev_free(c->d_scores);
     dev_free(c->d_count); dev_free(c->d_cand); dev_free(c->d_long_table); dev_free(c->d_partials);
-    dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_posted_blk);
+    dev_free(c->d_flag); dev_free(c->d_all_ss); dev_free(c->d_all_gs); dev_free(c->d_fpT); dev_free(c->d_bloom_touched);
     dev_free(c->d_qarena);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -1246,7 +1256,14 @@ void mk_host_free(mk_ctx *c, void *p)
     (void)hipHostFree(p);
 }
 
-int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length)
+static int append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains, uint32_t rate_ppm);
+int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length) { return append_synthetic(c, first_id, n, length, 0, 0); }
+int mk_index_append_synthetic_strains(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains, uint32_t rate_ppm)
+{
+    if (!strains || rate_ppm > 30000) { set_error("strains per species must be positive, the rate at most 30,000 ppm"); return MK_ERR_ARG; }
+    return append_synthetic(c, first_id, n, length, strains, rate_ppm);
+}
+static int append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains, uint32_t rate_ppm)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
     if (length < c->p.k) { set_error("sequence shorter than k"); return MK_ERR_ARG; }
@@ -1264,7 +1281,7 @@ int mk_index_append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t
         // build works from -- on the front stream, followed by this batch's front stage: the device is never idle
         // while the host settles the batch before
         MK_HIP(hipMemcpyAsync(c->d_pk_off[buf], pk_off, (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->front_stream));
-        MK_TRY(launch_synth_packed(c, first_id + g0, nb, length, c->d_pk[buf], c->d_pk_off[buf]));
+        MK_TRY(launch_synth_packed(c, first_id + g0, nb, length, c->d_pk[buf], c->d_pk_off[buf], strains, rate_ppm));
         MK_TRY(enqueue_front(c, off, nb, buf, kSynth, nullptr));
         MK_TRY(enqueue_back(c));
         MK_TRY(settle_older(c));
@@ -1278,6 +1295,7 @@ static int staged_columns(mk_ctx *c, bool to_device, uint32_t pb, uint32_t pe, u
 {
     if (pb > pe || pe > c->P) { set_error("partition range out of bounds"); return MK_ERR_ARG; }
     if (pb == pe || c->G == 0) return MK_OK;
+    MK_TRY(need_raw_cold(c));                                    // (dump_disk decompresses first too, Miekki.cpp:662-664)
     const uint64_t row = (uint64_t)c->G * c->W;
     const uint32_t rows_per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pe - pb, (256ull << 20) / row));
     uint8_t *d_stage = nullptr;
@@ -1314,6 +1332,7 @@ int mk_index_export_genomes(mk_ctx *c, const uint32_t *ids, uint32_t n, uint8_t 
     for (uint32_t j = 0; j < n; ++j)
         if (ids[j] < c->p.genome_id_base || ids[j] - c->p.genome_id_base >= c->G) { set_error("genome id %u is not in this index", ids[j]); return MK_ERR_ARG; }
     if (!n) return MK_OK;
+    MK_TRY(need_raw_cold(c));
     // in pieces of at most 64 genomes: 2^h x 64 x W bytes of staging (128 MiB at -h 20, 2-byte fingerprints)
     uint32_t *d_ids = nullptr;
     uint8_t *d_stage = nullptr;
@@ -1346,6 +1365,27 @@ int mk_index_export_genomes(mk_ctx *c, const uint32_t *ids, uint32_t n, uint8_t 
     return rc;
 }
 
+int mk_index_compress(mk_ctx *c, uint64_t *raw_bytes, uint64_t *packed_bytes)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    MK_HIP(hipStreamSynchronize(c->copy_stream));
+    if (c->h_Z) {                                                    // packed already: say what it came to
+        if (raw_bytes) *raw_bytes = (uint64_t)(c->P - c->P_hot) * c->ld;
+        if (packed_bytes) *packed_bytes = c->z_bytes;
+        return MK_OK;
+    }
+    return pack_cold(c, raw_bytes, packed_bytes);
+}
+
+int mk_index_decompress(mk_ctx *c)
+{
+    if (!c) { set_error("null context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c));
+    return need_raw_cold(c);
+}
+
 int mk_index_export_sizes(mk_ctx *c, uint64_t *genome_size, uint32_t *sketch_size)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
@@ -1372,6 +1412,7 @@ int mk_index_import_begin(mk_ctx *c, uint32_t n)
 {
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
+    MK_TRY(need_raw_cold(c));
     MK_HIP(hipStreamSynchronize(c->stream));
     c->G = 0;
     c->h_sketch_size.clear(); c->h_genome_size.clear();

@@ -131,13 +131,13 @@ __global__ void seed_fix_kernel(const char *__restrict__ seq, const uint64_t *__
 // base i of genome g is the 2-bit field (62 - 2 * (i % 32)) of genome_word(g, i / 32),
 // i.e. the packed word is that word with the order of its digits reversed.
 __global__ void synth_packed_kernel(uint64_t first_id, uint32_t n, uint64_t len, uint8_t *__restrict__ codes,
-                                    const uint64_t *__restrict__ code_off)
+                                    const uint64_t *__restrict__ code_off, uint32_t strains, uint32_t rate_ppm)
 {
     const uint64_t words = (len + 31) / 32;
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t g = blockIdx.y;
     if (w >= words || g >= n) return;
-    uint64_t v = reverse_digits(genome_word(first_id + g, w));
+    uint64_t v = reverse_digits(strains ? strain_word(first_id + g, w, strains, rate_ppm) : genome_word(first_id + g, w));
     const uint64_t m = len - w * 32;
     if (m < 32) v &= (1ULL << (2 * m)) - 1;
     reinterpret_cast<uint64_t *>(codes + code_off[g])[w] = v;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
     const uint32_t *__restrict__ dirty, const uint8_t *bloom, uint64_t bloom_dev_bytes, uint32_t *order,
     const uint32_t *__restrict__ full, uint8_t *__restrict__ fp_out, uint64_t *__restrict__ tables,
-    uint8_t *__restrict__ posted_blk, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
+    uint8_t *__restrict__ touched, uint32_t *__restrict__ active, unsigned long long *__restrict__ cardsum,
     SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
@@ -426,7 +426,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     constexpr key_t kNoKey = (key_t)~(key_t)0;
     constexpr uint32_t kThreads = 512, kWin = (1u << kBin) / kThreads;   // winners per thread
     __shared__ key_t table[1u << kBin];
-    __shared__ uint32_t blk_posted[(1u << kBin) / 256];
     __shared__ uint32_t s_act;
     __shared__ unsigned long long s_card;
     constexpr uint32_t kMetaChunk = 1280;                             // scatter workgroups whose meta words sit in LDS at a time (5 Mb: 1,221)
@@ -442,7 +441,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
     const uint32_t R = 1u << bs.low_bits;
     for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
-    if (threadIdx.x < (1u << kBin) / 256) blk_posted[threadIdx.x] = 0;
     if (threadIdx.x < (1u << kBin) / 32) to_check[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_act = 0; s_card = 0; n_noted = 0; }
     __syncthreads();
@@ -506,30 +504,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     // the flagged items are the first ones of their run (rare once the filter has filled up: none)
                     const uint32_t nf = q.m[u] & 127u, fend = nf == kAllFlagged ? end : first + nf;
                     // (lob: the item's low position byte, W == 2 only)
-                    auto fold = [&](item_t item, uint32_t lob, bool flagged) {
+                    auto fold = [&](uint32_t w, item_t item, uint32_t lob, bool flagged) {
                         const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
                         const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
                         key_t key;
                         if (KEY32) key = (key_t)((item & 0xff000fffu) | (w << 12));                // fingerprint << 24 | position
                         else key = ((key_t)(item >> (W == 1 ? 24 : 16)) << kKeyPos) | (key_t)((uint64_t)w * kSeg + pos);
-                        atomicMin(&table[part], key);
-                        if (flagged) {
-                            const uint32_t slot = atomicAdd(&n_noted, 1u);
-                            if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
+                        // (a look before the atomic: repeat-rich sequence sends the same k-mer -- same partition, same fingerprint,
+                        // a later position -- again and again, and 64 lanes of an atomic minimum on ONE entry cost 620 cycles where
+                        // a read of one entry is a broadcast, profiles/r3_ubench.txt; a key that cannot win is dropped here.
+                        // profiles/r4_repeat_rich.txt: 20 % of a genome in tandem repeats tripled this kernel's time without it)
+                        if (key < table[part]) atomicMin(&table[part], key);
+                        // (a young filter flags every item: 18,700 per workgroup.  One atomic WITH return per item on the one LDS
+                        // word costs 20 cycles per wave-instruction, 0.15 ms of LDS time per CU and batch; the lanes that hold a
+                        // flagged item reserve their places together instead: one atomic per wave-instruction.)
+                        const unsigned long long fl = __ballot(flagged);
+                        if (fl) {
+                            const uint32_t leader = (uint32_t)__ffsll((long long)fl) - 1u;
+                            uint32_t base = 0;
+                            if (lane == leader) base = atomicAdd(&n_noted, (uint32_t)__popcll(fl));
+                            base = (uint32_t)__shfl((int)base, (int)leader);
+                            const uint32_t slot = base + (uint32_t)__popcll(fl & ((1ull << lane) - 1ull));
+                            if (flagged && slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
                         }
                     };
 #pragma unroll
                     for (uint32_t e = 0; e < kIPL; ++e) {
                         const uint32_t at = a0 + j0 + e;
-                        if (at >= first && at < end) fold(q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend);
+                        if (at >= first && at < end) fold(w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend);
                     }
-                    for (uint32_t j = a0 + j0 + lpr * kIPL; j < end; j += lpr * kIPL) {        // runs longer than their lanes reach
-                        const uint64_t at = ((uint64_t)g * bs.nwg + w) * kSeg + j;
-                        const vec_t x = *reinterpret_cast<const vec_t *>(items + at);
-                        const uint32_t xl = W == 2 ? *reinterpret_cast<const uint32_t *>(low + at) : 0u;
+                    // Runs longer than their lanes reach.  Rare on ordinary sequence (the lanes cover mean + 4 sigma), the rule on
+                    // repeat-rich sequence: a tandem repeat sends a whole stretch of k-mers into ONE partition, i.e. hundreds or
+                    // thousands of items into one run.  Left to the run's own lpr lanes that is a chain of dependent loads, 32 items
+                    // at a time, while the rest of the workgroup waits at the barrier (profiles/r4_repeat_rich.txt: 20 % of a
+                    // genome in repeats made this kernel 3.5 x slower); the WHOLE WAVE takes such a tail, 256 items per load.
+                    unsigned long long tails = __ballot(end > a0 + lpr * kIPL);
+                    while (tails) {                                                             // (wave-uniform)
+                        const uint32_t l = (uint32_t)__ffsll((long long)tails) - 1u;            // first lane of a sub-group with a tail
+                        tails &= ~(((lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull))) << l);
+                        const uint32_t t_a0 = (uint32_t)__shfl((int)a0, (int)l), t_end = (uint32_t)__shfl((int)end, (int)l);
+                        const uint32_t t_fend = (uint32_t)__shfl((int)fend, (int)l), t_w = (uint32_t)__shfl((int)w, (int)l);
+                        for (uint32_t j = t_a0 + lpr * kIPL + lane * kIPL; j < t_end; j += 64u * kIPL) {
+                            const uint64_t at = ((uint64_t)g * bs.nwg + t_w) * kSeg + j;
+                            const vec_t x = *reinterpret_cast<const vec_t *>(items + at);
+                            const uint32_t xl = W == 2 ? *reinterpret_cast<const uint32_t *>(low + at) : 0u;
 #pragma unroll
-                        for (uint32_t e = 0; e < kIPL; ++e)
-                            if (j + e < end) fold(x[e], (xl >> (8 * e)) & 0xffu, j + e < fend);
+                            for (uint32_t e = 0; e < kIPL; ++e)
+                                if (j + e < t_end) fold(t_w, x[e], (xl >> (8 * e)) & 0xffu, j + e < t_fend);
+                        }
                     }
                 }
             };
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     }
     const uint64_t row0 = (uint64_t)g * sp.P + (uint64_t)bin * R;
     fp_t *__restrict__ fpo = reinterpret_cast<fp_t *>(fp_out) + row0;
-    uint32_t posted_mask = 0, act = 0, undecided = 0;
+    uint32_t act = 0, undecided = 0;
     unsigned long long card = 0;
     const bool pass_a = bloom && !(bs.tune & 1u);
 #pragma unroll
@@ -587,52 +609,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         card += has ? (unsigned long long)(1u << (31u - (fp >> sp.f))) : 0ull;   // Miekki.cpp:293: sum of 2^-exp, in units of 2^-31
         if (has && pass_a && (check_all || ((to_check[i >> 5] >> (i & 31u)) & 1u))) undecided |= 1u << j;
     }
-    // Pass A of the Bloom insert (see bloom_kernel<false>, sketch.hip) for those, one at a time: the canonical k-mer from
-    // the packed codes, first-level summary, the cell itself, and a first-writer key for every cell still empty.  The five
-    // positions of a k-mer are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32: when
-    // the low word cannot carry they are ONE position -- all but one k-mer in four million -- and of the five keys only
-    // the smallest, hash index 0, can ever win the cell (pass B re-derives all five and finds the same)
+    // The Bloom insert's first half (Miekki.cpp:121-131) for those, one at a time: the canonical k-mer from the packed codes,
+    // first-level summary, the cell itself, and a first-writer key for the cell when it is still empty -- (genome in batch,
+    // partition) and, below them, the BIT this k-mer would set: 1 << (hash % 8) -- with an atomic minimum.  The second half
+    // is a sweep over the cells that took a key (bloom_sweep_kernel, sketch.hip): the k-mer is not needed again.  The five
+    // positions of a k-mer are (canon + t_i) >> b with t_i < 1024 (universal_hash, utils.cpp:197-199) and b >= 32: when the
+    // low word cannot carry they are ONE position -- all but one k-mer in four million; otherwise at most two cells, each
+    // taking the bit of the lowest hash index that names it, which is what the reference's loop over the indices leaves.
+    // (Posting without the two looks while the filter is young was tried: at -h 20 two thirds of the cells are taken after the
+    // first batch, and an atomic on a taken cell costs more than the read that avoids it -- 2.22 against 2.11 ms per batch.)
     const uint64_t *__restrict__ gcodes = reinterpret_cast<const uint64_t *>(codes + code_off[g]);
     const uint64_t *__restrict__ gexcept = reinterpret_cast<const uint64_t *>(except + code_off[g] / 2);
     const bool has_x = dirty[g] != 0;                                 // workgroup-uniform
-    // (a young filter -- more flagged items than the list holds, check_all -- has no full groups to speak of: its winners
-    // skip the first-level summary and go to the cell, one L2 request less each)
-    auto probe = [&](uint64_t cell, uint32_t p) -> bool {
-        if (cell >= bloom_dev_bytes) return false;
+    auto post = [&](uint64_t hsh, uint32_t p) {
+        const uint64_t cell = hsh >> 3;
+        if (cell >= bloom_dev_bytes) return;
         const uint32_t grp = (uint32_t)(cell >> 3), sidx = grp >> 5;                              // 8, 256 cells
-        if (!check_all && ((full[sidx] >> (grp & 31u)) & 1u)) return false;
-        if (bloom[cell] != 0) return false;
-        atomicMin(&order[cell], (g << sp.h) | p);               // genome in batch, partition: pass B finds the hash index itself
-        return true;
+        if ((full[sidx] >> (grp & 31u)) & 1u) return;
+        if (bloom[cell] != 0) return;
+        atomicMin(&order[cell], (((g << sp.h) | p) << 3) | (uint32_t)(hsh & 7u));
+        touched[cell >> kBloomRegionLog2] = 1;                       // the sweep looks at this region of cells
     };
     while (undecided) {
         const uint32_t j = (uint32_t)__builtin_ctz(undecided), i = threadIdx.x + kThreads * j;
         undecided &= undecided - 1u;
         const uint64_t pos = (uint64_t)table[i] & ((1ULL << kKeyPos) - 1);
         const uint64_t cn = canon_from_packed(gcodes, gexcept, has_x, pos, sp.k);
-        const uint32_t p = bin * R + i, chi = (uint32_t)(cn >> 32);
-        bool posted = false;
+        const uint32_t p = bin * R + i;
         if ((uint32_t)cn <= 0xFFFFFC00u) {
-            posted = probe(chi >> (sp.bloom_log2 - 32u + 3u), p);
+            post(cn >> sp.bloom_log2, p);
         } else {
             const uint64_t anc = revhash64(cn);
-            for (uint32_t hi = 0; hi < kNumHash; ++hi) posted |= probe(bloom_pos(cn, anc, hi, sp.bloom_log2) >> 3, p);
+            uint64_t seen[2] = {~0ull, ~0ull};
+            for (uint32_t hi = 0; hi < kNumHash; ++hi) {
+                const uint64_t hsh = bloom_pos(cn, anc, hi, sp.bloom_log2);
+                if ((hsh >> 3) == seen[0] || (hsh >> 3) == seen[1]) continue;
+                seen[seen[0] == ~0ull ? 0 : 1] = hsh >> 3;
+                post(hsh, p);
+            }
         }
-        // what pass B needs: the canonical k-mers of the blocks in which something was posted
-        if (posted) { posted_mask |= 1u << j; blk_posted[i >> 8] = 1; tables[row0 + i] = cn; }
     }
     for (int o = 32; o > 0; o >>= 1) { act += __shfl_xor(act, o); card += __shfl_xor(card, o); }
     if (lane == 0 && act) { atomicAdd(&s_act, act); atomicAdd(&s_card, card); }
     __syncthreads();
     if (threadIdx.x == 0 && s_act) { atomicAdd(&active[g], s_act); atomicAdd(&cardsum[g], s_card); }
-    // (and no key in the other places of such a block)
-#pragma unroll
-    for (uint32_t j = 0; j < kWin; ++j) {
-        const uint32_t i = threadIdx.x + kThreads * j;
-        if (i < R && blk_posted[i >> 8] && !((posted_mask >> j) & 1u)) tables[row0 + i] = kEmptyKey;
-    }
-    const uint32_t nblk = max(1u, R >> 8), blk_per_genome = max(1u, sp.P >> 8);
-    if (threadIdx.x < nblk) posted_blk[(uint64_t)g * blk_per_genome + (uint64_t)bin * nblk + threadIdx.x] = (uint8_t)blk_posted[threadIdx.x];
 }
 
 // ---------------------------------------------------------------- host side
@@ -662,7 +682,10 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     bs.bloom_on = c->d_bloom && !(tune & 1u) && !for_queries ? 1u : 0u;   // (a query's k-mers are gated, not inserted)
     bs.sum_words = 0;
     if (bs.bloom_on && bloom_summary_bytes(c) <= 8192) bs.sum_words = (uint32_t)((bloom_summary_bytes(c) + 7) / 8);
-    bs.low_bits = std::min<uint32_t>(c->p.h, kBin);
+    // partitions per bin (log2): 2^12 at -h 20 and above; below that as many bins as at -h 20 -- 256 per genome -- rather than
+    // bins of 2^12: a reduce workgroup owns one (genome, bin), and at -h 17 thirty-two bins per genome were 2,048 workgroups of
+    // 150,000 items each for 256 CUs (0.87 ms per batch alone on the chip against 0.47 at -h 20)
+    bs.low_bits = std::min<uint32_t>(kBin, c->p.h > 8 ? c->p.h - 8 : c->p.h);
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
     bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);
@@ -745,12 +768,13 @@ int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, ui
     return MK_OK;
 }
 
-int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off)
+int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off,
+                        uint32_t strains, uint32_t rate_ppm)
 {
     if (!n || !len) return MK_OK;
     const uint64_t words = (len + 31) / 32;
     hipLaunchKernelGGL(synth_packed_kernel, dim3((uint32_t)((words + 255) / 256), n), dim3(256), 0, c->front_stream, first_id, n, len,
-                       d_codes, d_code_off);
+                       d_codes, d_code_off, strains, rate_ppm);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
@@ -875,14 +899,13 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
     const uint64_t fp_bytes = (uint64_t)c->build_batch * c->P * c->W;
     if (!c->d_fpT) {
         MK_HIP(hipMalloc((void **)&c->d_fpT, fp_bytes + 64));
-        MK_HIP(hipMalloc((void **)&c->d_posted_blk, (uint64_t)c->build_batch * std::max<uint32_t>(1, c->P >> 8)));
     }
     const SketchParams sp = make_sp(c);
 #define MK_REDUCE(Wv, K32)                                                                                                      \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, c->stream,                              \
                        reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), meta_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
-                       c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_posted_blk,                              \
+                       c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_bloom_touched,                           \
                        sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)
     if (c->W == 1) { if (sd.key32) MK_REDUCE(1, true); else MK_REDUCE(1, false); }
     else MK_REDUCE(2, false);

@@ -131,4 +131,24 @@ constexpr uint64_t kSeedQ = 0x4D49454B4B490002ULL;
 
 MK_HD uint64_t genome_word(uint64_t g, uint64_t word) { return splitmix64(kSeedG ^ (g << 32) ^ word); }
 
+// A collection of RELATED genomes (measurement aid: the column codec of SURVEY.md 8f row N4 pays on strains of one
+// species, README.md:136-138): genome g is strain g % strains of species g / strains.  Strain 0 is the species' genome
+// -- the synthetic genome `species` of SURVEY.md 8d itself -- the others are independent descendants of it: each
+// 32-base word carries, with probability 32 x rate, ONE substitution (position and new base from a hash of (g, word)).
+constexpr uint64_t kSeedS = 0x4D49454B4B490004ULL;
+MK_HD uint64_t strain_word(uint64_t g, uint64_t word, uint32_t strains, uint32_t rate_ppm)
+{
+    const uint64_t species = g / strains, t = g % strains;
+    uint64_t w = genome_word(species, word);
+    if (t == 0) return w;
+    const uint64_t r = splitmix64(kSeedS ^ (g << 32) ^ word);
+    // (a word mutates when the low 32 bits of r fall below 32 x rate x 2^32)
+    if ((r & 0xffffffffu) < (uint64_t)rate_ppm * 32u * 4295u) {                 // 4295 = 2^32 / 10^6
+        const uint32_t pos = (uint32_t)(r >> 32) & 31u, sh = 62u - 2u * pos;
+        const uint64_t old = (w >> sh) & 3u, nw = (old + 1u + ((r >> 40) % 3u)) & 3u;
+        w = (w & ~(3ULL << sh)) | (nw << sh);
+    }
+    return w;
+}
+
 }  // namespace mk

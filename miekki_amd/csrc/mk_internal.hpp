@@ -34,6 +34,7 @@ constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans
 constexpr uint64_t kEmptyKey = ~0ULL;
 constexpr int kPosBits = 40;                      // a minimum key in a table: fingerprint << 40 | position
 constexpr int kDefaultCopyStreams = 2;            // copy streams of a packed append (MIEKKI_COPY_STREAMS; see mk_ctx::copy_extra)
+constexpr uint32_t kBloomRegionLog2 = 16;          // cells per region of the Bloom sweep (bloom_sweep_kernel)
 constexpr uint32_t kSlabMaxQueries = 1u << 30;   // queries per launch of the slab schedule (no bound by default; see chunk_queries_slab)
 
 // packed query-sketch entry: partition in the low word, fingerprint in the high word
@@ -72,6 +73,14 @@ struct mk_ctx {
     uint8_t *h_M;                  // cold rows [P_hot, P) in page-locked host memory, same pitch (null: all rows in HBM)
     uint32_t P_hot;                // rows kept in HBM (= P when the matrix fits its budget)
     uint64_t hbm_matrix_budget;    // bytes of HBM the matrix may take (MIEKKI_HBM_MATRIX_MIB; 0 = whatever is free)
+    // the cold rows PACKED (cold.hip: mk_index_compress): h_M is null then, h_Z holds them, row i of the cold rows at
+    // h_Z + h_zoff[i]; d_zoff = the same offsets on the device; d_zstage = packed staging beside d_cold_stage's halves
+    uint8_t *h_Z;
+    uint64_t z_bytes;
+    uint64_t *d_zoff;
+    std::vector<uint64_t> h_zoff;
+    uint8_t *d_zstage[2];
+    uint64_t zstage_cap;
     uint8_t *d_cold_stage;         // HBM staging for cold partition ranges (slab schedule)
     uint64_t cold_stage_rows;      // rows of ONE of its two halves
     hipEvent_t ev_cold[5];         // copy done [2], scan done [2], entry
@@ -96,7 +105,7 @@ struct mk_ctx {
     uint8_t *d_bloom;
     uint64_t bloom_dev_bytes, bloom_bytes;
     uint32_t *d_bloom_order;       // first-writer arbitration keys (build only), lazily allocated: one per reachable cell,
-                                   // genome in batch << h | partition of the first k-mer (in that order) that found the cell empty
+                                   // (genome in batch << h | partition) << 3 | bit of the first k-mer (in that order) that asked for the cell
     // build scratch (lazily allocated)
     uint32_t build_batch;          // genomes per build batch (<= kBuildBatch, bounded by table memory)
     uint64_t *d_tables;            // build_batch x P min-keys
@@ -215,7 +224,7 @@ struct mk_ctx {
     uint64_t res_cap;
     uint64_t *d_long_table;        // P keys, long-query path
     uint8_t *d_fpT;                // build: fingerprints of the batch, genome-major [build_batch][P] (fused build kernel)
-    uint8_t *d_posted_blk;         // build: per (genome, 256 partitions) "a Bloom first-writer key was posted here"
+    uint8_t *d_bloom_touched;      // build: per region of 2^kBloomRegionLog2 cells "a first-writer key was posted here" (allocated with d_bloom_order)
     uint64_t *d_ovf;               // (genome << 32 | bucket, item) pairs that missed their slot
     uint32_t *d_ovf_count;
     // stats
@@ -301,7 +310,8 @@ int launch_pack(mk_ctx *c, int b, const char *d_seq, const uint64_t *h_off, uint
                 const uint64_t *d_code_off, hipStream_t st = nullptr);       // st: the front stream unless given
 int launch_seed_fix(mk_ctx *c, int b, const char *d_seq, const char *d_heads, uint32_t n, uint8_t *d_codes, uint8_t *d_except,
                     const uint64_t *d_code_off, hipStream_t st = nullptr);
-int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off);
+int launch_synth_packed(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len, uint8_t *d_codes, const uint64_t *d_code_off,
+                        uint32_t strains = 0, uint32_t rate_ppm = 0);      // strains != 0: related genomes (mk_device.hpp: strain_word)
 int launch_unpack(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d_except, const uint64_t *d_code_off, const char *d_heads,
                   const uint64_t *h_off, uint32_t n, char *d_seq);
 // front stage of a batch on c->front_stream: the scatter kernel into side `b` (*used = false: the shape does not suit
@@ -349,6 +359,13 @@ int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, 
 int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging);
 int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t *d_dst);   // d_dst[P][n] (W bytes each, dump byte order)
 inline MatRef mat_ref(const mk_ctx *c);
+
+// ---- cold.hip: the cold rows packed (delta vs the genome before + bit packing)
+int pack_cold(mk_ctx *c, uint64_t *raw_bytes, uint64_t *packed_bytes);
+int need_raw_cold(mk_ctx *c);                 // unpack if packed: for everything that needs the rows as they are
+int stage_cold_rows(mk_ctx *c, uint64_t r_lo, uint64_t r_hi, uint8_t *d_dst, int b, hipStream_t st);
+int ensure_zstage(mk_ctx *c, uint64_t rows);
+inline bool has_cold(const mk_ctx *c) { return c->h_M != nullptr || c->h_Z != nullptr; }
 
 // ---- scan.hip
 struct ScanArgs {

@@ -249,11 +249,9 @@ __global__ __launch_bounds__(256) void fp_transpose_reg_kernel(const uint8_t *__
         *reinterpret_cast<uint32_t *>(mat_row(M, p0 + j, ld) + col) = out[j];
 }
 
-template <bool WRITE>
-__global__ void bloom_kernel(uint64_t *__restrict__ tables, const char *__restrict__ seq, const uint64_t *__restrict__ off,
-                             const uint32_t *__restrict__ valid, uint8_t *bloom, uint64_t bloom_dev_bytes, uint32_t *order,
-                             const uint32_t *__restrict__ ovf_count, const uint32_t *__restrict__ full,
-                             const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit, SketchParams sp, uint32_t span);
+__global__ void bloom_sweep_kernel(const uint32_t *__restrict__ order, uint8_t *__restrict__ bloom, uint8_t *__restrict__ touched,
+                                   uint64_t bloom_dev_bytes);
+static int launch_bloom_sweep(mk_ctx *c);
 
 // What follows the fused reduce kernel of a batch (this file's or build.hip's): the batch's fingerprints
 // (d_fpT, genome-major) into the matrix rows, Bloom pass B over the blocks that posted a key, the summary.
@@ -278,13 +276,7 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
         hipLaunchKernelGGL(fp_transpose_kernel<2>, dim3((c->P + rows - 1) / rows), dim3(1024), 0, c->stream, c->d_fpT, n, g0,
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
-        // (pass B works from the canonical k-mers pass A left in d_tables: no sequence, no codes)
-        const uint32_t nblk = (c->P + 255) / 256, span = 16;
-        hipLaunchKernelGGL(bloom_kernel<true>, dim3((nblk + span - 1) / span, n), dim3(256), 0, c->stream, c->d_tables, (const char *)nullptr,
-                           (const uint64_t *)nullptr, (const uint32_t *)nullptr, c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order,
-                           c->d_ovf_count, c->d_bloom_full, c->d_posted_blk,
-                           kOvfScan, sp, span);
-        MK_HIP(hipGetLastError());
+        MK_TRY(launch_bloom_sweep(c));                               // the cells that took a key get their byte
         MK_TRY(launch_bloom_summary(c));
     }
     MK_HIP(hipGetLastError());
@@ -378,92 +370,88 @@ int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0
 }
 
 // ---------------------------------------------------------------- K3 Bloom insert
-// insert_bloom (Miekki.cpp:121-131) sets a zero cell to 1 << (hash % 8) of its FIRST
-// inserter in (genome, partition, hash index) order.  Pass A posts (genome in batch << h | partition) as a
-// 32-bit key per still-zero cell with an atomic minimum (at most 27 bits: a batch holds at most 2^30 / (8 x 2^h)
-// genomes); pass B lets the k-mer that holds a cell's key write the byte -- for the lowest of its hash indices that
-// names the cell, which is what the reference's loop over the indices does.  Keys are never reset: a cell with a
-// key was set in that very batch and nobody asks for its key again (cells that are replaced wholesale -- an import
-// -- take fresh keys with them, forget_bloom_summary).  Cells already non-zero are never touched.
-// The table is consumed: after pass A it holds canonical k-mers, not keys.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void bloom_kernel(uint64_t *__restrict__ tables,
-                                                    const char *__restrict__ seq,
-                                                    const uint64_t *__restrict__ off,
-                                                    const uint32_t *__restrict__ valid, uint8_t *bloom,
-                                                    uint64_t bloom_dev_bytes, uint32_t *order,
-                                                    const uint32_t *__restrict__ ovf_count,
-                                                    const uint32_t *__restrict__ full,
-                                                    const uint8_t *__restrict__ posted_blk, uint32_t ovf_limit,
-                                                    SketchParams sp, uint32_t span)
+// insert_bloom (Miekki.cpp:121-131) sets a zero cell to 1 << (hash % 8) of its FIRST inserter in (genome, partition,
+// hash index) order.  First half (here for the character path; build.hip's reduce kernel has its own): every selected
+// k-mer posts  (genome in batch << h | partition) << 3 | bit  for its cell with an atomic minimum -- at most 30 bits: a
+// batch holds at most 2^30 / (8 x 2^h) genomes -- when the cell is still empty.  Second half: a SWEEP over the regions of
+// cells that took a key (bloom_sweep_kernel): an empty cell with a key gets the key's bit.  No k-mer is looked at twice,
+// nothing is sorted, and the result does not depend on the order the k-mers arrive in.  Round 3 had the winner itself
+// come back for its cell (a second pass over the k-mers: one random read of an 8-byte key, a random byte written and the
+// key reset, per k-mer -- 5.4 ms for the first batch of a collection at -h 20, 0.7 ms per batch at -h 17); the sweep
+// streams 5 bytes per cell of the regions touched: 0.1 ms for all 64 MiB of cells, nothing once the filter has filled up.
+// Keys are never reset: a cell with a key is set by the sweep of that very batch, and a key on a cell that is set is
+// ignored (cells that are replaced wholesale -- an import -- take fresh keys with them, forget_bloom_summary).
+__global__ __launch_bounds__(256) void bloom_post_kernel(const uint64_t *__restrict__ tables, const char *__restrict__ seq,
+                                                         const uint64_t *__restrict__ off, const uint32_t *__restrict__ valid,
+                                                         const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
+                                                         uint32_t *__restrict__ order, uint8_t *__restrict__ touched,
+                                                         const uint32_t *__restrict__ ovf_count, const uint32_t *__restrict__ full,
+                                                         uint32_t ovf_limit, SketchParams sp)
 {
     if (ovf_count && *ovf_count > ovf_limit) return;    // see finalize_kernel
-    const uint32_t g = blockIdx.y;
-    // a workgroup walks `span` blocks of 256 partitions.  After the fused build kernel only the blocks in which a
-    // key was posted hold anything -- usually none once the filter has filled up -- so pass B looks at a run of
-    // flags per workgroup instead of launching one workgroup per flag
-  for (uint32_t blk = blockIdx.x * span; blk < (blockIdx.x + 1) * span; ++blk) {
-    if ((uint64_t)blk * 256 >= sp.P) return;
-    if (posted_blk && !posted_blk[(uint64_t)g * max(1u, sp.P >> 8) + blk]) continue;
-    const uint32_t p = blk * 256 + threadIdx.x;
+    const uint32_t g = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= sp.P) return;
-    uint64_t *slot = tables + (uint64_t)g * sp.P + p;
-    // the table streams through once: keep it from evicting the codes and the summary from L2
-    const uint64_t key = __builtin_nontemporal_load(slot);
-    if (key == kEmptyKey) continue;
-    uint64_t canon;
-    if (!WRITE) {
-        // pass A: the (fingerprint, position) key has served finalize; replace it by
-        // the winner's canonical k-mer so that pass B need not touch the sequence again
-        const uint64_t pos = key & ((1ULL << kPosBits) - 1);
-        canon = canon_at(seq + off[g], pos, sp.k, valid[g] != 0);
-    } else {
-        canon = key;
-    }
-    const uint32_t okey = (g << sp.h) | p;
-    bool posted = false;
+    const uint64_t key = __builtin_nontemporal_load(tables + (uint64_t)g * sp.P + p);   // fingerprint << kPosBits | position
+    if (key == kEmptyKey) return;
+    const uint64_t canon = canon_at(seq + off[g], key & ((1ULL << kPosBits) - 1), sp.k, valid[g] != 0);
+    auto post = [&](uint64_t hsh) {
+        const uint64_t cell = hsh >> 3, grp = cell >> 3;
+        if (cell >= bloom_dev_bytes) return;                // unreachable by construction
+        // the summary first (one bit per 8 cells, L2-resident): a full group has no zero cell
+        if (((full[grp >> 5] >> (grp & 31u)) & 1u) || bloom[cell] != 0) return;
+        atomicMin(&order[cell], (((g << sp.h) | p) << 3) | (uint32_t)(hsh & 7u));
+        touched[cell >> kBloomRegionLog2] = 1;
+    };
     if (__builtin_expect((uint32_t)canon <= 0xFFFFFC00u, 1)) {
-        // the five positions are ONE (the low word cannot carry, mk_device.hpp: bloom_pos): hash index 0 speaks for all
-        const uint64_t hsh = canon >> sp.bloom_log2, cell = hsh >> 3;
-        if (cell < bloom_dev_bytes) {
-            if (!WRITE) {
-                // the summary first (one bit per 8 cells, L2-resident): a full group has no zero cell
-                const uint64_t grp = cell >> 3;
-                if (!((full[grp >> 5] >> (grp & 31u)) & 1u) && bloom[cell] == 0) {
-                    atomicMin(&order[cell], okey);
-                    posted = true;
-                }
-            } else if (order[cell] == okey) {
-                bloom[cell] = (uint8_t)(1u << (hsh & 7));
-            }
-        }
+        post(canon >> sp.bloom_log2);                       // the five positions are ONE (mk_device.hpp: bloom_pos)
     } else {
         const uint64_t anc = revhash64(canon);
-        uint64_t wrote[2] = {~0ull, ~0ull};                      // (the positions name at most two cells)
+        uint64_t seen[2] = {~0ull, ~0ull};                  // at most two cells; each takes the bit of the lowest index that names it
         for (uint32_t i = 0; i < kNumHash; ++i) {
             const uint64_t hsh = bloom_pos(canon, anc, i, sp.bloom_log2);
-            const uint64_t cell = hsh >> 3;
-            if (cell >= bloom_dev_bytes) continue;              // unreachable by construction
-            if (!WRITE) {
-                const uint64_t grp = cell >> 3;
-                if ((full[grp >> 5] >> (grp & 31u)) & 1u) continue;
-                if (bloom[cell] == 0) {
-                    atomicMin(&order[cell], okey);
-                    posted = true;
-                }
-            } else if (cell != wrote[0] && cell != wrote[1] && order[cell] == okey && bloom[cell] == 0) {
-                // the reference's loop (Miekki.cpp:122-130): the FIRST index that finds the cell empty sets it
-                // (a cell that was taken before this batch may still hold an old key that happens to equal this one)
-                bloom[cell] = (uint8_t)(1u << (hsh & 7));
-                wrote[wrote[0] == ~0ull ? 0 : 1] = cell;
-            }
+            if ((hsh >> 3) == seen[0] || (hsh >> 3) == seen[1]) continue;
+            seen[seen[0] == ~0ull ? 0 : 1] = hsh >> 3;
+            post(hsh);
         }
     }
-    // a k-mer whose five cells were all set already (the common case once the filter
-    // has filled up) has nothing to do in pass B: blank its slot so that pass B stops
-    // at the first test
-    if (!WRITE) __builtin_nontemporal_store(posted ? canon : kEmptyKey, slot);
-  }
+}
+
+// One workgroup per region of 2^kBloomRegionLog2 cells; regions nobody posted to cost one byte read.
+__global__ __launch_bounds__(256) void bloom_sweep_kernel(const uint32_t *__restrict__ order, uint8_t *__restrict__ bloom,
+                                                          uint8_t *__restrict__ touched, uint64_t bloom_dev_bytes)
+{
+    const uint32_t r = blockIdx.x;
+    if (!touched[r]) return;                                // (uniform over the workgroup)
+    __syncthreads();
+    if (threadIdx.x == 0) touched[r] = 0;
+    const uint64_t base = (uint64_t)r << kBloomRegionLog2;
+    constexpr uint32_t kCells = 1u << kBloomRegionLog2;
+    for (uint32_t i = threadIdx.x * 4u; i < kCells; i += 256u * 4u) {
+        const uint64_t cell = base + i;
+        if (cell + 4 <= bloom_dev_bytes) {
+            const uint4 k = *reinterpret_cast<const uint4 *>(order + cell);       // (cell is a multiple of four)
+            const uint32_t b = *reinterpret_cast<const uint32_t *>(bloom + cell);
+            uint32_t nb = b;
+            if (!(b & 0x000000ffu) && k.x != 0xffffffffu) nb |= (1u << (k.x & 7u));
+            if (!(b & 0x0000ff00u) && k.y != 0xffffffffu) nb |= (1u << (k.y & 7u)) << 8;
+            if (!(b & 0x00ff0000u) && k.z != 0xffffffffu) nb |= (1u << (k.z & 7u)) << 16;
+            if (!(b & 0xff000000u) && k.w != 0xffffffffu) nb |= (1u << (k.w & 7u)) << 24;
+            if (nb != b) *reinterpret_cast<uint32_t *>(bloom + cell) = nb;
+        } else {
+            for (uint64_t c2 = cell; c2 < bloom_dev_bytes && c2 < cell + 4; ++c2)
+                if (bloom[c2] == 0 && order[c2] != 0xffffffffu) bloom[c2] = (uint8_t)(1u << (order[c2] & 7u));
+        }
+    }
+}
+
+static int launch_bloom_sweep(mk_ctx *c)
+{
+    if (!c->d_bloom || !c->d_bloom_order) return MK_OK;
+    const uint32_t regions = (uint32_t)((c->bloom_dev_bytes >> kBloomRegionLog2) + 1);
+    hipLaunchKernelGGL(bloom_sweep_kernel, dim3(regions), dim3(256), 0, c->stream, c->d_bloom_order, c->d_bloom, c->d_bloom_touched,
+                       c->bloom_dev_bytes);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
 }
 
 // full[grp] = all eight cells of group grp are non-zero.  Cells never go back to zero, so a
@@ -566,14 +554,10 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort)
 {
     if (!n || !c->d_bloom) return MK_OK;
-    dim3 grid((c->P + 255) / 256, n);
-    hipLaunchKernelGGL(bloom_kernel<false>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort,
-                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
-    hipLaunchKernelGGL(bloom_kernel<true>, grid, dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
-                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, d_abort,
-                       c->d_bloom_full, (const uint8_t *)nullptr, kOvfCap, make_sp(c), 1u);
+    hipLaunchKernelGGL(bloom_post_kernel, dim3((c->P + 255) / 256, n), dim3(256), 0, c->stream, d_tables, d_seq, d_off, d_valid,
+                       c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_touched, d_abort, c->d_bloom_full, kOvfCap, make_sp(c));
     MK_HIP(hipGetLastError());
+    MK_TRY(launch_bloom_sweep(c));
     return launch_bloom_summary(c);
 }
 

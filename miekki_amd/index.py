@@ -70,6 +70,21 @@ class Miekki:
     def reserve(self, n_genomes):
         L.check(self._lib.mk_reserve(self._h, n_genomes))
 
+    def compress_index(self):
+        """Miekki::compress_index (Miekki.cpp:863-868) for the rows beyond the matrix's HBM budget: returns
+        (raw bytes, packed bytes) of those rows -- equal when nothing was packed (no cold rows, or nothing to gain)."""
+        raw, packed = C.c_uint64(0), C.c_uint64(0)
+        L.check(self._lib.mk_index_compress(self._h, C.byref(raw), C.byref(packed)))
+        return raw.value, packed.value
+
+    def decompress_index(self):
+        """Miekki::decompress_index (Miekki.cpp:872-877)."""
+        L.check(self._lib.mk_index_decompress(self._h))
+
+    def insert_synthetic_strains(self, first_id, n, length, strains, rate_ppm):
+        L.check(self._lib.mk_index_append_synthetic_strains(self._h, first_id, n, length, strains, rate_ppm))
+        self.file_names += [f"strain:{first_id + i}" for i in range(n)]
+
     def stats(self):
         s = L.Stats()
         L.check(self._lib.mk_get_stats(self._h, C.byref(s)))

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mk_create": (i32, [PP(Params), PP(vp)]),
     "mk_destroy": (None, [vp]),
     "mk_reserve": (i32, [vp, u32]),
+    "mk_index_compress": (i32, [vp, PP(u64), PP(u64)]),
+    "mk_index_decompress": (i32, [vp]),
     "mk_index_size": (u32, [vp]),
     "mk_get_params": (i32, [vp, PP(Params)]),
     "mk_get_stats": (i32, [vp, PP(Stats)]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "mk_host_alloc": (i32, [vp, u64, PP(vp)]),
     "mk_host_free": (None, [vp, vp]),
     "mk_index_append_synthetic": (i32, [vp, u64, u32, u64]),
+    "mk_index_append_synthetic_strains": (i32, [vp, u64, u32, u64, u32, u32]),
     "mk_index_export_columns": (i32, [vp, u32, u32, vp]),
     "mk_index_export_genomes": (i32, [vp, vp, u32, vp]),
     "mk_index_export_sizes": (i32, [vp, vp, vp]),

@@ -73,6 +73,30 @@ def strain(species: int, strain_id: int, length: int, rate: float) -> bytes:
     return seq.tobytes()
 
 
+SEED_S = 0x4D49454B4B490004
+
+
+def strain_device(g: int, strains: int, rate_ppm: int, off: int, n: int) -> bytes:
+    """n bases from position off of genome g of the DEVICE's strain generator (mk_index_append_synthetic_strains;
+    mk_device.hpp: strain_word): strain g % strains of species g // strains -- the species' genome is the synthetic genome
+    `species` itself, every other strain carries per 32-base word, with probability 32 x rate, one substitution."""
+    species, t = divmod(g, strains)
+    w0, w1 = off >> 5, (off + n + 31) >> 5
+    idx = np.arange(w0, w1, dtype=np.uint64)
+    words = splitmix64(np.uint64(SEED_G) ^ (np.uint64(species) << np.uint64(32)) ^ idx)
+    if t:
+        r = splitmix64(np.uint64(SEED_S) ^ (np.uint64(g) << np.uint64(32)) ^ idx)
+        hit = (r & np.uint64(0xffffffff)) < np.uint64(rate_ppm * 32 * 4295)
+        sh = np.uint64(62) - np.uint64(2) * ((r >> np.uint64(32)) & np.uint64(31))
+        old = (words >> sh) & np.uint64(3)
+        new = (old + np.uint64(1) + ((r >> np.uint64(40)) % np.uint64(3))) & np.uint64(3)
+        words = np.where(hit, (words & ~(np.uint64(3) << sh)) | (new << sh), words)
+    shifts = (np.uint64(62) - np.uint64(2) * np.arange(32, dtype=np.uint64))
+    codes = ((words[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+    lo = off - (w0 << 5)
+    return _ACGT[codes[lo:lo + n]].tobytes()
+
+
 def tandem_rich(g: int, length: int, share: float, unit_lo: int = 2, unit_hi: int = 60) -> bytes:
     """Genome g with about `share` of its length in tandem repeats and homopolymer runs (seeded): runs of 200-5,000
     bases made of a 1-60 base unit, between stretches of the usual random sequence.  Repeat-rich input is what makes

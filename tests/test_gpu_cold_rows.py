@@ -129,3 +129,81 @@ def test_reserved_cold_matrix_against_oracle(hip, monkeypatch):
         check_against_oracle(ix, o, seqs, np.random.default_rng(77))
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("fpb,rate_ppm,G", [(8, 1000, 1500), (16, 10_000, 700), (8, 0, 1100)])
+def test_packed_cold_rows_against_oracle(hip, monkeypatch, tmp_path, fpb, rate_ppm, G):
+    """The cold rows PACKED (mk_index_compress: per 1,024 genomes of a row a "differs from the genome before" bit each +
+    the differing fingerprints; cold.hip) -- a collection of related strains, species by species in the list, so that
+    there is something to pack (rate 0: every strain equals its species -- runs of 25 equal fingerprints; the 2-byte case
+    at 1 %: most fingerprints differ and some rows are kept as they are).  Every query path must answer from the packed
+    rows what the oracle answers (slab ranges staged packed and expanded in HBM, small sets, the plain and dense kernels
+    over packed windows); exports, a dump, an append and a second compress go through the automatic unpacking."""
+    from oracle import oracle as orc
+    k, h, strains = 21, 12, 25
+    L_ = 14_000
+    seqs = [synth.strain_device(g, strains, rate_ppm, 0, L_) for g in range(G)]
+    monkeypatch.setenv("MIEKKI_SLAB_MIB", "1")                   # four partition ranges at h = 12
+    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "1")             # 1 MiB of a 4 ... 8 MiB matrix stays in HBM
+    o = orc.OracleMiekki(k, h, fpb, 32, 10)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, fpb, 32, 10)
+    loaded = None
+    rng = np.random.default_rng(11 + G)
+    try:
+        ix.reserve(G)
+        ix.insert_synthetic_strains(0, G, L_, strains, rate_ppm)  # the device's generator of the same strains
+        raw, packed = ix.compress_index()
+        assert raw > 0 and packed < raw, (raw, packed)
+        if rate_ppm <= 1000:
+            assert packed < 0.5 * raw                                # 0.1 % divergence: most fingerprints repeat the genome before
+        assert ix.compress_index() == (raw, packed)                  # packed already
+        qs, rows = check_against_oracle(ix, o, seqs, rng)            # (its export of the index stream unpacks ...)
+        assert ix.compress_index()[1] == packed                      # ... and packing again gives the same bytes
+        got, _ = ix.query(qs, 10, 3, 5.0)                            # streamed from packed rows this time
+        same_hits(got, o, rows, 10, 3, 5.0)
+        got16, _ = ix.query(qs[:16], 10, 3, 5.0)
+        same_hits(got16, o, rows[:16], 10, 3, 5.0)
+        np.testing.assert_array_equal(ix.query_sequences(qs[:48]), rows[:48])          # plain kernel over packed windows
+        long_q = [seqs[7][:9000], seqs[8], seqs[G - 1]]
+        np.testing.assert_array_equal(ix.query_sequences(long_q), o.query_sequences(long_q))   # dense kernel over packed windows
+        ix.dump_disk(str(tmp_path / "packed.gz"))                    # unpacks by itself (Miekki.cpp:662-664 does the same)
+        loaded = hip.Miekki.load(str(tmp_path / "packed.gz"))
+        assert masked_sha(b"".join(loaded.serialize())) == masked_sha(o.serialize().tobytes())
+        assert ix.compress_index()[1] == packed
+        more = [synth.strain_device(G + g, strains, rate_ppm, 0, L_) for g in range(70)]
+        ix.insert_sequences(more)                                    # an append into a packed index unpacks it first
+        o.insert_sequences(more)
+        raw2, packed2 = ix.compress_index()
+        assert packed2 < raw2
+        qs2 = [s[100:1200] for s in (seqs + more)[::3]][:520] + [more[3][:800]] * 8
+        same_hits(ix.query(qs2, 10, 3, 5.0)[0], o, o.query_sequences(qs2), 10, 3, 5.0)
+        ix.decompress_index()
+        assert masked_sha(b"".join(ix.serialize())) == masked_sha(o.serialize().tobytes())
+    finally:
+        ix.close()
+        if loaded is not None:
+            loaded.close()
+
+
+def test_independent_genomes_are_left_unpacked(hip, monkeypatch):
+    """Unrelated genomes: no row shrinks (profiles/r3_column_entropy.txt), mk_index_compress measures that and leaves the
+    rows as they are."""
+    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "1")
+    ix = hip.Miekki(21, 12, 8, 32, 10)
+    try:
+        ix.reserve(1200)
+        ix.insert_synthetic(0, 1200, 9000)
+        raw, packed = ix.compress_index()
+        assert raw > 0 and packed == raw
+        hits, _ = ix.query([synth.genome_bases(5, 100, 1500)], 3, 3, 1.0)
+        assert hits[0] and hits[0][0].genome == 5
+    finally:
+        ix.close()
+    monkeypatch.delenv("MIEKKI_HBM_MATRIX_MIB")                      # (the budget is read when the context is made)
+    ix = hip.Miekki(21, 12, 8, 32, 10)                               # and an index without cold rows: nothing to do
+    try:
+        ix.insert_synthetic(0, 100, 9000)
+        assert ix.compress_index() == (0, 0)
+    finally:
+        ix.close()

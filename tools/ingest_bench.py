@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Steady-state rate of `miekki -l` (host parse + H2D + device build) on many FASTA files.
-    python tools/ingest_bench.py [n_genomes] [threads] [distinct]
+    python tools/ingest_bench.py [n_genomes] [threads] [distinct] [gz]
 The list names n_genomes files; only `distinct` different ones are written, the rest are
-symlinks to them (the page cache is warm either way; the device work per genome is the same)."""
-import os, re, subprocess, sys, tempfile, time
+symlinks to them (the page cache is warm either way; the device work per genome is the same).
+gz: the files are gzip members (level 6, what NCBI ships and what the reference's zstr reader inflates on the fly,
+zstr.hpp:78-82): every reader thread then spends its time in zlib's inflate."""
+import gzip, os, re, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
@@ -11,22 +13,25 @@ import synth
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+GZ = len(sys.argv) > 4 and sys.argv[4] == "gz"
 L = 5_000_000
 cli = os.path.join(ROOT, "miekki_amd", "miekki")
 with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     t0 = time.time()
     with open(os.path.join(d, "genomes.lst"), "w") as lst:
         for g in range(G):
-            fn = os.path.join(d, f"g{g}.fa")
+            ext = ".fa.gz" if GZ else ".fa"
+            fn = os.path.join(d, f"g{g}{ext}")
             if g < D:
+                data = synth.fasta(f"genome{g}", synth.genome_bases(g, 0, L))
                 with open(fn, "wb") as f:
-                    f.write(synth.fasta(f"genome{g}", synth.genome_bases(g, 0, L)))
+                    f.write(gzip.compress(data, 6) if GZ else data)
             else:
-                os.symlink(os.path.join(d, f"g{g % D}.fa"), fn)
+                os.symlink(os.path.join(d, f"g{g % D}{ext}"), fn)
             lst.write(fn + "\n")
     with open(os.path.join(d, "q.fa"), "wb") as f:
         f.write(b">q0\n" + synth.genome_bases(3, 1000, 1000) + b"\n")
-    print(f"generated {D} distinct genomes ({G} listed) in {time.time() - t0:.1f}s", flush=True)
+    print(f"generated {D} distinct {'gzipped ' if GZ else ''}genomes ({G} listed) in {time.time() - t0:.1f}s", flush=True)
     for rep in range(2):
         t0 = time.time()
         out = subprocess.run([cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1"),
