@@ -53,7 +53,7 @@ void ParallelGzipWriter::deflate_block(Job *j)
 {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
+    if (deflateInit2(&zs, j->level, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
     const size_t bound = deflateBound(&zs, (uLong)j->in.size()) + 64;
     j->out.resize(kHeader + bound + 8);
     zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
@@ -79,7 +79,29 @@ void ParallelGzipWriter::submit()
     std::unique_ptr<Job> j(new Job());
     j->in.swap(cur_);
     cur_.reserve(kBlock);
-    j->strategy = strategy_;
+    j->strategy = strategy_; j->level = level_;
+    Job *raw = j.get();
+    j->th = std::thread(deflate_block, raw);
+    jobs_.push_back(std::move(j));
+    while (jobs_.size() >= nthreads_) drain_one();
+}
+
+uint8_t *ParallelGzipWriter::begin_block()
+{
+    if (!cur_.empty() || open_) return nullptr;
+    open_.reset(new Job());
+    open_->in.resize(kBlock);
+    return open_->in.data();
+}
+
+void ParallelGzipWriter::end_block(size_t n)
+{
+    if (!open_) return;
+    std::unique_ptr<Job> j = std::move(open_);
+    if (!n) return;
+    wrote_any_ = true;
+    j->in.resize(std::min(n, kBlock));
+    j->strategy = strategy_; j->level = level_;
     Job *raw = j.get();
     j->th = std::thread(deflate_block, raw);
     jobs_.push_back(std::move(j));
@@ -94,6 +116,7 @@ void ParallelGzipWriter::write_zeros(size_t n)
     if (n >= kBlock && zero_member_.empty()) {
         Job j;
         j.in.assign(kBlock, 0);
+        j.level = 1;
         deflate_block(&j);
         if (j.bad) failed_ = true; else zero_member_.swap(j.out);
     }

@@ -37,10 +37,18 @@ public:
     // columns have no repeats for LZ77 to find (profiles/r3_column_entropy.txt: level 1 gets 1.35:1, an order-0 entropy
     // coder 1.39:1): Huffman-only codes them as small, several times faster.  Any inflater reads either.
     void set_strategy(int strategy) { strategy_ = strategy; }
+    // level 0 = stored blocks (no deflate work at all, the file grows by what level 1 would have saved), 1 = the reference's
+    void set_level(int level) { level_ = level; }
+    // A whole block handed over without a copy: begin_block() returns kBlock bytes the caller fills (only at a block
+    // boundary -- nothing buffered by write(); nullptr otherwise), end_block(n) submits the first n of them.  The dump of
+    // a 105 GB index otherwise copies every byte once more on the one thread that also feeds the GPU's exports.
+    void flush_block() { if (!cur_.empty()) submit(); }   // what is buffered becomes a (short) member of its own
+    uint8_t *begin_block();
+    void end_block(size_t n);
     bool finish();                       // flushes, closes; false on any error
     static constexpr size_t kBlock = 32u << 20;
 private:
-    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; int strategy = 0; bool ready = false; };
+    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; int strategy = 0, level = 1; bool ready = false; };
     static void deflate_block(Job *j);
     void submit();
     void drain_one();
@@ -50,6 +58,8 @@ private:
     std::deque<std::unique_ptr<Job>> jobs_;
     bool failed_ = false, wrote_any_ = false;
     int strategy_ = 0;                   // Z_DEFAULT_STRATEGY
+    int level_ = 1;
+    std::unique_ptr<Job> open_;          // begin_block() .. end_block()
     std::vector<uint8_t> zero_member_;   // the gzip member of kBlock zero bytes, made on first use
 };
 

@@ -67,12 +67,28 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     if (!w.ok()) { err = "cannot open " + path; return -1; }
     Header hd{p.k, p.h, p.fp_bits, 5, G, p.bloom_log2, p.bloom_log2 ? 1ull << p.bloom_log2 : 0, 0, 0, p.threshold, 1};
     w.write(&hd, sizeof hd);
+    w.flush_block();                                               // (the header as a member of its own: the columns start at a block boundary)
     bool ok = true;
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
     std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1)), part;
     w.set_strategy(Z_HUFFMAN_ONLY);                                // fingerprints: nothing for LZ77 to find (gzpar.hpp)
+    // MIEKKI_DUMP_LEVEL=0: the columns as stored blocks -- no deflate work (a 105 GB index then dumps at the rate the
+    // rows leave the GPU), a file a third larger; any gzip reader, the reference's included, reads it all the same
+    if (const char *e = getenv("MIEKKI_DUMP_LEVEL")) w.set_level(atoi(e) == 0 ? 0 : 1);
+    // one GPU: the rows of a block are exported straight into the block (no copy on this thread, which feeds the exports)
+    const uint32_t rows_blk = row && row <= ParallelGzipWriter::kBlock ? (uint32_t)(ParallelGzipWriter::kBlock / row) : 0;
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
+        if (D == 1 && G && rows_blk) {
+            uint8_t *blk = w.begin_block();
+            if (blk) {
+                const uint32_t pe1 = std::min(P, pb + rows_blk);
+                if (mk_index_export_columns(ctxs[0], pb, pe1, blk) != MK_OK) { err = mk_last_error(); ok = false; w.end_block(0); break; }
+                w.end_block((size_t)(pe1 - pb) * row);
+                pb = pe1 - rows;                                   // (the loop adds `rows`)
+                continue;
+            }
+        }
         const uint32_t pe = std::min(P, pb + rows);
         if (D == 1) {
             if (G && mk_index_export_columns(ctxs[0], pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; break; }
@@ -94,6 +110,7 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     for (size_t d = 0; ok && d < D; ++d)
         if (mk_index_export_sizes(ctxs[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) { err = mk_last_error(); ok = false; }
     w.set_strategy(Z_DEFAULT_STRATEGY);
+    w.set_level(1);
     if (ok) w.write(gs.data(), (size_t)G * 8);
     // the filter: the cells a 2k-bit k-mer can reach come from the device (every shard holds the global filter), the rest
     // of the reference's 2^(b-3) bytes -- 960 MiB of the 1 GiB at k = 31, b = 33 -- are zeros by construction

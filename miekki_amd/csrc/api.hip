@@ -945,6 +945,17 @@ static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, const ui
     a.tile_genomes = tile_genomes(c); a.G = c->G; a.nq = n; a.nresults = nresults;
     a.min_score = min_score; a.min_inter = min_inter; a.sketch_size = c->d_sketch_size;
     a.genome_size = c->d_genome_size; a.genome_id_base = c->p.genome_id_base; a.cap = cap;
+    a.ratio = nullptr;
+    if (d_partials) {                                              // the slab schedule's selection screens with one float per genome
+        if (c->ratio_cap < c->capG) {
+            dev_free(c->d_ratio);
+            c->ratio_cap = 0;
+            MK_TRY(dev_alloc(&c->d_ratio, (uint64_t)c->capG));
+            c->ratio_cap = c->capG; c->ratio_gen = 0;
+        }
+        if (c->ratio_gen != c->gen) { MK_TRY(launch_ratio(c, c->d_ratio, c->capG)); c->ratio_gen = c->gen; }
+        a.ratio = c->d_ratio;
+    }
     a.count = d_count; a.cand = d_cand; a.rows = d_rows;
     ScopedTimer t(c, 2);
     return launch_select(c, a);
@@ -981,6 +992,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->P = 1u << p->h; c->W = p->fp_bits / 8; c->f = p->fp_bits - kMantisBits;
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
+    c->d_ratio = nullptr; c->ratio_gen = 0; c->ratio_cap = 0;
     c->h_Z = nullptr; c->z_bytes = 0; c->d_zoff = nullptr; c->d_zstage[0] = c->d_zstage[1] = nullptr; c->zstage_cap = 0;
     c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
     for (int i = 0; i < 5; ++i) c->ev_cold[i] = nullptr;
@@ -1045,7 +1057,7 @@ void mk_destroy(mk_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom);
+    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom); dev_free(c->d_ratio);
     if (c->h_M) (void)hipHostFree(c->h_M);
     if (c->h_Z) (void)hipHostFree(c->h_Z);
     dev_free(c->d_zoff); dev_free(c->d_zstage[0]); dev_free(c->d_zstage[1]);

@@ -504,7 +504,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     // the flagged items are the first ones of their run (rare once the filter has filled up: none)
                     const uint32_t nf = q.m[u] & 127u, fend = nf == kAllFlagged ? end : first + nf;
                     // (lob: the item's low position byte, W == 2 only)
-                    auto fold = [&](uint32_t w, item_t item, uint32_t lob, bool flagged) {
+                    // The run's flagged items -- the first (fend - first) of it -- get their places in the list from ONE atomic per
+                    // run, by the run's first lane (a young filter flags every item, 18,700 per workgroup: one atomic WITH return
+                    // each on one LDS word cost 0.15 ms of LDS time per CU and batch; the meta word already says how many there are)
+                    uint32_t nbase = 0;
+                    {
+                        const uint32_t nflag = fend - first;                        // (0 for a lane without a run)
+                        if (nflag && lane % lpr == 0) nbase = atomicAdd(&n_noted, nflag);
+                        nbase = (uint32_t)__shfl((int)nbase, (int)(lane - lane % lpr));
+                    }
+                    // slot: the item's place in the list of flagged items, or beyond it for an item that is not flagged
+                    auto fold = [&](uint32_t w, item_t item, uint32_t lob, uint32_t slot) {
                         const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
                         const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
                         key_t key;
@@ -515,23 +525,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                         // a read of one entry is a broadcast, profiles/r3_ubench.txt; a key that cannot win is dropped here.
                         // profiles/r4_repeat_rich.txt: 20 % of a genome in tandem repeats tripled this kernel's time without it)
                         if (key < table[part]) atomicMin(&table[part], key);
-                        // (a young filter flags every item: 18,700 per workgroup.  One atomic WITH return per item on the one LDS
-                        // word costs 20 cycles per wave-instruction, 0.15 ms of LDS time per CU and batch; the lanes that hold a
-                        // flagged item reserve their places together instead: one atomic per wave-instruction.)
-                        const unsigned long long fl = __ballot(flagged);
-                        if (fl) {
-                            const uint32_t leader = (uint32_t)__ffsll((long long)fl) - 1u;
-                            uint32_t base = 0;
-                            if (lane == leader) base = atomicAdd(&n_noted, (uint32_t)__popcll(fl));
-                            base = (uint32_t)__shfl((int)base, (int)leader);
-                            const uint32_t slot = base + (uint32_t)__popcll(fl & ((1ull << lane) - 1ull));
-                            if (flagged && slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
-                        }
+                        if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
                     };
 #pragma unroll
                     for (uint32_t e = 0; e < kIPL; ++e) {
                         const uint32_t at = a0 + j0 + e;
-                        if (at >= first && at < end) fold(w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend);
+                        if (at >= first && at < end) fold(w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend ? nbase + (at - first) : ~0u);
                     }
                     // Runs longer than their lanes reach.  Rare on ordinary sequence (the lanes cover mean + 4 sigma), the rule on
                     // repeat-rich sequence: a tandem repeat sends a whole stretch of k-mers into ONE partition, i.e. hundreds or
@@ -544,13 +543,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                         tails &= ~(((lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull))) << l);
                         const uint32_t t_a0 = (uint32_t)__shfl((int)a0, (int)l), t_end = (uint32_t)__shfl((int)end, (int)l);
                         const uint32_t t_fend = (uint32_t)__shfl((int)fend, (int)l), t_w = (uint32_t)__shfl((int)w, (int)l);
+                        const uint32_t t_first = (uint32_t)__shfl((int)first, (int)l), t_nbase = (uint32_t)__shfl((int)nbase, (int)l);
                         for (uint32_t j = t_a0 + lpr * kIPL + lane * kIPL; j < t_end; j += 64u * kIPL) {
                             const uint64_t at = ((uint64_t)g * bs.nwg + t_w) * kSeg + j;
                             const vec_t x = *reinterpret_cast<const vec_t *>(items + at);
                             const uint32_t xl = W == 2 ? *reinterpret_cast<const uint32_t *>(low + at) : 0u;
 #pragma unroll
                             for (uint32_t e = 0; e < kIPL; ++e)
-                                if (j + e < t_end) fold(t_w, x[e], (xl >> (8 * e)) & 0xffu, j + e < t_fend);
+                                if (j + e < t_end) fold(t_w, x[e], (xl >> (8 * e)) & 0xffu, j + e < t_fend ? t_nbase + (j + e - t_first) : ~0u);
                         }
                     }
                 }

@@ -87,6 +87,8 @@ struct mk_ctx {
     uint32_t capG, G;
     uint32_t *d_sketch_size;
     uint64_t *d_genome_size;
+    float *d_ratio;                // genome_size / sketch_size (select.hip), capG entries, current as of ratio_gen
+    uint64_t ratio_gen, ratio_cap;
     void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
     uint64_t exact_cap[10];
     bool exact_have_B;             // set B of the genome loaded last (mk_exact_load_genome) is resident
@@ -444,12 +446,14 @@ struct SelectArgs {
     const uint32_t *sketch_size;
     const uint64_t *genome_size;
     uint32_t genome_id_base, cap;
+    const float *ratio;            // genome_size / sketch_size per genome (slab schedule: the screen's one load), or null
     uint32_t *count;               // [nq]
     mk_hit *cand;                  // [nq][cap]
     uint64_t *rows;                // compact form instead of count/cand: [nq][1 + cap], see mk_qset_run_compact
 };
 constexpr uint32_t kSelectMaxResults = 64;   // top-N sizes the device selection supports
 int launch_select(mk_ctx *c, const SelectArgs &a);
+int launch_ratio(mk_ctx *c, float *d_ratio, uint32_t padded);
 
 // ---- merge.hip (K6b): filter_results' heap over the entrant rows of `world` shards
 constexpr uint32_t kMergeOverflow = 0xffffffffu;   // nhits value of a query some shard's row overflowed for
