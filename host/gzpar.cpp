@@ -21,13 +21,55 @@ bool is_mk_header(const uint8_t *h)
 }  // namespace
 
 // ------------------------------------------------------------------ writer
+// Three kinds of threads: the caller's (fills blocks), one deflate thread per block in flight, and ONE output thread that
+// takes the finished members in order and writes them -- so that the caller neither deflates nor waits for the file.
 ParallelGzipWriter::ParallelGzipWriter(const std::string &path, unsigned threads)
-    : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads)) {}
+    : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads))
+{
+    if (f_) out_thread_ = std::thread([this] { output_loop(); });
+}
 
 ParallelGzipWriter::~ParallelGzipWriter()
 {
-    for (auto &j : jobs_) if (j->th.joinable()) j->th.join();
-    if (f_) fclose(f_);
+    (void)finish();
+}
+
+void ParallelGzipWriter::output_loop()
+{
+    for (;;) {
+        std::unique_ptr<Job> j;
+        {
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [this] { return !jobs_.empty() || closing_; });
+            if (jobs_.empty()) return;
+            j = std::move(jobs_.front());
+            jobs_.pop_front();
+        }
+        if (!j->ready) j->th.join();
+        if (j->bad || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
+        if (j->on_done) j->on_done();
+        {
+            std::lock_guard<std::mutex> g(m_);
+            --in_flight_;
+        }
+        cv_.notify_all();
+    }
+}
+
+// hand a job to the output thread (in order); waits while as many blocks are in flight as there are threads
+void ParallelGzipWriter::enqueue(std::unique_ptr<Job> j)
+{
+    wrote_any_ = true;
+    if (!f_) { failed_ = true; if (j->on_done) j->on_done(); return; }
+    Job *raw = j.get();
+    if (!raw->ready) raw->th = std::thread(deflate_block, raw);
+    {
+        std::unique_lock<std::mutex> g(m_);
+        jobs_.push_back(std::move(j));
+        ++in_flight_;
+        cv_.notify_all();
+        cv_.wait(g, [this] { return in_flight_ < nthreads_ + 2; });
+    }
 }
 
 void ParallelGzipWriter::write(const void *p, size_t n)
@@ -43,20 +85,29 @@ void ParallelGzipWriter::write(const void *p, size_t n)
 
 bool ParallelGzipWriter::finish()
 {
-    if (!cur_.empty() || !wrote_any_) submit();                  // an empty stream is still one (empty) member
-    while (!jobs_.empty()) drain_one();
+    if (finished_) return !failed_;
+    finished_ = true;
+    if (f_ && (!cur_.empty() || !wrote_any_)) submit();          // an empty stream is still one (empty) member
+    {
+        std::lock_guard<std::mutex> g(m_);
+        closing_ = true;
+    }
+    cv_.notify_all();
+    if (out_thread_.joinable()) out_thread_.join();
     if (f_) { if (fclose(f_) != 0) failed_ = true; f_ = nullptr; }
     return !failed_;
 }
 
 void ParallelGzipWriter::deflate_block(Job *j)
 {
+    const uint8_t *in = j->ext ? j->ext : j->in.data();
+    const size_t n = j->ext ? j->ext_n : j->in.size();
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (deflateInit2(&zs, j->level, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
-    const size_t bound = deflateBound(&zs, (uLong)j->in.size()) + 64;
+    const size_t bound = deflateBound(&zs, (uLong)n) + 64;
     j->out.resize(kHeader + bound + 8);
-    zs.next_in = j->in.data(); zs.avail_in = (uInt)j->in.size();
+    zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)n;
     zs.next_out = j->out.data() + kHeader; zs.avail_out = (uInt)bound;
     if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
     const uint64_t payload = zs.total_out;
@@ -67,45 +118,30 @@ void ParallelGzipWriter::deflate_block(Job *j)
     put_le(h + 10, 12, 2); h[12] = 'M'; h[13] = 'K'; put_le(h + 14, 8, 2);
     put_le(h + 16, payload, 8);
     uint8_t *t = h + kHeader + payload;
-    put_le(t, crc32(crc32(0L, Z_NULL, 0), j->in.data(), (uInt)j->in.size()), 4);
-    put_le(t + 4, j->in.size() & 0xffffffffu, 4);
+    put_le(t, crc32(crc32(0L, Z_NULL, 0), in, (uInt)n), 4);
+    put_le(t + 4, n & 0xffffffffu, 4);
     j->out.resize(kHeader + payload + 8);
     std::vector<uint8_t>().swap(j->in);
 }
 
 void ParallelGzipWriter::submit()
 {
-    wrote_any_ = true;
     std::unique_ptr<Job> j(new Job());
     j->in.swap(cur_);
     cur_.reserve(kBlock);
     j->strategy = strategy_; j->level = level_;
-    Job *raw = j.get();
-    j->th = std::thread(deflate_block, raw);
-    jobs_.push_back(std::move(j));
-    while (jobs_.size() >= nthreads_) drain_one();
+    enqueue(std::move(j));
 }
 
-uint8_t *ParallelGzipWriter::begin_block()
+bool ParallelGzipWriter::write_block(const uint8_t *p, size_t n, std::function<void()> on_done)
 {
-    if (!cur_.empty() || open_) return nullptr;
-    open_.reset(new Job());
-    open_->in.resize(kBlock);
-    return open_->in.data();
-}
-
-void ParallelGzipWriter::end_block(size_t n)
-{
-    if (!open_) return;
-    std::unique_ptr<Job> j = std::move(open_);
-    if (!n) return;
-    wrote_any_ = true;
-    j->in.resize(std::min(n, kBlock));
+    if (!cur_.empty() || n > kBlock) return false;
+    if (!n) { if (on_done) on_done(); return true; }
+    std::unique_ptr<Job> j(new Job());
+    j->ext = p; j->ext_n = n; j->on_done = std::move(on_done);
     j->strategy = strategy_; j->level = level_;
-    Job *raw = j.get();
-    j->th = std::thread(deflate_block, raw);
-    jobs_.push_back(std::move(j));
-    while (jobs_.size() >= nthreads_) drain_one();
+    enqueue(std::move(j));
+    return true;
 }
 
 void ParallelGzipWriter::write_zeros(size_t n)
@@ -121,23 +157,13 @@ void ParallelGzipWriter::write_zeros(size_t n)
         if (j.bad) failed_ = true; else zero_member_.swap(j.out);
     }
     while (n >= kBlock && !failed_) {                             // whole blocks: the ready-made member, in order
-        wrote_any_ = true;
         std::unique_ptr<Job> j(new Job());
         j->out = zero_member_;
         j->ready = true;
-        jobs_.push_back(std::move(j));
-        while (jobs_.size() >= nthreads_) drain_one();
+        enqueue(std::move(j));
         n -= kBlock;
     }
     while (n) { const size_t take = std::min(n, zeros.size()); write(zeros.data(), take); n -= take; }
-}
-
-void ParallelGzipWriter::drain_one()
-{
-    std::unique_ptr<Job> j = std::move(jobs_.front());
-    jobs_.pop_front();
-    if (!j->ready) j->th.join();
-    if (j->bad || !f_ || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
 }
 
 // ------------------------------------------------------------------ reader

@@ -15,8 +15,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,27 +42,38 @@ public:
     void set_strategy(int strategy) { strategy_ = strategy; }
     // level 0 = stored blocks (no deflate work at all, the file grows by what level 1 would have saved), 1 = the reference's
     void set_level(int level) { level_ = level; }
-    // A whole block handed over without a copy: begin_block() returns kBlock bytes the caller fills (only at a block
-    // boundary -- nothing buffered by write(); nullptr otherwise), end_block(n) submits the first n of them.  The dump of
-    // a 105 GB index otherwise copies every byte once more on the one thread that also feeds the GPU's exports.
     void flush_block() { if (!cur_.empty()) submit(); }   // what is buffered becomes a (short) member of its own
-    uint8_t *begin_block();
-    void end_block(size_t n);
+    // A whole block handed over without a copy: n <= kBlock bytes at p, which stay the CALLER's (page-locked memory the
+    // GPU exported into, say) until on_done runs on the output thread, after the member has been written.  Only at a block
+    // boundary (nothing buffered by write()): false otherwise, and nothing is taken.
+    bool write_block(const uint8_t *p, size_t n, std::function<void()> on_done);
     bool finish();                       // flushes, closes; false on any error
     static constexpr size_t kBlock = 32u << 20;
 private:
-    struct Job { std::vector<uint8_t> in, out; std::thread th; bool bad = false; int strategy = 0, level = 1; bool ready = false; };
+    struct Job {
+        std::vector<uint8_t> in, out;
+        const uint8_t *ext = nullptr; size_t ext_n = 0;          // write_block: the caller's bytes instead of `in`
+        std::function<void()> on_done;
+        std::thread th;
+        bool bad = false, ready = false;                         // ready: `out` is final already (a run of zeros)
+        int strategy = 0, level = 1;
+    };
     static void deflate_block(Job *j);
     void submit();
-    void drain_one();
+    void enqueue(std::unique_ptr<Job> j);
+    void output_loop();
     FILE *f_;
     unsigned nthreads_;
     std::vector<uint8_t> cur_;
-    std::deque<std::unique_ptr<Job>> jobs_;
+    std::deque<std::unique_ptr<Job>> jobs_;                      // handed to the output thread, in stream order
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread out_thread_;
+    unsigned in_flight_ = 0;
+    bool closing_ = false, finished_ = false;
     bool failed_ = false, wrote_any_ = false;
     int strategy_ = 0;                   // Z_DEFAULT_STRATEGY
     int level_ = 1;
-    std::unique_ptr<Job> open_;          // begin_block() .. end_block()
     std::vector<uint8_t> zero_member_;   // the gzip member of kBlock zero bytes, made on first use
 };
 

@@ -76,18 +76,33 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     // MIEKKI_DUMP_LEVEL=0: the columns as stored blocks -- no deflate work (a 105 GB index then dumps at the rate the
     // rows leave the GPU), a file a third larger; any gzip reader, the reference's included, reads it all the same
     if (const char *e = getenv("MIEKKI_DUMP_LEVEL")) w.set_level(atoi(e) == 0 ? 0 : 1);
-    // one GPU: the rows of a block are exported straight into the block (no copy on this thread, which feeds the exports)
+    // One GPU: the rows of a block are exported straight into PAGE-LOCKED blocks (a DMA at the PCIe rate, no copy on this
+    // thread) that the writer deflates and writes from where they lie; a block comes back to the pool once its member is
+    // on file.  (Through pageable buffers a 105 GB index left the GPU at 2.7 GB/s: that, not deflate, bounded the dump.)
     const uint32_t rows_blk = row && row <= ParallelGzipWriter::kBlock ? (uint32_t)(ParallelGzipWriter::kBlock / row) : 0;
+    struct Pool { std::mutex m; std::condition_variable cv; std::vector<uint8_t *> free; } pool;
+    std::vector<void *> pinned;
+    if (D == 1 && G && rows_blk) {
+        for (unsigned i = 0; i < threads + 4; ++i) {
+            void *b = nullptr;
+            if (mk_host_alloc(ctxs[0], ParallelGzipWriter::kBlock, &b) != MK_OK) break;
+            pinned.push_back(b); pool.free.push_back((uint8_t *)b);
+        }
+    }
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
-        if (D == 1 && G && rows_blk) {
-            uint8_t *blk = w.begin_block();
-            if (blk) {
-                const uint32_t pe1 = std::min(P, pb + rows_blk);
-                if (mk_index_export_columns(ctxs[0], pb, pe1, blk) != MK_OK) { err = mk_last_error(); ok = false; w.end_block(0); break; }
-                w.end_block((size_t)(pe1 - pb) * row);
-                pb = pe1 - rows;                                   // (the loop adds `rows`)
-                continue;
+        if (pinned.size() >= 3) {
+            uint8_t *blk;
+            {
+                std::unique_lock<std::mutex> g(pool.m);
+                pool.cv.wait(g, [&] { return !pool.free.empty(); });
+                blk = pool.free.back(); pool.free.pop_back();
             }
+            const uint32_t pe1 = std::min(P, pb + rows_blk);
+            auto give_back = [&pool, blk] { { std::lock_guard<std::mutex> g(pool.m); pool.free.push_back(blk); } pool.cv.notify_one(); };
+            if (mk_index_export_columns(ctxs[0], pb, pe1, blk) != MK_OK) { err = mk_last_error(); ok = false; give_back(); break; }
+            if (!w.write_block(blk, (size_t)(pe1 - pb) * row, give_back)) { w.write(blk, (size_t)(pe1 - pb) * row); give_back(); }
+            pb = pe1 - rows;                                       // (the loop adds `rows`)
+            continue;
         }
         const uint32_t pe = std::min(P, pb + rows);
         if (D == 1) {
@@ -123,7 +138,8 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     }
     if (ok) w.write_zeros((size_t)(nb - reach));
     if (ok) w.write(ss.data(), (size_t)G * 4);
-    if (!w.finish()) ok = false;
+    if (!w.finish()) ok = false;                                   // (every block is back in the pool after this)
+    for (void *b : pinned) mk_host_free(ctxs[0], b);
     if (!ok && err.empty()) err = "write error on " + path;
     return ok ? 0 : -1;
 }
@@ -163,13 +179,19 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
     const uint32_t P = ok ? 1u << hd.h : 0;
     const uint64_t row = (uint64_t)G * W;
     const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
-    std::vector<uint8_t> buf((size_t)std::max<uint64_t>(rows * row, 1)), part;
+    std::vector<uint8_t> buf, part;
+    // (the chunk the columns pass through is page-locked when there is a context to ask: its upload is then a DMA)
+    void *pinned = nullptr;
+    const size_t chunk_bytes = (size_t)std::max<uint64_t>(rows * row, 1);
+    if (ok && !out.empty() && mk_host_alloc(out[0], chunk_bytes, &pinned) != MK_OK) pinned = nullptr;
+    if (!pinned) buf.resize(chunk_bytes);
+    uint8_t *const cbuf = pinned ? (uint8_t *)pinned : buf.data();
     for (uint32_t pb = 0; ok && pb < P; pb += rows) {
         const uint32_t pe = std::min(P, pb + rows);
-        ok = f.read(buf.data(), (size_t)(pe - pb) * row);
+        ok = f.read(cbuf, (size_t)(pe - pb) * row);
         if (!ok) { err = "truncated index columns"; break; }
         if (D == 1) {
-            if (G && mk_index_import_columns(out[0], pb, pe, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+            if (G && mk_index_import_columns(out[0], pb, pe, cbuf) != MK_OK) { err = mk_last_error(); ok = false; }
             continue;
         }
         for (size_t d = 0; ok && d < D; ++d) {
@@ -177,10 +199,11 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
             if (!prow) continue;
             part.resize((size_t)(pe - pb) * prow);
             for (uint32_t r = 0; r < pe - pb; ++r)
-                memcpy(part.data() + (uint64_t)r * prow, buf.data() + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
+                memcpy(part.data() + (uint64_t)r * prow, cbuf + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
             if (mk_index_import_columns(out[d], pb, pe, part.data()) != MK_OK) { err = mk_last_error(); ok = false; }
         }
     }
+    if (pinned) mk_host_free(out[0], pinned);
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
     if (ok && !(ok = f.read(gs.data(), (size_t)G * 8))) err = "truncated genome sizes";

@@ -993,6 +993,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     c->empty = p->fp_bits == 8 ? 255u : 65535u;
     c->d_M = nullptr; c->ld = 0; c->capG = 0; c->G = 0; c->d_sketch_size = nullptr; c->d_genome_size = nullptr;
     c->d_ratio = nullptr; c->ratio_gen = 0; c->ratio_cap = 0;
+    c->d_colstage = nullptr; c->colstage_cap = 0;
     c->h_Z = nullptr; c->z_bytes = 0; c->d_zoff = nullptr; c->d_zstage[0] = c->d_zstage[1] = nullptr; c->zstage_cap = 0;
     c->h_M = nullptr; c->P_hot = c->P; c->d_cold_stage = nullptr; c->cold_stage_rows = 0; c->hbm_matrix_budget = 0;
     for (int i = 0; i < 5; ++i) c->ev_cold[i] = nullptr;
@@ -1057,7 +1058,7 @@ void mk_destroy(mk_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom); dev_free(c->d_ratio);
+    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom); dev_free(c->d_ratio); dev_free(c->d_colstage);
     if (c->h_M) (void)hipHostFree(c->h_M);
     if (c->h_Z) (void)hipHostFree(c->h_Z);
     dev_free(c->d_zoff); dev_free(c->d_zstage[0]); dev_free(c->d_zstage[1]);
@@ -1310,8 +1311,14 @@ static int staged_columns(mk_ctx *c, bool to_device, uint32_t pb, uint32_t pe, u
     MK_TRY(need_raw_cold(c));                                    // (dump_disk decompresses first too, Miekki.cpp:662-664)
     const uint64_t row = (uint64_t)c->G * c->W;
     const uint32_t rows_per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(pe - pb, (256ull << 20) / row));
-    uint8_t *d_stage = nullptr;
-    MK_TRY(dev_alloc(&d_stage, (uint64_t)rows_per * row));
+    // (the staging buffer stays with the context: a dump or a load calls this a few thousand times)
+    if ((uint64_t)rows_per * row > c->colstage_cap) {
+        dev_free(c->d_colstage);
+        c->colstage_cap = 0;
+        MK_TRY(dev_alloc(&c->d_colstage, (uint64_t)rows_per * row));
+        c->colstage_cap = (uint64_t)rows_per * row;
+    }
+    uint8_t *d_stage = c->d_colstage;
     int rc = MK_OK;
     for (uint32_t p = pb; p < pe && rc == MK_OK; p += rows_per) {
         const uint32_t r = std::min(rows_per, pe - p);
@@ -1326,7 +1333,6 @@ static int staged_columns(mk_ctx *c, bool to_device, uint32_t pb, uint32_t pe, u
         if (rc == MK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MK_ERR_DEVICE;
     }
     if (rc == MK_ERR_DEVICE) set_error("column transfer failed: %s", hipGetErrorString(hipGetLastError()));
-    dev_free(d_stage);
     return rc;
 }
 

@@ -682,10 +682,11 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     bs.bloom_on = c->d_bloom && !(tune & 1u) && !for_queries ? 1u : 0u;   // (a query's k-mers are gated, not inserted)
     bs.sum_words = 0;
     if (bs.bloom_on && bloom_summary_bytes(c) <= 8192) bs.sum_words = (uint32_t)((bloom_summary_bytes(c) + 7) / 8);
-    // partitions per bin (log2): 2^12 at -h 20 and above; below that as many bins as at -h 20 -- 256 per genome -- rather than
-    // bins of 2^12: a reduce workgroup owns one (genome, bin), and at -h 17 thirty-two bins per genome were 2,048 workgroups of
-    // 150,000 items each for 256 CUs (0.87 ms per batch alone on the chip against 0.47 at -h 20)
-    bs.low_bits = std::min<uint32_t>(kBin, c->p.h > 8 ? c->p.h - 8 : c->p.h);
+    // partitions per bin (log2): 2^12, fewer only when the sketch has fewer.  (Smaller bins at small h -- 256 bins per genome
+    // whatever h -- were measured at -h 17: 2^9-partition bins 47.0k sketches/s, 2^10 52.8k, 2^11 55.1k, 2^12 54.2k; and at
+    // -h 20 2^10 32.4k, 2^11 40.8k against 53.5k: a reduce workgroup's LDS table wants many entries per lane.)
+    bs.low_bits = std::min<uint32_t>(kBin, c->p.h);
+    if (const char *e = getenv("MIEKKI_BUILD_LOW_BITS")) bs.low_bits = std::min<uint32_t>(std::min<uint32_t>(kBin, c->p.h), (uint32_t)std::max(1, atoi(e)));   // tuning knob
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
     bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);

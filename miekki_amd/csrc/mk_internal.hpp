@@ -89,6 +89,8 @@ struct mk_ctx {
     uint64_t *d_genome_size;
     float *d_ratio;                // genome_size / sketch_size (select.hip), capG entries, current as of ratio_gen
     uint64_t ratio_gen, ratio_cap;
+    uint8_t *d_colstage;           // staging of mk_index_export_columns / _import_columns (kept between calls)
+    uint64_t colstage_cap;
     void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
     uint64_t exact_cap[10];
     bool exact_have_B;             // set B of the genome loaded last (mk_exact_load_genome) is resident

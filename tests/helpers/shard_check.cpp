@@ -1,5 +1,5 @@
 // Test helper (no GPU needed): prints the device list host/multi_gpu.cpp derives from the environment
-// and the shard table of `n` items over `parts` shards.   shard_check <n> <parts>
+// the shard table of `n` items over `parts` shards and the entrant-row width for a shard of n genomes.   shard_check <n> <parts>
 #include <cstdio>
 #include <cstdlib>
 
@@ -17,5 +17,7 @@ int main(int argc, char **argv)
         mkhost::shard_range(n, s, parts, b, e);
         printf("shard %u %llu %llu\n", s, (unsigned long long)b, (unsigned long long)e);
     }
+    // entrant slots per exchange row for a top-10 / top-5 heap over a shard of n genomes (multi_gpu.hpp: entrant_cap)
+    printf("cap %u %u\n", mkhost::entrant_cap(10, n), mkhost::entrant_cap(5, n));
     return 0;
 }

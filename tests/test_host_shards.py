@@ -26,7 +26,8 @@ def run(exe, n, parts, **env):
     e.update(env)
     out = subprocess.run([exe, str(n), str(parts)], stdout=subprocess.PIPE, env=e, check=True, timeout=120).stdout.decode().splitlines()
     devs = [int(x) for x in out[0].split()[1:]]
-    shards = [tuple(int(x) for x in l.split()[2:]) for l in out[1:]]
+    shards = [tuple(int(x) for x in l.split()[2:]) for l in out[1:] if l.startswith("shard")]
+    run.caps = tuple(int(x) for x in [l for l in out if l.startswith("cap")][0].split()[1:])
     return devs, shards
 
 
@@ -43,3 +44,13 @@ def test_shard_tables_are_the_python_rule(exe):
         _, shards = run(exe, n, parts)
         assert shards == [shard_range(n, r, parts) for r in range(parts)]
         assert shards[0][0] == 0 and shards[-1][1] == n
+
+
+def test_entrant_row_width_is_the_python_rule(exe):
+    """host/multi_gpu.hpp: entrant_cap (the `miekki` binary) and miekki_amd/shard.py: entrant_cap (bench.py) are one rule:
+    every rank of a run must size its exchange rows alike."""
+    from miekki_amd.shard import entrant_cap
+    for n in (0, 7, 1000, 12_500, 50_000, 100_000, 4_000_000):
+        run(exe, n, 1)
+        assert run.caps == (entrant_cap(10, n), entrant_cap(5, n)), n
+    assert entrant_cap(10, 12_500) == entrant_cap(10, 50_000) == entrant_cap(10, 100_000) == 128

@@ -47,6 +47,37 @@ def test_parallel_gzip_round_trips_and_is_plain_gzip(tmp_path, size):
         assert mkgz(["d", other, "4"]) == data
 
 
+@pytest.mark.parametrize("stored", [False, True])
+def test_index_writer_forms_are_plain_gzip_too(tmp_path, stored):
+    """The dump's special forms (host/index_io.cpp through gzpar): the 39-byte head as a member of its own, blocks filled
+    in place, Huffman-only deflate for the fingerprint columns -- or stored blocks, MIEKKI_DUMP_LEVEL=0 -- and the
+    ready-made member for every whole block of zeros (the unreachable part of the reference's 1 GiB Bloom filter): our
+    reader, zlib and therefore the reference's zstr read the same stream back."""
+    rng = np.random.default_rng(3)
+    cols = (rng.integers(0, 60, (70 << 20) + 999, dtype=np.uint8) + 190).tobytes()      # fingerprint-like columns
+    data = bytes(39) + cols + bytes(8 * 1000) + b"\x01\x02" * 4000 + bytes((100 << 20) + 17) + b"tail" * 1000
+    path = str(tmp_path / "i.gz")
+    env = dict(os.environ, MKGZ_STORED="1") if stored else dict(os.environ)
+    r = subprocess.run([MKGZ, "i", path, "6"], input=data, stdout=subprocess.PIPE, env=env)
+    assert r.returncode == 0
+    assert mkgz(["d", path, "5"]) == data
+    raw = open(path, "rb").read()
+    assert gzip.decompress(raw) == data
+    if stored:
+        assert len(raw) > len(cols)                                             # the columns went in as they are
+    else:
+        assert len(raw) < 0.85 * len(cols)                                      # uniform over 60 values: 5.9 of 8 bits per byte
+    # the 100 MiB of zeros (less what the block before them took): ready-made members (a few KB each, identical), not deflate runs
+    head = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x04\x03\x0c\x00MK\x08\x00"
+    sizes = []
+    at = raw.find(head)
+    while at >= 0:
+        nxt = raw.find(head, at + 1)
+        sizes.append((nxt if nxt >= 0 else len(raw)) - at)
+        at = nxt
+    assert sum(1 for a, b in zip(sizes, sizes[1:]) if a == b and a < 200_000) >= 1   # identical small members in a row
+
+
 def test_corrupt_member_is_detected(tmp_path):
     data = bytes(range(256)) * 4000
     path = str(tmp_path / "x.gz")
