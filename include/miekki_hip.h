@@ -129,6 +129,13 @@ int mk_probe_synth_genomes(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t 
  * the batch in flight, so results are always those of a synchronous build. */
 int mk_index_append(mk_ctx *ctx, const char *const *seqs, const uint64_t *lens, uint32_t n);
 
+/* Miekki::insert_sequence (Miekki.cpp:243-273; behind index_file, 518-536 -- neither is reached from the reference's
+ * CLI, both are public members).  One genome; sketch, column and Bloom inserts are insert_sequences', the size estimate
+ * is this member's own: the count of active partitions is a double there, so its square does not wrap at 2^32 the way
+ * insert_sequences' u32 does (Miekki.cpp:289, 306) -- genome_size differs from mk_index_append's above 65,535 active
+ * partitions, i.e. from -h 17 on. */
+int mk_index_insert_sequence(mk_ctx *ctx, const char *seq, uint64_t len);
+
 /* ---- packed ingest (2-bit packing overlapped with the copy to the GPU) ----
  * A sequence as 2 bits per base and, only when it holds characters other than A, C, G, T, one
  * exception bit per base -- a quarter (three eighths) of the bytes mk_index_append moves:

@@ -305,11 +305,12 @@ int ensure_packed(mk_ctx *c, int buf, uint64_t code_bytes)
 }
 
 // genome_size / sketch_size of Miekki.cpp:303-311 from the device's exact sums
-static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t len)
+// (`single`: insert_sequence, Miekki.cpp:245-270, counts the active partitions in a double -- its square does not wrap)
+static uint64_t estimate_genome_size(uint32_t active, uint64_t cardsum, uint64_t len, bool single)
 {
     const double card = (double)cardsum / 2147483648.0;          // sum of 2^-exp, exact
     const uint32_t sq = active * active;                         // u32 wrap-around, Miekki.cpp:306
-    const double est = 0.72134 * (double)sq / card;
+    const double est = single ? 0.72134 * ((double)active * (double)active) / card : 0.72134 * (double)sq / card;
     if (est > (double)len) return len;
     if (std::isnan(est)) return 0x8000000000000000ull;           // what the x86 conversion yields
     return (uint64_t)est;
@@ -332,7 +333,7 @@ static int enqueue_front(mk_ctx *c, const uint64_t *h_off, uint32_t n, int buf, 
 {
     mk_ctx::BuildSide &sd = c->side[buf];
     mk_ctx::BuildInFlight &f = c->front;
-    f.n = n; f.buf = buf; f.binned = false;
+    f.n = n; f.buf = buf; f.binned = false; f.single = c->next_single;
     f.have_chars = form == kChars; f.have_heads = form == kPacked;
     memcpy(f.off, h_off, (size_t)(n + 1) * 8);
     memcpy(c->h_img->off[buf], h_off, (size_t)(n + 1) * 8);
@@ -437,7 +438,7 @@ static int settle_one(mk_ctx *c, mk_ctx::BuildInFlight &b)
     for (uint32_t g = 0; g < n; ++g) {
         const uint64_t len = b.off[g + 1] - b.off[g];
         up.ss[g] = sd.h_back->act[g];
-        up.gs[g] = estimate_genome_size(up.ss[g], sd.h_back->card[g], len);
+        up.gs[g] = estimate_genome_size(up.ss[g], sd.h_back->card[g], len, b.single);
         c->h_sketch_size.push_back(up.ss[g]);
         c->h_genome_size.push_back(up.gs[g]);
         if (up.ss[g] == 0) c->has_empty_sketch = true;
@@ -1196,6 +1197,18 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
         g0 += nb;
     }
     return MK_OK;
+}
+
+// insert_sequence (Miekki.cpp:243-273), the one-genome form behind index_file (518-536; the reference's CLI never calls
+// either): sketch, column and Bloom inserts are insert_sequences'; only the size estimate differs -- it keeps the count of
+// active partitions in a double, so its square does not wrap at 2^32 (more than 65,535 active partitions: -h 17 and up).
+int mk_index_insert_sequence(mk_ctx *c, const char *seq, uint64_t len)
+{
+    if (!c || !seq) { set_error("null argument"); return MK_ERR_ARG; }
+    c->next_single = true;
+    const int rc = mk_index_append(c, &seq, &len, 1);
+    c->next_single = false;
+    return rc;
 }
 
 // insert_sequences for sequences that arrive packed: a quarter of the bytes cross

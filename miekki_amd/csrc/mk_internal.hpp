@@ -97,6 +97,7 @@ struct mk_ctx {
     uint64_t exact_nB;             // its number of distinct k-mers
     uint32_t exact_log2B;
     bool has_empty_sketch;         // some genome has sketch_size 0 (see nan_candidates_possible in api.hip)
+    bool next_single = false;      // the batch being queued comes from mk_index_insert_sequence
     // sizes of ALL genomes of a sharded index (mk_merge_set_sizes), for the compact merge on the
     // context that receives the gathered rows
     uint32_t *d_all_ss;
@@ -144,6 +145,7 @@ struct mk_ctx {
         bool on, binned;
         bool have_chars;           // the batch's characters are in d_seq[buf] (else only its packed form exists, in d_pk[buf])
         bool have_heads;           // d_heads[buf] holds the sequences' first 32 characters (packed input)
+        bool single;               // mk_index_insert_sequence: the size estimate of Miekki.cpp:243-273 (active count in a double)
         uint32_t n;
         uint32_t g0;               // its first column of the matrix (set when the back stage is queued)
         int buf;

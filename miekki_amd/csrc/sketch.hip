@@ -919,9 +919,12 @@ constexpr uint32_t kMidPer = kMidSeg / 256;
 constexpr uint32_t kMidPosBits = 18;               // positions a key can hold: queries up to 2^18 k-mers
 struct MidWork { uint32_t q_local, chunk; };
 
-__device__ __forceinline__ uint32_t mid_home(uint32_t bucket, uint32_t nslots)
+// A partition's home slot rises with the partition (partitions are hash bits: they spread evenly as they are), so that
+// the sweep over the slots meets the winners in NEARLY partition order -- neighbours displaced by a few places, 256-slot
+// blocks appended in the order their workgroups arrive -- and the scan walks the matrix rows nearly in order.
+__device__ __forceinline__ uint32_t mid_home(uint32_t bucket, uint32_t nslots, uint32_t h)
 {
-    return (uint32_t)(((uint64_t)(bucket * 0x9E3779B1u) * nslots) >> 32);
+    return (uint32_t)(((uint64_t)bucket * nslots) >> h);
 }
 
 __global__ __launch_bounds__(256) void mid_insert_kernel(const char *__restrict__ seq, const uint64_t *__restrict__ off,
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(256) void mid_insert_kernel(const char *__restrict_
         const uint32_t pass = !bloom || bloom_check(bloom, bloom_dev_bytes, canon, anc, sp.bloom_log2, bloom_full);
         const unsigned long long key = ((unsigned long long)bucket << (kMidPosBits + 17)) | ((unsigned long long)fp << (kMidPosBits + 1)) |
                                        ((unsigned long long)(i_begin + i0 + e) << 1) | pass;
-        uint32_t at = mid_home(bucket, nslots);
+        uint32_t at = mid_home(bucket, nslots, sp.h);
         for (;;) {                                                    // fewer distinct partitions than slots: the walk ends
             const unsigned long long old = atomicCAS(&tab[at], (unsigned long long)kEmptyKey, key);
             if (old == kEmptyKey) break;

@@ -94,6 +94,26 @@ class Miekki:
         L.check(self._lib.mk_reset_stats(self._h))
 
     # ---- index build (Miekki.cpp:277-314, 540-588)
+    def insert_sequence(self, seq, title=""):
+        """Miekki::insert_sequence (Miekki.cpp:243-273): one genome, its own size estimate (no u32 wrap of active^2)."""
+        seq = bytes(seq)
+        L.check(self._lib.mk_index_insert_sequence(self._h, seq, len(seq)))
+        self.file_names.append(title)
+
+    def index_file(self, path):
+        """Miekki::index_file (Miekki.cpp:518-536): every non-header line of a (gzip'd) FASTA file as ONE genome."""
+        import gzip
+        import os
+        if not os.path.exists(path):
+            print(f"Missed file: {path}")
+            return
+        raw = open(path, "rb").read()
+        if raw[:2] == b"\x1f\x8b":
+            raw = gzip.decompress(raw)
+        ref = b"".join(ln for ln in raw.split(b"\n") if not ln.startswith(b">"))
+        if len(ref) >= self.kmer_size:
+            self.insert_sequence(ref, path)
+
     def insert_sequences(self, seqs, names=None):
         seqs = [bytes(s) for s in seqs]
         if not seqs:

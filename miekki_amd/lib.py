@@ -57,6 +57,7 @@ SIGNATURES = {
     "mk_probe_stream_read": (i32, [vp, u32, PP(C.c_double), PP(u64)]),
     "mk_probe_synth_genomes": (i32, [vp, u64, u32, u64, vp]),
     "mk_index_append": (i32, [vp, vp, vp, u32]),
+    "mk_index_insert_sequence": (i32, [vp, vp, u64]),
     "mk_index_append_packed": (i32, [vp, vp, u32]),
     "mk_pack_code_words": (u64, [u64]),
     "mk_pack_except_words": (u64, [u64]),

@@ -266,6 +266,23 @@ void mko_insert_sequences(mko_index *ix, const char *const *seqs, const uint64_t
     free(fp); free(hs);
 }
 
+/* Miekki.cpp:243-273 (behind index_file 518-536): insert_sequences for one genome, except that active_minimizer is a
+ * double here (line 246), so active*active at line 265 does not wrap */
+void mko_insert_sequence(mko_index *ix, const char *seq, uint64_t len)
+{
+    const uint64_t g = ix->G;
+    mko_insert_sequences(ix, &seq, &len, 1);                     /* sketch, add_index, Bloom: the same statements */
+    const uint32_t shift = ix->fp_bits - NUMBER_BIT_MANTIS;
+    double card = 0, active = 0;
+    for (uint32_t i = 0; i < ix->nmin; ++i) {
+        uint32_t fp = ix->W == 2 ? (uint32_t)ix->col[i][2 * g] * 256u + ix->col[i][2 * g + 1] : ix->col[i][g];
+        if (fp != ix->empty) { card += 1.0 / (double)((uint64_t)1 << (fp >> shift)); active += 1; }
+    }
+    card = 0.72134 * (active * active) / card;                   /* line 265 */
+    if (card > (double)len) ix->genome_size[g] = len;            /* 266-270 */
+    else ix->genome_size[g] = (uint64_t)card;
+}
+
 static uint32_t col_value(const mko_index *ix, uint32_t p, uint32_t g)   /* get_minimizers 881-898 */
 {
     const uint8_t *c = ix->col[p];

@@ -77,6 +77,7 @@ void mko_insert_bloom(mko_index *ix, uint64_t num);       /* Miekki.cpp:121-131 
 /* Miekki.cpp:277-314 (the `-l` path).  Genome ids = call order. */
 void mko_insert_sequences(mko_index *ix, const char *const *seqs, const uint64_t *lens,
                           uint32_t n);
+void mko_insert_sequence(mko_index *ix, const char *seq, uint64_t len);   /* Miekki.cpp:243-273 */
 
 /* Miekki.cpp:344-372: scores[nq][G] row-major, zero-initialised here. */
 void mko_query_sequences(const mko_index *ix, const char *const *seqs, const uint64_t *lens,

@@ -44,6 +44,7 @@ def _load():
         "mko_sketch_solid": (None, [vp, cp, u64, vp]),
         "mko_check_bloom": (C.c_int, [vp, u64]),
         "mko_insert_sequences": (None, [vp, vp, vp, u32]),
+        "mko_insert_sequence": (None, [vp, vp, u64]),
         "mko_query_sequences": (None, [vp, vp, vp, u32, vp]),
         "mko_query_sequence": (u32, [vp, cp, u64, vp]),
         "mko_filter_results": (u32, [vp, vp, u32, u32, C.c_double, vp]),
@@ -148,6 +149,10 @@ class OracleMiekki:
     def insert_sequences(self, seqs):
         ptrs, lens = _seq_arrays(seqs)
         self._L.mko_insert_sequences(self._h, ptrs, lens, len(seqs))
+
+    def insert_sequence(self, seq: bytes):
+        seq = bytes(seq)
+        self._L.mko_insert_sequence(self._h, seq, len(seq))
 
     def query_sequences(self, seqs):
         ptrs, lens = _seq_arrays(seqs)

@@ -104,6 +104,24 @@ static int cmd_golden(int argc, char** argv)
     return 0;
 }
 
+// single <dir> <k> <h> <f> <b> <threshold>: every file of <dir>/genomes.lst through index_file (Miekki.cpp:518-536),
+// i.e. the one-genome insert_sequence (243-273) whose size estimate differs from insert_sequences'; the index is
+// written to <dir>/single_idx.gz
+static int cmd_single(int argc, char** argv)
+{
+    if (argc < 8) { fprintf(stderr, "usage: single dir k h f b threshold\n"); return 2; }
+    string dir = argv[2];
+    uint32_t k = atoi(argv[3]), h = atoi(argv[4]), f = atoi(argv[5]), b = atoi(argv[6]);
+    uint32_t thr = uint32_t(atof(argv[7]));
+    Miekki ix(k, h, 5 + f, 5, 0, dir + "/harness_out.txt", b, thr, 1);
+    ifstream in(dir + "/genomes.lst");
+    string path;
+    while (getline(in, path)) if (path.size() > 3) ix.index_file(dir + "/" + path);
+    ix.dump_disk(dir + "/single_idx.gz");
+    printf("\nsingle: G=%u\n", (unsigned)ix.index_size);
+    return 0;
+}
+
 // filter <in.bin> <out.bin>: synthetic filter_results cases (tie behaviour).
 // in: u32 ncase; per case: u32 G, u32 nres, u32 min_score, f64 min_inter,
 //     u32 sketch_size[G], u64 genome_size[G], u32 scores[G]
@@ -252,6 +270,7 @@ int main(int argc, char** argv)
     if (argc < 2) { fprintf(stderr, "usage: ref_harness golden|filter|scanbench|sketchbench ...\n"); return 2; }
     if (!strcmp(argv[1], "golden")) return cmd_golden(argc, argv);
     if (!strcmp(argv[1], "filter")) return cmd_filter(argc, argv);
+    if (!strcmp(argv[1], "single")) return cmd_single(argc, argv);
     if (!strcmp(argv[1], "scanbench")) return cmd_scanbench(argc, argv);
     if (!strcmp(argv[1], "sketchbench")) return cmd_sketchbench(argc, argv);
     return 2;

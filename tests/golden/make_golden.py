@@ -229,6 +229,32 @@ def make_out_only(name):
     print(f"{name}: -a output {len(txt)}B, {len(txt.splitlines())} lines")
 
 
+def make_single(name):
+    """The case's genome files through the reference's index_file / insert_sequence (Miekki.cpp:518-536, 243-273) one by
+    one: the sizes and the digest of the index stream that one-genome path leaves."""
+    case = synth.CASES[name]()
+    sfx = "16" if case.fp_bits == 16 else ""
+    harness = os.path.join(REFDIR, "ref_harness" + sfx)
+    W = case.fp_bits // 8
+    with tempfile.TemporaryDirectory(prefix="mkgold_") as d:
+        for fn, data, gz in case.genome_files:
+            with open(os.path.join(d, fn), "wb") as f:
+                f.write(gzip.compress(data, 1) if gz else data)
+        with open(os.path.join(d, "genomes.lst"), "wb") as f:
+            f.write(b"".join(fn.encode() + b"\n" for fn, _, _ in case.genome_files))
+            f.write(b"missing_file.fa\n")
+        run([harness, "single", d, str(case.k), str(case.h), str(case.f), str(case.b), str(case.threshold)], d)
+        raw = gzip.decompress(open(os.path.join(d, "single_idx.gz"), "rb").read())
+    st = parse_stream(raw, W)
+    assert st["G"] == len(case.genome_sequences())
+    masked = bytearray(raw); masked[32] = 0; masked[38] = 0
+    batch = np.load(os.path.join(HERE, f"{name}.npz"))
+    np.savez_compressed(os.path.join(HERE, f"{name}_single.npz"), G=st["G"], genome_size=st["gsz"].copy(),
+                        sketch_size=st["ssz"].copy(), stream_sha_masked=sha(bytes(masked)), stream_len=len(raw))
+    differ = int((batch["genome_size"] != st["gsz"]).sum())
+    print(f"{name}_single: G={st['G']} genome_size differs from insert_sequences' for {differ} genomes")
+
+
 def make_filter_cases():
     """Synthetic filter_results inputs built to hit heap ties and replacement."""
     rng = np.random.default_rng(20261003)
@@ -259,10 +285,13 @@ def make_filter_cases():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16", "exact:flush", "out:dups"])
+    names = sys.argv[1:] or (list(synth.CASES) + ["filter", "exactA:messy", "exactA:h20", "exactA:w16", "exact:flush", "out:dups",
+                                 "single:h16z", "single:h20", "single:w16", "single:messy"])
     for n in names:
         if n == "filter":
             make_filter_cases()
+        elif n.startswith("single:"):
+            make_single(n.split(":", 1)[1])
         elif n.startswith("out:"):
             make_out_only(n.split(":", 1)[1])
         elif n.startswith("exact:"):

@@ -127,6 +127,36 @@ def test_out_txt_matches_reference_cli(built, name, golden_dir, tmp_path):
     assert (tmp_path / "out.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
 
 
+@pytest.mark.parametrize("name", ["h16z", "h20", "w16", "messy"])
+def test_insert_sequence_matches_reference_index_file(hip, golden_dir, name, tmp_path):
+    """mk_index_insert_sequence / Miekki.index_file against the reference's own index_file run (Miekki.cpp:518-536,
+    243-273; `*_single.npz`): sizes and the whole index stream -- the size estimate differs from insert_sequences' where
+    active^2 passes 2^32 (h16z: 65536^2 wraps to 0 there, not here)."""
+    case = synth.CASES[name]()
+    gold = np.load(os.path.join(golden_dir, f"{name}_single.npz"))
+    ix = hip.Miekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+    try:
+        for n, (fn, data, gz) in enumerate(case.genome_files):
+            if n % 2:                                            # through the file reader (plain and gzip'd) ...
+                path = tmp_path / fn
+                path.write_bytes(gzip.compress(data, 1) if gz else data)
+                ix.index_file(str(path))
+            else:                                                # ... and as a sequence
+                seq = b"".join(ln for ln in data.split(b"\n") if not ln.startswith(b">"))
+                if len(seq) >= case.k:
+                    ix.insert_sequence(seq, fn)
+        ix.index_file(str(tmp_path / "missing_file.fa"))          # "Missed file: ..." and nothing else
+        assert ix.index_size == int(gold["G"])
+        np.testing.assert_array_equal(ix.sketch_size, gold["sketch_size"])
+        np.testing.assert_array_equal(ix.genome_size, gold["genome_size"])
+        raw = bytearray(stream_of(ix))
+        assert len(raw) == int(gold["stream_len"])
+        raw[32] = 0; raw[38] = 0
+        assert sha(bytes(raw)) == str(gold["stream_sha_masked"])
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("name", ["messy", "w16"])
 def test_dump_and_load_round_trip(hip, built, name, tmp_path):
     case, gold, ix = built(name)

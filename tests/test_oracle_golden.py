@@ -209,3 +209,25 @@ def test_tie_heavy_collection_matches_reference_cli(golden_dir):
     got = b"".join(ix.format_query_line(hd, ix.filter_results(scores[q], 10, 10, 0.5 * case.threshold))
                    for q, (hd, _) in enumerate(recs))
     assert got == open(os.path.join(golden_dir, "dups_out.txt"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["h16z", "h20", "w16", "messy"])
+def test_insert_sequence_matches_reference_index_file(name):
+    """The one-genome path (Miekki.cpp:243-273 behind index_file 518-536): the reference ran every genome file of the
+    case through index_file (tests/golden/make_golden.py single:<case>); its size estimate keeps the active count in a
+    double -- at -h 16 a full sketch gives 65536^2 = 2^32, which insert_sequences' u32 wraps to 0."""
+    case = synth.CASES[name]()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}_single.npz"))
+    ix = orc.OracleMiekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+    for s in case.genome_sequences():
+        ix.insert_sequence(s)
+    assert ix.index_size == int(gold["G"])
+    np.testing.assert_array_equal(ix.sketch_size, gold["sketch_size"])
+    np.testing.assert_array_equal(ix.genome_size, gold["genome_size"])
+    raw = ix.serialize()
+    assert raw.size == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    assert sha(raw.tobytes()) == str(gold["stream_sha_masked"])
+    if name == "h16z":
+        batch = np.load(os.path.join(os.path.dirname(__file__), "golden", "h16z.npz"))
+        assert (batch["genome_size"][:2] == 0).all() and (gold["genome_size"][:2] > 0).all()
