@@ -1,5 +1,7 @@
 #include "fasta_reader.hpp"
 
+#include "fastz.hpp"
+
 #include <fcntl.h>
 #include <sched.h>
 #include <immintrin.h>
@@ -138,8 +140,32 @@ size_t pack_fasta(const char *text, size_t n, uint64_t *codes, uint64_t *except,
     return avx2 ? pack_fasta_t<true>(text, n, codes, except, head, dirty) : pack_fasta_t<false>(text, n, codes, except, head, dirty);
 }
 
+// the members of a gzip file one after the other through fastz (whole buffers: the file is mapped, a member's size stands
+// in its last four bytes); false = something it does not take -- the caller then lets zlib read the file
+static bool gunzip_members(const uint8_t *in, size_t in_size, std::vector<char> &out)
+{
+    if (in_size < 18) return false;
+    uint32_t isize_last;
+    memcpy(&isize_last, in + in_size - 4, 4);                     // right for the usual file of ONE member below 4 GiB
+    out.resize(std::max<size_t>((size_t)isize_last + 64, 1 << 16));
+    size_t at = 0, produced = 0;
+    while (at < in_size) {
+        size_t used = 0, got = 0;
+        int rc = mkhost::gunzip_member(in + at, in_size - at, (uint8_t *)out.data() + produced, out.size() - produced, &used, &got);
+        while (rc == mkhost::FZ_OUT_FULL && out.size() < (64ull << 30)) {     // more members than one, or 4 GiB and more: grow, once more
+            out.resize(out.size() * 2);
+            rc = mkhost::gunzip_member(in + at, in_size - at, (uint8_t *)out.data() + produced, out.size() - produced, &used, &got);
+        }
+        if (rc != mkhost::FZ_OK) return false;
+        at += used; produced += got;
+    }
+    out.resize(produced);
+    return true;
+}
+
 static bool gunzip_all(const char *in, size_t in_size, std::vector<char> &out)
 {
+    if (gunzip_members((const uint8_t *)in, in_size, out)) return true;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return false;

@@ -31,7 +31,7 @@ def dumper(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("rd") / "reader_dump")
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-o", exe,
                     os.path.join(ROOT, "tests", "helpers", "reader_dump.cpp"),
-                    os.path.join(ROOT, "host", "fasta_reader.cpp"), "-lz", "-lpthread"], check=True)
+                    os.path.join(ROOT, "host", "fasta_reader.cpp"), os.path.join(ROOT, "host", "fastz.cpp"), "-lz", "-lpthread"], check=True)
     return exe
 
 
