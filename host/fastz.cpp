@@ -181,11 +181,11 @@ bool build_table(uint32_t *tab, int tb, const uint8_t *lens, uint32_t n, Kind ki
     return true;
 }
 
-// Literals two at a time: index = the next kPairBits bits; an entry holds the one or two literals whose codes those bits
-// spell out completely (bytes in bits 0-15, bits to drop in 16-23, how many in 24-25), or zero when the first symbol is
-// anything else (a length, the end of the block, a code longer than the index).  Fingerprint columns are nothing but
-// literals of 4 - 9 bits, FASTA text mostly literals of 2 - 3: the chain  load -> shift -> mask -> load  that decides a
-// Huffman decoder's pace is walked once per pair.
+// Literals up to three at a time: index = the next kPairBits bits; an entry holds the one to three literals whose codes
+// those bits spell out completely (bytes in bits 0-23, bits to drop in 24-27, how many in 28-29), or zero when the first
+// symbol is anything else (a length, the end of the block, a code longer than the index).  Fingerprint columns are
+// nothing but literals of 4 - 9 bits, FASTA text mostly literals of 2 - 3: the chain  load -> shift -> mask -> load  that
+// decides a Huffman decoder's pace is walked once per two or three of them.
 constexpr int kPairBits = 12;
 
 struct Tables {
@@ -198,16 +198,14 @@ void build_pairs(Tables &t)
 {
     constexpr uint32_t lmask = (1u << kLitBits) - 1;
     for (uint32_t i = 0; i < (1u << kPairBits); ++i) {
-        const uint32_t e1 = t.lit[i & lmask];
-        uint32_t v = 0;
-        if ((e1 & kLitFlag) && !(e1 & kSubFlag)) {               // (a primary entry: at most kLitBits <= kPairBits bits)
-            const uint32_t l1 = e1 & 0xff, e2 = t.lit[(i >> l1) & lmask], l2 = e2 & 0xff;
-            if ((e2 & kLitFlag) && !(e2 & kSubFlag) && l1 + l2 <= (uint32_t)kPairBits)
-                v = (e1 >> 16) | (e2 >> 16) << 8 | (l1 + l2) << 16 | 2u << 24;
-            else
-                v = (e1 >> 16) | l1 << 16 | 1u << 24;
+        uint32_t v = 0, bits = 0, cnt = 0;
+        while (cnt < 3) {
+            const uint32_t e = t.lit[(i >> bits) & lmask], l = e & 0xff;
+            if (!(e & kLitFlag) || (e & kSubFlag) || bits + l > (uint32_t)kPairBits) break;   // (a primary entry: at most kLitBits bits)
+            v |= (e >> 16) << (8 * cnt);
+            bits += l; ++cnt;
         }
-        t.pair[i] = v;
+        t.pair[i] = cnt ? v | bits << 24 | cnt << 28 : 0;
     }
 }
 
@@ -321,18 +319,18 @@ int inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out0, size_t out_cap,
 #define MK_REFILL() do { s.bb |= load64(s.in) << s.bc; s.in += (63 - s.bc) >> 3; s.bc |= 56; } while (0)
 #define MK_LIT_LOOKUP(e) do { e = lit[s.bb & lmask]; if (e & kSubFlag) e = lit[(e >> 16) + ((s.bb >> kLitBits) & ((1u << ((e >> 8) & 15)) - 1))]; } while (0)
             MK_REFILL();
-            // up to four lookups of twelve bits on one refill; two bytes are stored whatever the count (there is room)
+            // up to four lookups of twelve bits on one refill; four bytes are stored whatever the count (there is room)
             uint32_t pr = pair[s.bb & pmask];
             if (pr) {
                 int turns = 3;
                 do {
-                    memcpy(out, &pr, 2);
-                    out += pr >> 24; s.bb >>= (pr >> 16) & 0xff; s.bc -= (pr >> 16) & 0xff;
+                    memcpy(out, &pr, 4);
+                    out += pr >> 28; s.bb >>= (pr >> 24) & 15; s.bc -= (pr >> 24) & 15;
                     pr = pair[s.bb & pmask];
                 } while (pr && --turns);
                 if (pr) {
-                    memcpy(out, &pr, 2);
-                    out += pr >> 24; s.bb >>= (pr >> 16) & 0xff; s.bc -= (pr >> 16) & 0xff;
+                    memcpy(out, &pr, 4);
+                    out += pr >> 28; s.bb >>= (pr >> 24) & 15; s.bc -= (pr >> 24) & 15;
                     continue;
                 }
                 MK_REFILL();

@@ -2,7 +2,13 @@
 
 #include "fastz.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mkhost {
@@ -20,15 +26,39 @@ bool is_mk_header(const uint8_t *h)
            h[13] == 'K' && get_le(h + 14, 2) == 8;
 }
 
+bool pwrite_all(int fd, const uint8_t *p, size_t n, uint64_t at)
+{
+    while (n) {
+        const ssize_t w = pwrite(fd, p, std::min<size_t>(n, 1u << 30), (off_t)at);
+        if (w <= 0) return false;
+        p += w; n -= (size_t)w; at += (uint64_t)w;
+    }
+    return true;
+}
+
+bool pread_all(int fd, uint8_t *p, size_t n, uint64_t at)
+{
+    while (n) {
+        const ssize_t r = pread(fd, p, std::min<size_t>(n, 1u << 30), (off_t)at);
+        if (r <= 0) return false;
+        p += r; n -= (size_t)r; at += (uint64_t)r;
+    }
+    return true;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ writer
 // Three kinds of threads: the caller's (fills blocks), one deflate thread per block in flight, and ONE output thread that
 // takes the finished members in order and writes them -- so that the caller neither deflates nor waits for the file.
+// (One writer on purpose.  Members written by the threads that made them -- each at its own offset, pwrite or a copy into
+// a mapping of the file -- were measured against it on the GPU boxes' memory file system, profiles/r4_tmpfs_io.txt: one
+// thread writes 7.2 GB/s, four 3.8 - 5.6, sixteen 3.7 - 3.9: allocating a file's pages does not scale across threads there,
+// and a 76 GB dump took 13.7 / 22.9 s that way.)
 ParallelGzipWriter::ParallelGzipWriter(const std::string &path, unsigned threads)
-    : f_(fopen(path.c_str(), "wb")), nthreads_(std::max(1u, threads))
+    : fd_(open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644)), nthreads_(std::max(1u, threads))
 {
-    if (f_) out_thread_ = std::thread([this] { output_loop(); });
+    if (fd_ >= 0) out_thread_ = std::thread([this] { output_loop(); });
 }
 
 ParallelGzipWriter::~ParallelGzipWriter()
@@ -47,8 +77,11 @@ void ParallelGzipWriter::output_loop()
             j = std::move(jobs_.front());
             jobs_.pop_front();
         }
-        if (!j->ready) j->th.join();
-        if (j->bad || fwrite(j->out.data(), 1, j->out.size(), f_) != j->out.size()) failed_ = true;
+        j->th.join();
+        const uint8_t *data = j->ready ? j->ready->data() : j->out.get();
+        const size_t n = j->ready ? j->ready->size() : j->out_n;
+        if (j->bad || !pwrite_all(fd_, data, n, file_off_)) failed_ = true; else file_off_ += n;
+        j->out.reset();
         if (j->on_done) j->on_done();
         {
             std::lock_guard<std::mutex> g(m_);
@@ -58,13 +91,13 @@ void ParallelGzipWriter::output_loop()
     }
 }
 
-// hand a job to the output thread (in order); waits while as many blocks are in flight as there are threads
+// hand a job to its thread and to the output thread (in order); waits while as many blocks are in flight as there are threads
 void ParallelGzipWriter::enqueue(std::unique_ptr<Job> j)
 {
     wrote_any_ = true;
-    if (!f_) { failed_ = true; if (j->on_done) j->on_done(); return; }
+    if (fd_ < 0) { failed_ = true; if (j->on_done) j->on_done(); return; }
     Job *raw = j.get();
-    if (!raw->ready) raw->th = std::thread(deflate_block, raw);
+    raw->th = std::thread([raw] { if (!raw->ready) deflate_block(raw); });
     {
         std::unique_lock<std::mutex> g(m_);
         jobs_.push_back(std::move(j));
@@ -89,14 +122,14 @@ bool ParallelGzipWriter::finish()
 {
     if (finished_) return !failed_;
     finished_ = true;
-    if (f_ && (!cur_.empty() || !wrote_any_)) submit();          // an empty stream is still one (empty) member
+    if (fd_ >= 0 && (!cur_.empty() || !wrote_any_)) submit();    // an empty stream is still one (empty) member
     {
         std::lock_guard<std::mutex> g(m_);
         closing_ = true;
     }
     cv_.notify_all();
     if (out_thread_.joinable()) out_thread_.join();
-    if (f_) { if (fclose(f_) != 0) failed_ = true; f_ = nullptr; }
+    if (fd_ >= 0) { if (close(fd_) != 0) failed_ = true; fd_ = -1; }
     return !failed_;
 }
 
@@ -108,21 +141,21 @@ void ParallelGzipWriter::deflate_block(Job *j)
     if (j->strategy == Z_HUFFMAN_ONLY && j->level != 0) {
         // literals and Huffman codes only: fastz's coder (one pass for the histogram, one for the bits), not zlib's deflate
         // with its match finder idling (80 -> 500 MB/s per thread on fingerprint columns, the same stream size)
-        j->out.resize(kHeader + huffman_only_bound(n) + 8);
-        payload = deflate_huffman_only(in, n, j->out.data() + kHeader);
+        j->out.reset(new uint8_t[kHeader + huffman_only_bound(n) + 8]);
+        payload = deflate_huffman_only(in, n, j->out.get() + kHeader);
     } else {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, j->level, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
         const size_t bound = deflateBound(&zs, (uLong)n) + 64;
-        j->out.resize(kHeader + bound + 8);
+        j->out.reset(new uint8_t[kHeader + bound + 8]);
         zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)n;
-        zs.next_out = j->out.data() + kHeader; zs.avail_out = (uInt)bound;
+        zs.next_out = j->out.get() + kHeader; zs.avail_out = (uInt)bound;
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
         payload = zs.total_out;
         deflateEnd(&zs);
     }
-    uint8_t *h = j->out.data();
+    uint8_t *h = j->out.get();
     h[0] = 0x1f; h[1] = 0x8b; h[2] = 8; h[3] = 4;                // FLG.FEXTRA
     put_le(h + 4, 0, 4); h[8] = 4; h[9] = 3;                     // mtime 0, XFL = fastest, OS = unix
     put_le(h + 10, 12, 2); h[12] = 'M'; h[13] = 'K'; put_le(h + 14, 8, 2);
@@ -130,7 +163,7 @@ void ParallelGzipWriter::deflate_block(Job *j)
     uint8_t *t = h + kHeader + payload;
     put_le(t, crc32_fast(0, in, n), 4);
     put_le(t + 4, n & 0xffffffffu, 4);
-    j->out.resize(kHeader + payload + 8);
+    j->out_n = kHeader + payload + 8;
     std::vector<uint8_t>().swap(j->in);
 }
 
@@ -164,12 +197,11 @@ void ParallelGzipWriter::write_zeros(size_t n)
         j.in.assign(kBlock, 0);
         j.level = 1;
         deflate_block(&j);
-        if (j.bad) failed_ = true; else zero_member_.swap(j.out);
+        if (j.bad) failed_ = true; else zero_member_.assign(j.out.get(), j.out.get() + j.out_n);
     }
     while (n >= kBlock && !failed_) {                             // whole blocks: the ready-made member, in order
         std::unique_ptr<Job> j(new Job());
-        j->out = zero_member_;
-        j->ready = true;
+        j->ready = &zero_member_;
         enqueue(std::move(j));
         n -= kBlock;
     }
@@ -179,16 +211,22 @@ void ParallelGzipWriter::write_zeros(size_t n)
 // ------------------------------------------------------------------ reader
 ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads) : nthreads_(std::max(1u, threads))
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) { failed_ = true; return; }
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { failed_ = true; return; }
     uint8_t h[kHeader];
-    const size_t got = fread(h, 1, kHeader, f);
-    if (got == kHeader && is_mk_header(h)) {
-        fseek(f, 0, SEEK_SET);
-        f_ = f;
-        prefetch();
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, h, kHeader, 0) == (ssize_t)kHeader && is_mk_header(h)) {
+        fd_ = fd;
+        file_size_ = (uint64_t)st.st_size;
+        // the members are inflated straight out of a mapping of the file: no read() into a buffer first (MIEKKI_LOAD_IO=pread
+        // reads them into buffers instead; the two were level on the GPU boxes, 20 - 25 GB/s with sixteen threads)
+        const char *e = getenv("MIEKKI_LOAD_IO");
+        if (!e || strcmp(e, "pread")) {
+            void *m = mmap(nullptr, (size_t)file_size_, PROT_READ, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) map_ = (const uint8_t *)m;
+        }
     } else {
-        fclose(f);
+        close(fd);
         gz_ = gzopen(path.c_str(), "rb");                        // gzip of any make, or plain bytes
         if (!gz_) failed_ = true; else gzbuffer(gz_, 1 << 20);
     }
@@ -197,54 +235,77 @@ ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads
 ParallelGzipReader::~ParallelGzipReader()
 {
     for (auto &j : jobs_) if (j->th.joinable()) j->th.join();
-    if (f_) fclose(f_);
+    if (map_) munmap((void *)map_, (size_t)file_size_);
+    if (fd_ >= 0) close(fd_);
     if (gz_) gzclose(gz_);
 }
 
-bool ParallelGzipReader::read_member_header(uint64_t &payload)
+// header and trailer of the member at scan_: a few bytes each, so that a member's size is known before anything is inflated
+bool ParallelGzipReader::next_member(Member &m)
 {
-    uint8_t h[kHeader];
-    const size_t got = fread(h, 1, kHeader, f_);
-    if (got == 0) { eof_ = true; return false; }
-    if (got != kHeader || !is_mk_header(h)) { failed_ = true; return false; }
-    payload = get_le(h + 16, 8);
+    if (have_peek_) { m = peek_; have_peek_ = false; return true; }
+    if (eof_ || failed_) return false;
+    if (scan_ == file_size_) { eof_ = true; return false; }
+    uint8_t h[kHeader], t[8];
+    if (scan_ + kHeader + 8 > file_size_ || !pread_all(fd_, h, kHeader, scan_) || !is_mk_header(h)) { failed_ = true; return false; }
+    m.payload = get_le(h + 16, 8);
+    m.at = scan_ + kHeader;
+    if (m.payload > (1ull << 31) || m.at + m.payload + 8 > file_size_ || !pread_all(fd_, t, 8, m.at + m.payload)) { failed_ = true; return false; }
+    m.crc = (uint32_t)get_le(t, 4);
+    m.isize = (uint32_t)get_le(t + 4, 4);
+    if (m.isize > (1u << 30)) { failed_ = true; return false; }   // (the writer's members hold kBlock bytes at most)
+    scan_ = m.at + m.payload + 8;
     return true;
 }
 
-void ParallelGzipReader::inflate_block(Job *j)
+void ParallelGzipReader::inflate_member(Job *j, int fd, const uint8_t *map)
 {
-    const size_t payload = j->in.size() - 8;
-    const uint32_t crc = (uint32_t)get_le(j->in.data() + payload, 4), isize = (uint32_t)get_le(j->in.data() + payload + 4, 4);
-    j->out.resize((size_t)isize + 1);                            // one spare byte: an empty member still needs room to finish
+    const size_t payload = (size_t)j->m.payload, isize = j->m.isize;
+    std::unique_ptr<uint8_t[]> buf;
+    const uint8_t *src = map ? map + j->m.at : nullptr;
+    if (!src) {
+        buf.reset(new uint8_t[payload + 16]);
+        if (!pread_all(fd, buf.get(), payload, j->m.at)) { j->bad = true; return; }
+        src = buf.get();
+    }
     size_t used = 0, got = 0;
-    if (inflate_raw(j->in.data(), payload, j->out.data(), isize, &used, &got) != FZ_OK || got != isize || used != payload) {
-        // whatever fastz does not take goes to zlib, which then decides what the member is worth
+    if (inflate_raw(src, payload, j->dst, isize, &used, &got) != FZ_OK || got != isize || used != payload) {
+        // whatever fastz does not take goes to zlib, which then decides what the member is worth (one spare byte of room:
+        // an empty member still needs some to finish)
+        std::unique_ptr<uint8_t[]> tmp(new uint8_t[isize + 1]);
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { j->bad = true; return; }
-        zs.next_in = j->in.data(); zs.avail_in = (uInt)payload;
-        zs.next_out = j->out.data(); zs.avail_out = isize + 1;
+        zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)payload;
+        zs.next_out = tmp.get(); zs.avail_out = (uInt)isize + 1;
         const int rc = inflate(&zs, Z_FINISH);
         if (rc != Z_STREAM_END || zs.total_out != isize) j->bad = true;
         inflateEnd(&zs);
+        if (!j->bad && isize) memcpy(j->dst, tmp.get(), isize);
     }
-    j->out.resize(isize);
-    if (!j->bad && crc32_fast(0, j->out.data(), isize) != crc) j->bad = true;
-    std::vector<uint8_t>().swap(j->in);
+    if (!j->bad && crc32_fast(0, j->dst, isize) != j->m.crc) j->bad = true;
 }
 
+void ParallelGzipReader::start(std::unique_ptr<Job> j)
+{
+    Job *raw = j.get();
+    const int fd = fd_;
+    const uint8_t *map = map_;
+    raw->th = std::thread([raw, fd, map] { inflate_member(raw, fd, map); });
+    jobs_.push_back(std::move(j));
+}
+
+// members ahead of the reader, into buffers of their own: for callers that read in small pieces
 void ParallelGzipReader::prefetch()
 {
-    while (!eof_ && !failed_ && jobs_.size() < nthreads_ + 1) {
-        uint64_t payload = 0;
-        if (!read_member_header(payload)) break;
-        if (payload > (1ull << 31)) { failed_ = true; break; }
+    while (!failed_ && jobs_.size() < depth_) {
+        Member m;
+        if (!next_member(m)) break;
         std::unique_ptr<Job> j(new Job());
-        j->in.resize((size_t)payload + 8);
-        if (fread(j->in.data(), 1, j->in.size(), f_) != j->in.size()) { failed_ = true; break; }
-        Job *raw = j.get();
-        j->th = std::thread(inflate_block, raw);
-        jobs_.push_back(std::move(j));
+        j->m = m;
+        j->own.reset(new uint8_t[(size_t)m.isize + 1]);
+        j->dst = j->own.get();
+        start(std::move(j));
     }
 }
 
@@ -262,26 +323,59 @@ size_t ParallelGzipReader::read_some(void *dst, size_t n)
         }
         return done;
     }
-    if (!f_) return 0;
+    if (fd_ < 0) return 0;
     uint8_t *c = (uint8_t *)dst;
-    while (done < n) {
-        if (cur_pos_ == cur_.size()) {
-            if (jobs_.empty()) prefetch();
-            if (jobs_.empty()) break;                              // end of stream
+    while (done < n && !failed_) {
+        if (cur_pos_ < cur_n_) {                                  // what is left of the member being handed out
+            const size_t take = std::min(n - done, cur_n_ - cur_pos_);
+            memcpy(c + done, cur_.get() + cur_pos_, take);
+            cur_pos_ += take; done += take;
+            continue;
+        }
+        if (!jobs_.empty()) {                                     // the next member that went into a buffer of its own
             std::unique_ptr<Job> j = std::move(jobs_.front());
             jobs_.pop_front();
             j->th.join();
             if (j->bad) { failed_ = true; break; }
-            cur_.swap(j->out);
-            cur_pos_ = 0;
+            cur_ = std::move(j->own);
+            cur_n_ = j->m.isize; cur_pos_ = 0;
+            // a caller that keeps coming back for pieces gets more members ahead of it each time
+            depth_ = std::min(nthreads_ + 1, depth_ * 2);
             prefetch();
             continue;
         }
-        const size_t take = std::min(n - done, cur_.size() - cur_pos_);
-        memcpy(c + done, cur_.data() + cur_pos_, take);
-        cur_pos_ += take; done += take;
+        Member m;
+        if (!next_member(m)) break;                               // end of the stream (or an error: failed_)
+        if (m.isize <= n - done) {
+            // whole members that fit what is asked for: inflated where they are wanted, nthreads_ at a time
+            std::deque<std::unique_ptr<Job>> direct;
+            bool more = true;
+            while (more) {
+                std::unique_ptr<Job> j(new Job());
+                j->m = m;
+                j->dst = c + done;
+                done += m.isize;
+                Job *raw = j.get();
+                const int fd = fd_;
+                const uint8_t *map = map_;
+                raw->th = std::thread([raw, fd, map] { inflate_member(raw, fd, map); });
+                direct.push_back(std::move(j));
+                if (direct.size() >= nthreads_) {
+                    direct.front()->th.join();
+                    if (direct.front()->bad) failed_ = true;
+                    direct.pop_front();
+                }
+                more = !failed_ && next_member(m);
+                if (more && m.isize > n - done) { peek_ = m; have_peek_ = true; more = false; }
+            }
+            for (auto &j : direct) { j->th.join(); if (j->bad) failed_ = true; }
+            depth_ = 1;
+            continue;
+        }
+        peek_ = m; have_peek_ = true;                             // larger than what is asked for: through a buffer of its own
+        prefetch();
     }
-    return done;
+    return failed_ ? 0 : done;
 }
 
 }  // namespace mkhost

@@ -1,15 +1,18 @@
 // Parallel gzip for the index file (host only, plain zlib + std::thread).
 //
 // Writer: the byte stream is cut into 32 MiB blocks, each deflated (level 1, like
-// zstr::ofstream, zstr.hpp:82) by its own thread into its own gzip MEMBER, written
-// in order.  Every member's header carries an FEXTRA subfield "MK" with the
+// zstr::ofstream, zstr.hpp:82) by its own thread into its own gzip MEMBER, written in order by one
+// output thread.  Every member's header carries an FEXTRA subfield "MK" with the
 // compressed payload size, the way BGZF does, so that a reader can find member
 // boundaries without inflating.  Any gzip reader -- zlib's gzread, the reference's
 // zstr::ifstream (which restarts its inflator at each member end, zstr.hpp:186-190),
 // gunzip -- reads such a file as one stream.
 //
-// Reader: members with the "MK" subfield are inflated concurrently and delivered in
-// order; anything else (the reference's own dumps, plain files) goes through gzread.
+// Reader: members with the "MK" subfield are read (pread) and inflated concurrently,
+// each by its own thread -- straight into the caller's buffer when a request covers
+// whole members (the index loader asks for a few hundred megabytes of columns at a
+// time, into page-locked memory), through a buffer of their own otherwise; anything
+// else (the reference's own dumps, plain files) goes through gzread.
 #pragma once
 #include <zlib.h>
 
@@ -30,7 +33,7 @@ class ParallelGzipWriter {
 public:
     ParallelGzipWriter(const std::string &path, unsigned threads);
     ~ParallelGzipWriter();
-    bool ok() const { return f_ && !failed_; }
+    bool ok() const { return fd_ >= 0 && !failed_; }
     void write(const void *p, size_t n);
     // n zero bytes.  Whole blocks of zeros -- the reference's index always carries its full 2^(b-3)-byte Bloom filter,
     // of which a 2k-bit k-mer reaches only the first part: 960 MiB of zeros at k = 31, b = 33 -- are not deflated again
@@ -51,18 +54,20 @@ public:
     static constexpr size_t kBlock = 32u << 20;
 private:
     struct Job {
-        std::vector<uint8_t> in, out;
+        std::vector<uint8_t> in;
+        std::unique_ptr<uint8_t[]> out; size_t out_n = 0;         // the finished member
         const uint8_t *ext = nullptr; size_t ext_n = 0;          // write_block: the caller's bytes instead of `in`
+        const std::vector<uint8_t> *ready = nullptr;             // a member made earlier (a run of zeros): nothing to deflate
         std::function<void()> on_done;
         std::thread th;
-        bool bad = false, ready = false;                         // ready: `out` is final already (a run of zeros)
+        bool bad = false;
         int strategy = 0, level = 1;
     };
     static void deflate_block(Job *j);
     void submit();
     void enqueue(std::unique_ptr<Job> j);
     void output_loop();
-    FILE *f_;
+    int fd_ = -1;
     unsigned nthreads_;
     std::vector<uint8_t> cur_;
     std::deque<std::unique_ptr<Job>> jobs_;                      // handed to the output thread, in stream order
@@ -74,6 +79,7 @@ private:
     bool failed_ = false, wrote_any_ = false;
     int strategy_ = 0;                   // Z_DEFAULT_STRATEGY
     int level_ = 1;
+    uint64_t file_off_ = 0;              // where the output thread writes next
     std::vector<uint8_t> zero_member_;   // the gzip member of kBlock zero bytes, made on first use
 };
 
@@ -81,23 +87,37 @@ class ParallelGzipReader {
 public:
     ParallelGzipReader(const std::string &path, unsigned threads);
     ~ParallelGzipReader();
-    bool ok() const { return (f_ || gz_) && !failed_; }
+    bool ok() const { return (fd_ >= 0 || gz_) && !failed_; }
     // up to n bytes; 0 at the end of the stream (or on error: check ok())
     size_t read_some(void *dst, size_t n);
     // exactly n bytes or false (truncated / corrupt)
     bool read(void *dst, size_t n) { return read_some(dst, n) == n; }
-    bool parallel() const { return f_ != nullptr; }
+    bool parallel() const { return fd_ >= 0; }
+    unsigned threads() const { return nthreads_; }
 private:
-    struct Job { std::vector<uint8_t> in, out; uint32_t crc = 0, isize = 0; std::thread th; bool bad = false; };
-    static void inflate_block(Job *j);
-    bool read_member_header(uint64_t &payload);   // positions f_ at the payload; false at clean EOF or on error
+    struct Member { uint64_t at = 0, payload = 0; uint32_t crc = 0, isize = 0; };   // `at`: where the deflate stream starts
+    struct Job {
+        Member m;
+        uint8_t *dst = nullptr;                                  // the caller's memory, or `own`
+        std::unique_ptr<uint8_t[]> own;
+        std::thread th;
+        bool bad = false;
+    };
+    static void inflate_member(Job *j, int fd, const uint8_t *map);
+    bool next_member(Member &m);         // the member at scan_; false at the clean end of the file or on error
     void prefetch();
-    FILE *f_ = nullptr;                  // "MK" member mode
+    void start(std::unique_ptr<Job> j);
+    int fd_ = -1;                        // "MK" member mode
+    const uint8_t *map_ = nullptr;       // the whole file, mapped (members are inflated from where they lie)
     gzFile gz_ = nullptr;                // generic mode
     unsigned nthreads_;
-    std::deque<std::unique_ptr<Job>> jobs_;
-    std::vector<uint8_t> cur_;
-    size_t cur_pos_ = 0;
+    uint64_t scan_ = 0, file_size_ = 0;
+    bool have_peek_ = false;
+    Member peek_;
+    std::deque<std::unique_ptr<Job>> jobs_;                      // members on their way into buffers of their own, in order
+    std::unique_ptr<uint8_t[]> cur_;     // the member being handed out piecewise
+    size_t cur_n_ = 0, cur_pos_ = 0;
+    unsigned depth_ = 1;                 // how far small reads look ahead: grows while they keep coming
     bool eof_ = false, failed_ = false;
 };
 

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -148,6 +149,11 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
                unsigned threads)
 {
     out.clear();
+    // MIEKKI_IO_TRACE=1: where a load spends its time (stderr)
+    const bool trace = getenv("MIEKKI_IO_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+    const auto t_begin = now();
     ParallelGzipReader f(path, threads);
     if (!f.ok()) { err = "cannot open " + path; return -1; }
     Header hd;
@@ -178,45 +184,78 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
     }
     const uint32_t P = ok ? 1u << hd.h : 0;
     const uint64_t row = (uint64_t)G * W;
-    const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, row ? kChunk / row : P));
-    std::vector<uint8_t> buf, part;
-    // (the chunk the columns pass through is page-locked when there is a context to ask: its upload is then a DMA)
-    void *pinned = nullptr;
+    // The columns pass through TWO page-locked chunks of as many whole writer blocks as there are threads to inflate them
+    // (the reader inflates a member straight into the chunk when the request covers it -- and a chunk cut at the writer's
+    // block size covers whole members only): while the members of one chunk are read and inflated, the chunk before it
+    // goes to the device(s) on a thread of its own.
+    const uint64_t blk_rows = row && row <= ParallelGzipWriter::kBlock ? ParallelGzipWriter::kBlock / row : 0;
+    const uint64_t want_rows = blk_rows ? blk_rows * std::max(2u, f.parallel() ? f.threads() : 2u) : (row ? std::max<uint64_t>(1, kChunk / row) : P);
+    const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, want_rows));
     const size_t chunk_bytes = (size_t)std::max<uint64_t>(rows * row, 1);
-    if (ok && !out.empty() && mk_host_alloc(out[0], chunk_bytes, &pinned) != MK_OK) pinned = nullptr;
-    if (!pinned) buf.resize(chunk_bytes);
-    uint8_t *const cbuf = pinned ? (uint8_t *)pinned : buf.data();
-    for (uint32_t pb = 0; ok && pb < P; pb += rows) {
-        const uint32_t pe = std::min(P, pb + rows);
-        ok = f.read(cbuf, (size_t)(pe - pb) * row);
-        if (!ok) { err = "truncated index columns"; break; }
-        if (D == 1) {
-            if (G && mk_index_import_columns(out[0], pb, pe, cbuf) != MK_OK) { err = mk_last_error(); ok = false; }
-            continue;
-        }
-        for (size_t d = 0; ok && d < D; ++d) {
-            const uint64_t prow = (uint64_t)(at[d + 1] - at[d]) * W;
-            if (!prow) continue;
-            part.resize((size_t)(pe - pb) * prow);
-            for (uint32_t r = 0; r < pe - pb; ++r)
-                memcpy(part.data() + (uint64_t)r * prow, cbuf + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
-            if (mk_index_import_columns(out[d], pb, pe, part.data()) != MK_OK) { err = mk_last_error(); ok = false; }
-        }
+    void *pinned[2] = {nullptr, nullptr};
+    std::vector<uint8_t> pageable[2];
+    uint8_t *cbuf[2];
+    for (int k = 0; k < 2; ++k) {
+        if (ok && !out.empty() && mk_host_alloc(out[0], chunk_bytes, &pinned[k]) != MK_OK) pinned[k] = nullptr;
+        if (!pinned[k]) pageable[k].resize(chunk_bytes);
+        cbuf[k] = pinned[k] ? (uint8_t *)pinned[k] : pageable[k].data();
     }
-    if (pinned) mk_host_free(out[0], pinned);
+    double t_read = 0, t_wait = 0;
+    if (trace) fprintf(stderr, "[load] contexts, matrix and page-locked chunks ready after %.2f s\n", since(t_begin));
+    const auto t_cols = now();
+    std::thread importer;
+    bool import_ok = true;
+    std::string import_err;
+    int k = 0;
+    for (uint32_t pb = 0; ok && pb < P; pb += rows, k ^= 1) {
+        const uint32_t pe = std::min(P, pb + rows);
+        uint8_t *const b = cbuf[k];
+        auto t0 = now();
+        ok = f.read(b, (size_t)(pe - pb) * row);
+        t_read += since(t0);
+        t0 = now();
+        if (importer.joinable()) importer.join();                 // the chunk before this one is on the device(s)
+        t_wait += since(t0);
+        if (!ok) { err = "truncated index columns"; break; }
+        if (!import_ok) break;
+        importer = std::thread([&, b, pb, pe] {
+            if (D == 1) {
+                if (G && mk_index_import_columns(out[0], pb, pe, b) != MK_OK) { import_err = mk_last_error(); import_ok = false; }
+                return;
+            }
+            std::vector<uint8_t> part;
+            for (size_t d = 0; import_ok && d < D; ++d) {
+                const uint64_t prow = (uint64_t)(at[d + 1] - at[d]) * W;
+                if (!prow) continue;
+                part.resize((size_t)(pe - pb) * prow);
+                for (uint32_t r = 0; r < pe - pb; ++r)
+                    memcpy(part.data() + (uint64_t)r * prow, b + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
+                if (mk_index_import_columns(out[d], pb, pe, part.data()) != MK_OK) { import_err = mk_last_error(); import_ok = false; }
+            }
+        });
+    }
+    if (importer.joinable()) importer.join();
+    if (trace)
+        fprintf(stderr, "[load] columns %.2f s (chunks of %.0f MiB: read + inflate %.2f s, waiting for the upload of the chunk before %.2f s)\n",
+                since(t_cols), chunk_bytes / 1048576.0, t_read, t_wait);
+    if (ok && !import_ok) { err = import_err; ok = false; }
+    for (int q = 0; q < 2; ++q) if (pinned[q]) mk_host_free(out[0], pinned[q]);
+    std::vector<uint8_t> buf;
     std::vector<uint64_t> gs(G);
     std::vector<uint32_t> ss(G);
     if (ok && !(ok = f.read(gs.data(), (size_t)G * 8))) err = "truncated genome sizes";
     const uint64_t nb = ok ? hd.bloom_bits / 8 : 0;
-    buf.resize((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(nb, 1)));
-    for (uint64_t o = 0; ok && o < nb; o += kChunk) {
-        const uint64_t e = std::min(nb, o + kChunk);
+    const uint64_t bchunk = std::max<uint64_t>(kChunk, (uint64_t)ParallelGzipWriter::kBlock * std::min(8u, f.threads()));
+    buf.resize((size_t)std::min<uint64_t>(bchunk, std::max<uint64_t>(nb, 1)));
+    for (uint64_t o = 0; ok && o < nb; o += bchunk) {
+        const uint64_t e = std::min(nb, o + bchunk);
         ok = f.read(buf.data(), (size_t)(e - o));
         if (!ok) { err = "truncated Bloom filter"; break; }
         for (size_t d = 0; ok && d < D; ++d)                        // the one global filter, on every shard
             if (mk_index_import_bloom(out[d], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
     }
     if (ok && !(ok = f.read(ss.data(), (size_t)G * 4))) err = "truncated sketch sizes";
+    if (trace) fprintf(stderr, "[load] sizes and Bloom filter read after %.2f s\n", since(t_begin));
     for (size_t d = 0; ok && d < D; ++d)
         if (at[d + 1] > at[d] && mk_index_import_sizes(out[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) {
             err = mk_last_error();
@@ -227,6 +266,7 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
         out.clear();
         return -1;
     }
+    if (trace) fprintf(stderr, "[load] done after %.2f s\n", since(t_begin));
     return 0;
 }
 

@@ -507,30 +507,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     // The run's flagged items -- the first (fend - first) of it -- get their places in the list from ONE atomic per
                     // run, by the run's first lane (a young filter flags every item, 18,700 per workgroup: one atomic WITH return
                     // each on one LDS word cost 0.15 ms of LDS time per CU and batch; the meta word already says how many there are)
+                    // (Once the filter has filled up no run of a wave-load has a flagged item -- the usual case of a large build: the
+                    // whole wave then takes the form of the item loop without slots, bounds against `fend` and the list's store.)
+                    const bool noting = __ballot(fend != first) != 0ull;                // wave-uniform
                     uint32_t nbase = 0;
-                    {
+                    if (noting) {
                         const uint32_t nflag = fend - first;                        // (0 for a lane without a run)
                         if (nflag && lane % lpr == 0) nbase = atomicAdd(&n_noted, nflag);
                         nbase = (uint32_t)__shfl((int)nbase, (int)(lane - lane % lpr));
                     }
                     // slot: the item's place in the list of flagged items, or beyond it for an item that is not flagged
-                    auto fold = [&](uint32_t w, item_t item, uint32_t lob, uint32_t slot) {
+                    auto fold = [&](auto with_list, uint32_t w, item_t item, uint32_t lob, uint32_t slot) {
                         const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
-                        const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
                         key_t key;
                         if (KEY32) key = (key_t)((item & 0xff000fffu) | (w << 12));                // fingerprint << 24 | position
-                        else key = ((key_t)(item >> (W == 1 ? 24 : 16)) << kKeyPos) | (key_t)((uint64_t)w * kSeg + pos);
+                        else {
+                            const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
+                            key = ((key_t)(item >> (W == 1 ? 24 : 16)) << kKeyPos) | (key_t)((uint64_t)w * kSeg + pos);
+                        }
                         // (a look before the atomic: repeat-rich sequence sends the same k-mer -- same partition, same fingerprint,
                         // a later position -- again and again, and 64 lanes of an atomic minimum on ONE entry cost 620 cycles where
                         // a read of one entry is a broadcast, profiles/r3_ubench.txt; a key that cannot win is dropped here.
                         // profiles/r4_repeat_rich.txt: 20 % of a genome in tandem repeats tripled this kernel's time without it)
                         if (key < table[part]) atomicMin(&table[part], key);
-                        if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
+                        if constexpr (decltype(with_list)::value) {
+                            const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
+                            if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
+                        }
                     };
+                    if (noting) {
 #pragma unroll
-                    for (uint32_t e = 0; e < kIPL; ++e) {
-                        const uint32_t at = a0 + j0 + e;
-                        if (at >= first && at < end) fold(w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend ? nbase + (at - first) : ~0u);
+                        for (uint32_t e = 0; e < kIPL; ++e) {
+                            const uint32_t at = a0 + j0 + e;
+                            if (at >= first && at < end)
+                                fold(std::true_type{}, w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend ? nbase + (at - first) : ~0u);
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t e = 0; e < kIPL; ++e) {
+                            const uint32_t at = a0 + j0 + e;
+                            if (at >= first && at < end) fold(std::false_type{}, w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, ~0u);
+                        }
                     }
                     // Runs longer than their lanes reach.  Rare on ordinary sequence (the lanes cover mean + 4 sigma), the rule on
                     // repeat-rich sequence: a tandem repeat sends a whole stretch of k-mers into ONE partition, i.e. hundreds or
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                             const uint32_t xl = W == 2 ? *reinterpret_cast<const uint32_t *>(low + at) : 0u;
 #pragma unroll
                             for (uint32_t e = 0; e < kIPL; ++e)
-                                if (j + e < t_end) fold(t_w, x[e], (xl >> (8 * e)) & 0xffu, j + e < t_fend ? t_nbase + (j + e - t_first) : ~0u);
+                                if (j + e < t_end) fold(std::true_type{}, t_w, x[e], (xl >> (8 * e)) & 0xffu, j + e < t_fend ? t_nbase + (j + e - t_first) : ~0u);
                         }
                     }
                 }

@@ -22,8 +22,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "Miekki")
 MKGZ = os.path.join(ROOT, "miekki_amd", "mkgz")
 
 
-def mkgz(args, data=None):
-    r = subprocess.run([MKGZ, *args], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+def mkgz(args, data=None, env=None):
+    r = subprocess.run([MKGZ, *args], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode(errors="replace")
     return r.stdout
 
@@ -45,6 +45,17 @@ def test_parallel_gzip_round_trips_and_is_plain_gzip(tmp_path, size):
     open(other, "wb").write(data)
     if size >= 2 and data[:2] != b"\x1f\x8b":
         assert mkgz(["d", other, "4"]) == data
+
+
+@pytest.mark.parametrize("io", ["mmap", "pread"])
+def test_reader_io_paths(tmp_path, io):
+    """The reader inflates members out of a mapping of the file, or out of buffers it preads (MIEKKI_LOAD_IO): same bytes."""
+    rng = np.random.default_rng(11)
+    data = (rng.integers(0, 50, (70 << 20) + 4321, dtype=np.uint8) + 100).tobytes()
+    path = str(tmp_path / "x.gz")
+    mkgz(["c", path, "6"], data)
+    assert gzip.decompress(open(path, "rb").read()) == data
+    assert mkgz(["d", path, "5"], env=dict(os.environ, MIEKKI_LOAD_IO=io)) == data
 
 
 @pytest.mark.parametrize("stored", [False, True])
