@@ -82,6 +82,36 @@ uint32_t crc32_fast(uint32_t crc, const void *p, size_t n)
     return crc;
 }
 
+// Polynomials over GF(2) modulo the CRC's, bit-reflected (x^0 is the top bit): a * b, and x^n by squaring.
+static uint32_t gf2_mul(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if (!(a & (m - 1))) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+static uint32_t gf2_x_pow(uint64_t n)                                  // x^n
+{
+    static const struct Pow { uint32_t v[64]; Pow() { v[0] = 1u << 30; for (int k = 1; k < 64; ++k) v[k] = gf2_mul(v[k - 1], v[k - 1]); } } pw;   // x^(2^k)
+    uint32_t r = 1u << 31;
+    for (int k = 0; n; ++k, n >>= 1) if (n & 1) r = gf2_mul(r, pw.v[k]);
+    return r;
+}
+
+uint32_t crc32_shift(uint32_t raw, uint64_t n_bytes) { return raw ? gf2_mul(gf2_x_pow(n_bytes * 8), raw) : 0; }
+uint32_t crc32_shift_factor(uint64_t n_bytes) { return gf2_x_pow(n_bytes * 8); }
+uint32_t crc32_shift_by(uint32_t factor, uint32_t raw) { return raw ? gf2_mul(factor, raw) : 0; }
+uint32_t crc32_from_raw(uint32_t raw, uint64_t n_bytes) { return ~(raw ^ crc32_shift(0xffffffffu, n_bytes)); }
+uint32_t crc32_raw(const void *p, size_t n)
+{
+    // zlib's value with its start value and complement taken out again
+    return ~crc32_fast(0, p, n) ^ crc32_shift(0xffffffffu, n);
+}
+
 // ------------------------------------------------------------------------------------------------ inflate
 namespace {
 
@@ -255,6 +285,9 @@ int inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out0, size_t out_cap,
     s.in = in; s.in_end = in + in_len;
     uint8_t *out = out0, *const out_end = out0 + out_cap;
     Tables dyn;
+    uint8_t dyn_lens[320];
+    uint32_t dyn_hlit = 0, dyn_hdist = 0;
+    bool have_dyn = false;
     bool final_block = false;
     while (!final_block) {
         s.fill();
@@ -305,10 +338,16 @@ int inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out0, size_t out_cap,
             }
             if (s.overran()) return FZ_IN_SHORT;
             if (!lens[256]) return FZ_BAD;                        // a block must be able to end
-            uint8_t dl[32];
-            memcpy(dl, lens + hlit, hdist);
-            if (!build_table(dyn.lit, kLitBits, lens, hlit, kLitLen) || !build_table(dyn.dist, kDistBits, dl, hdist, kDist)) return FZ_BAD;
-            build_pairs(dyn);
+            // (the same code as the block before -- deflate_huffman_only repeats one code over 64 short blocks: its tables stand)
+            if (!(have_dyn && hlit == dyn_hlit && hdist == dyn_hdist && !memcmp(lens, dyn_lens, hlit + hdist))) {
+                uint8_t dl[32];
+                memcpy(dl, lens + hlit, hdist);
+                have_dyn = false;
+                if (!build_table(dyn.lit, kLitBits, lens, hlit, kLitLen) || !build_table(dyn.dist, kDistBits, dl, hdist, kDist)) return FZ_BAD;
+                build_pairs(dyn);
+                memcpy(dyn_lens, lens, hlit + hdist);
+                dyn_hlit = hlit; dyn_hdist = hdist; have_dyn = true;
+            }
             lit = dyn.lit; dist = dyn.dist; pair = dyn.pair;
         }
         // ---- the block's symbols
@@ -439,7 +478,7 @@ int gunzip_member(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap
 // ------------------------------------------------------------------------------------------------ Huffman-only deflate
 namespace {
 
-constexpr size_t kHuffBlock = 256u << 10;          // bytes per block = per Huffman code
+constexpr size_t kHuffSuper = HuffIndex::kSuper, kHuffSub = HuffIndex::kSub;   // bytes per Huffman code, bytes per block
 
 // Code lengths of at most `limit` bits for the symbols with freq > 0 (at least two of them), optimal when the plain
 // Huffman code is not deeper than the limit and made to fit otherwise: the deepest leaves move up to the limit and, until
@@ -511,17 +550,24 @@ struct BitOut {
 
 size_t huffman_only_bound(size_t n)
 {
-    // a block never takes more than its stored form (5 bytes per 65,535 + the bytes) plus the partial byte before it
-    return n + (n / 65535 + n / kHuffBlock + 2) * 6 + 24;
+    // a stretch of kHuffSuper bytes never takes more than its stored form (5 bytes per 65,535 + the bytes) plus the partial
+    // byte before it
+    return n + (n / 65535 + n / kHuffSuper + 2) * 6 + 24;
 }
 
-size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
+// One Huffman code per kHuffSuper bytes (a histogram, code lengths of at most 12 bits), and under it one deflate block per
+// kHuffSub bytes, every one with the code's header again (~1 % of the stream): blocks that an inflater reads one after the
+// other like any others -- and that a decoder which is TOLD where each block's first symbol lies (HuffIndex: the index
+// file keeps it in the members' extra fields) can take all at once, one lane per block (huff.hip on the GPU).  Twelve bits
+// so that such a decoder's table is one 4,096-entry lookup without a second level.
+size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out, HuffIndex *index)
 {
     BitOut o;
     o.p = out;
+    if (index) { index->lens.clear(); index->sym_bit.clear(); index->all_coded = true; }
     if (!n) { o.put(1, 1); o.put(1, 2); o.put(0, 7); o.finish(); return (size_t)(o.p - out); }   // a final fixed-code block: end-of-block
     for (size_t at = 0; at < n;) {
-        const size_t take = std::min(kHuffBlock, n - at);
+        const size_t take = std::min(kHuffSuper, n - at);
         const uint8_t *b = in + at;
         const bool last = at + take == n;
         // histogram in four parts: runs of one value do not wait on one counter
@@ -530,11 +576,12 @@ size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
         size_t i = 0;
         for (; i + 4 <= take; i += 4) { ++h[0][b[i]]; ++h[1][b[i + 1]]; ++h[2][b[i + 2]]; ++h[3][b[i + 3]]; }
         for (; i < take; ++i) ++h[0][b[i]];
+        const uint32_t nsub = (uint32_t)((take + kHuffSub - 1) / kHuffSub);
         uint32_t freq[257];
         for (int v = 0; v < 256; ++v) freq[v] = h[0][v] + h[1][v] + h[2][v] + h[3][v];
-        freq[256] = 1;                                            // end-of-block
+        freq[256] = nsub;                                         // end-of-block, once per block
         uint8_t lens[257 + 2];
-        code_lengths(freq, 257, 15, lens);
+        code_lengths(freq, 257, HuffIndex::kMaxLen, lens);
         lens[257] = lens[258] = 1;                                // two distance codes of one bit: a complete code nobody uses (zlib writes the same)
         // the lengths, run-length coded with the code-length alphabet (16: repeat the last 3-6 times, 17 / 18: 3-10 / 11-138 zeros)
         uint8_t rl_sym[259 + 8];
@@ -565,8 +612,9 @@ size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
         codes_of(lens, 257, code);
         uint32_t hclen = 19;
         while (hclen > 4 && !plen[kPreOrder[hclen - 1]]) --hclen;
-        uint64_t bits = 3 + 5 + 5 + 4 + 3 * hclen;
-        for (uint32_t k = 0; k < nrl; ++k) bits += plen[rl_sym[k]] + (rl_sym[k] == 16 ? 2 : rl_sym[k] == 17 ? 3 : rl_sym[k] == 18 ? 7 : 0);
+        uint64_t hbits = 3 + 5 + 5 + 4 + 3 * hclen;
+        for (uint32_t k = 0; k < nrl; ++k) hbits += plen[rl_sym[k]] + (rl_sym[k] == 16 ? 2 : rl_sym[k] == 17 ? 3 : rl_sym[k] == 18 ? 7 : 0);
+        uint64_t bits = hbits * nsub;
         for (int v = 0; v < 257; ++v) bits += (uint64_t)freq[v] * lens[v];
         if ((bits + 7) / 8 >= take + 5 * ((take + 65534) / 65535)) {
             // stored blocks of up to 65,535 bytes each
@@ -579,31 +627,39 @@ size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
                 o.p += 4 + m;
                 d += m;
             }
+            if (index) index->all_coded = false;
             at += take;
             continue;
         }
-        o.put(last ? 1 : 0, 1); o.put(2, 2);
-        o.put(257 - 257, 5); o.put(2 - 1, 5); o.put(hclen - 4, 4);
-        o.flush();
-        for (uint32_t k = 0; k < hclen; ++k) { o.put(plen[kPreOrder[k]], 3); if ((k & 7) == 7) o.flush(); }
-        o.flush();
-        for (uint32_t k = 0; k < nrl; ++k) {
-            o.put(pcode[rl_sym[k]], plen[rl_sym[k]]);
-            if (rl_sym[k] >= 16) o.put(rl_extra[k], rl_sym[k] == 16 ? 2 : rl_sym[k] == 17 ? 3 : 7);
-            o.flush();
-        }
-        // the bytes: code and length of a value in one word, three values per flush (3 x 15 bits + the 7 left over < 64)
+        if (index) index->lens.insert(index->lens.end(), lens, lens + 257);
+        // code and length of a value in one word
         uint32_t cl[256];
         for (int v = 0; v < 256; ++v) cl[v] = (uint32_t)code[v] | (uint32_t)lens[v] << 16;
-        i = 0;
-        for (; i + 3 <= take; i += 3) {
-            const uint32_t a = cl[b[i]], c = cl[b[i + 1]], d = cl[b[i + 2]];
-            o.put(a & 0xffff, a >> 16); o.put(c & 0xffff, c >> 16); o.put(d & 0xffff, d >> 16);
+        for (uint32_t sb = 0; sb < nsub; ++sb) {
+            const uint8_t *q = b + (size_t)sb * kHuffSub;
+            const size_t m = std::min(kHuffSub, take - (size_t)sb * kHuffSub);
+            o.put(last && sb + 1 == nsub ? 1 : 0, 1); o.put(2, 2);
+            o.put(257 - 257, 5); o.put(2 - 1, 5); o.put(hclen - 4, 4);
+            o.flush();
+            for (uint32_t k = 0; k < hclen; ++k) { o.put(plen[kPreOrder[k]], 3); if ((k & 7) == 7) o.flush(); }
+            o.flush();
+            for (uint32_t k = 0; k < nrl; ++k) {
+                o.put(pcode[rl_sym[k]], plen[rl_sym[k]]);
+                if (rl_sym[k] >= 16) o.put(rl_extra[k], rl_sym[k] == 16 ? 2 : rl_sym[k] == 17 ? 3 : 7);
+                o.flush();
+            }
+            if (index) index->sym_bit.push_back((uint64_t)(o.p - out) * 8 + o.bc);
+            // the bytes, four values per flush (4 x 12 bits + the 7 left over < 64)
+            i = 0;
+            for (; i + 4 <= m; i += 4) {
+                const uint32_t a = cl[q[i]], c = cl[q[i + 1]], d = cl[q[i + 2]], e = cl[q[i + 3]];
+                o.put(a & 0xffff, a >> 16); o.put(c & 0xffff, c >> 16); o.put(d & 0xffff, d >> 16); o.put(e & 0xffff, e >> 16);
+                o.flush();
+            }
+            for (; i < m; ++i) { const uint32_t a = cl[q[i]]; o.put(a & 0xffff, a >> 16); o.flush(); }
+            o.put(code[256], lens[256]);
             o.flush();
         }
-        for (; i < take; ++i) { const uint32_t a = cl[b[i]]; o.put(a & 0xffff, a >> 16); o.flush(); }
-        o.put(code[256], lens[256]);
-        o.flush();
         at += take;
     }
     o.finish();

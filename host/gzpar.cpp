@@ -15,14 +15,15 @@ namespace mkhost {
 
 namespace {
 
-constexpr size_t kHeader = 24;     // fixed gzip header (10) + XLEN (2) + "MK" subfield (4 + 8)
+constexpr size_t kHeader = 24;     // fixed gzip header (10) + XLEN (2) + "MK" subfield (4 + 8); an "MH" subfield may follow
+constexpr size_t kMaxHeader = kHeader + 65535;
 
 void put_le(uint8_t *p, uint64_t v, int n) { for (int i = 0; i < n; ++i) p[i] = (uint8_t)(v >> (8 * i)); }
 uint64_t get_le(const uint8_t *p, int n) { uint64_t v = 0; for (int i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i); return v; }
 
 bool is_mk_header(const uint8_t *h)
 {
-    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && get_le(h + 10, 2) == 12 && h[12] == 'M' &&
+    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && get_le(h + 10, 2) >= 12 && h[12] == 'M' &&
            h[13] == 'K' && get_le(h + 14, 2) == 8;
 }
 
@@ -78,7 +79,7 @@ void ParallelGzipWriter::output_loop()
             jobs_.pop_front();
         }
         j->th.join();
-        const uint8_t *data = j->ready ? j->ready->data() : j->out.get();
+        const uint8_t *data = j->ready ? j->ready->data() : j->out.get() + j->out_at;
         const size_t n = j->ready ? j->ready->size() : j->out_n;
         if (j->bad || !pwrite_all(fd_, data, n, file_off_)) failed_ = true; else file_off_ += n;
         j->out.reset();
@@ -138,32 +139,46 @@ void ParallelGzipWriter::deflate_block(Job *j)
     const uint8_t *in = j->ext ? j->ext : j->in.data();
     const size_t n = j->ext ? j->ext_n : j->in.size();
     uint64_t payload = 0;
+    // the member is built behind room for the largest header; the header is then written right in front of the stream
+    std::vector<uint8_t> mh;                                     // the "MH" subfield's data, when there is one
     if (j->strategy == Z_HUFFMAN_ONLY && j->level != 0) {
         // literals and Huffman codes only: fastz's coder (one pass for the histogram, one for the bits), not zlib's deflate
         // with its match finder idling (80 -> 500 MB/s per thread on fingerprint columns, the same stream size)
-        j->out.reset(new uint8_t[kHeader + huffman_only_bound(n) + 8]);
-        payload = deflate_huffman_only(in, n, j->out.get() + kHeader);
+        j->out.reset(new uint8_t[kMaxHeader + huffman_only_bound(n) + 8]);
+        HuffIndex hx;
+        payload = deflate_huffman_only(in, n, j->out.get() + kMaxHeader, &hx);
+        const size_t want = 8 + hx.lens.size() + 4 * hx.sym_bit.size();
+        if (hx.all_coded && n && want + 4 + 12 <= 65535 && payload < (1ull << 29)) {
+            mh.resize(want);
+            put_le(mh.data(), hx.lens.size() / 257, 4);
+            put_le(mh.data() + 4, hx.sym_bit.size(), 4);
+            memcpy(mh.data() + 8, hx.lens.data(), hx.lens.size());
+            for (size_t i = 0; i < hx.sym_bit.size(); ++i) put_le(mh.data() + 8 + hx.lens.size() + 4 * i, hx.sym_bit[i], 4);
+        }
     } else {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, j->level, Z_DEFLATED, -15, 8, j->strategy) != Z_OK) { j->bad = true; return; }   // raw deflate
         const size_t bound = deflateBound(&zs, (uLong)n) + 64;
-        j->out.reset(new uint8_t[kHeader + bound + 8]);
+        j->out.reset(new uint8_t[kMaxHeader + bound + 8]);
         zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)n;
-        zs.next_out = j->out.get() + kHeader; zs.avail_out = (uInt)bound;
+        zs.next_out = j->out.get() + kMaxHeader; zs.avail_out = (uInt)bound;
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) j->bad = true;
         payload = zs.total_out;
         deflateEnd(&zs);
     }
-    uint8_t *h = j->out.get();
+    const size_t xlen = 12 + (mh.empty() ? 0 : 4 + mh.size()), hsize = 12 + xlen;
+    uint8_t *h = j->out.get() + kMaxHeader - hsize;
     h[0] = 0x1f; h[1] = 0x8b; h[2] = 8; h[3] = 4;                // FLG.FEXTRA
     put_le(h + 4, 0, 4); h[8] = 4; h[9] = 3;                     // mtime 0, XFL = fastest, OS = unix
-    put_le(h + 10, 12, 2); h[12] = 'M'; h[13] = 'K'; put_le(h + 14, 8, 2);
+    put_le(h + 10, xlen, 2); h[12] = 'M'; h[13] = 'K'; put_le(h + 14, 8, 2);
     put_le(h + 16, payload, 8);
-    uint8_t *t = h + kHeader + payload;
+    if (!mh.empty()) { h[24] = 'M'; h[25] = 'H'; put_le(h + 26, mh.size(), 2); memcpy(h + 28, mh.data(), mh.size()); }
+    uint8_t *t = j->out.get() + kMaxHeader + payload;
     put_le(t, crc32_fast(0, in, n), 4);
     put_le(t + 4, n & 0xffffffffu, 4);
-    j->out_n = kHeader + payload + 8;
+    j->out_at = kMaxHeader - hsize;
+    j->out_n = hsize + payload + 8;
     std::vector<uint8_t>().swap(j->in);
 }
 
@@ -197,7 +212,7 @@ void ParallelGzipWriter::write_zeros(size_t n)
         j.in.assign(kBlock, 0);
         j.level = 1;
         deflate_block(&j);
-        if (j.bad) failed_ = true; else zero_member_.assign(j.out.get(), j.out.get() + j.out_n);
+        if (j.bad) failed_ = true; else zero_member_.assign(j.out.get() + j.out_at, j.out.get() + j.out_at + j.out_n);
     }
     while (n >= kBlock && !failed_) {                             // whole blocks: the ready-made member, in order
         std::unique_ptr<Job> j(new Job());
@@ -218,10 +233,11 @@ ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads
     if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, h, kHeader, 0) == (ssize_t)kHeader && is_mk_header(h)) {
         fd_ = fd;
         file_size_ = (uint64_t)st.st_size;
-        // the members are inflated straight out of a mapping of the file: no read() into a buffer first (MIEKKI_LOAD_IO=pread
-        // reads them into buffers instead; the two were level on the GPU boxes, 20 - 25 GB/s with sixteen threads)
+        // MIEKKI_LOAD_IO=mmap inflates the members straight out of a mapping of the file instead of reading them into
+        // buffers first: level with pread on the GPU boxes while it runs (20 - 25 GB/s with sixteen threads), but taking a
+        // 76 GB mapping down again costs 2.5 s at the end -- not the default
         const char *e = getenv("MIEKKI_LOAD_IO");
-        if (!e || strcmp(e, "pread")) {
+        if (e && !strcmp(e, "mmap")) {
             void *m = mmap(nullptr, (size_t)file_size_, PROT_READ, MAP_SHARED, fd, 0);
             if (m != MAP_FAILED) map_ = (const uint8_t *)m;
         }
@@ -248,14 +264,63 @@ bool ParallelGzipReader::next_member(Member &m)
     if (scan_ == file_size_) { eof_ = true; return false; }
     uint8_t h[kHeader], t[8];
     if (scan_ + kHeader + 8 > file_size_ || !pread_all(fd_, h, kHeader, scan_) || !is_mk_header(h)) { failed_ = true; return false; }
+    const uint64_t xlen = get_le(h + 10, 2);
+    m = Member();
+    m.begin = scan_;
     m.payload = get_le(h + 16, 8);
-    m.at = scan_ + kHeader;
+    m.at = scan_ + 12 + xlen;
     if (m.payload > (1ull << 31) || m.at + m.payload + 8 > file_size_ || !pread_all(fd_, t, 8, m.at + m.payload)) { failed_ = true; return false; }
     m.crc = (uint32_t)get_le(t, 4);
     m.isize = (uint32_t)get_le(t + 4, 4);
     if (m.isize > (1u << 30)) { failed_ = true; return false; }   // (the writer's members hold kBlock bytes at most)
+    if (xlen > 12 + 4) {                                          // a second subfield: the block index of a Huffman-only stream
+        std::vector<uint8_t> x((size_t)xlen - 12);
+        if (!pread_all(fd_, x.data(), x.size(), scan_ + kHeader)) { failed_ = true; return false; }
+        const size_t len = (size_t)get_le(x.data() + 2, 2);
+        if (x[0] == 'M' && x[1] == 'H' && len + 4 <= x.size() && len >= 8) {
+            const uint8_t *d = x.data() + 4;
+            const uint64_t nsuper = get_le(d, 4), nsub = get_le(d + 4, 4);
+            const uint64_t want_super = ((uint64_t)m.isize + HuffIndex::kSuper - 1) / HuffIndex::kSuper;
+            uint64_t want_sub = 0;
+            for (uint64_t sp = 0; sp < want_super; ++sp)
+                want_sub += (std::min<uint64_t>(HuffIndex::kSuper, m.isize - sp * HuffIndex::kSuper) + HuffIndex::kSub - 1) / HuffIndex::kSub;
+            if (nsuper == want_super && nsub == want_sub && len == 8 + nsuper * 257 + nsub * 4) {   // (anything else: not an index this reader knows)
+                m.lens.assign(d + 8, d + 8 + nsuper * 257);
+                m.sym_bit.resize((size_t)nsub);
+                for (size_t i = 0; i < nsub; ++i) m.sym_bit[i] = (uint32_t)get_le(d + 8 + nsuper * 257 + 4 * i, 4);
+                m.indexed = true;
+            }
+        }
+    }
     scan_ = m.at + m.payload + 8;
     return true;
+}
+
+bool ParallelGzipReader::list_members(std::vector<Member> &out)
+{
+    out.clear();
+    if (fd_ < 0 || failed_ || cur_pos_ < cur_n_ || !jobs_.empty()) return false;
+    const uint64_t keep_scan = have_peek_ ? peek_.begin : scan_;
+    const bool keep_eof = eof_;
+    Member m;
+    while (next_member(m)) out.push_back(m);
+    const bool ok = !failed_;
+    have_peek_ = false; eof_ = keep_eof; scan_ = keep_scan;
+    return ok;
+}
+
+bool ParallelGzipReader::seek_member(uint64_t begin)
+{
+    if (fd_ < 0 || failed_ || cur_pos_ < cur_n_ || !jobs_.empty() || begin > file_size_) return false;
+    have_peek_ = false; eof_ = false; scan_ = begin;
+    return true;
+}
+
+bool ParallelGzipReader::read_raw(uint64_t at, void *dst, size_t n) const
+{
+    if (fd_ < 0 || at + n > file_size_) return false;
+    if (map_) { memcpy(dst, map_ + at, n); return true; }
+    return pread_all(fd_, (uint8_t *)dst, n, at);
 }
 
 void ParallelGzipReader::inflate_member(Job *j, int fd, const uint8_t *map)

@@ -4,7 +4,10 @@
 // zstr::ofstream, zstr.hpp:82) by its own thread into its own gzip MEMBER, written in order by one
 // output thread.  Every member's header carries an FEXTRA subfield "MK" with the
 // compressed payload size, the way BGZF does, so that a reader can find member
-// boundaries without inflating.  Any gzip reader -- zlib's gzread, the reference's
+// boundaries without inflating; members coded with Huffman codes only (the index's
+// fingerprint columns) carry a second subfield "MH": the code lengths of every MiB and
+// the bit at which every 16 KiB block's first symbol starts (fastz.hpp, HuffIndex) --
+// what a decoder needs to take all blocks at once (the GPU inflates them: huff.hip).  Any gzip reader -- zlib's gzread, the reference's
 // zstr::ifstream (which restarts its inflator at each member end, zstr.hpp:186-190),
 // gunzip -- reads such a file as one stream.
 //
@@ -15,6 +18,8 @@
 // else (the reference's own dumps, plain files) goes through gzread.
 #pragma once
 #include <zlib.h>
+
+#include "fastz.hpp"
 
 #include <cstdint>
 #include <cstdio>
@@ -55,7 +60,7 @@ public:
 private:
     struct Job {
         std::vector<uint8_t> in;
-        std::unique_ptr<uint8_t[]> out; size_t out_n = 0;         // the finished member
+        std::unique_ptr<uint8_t[]> out; size_t out_at = 0, out_n = 0;   // the finished member: out[out_at .. out_at + out_n)
         const uint8_t *ext = nullptr; size_t ext_n = 0;          // write_block: the caller's bytes instead of `in`
         const std::vector<uint8_t> *ready = nullptr;             // a member made earlier (a run of zeros): nothing to deflate
         std::function<void()> on_done;
@@ -94,8 +99,23 @@ public:
     bool read(void *dst, size_t n) { return read_some(dst, n) == n; }
     bool parallel() const { return fd_ >= 0; }
     unsigned threads() const { return nthreads_; }
+    // One member as the file holds it: where its deflate stream lies, what it inflates to, and -- for members with the
+    // "MH" subfield -- the block index of that stream.
+    struct Member {
+        uint64_t begin = 0, at = 0, payload = 0;                 // the member's first byte, its deflate stream's first byte and length
+        uint32_t crc = 0, isize = 0;
+        bool indexed = false;
+        std::vector<uint8_t> lens;                               // 257 code lengths per MiB of output
+        std::vector<uint32_t> sym_bit;                           // per 16 KiB block: bit of the deflate stream where its first symbol starts
+    };
+    // The members from the reader's position to the end of the file (headers and trailers only; nothing is inflated, the
+    // position stays).  Only at a member boundary -- nothing read ahead, nothing half handed out: false otherwise.
+    bool list_members(std::vector<Member> &out);
+    // continue reading at the member that starts at file offset `begin` (one of list_members')
+    bool seek_member(uint64_t begin);
+    // `n` bytes of the file as they are (a member's deflate stream, say)
+    bool read_raw(uint64_t at, void *dst, size_t n) const;
 private:
-    struct Member { uint64_t at = 0, payload = 0; uint32_t crc = 0, isize = 0; };   // `at`: where the deflate stream starts
     struct Job {
         Member m;
         uint8_t *dst = nullptr;                                  // the caller's memory, or `own`

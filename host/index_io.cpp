@@ -1,10 +1,12 @@
 #include "index_io.hpp"
 
+#include "fastz.hpp"
 #include "gzpar.hpp"
 
 #include <sys/stat.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -180,7 +182,9 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
         mk_ctx *ctx = nullptr;
         if (mk_create(&p, &ctx) != MK_OK) { err = mk_last_error(); ok = false; break; }
         out.push_back(ctx);
+        if (trace) fprintf(stderr, "[load] context %zu created after %.2f s\n", d, since(t_begin));
         if (mk_index_import_begin(ctx, at[d + 1] - at[d]) != MK_OK) { err = mk_last_error(); ok = false; }
+        if (trace) fprintf(stderr, "[load] its matrix allocated after %.2f s\n", since(t_begin));
     }
     const uint32_t P = ok ? 1u << hd.h : 0;
     const uint64_t row = (uint64_t)G * W;
@@ -195,19 +199,147 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
     void *pinned[2] = {nullptr, nullptr};
     std::vector<uint8_t> pageable[2];
     uint8_t *cbuf[2];
-    for (int k = 0; k < 2; ++k) {
+    cbuf[0] = cbuf[1] = nullptr;
+    double t_read = 0, t_wait = 0;
+    // ---- the columns, inflated on the GPU.  This program's own dumps keep them as Huffman-only deflate blocks and list
+    // the blocks in the members' extra fields (gzpar.hpp, "MH"): when every member of the column stretch is such a one and
+    // holds whole rows (the dump's blocks do), the members' bytes go to the device as they are -- read by `threads` threads
+    // into one of two page-locked buffers while the chunk before is on the device -- and mk_index_import_columns_huffman
+    // inflates them there, one lane per 16 KiB block; the host folds the blocks' CRC remainders and holds them against
+    // every member's trailer.  Anything else (the reference's dumps, stored columns, an index spread over several
+    // devices, MIEKKI_LOAD_INFLATE=host) is inflated by the reader's threads below.
+    uint32_t rows_done = 0;
+    {
+        std::vector<ParallelGzipReader::Member> mem;
+        const char *how = getenv("MIEKKI_LOAD_INFLATE");
+        size_t K = 0;
+        uint64_t covered = 0;
+        if (ok && D == 1 && G && row && f.parallel() && !(how && !strcmp(how, "host")) && f.list_members(mem)) {
+            while (K < mem.size() && covered < (uint64_t)P * row && mem[K].indexed && mem[K].isize % row == 0 && mem[K].payload < (1u << 29)) covered += mem[K++].isize;
+            if (covered != (uint64_t)P * row) K = 0;
+        }
+        if (K) {
+            const uint64_t cap_out = 768ull << 20;
+            void *stage[2] = {nullptr, nullptr};
+            for (int q = 0; q < 2; ++q) if (mk_host_alloc(out[0], cap_out, &stage[q]) != MK_OK) stage[q] = nullptr;
+            if (stage[0] && stage[1]) {
+                struct Chunk {
+                    uint32_t pb = 0, pe = 0; size_t m0 = 0, m1 = 0; uint64_t bytes = 0;
+                    std::vector<uint64_t> pay_off; std::vector<mk_huff_block> blocks; std::vector<uint8_t> lens; std::vector<uint32_t> crc;
+                };
+                Chunk ch[2];
+                std::thread up;
+                bool up_ok = true;
+                std::string up_err;
+                const uint32_t k16 = crc32_shift_factor(HuffIndex::kSub);
+                size_t m = 0;
+                uint32_t pb = 0;
+                int cur = 0;
+                const auto t_gpu = now();
+                double t_rd = 0, t_up = 0;
+                while (ok && m < K) {
+                    Chunk &c = ch[cur];
+                    c = Chunk();
+                    c.pb = pb; c.m0 = m;
+                    uint64_t out_bytes = 0;
+                    while (m < K && out_bytes + mem[m].isize <= cap_out && c.bytes + mem[m].payload + 16 <= cap_out) {
+                        c.pay_off.push_back(c.bytes);
+                        c.bytes += (mem[m].payload + 15) / 16 * 16;
+                        out_bytes += mem[m].isize;
+                        ++m;
+                    }
+                    if (m == c.m0) { err = "an index member larger than the loader's chunks"; ok = false; break; }
+                    c.m1 = m;
+                    c.pe = pb + (uint32_t)(out_bytes / row);
+                    pb = c.pe;
+                    // the members' streams, by `threads` threads; the block list beside it
+                    auto t0 = now();
+                    {
+                        std::vector<std::thread> rd;
+                        std::atomic<size_t> next{c.m0};
+                        std::atomic<bool> rd_ok{true};
+                        uint8_t *dst = (uint8_t *)stage[cur];
+                        for (unsigned t = 0; t < std::max(1u, threads); ++t)
+                            rd.emplace_back([&] {
+                                for (size_t i; (i = next.fetch_add(1)) < c.m1;)
+                                    if (!f.read_raw(mem[i].at, dst + c.pay_off[i - c.m0], (size_t)mem[i].payload)) rd_ok = false;
+                            });
+                        uint64_t out_at = 0;
+                        for (size_t i = c.m0; i < c.m1; ++i) {
+                            const ParallelGzipReader::Member &mm = mem[i];
+                            size_t sub = 0;
+                            for (uint64_t sp = 0; sp * HuffIndex::kSuper < mm.isize; ++sp) {
+                                const uint64_t sbytes = std::min<uint64_t>(HuffIndex::kSuper, mm.isize - sp * HuffIndex::kSuper);
+                                const uint32_t code = (uint32_t)(c.lens.size() / 257);
+                                c.lens.insert(c.lens.end(), mm.lens.begin() + sp * 257, mm.lens.begin() + (sp + 1) * 257);
+                                for (uint32_t q = 0; q < 64; ++q) {
+                                    mk_huff_block b{0, 0, 0, code};
+                                    if ((uint64_t)q * HuffIndex::kSub < sbytes) {
+                                        b.bit = c.pay_off[i - c.m0] * 8 + mm.sym_bit[sub++];
+                                        b.out = out_at + sp * HuffIndex::kSuper + (uint64_t)q * HuffIndex::kSub;
+                                        b.out_len = (uint32_t)std::min<uint64_t>(HuffIndex::kSub, sbytes - (uint64_t)q * HuffIndex::kSub);
+                                    }
+                                    c.blocks.push_back(b);
+                                }
+                            }
+                            out_at += mm.isize;
+                        }
+                        c.crc.assign(c.blocks.size(), 0);
+                        for (auto &t : rd) t.join();
+                        if (!rd_ok) { err = "cannot read the index members"; ok = false; }
+                    }
+                    t_rd += since(t0);
+                    t0 = now();
+                    if (up.joinable()) up.join();
+                    t_up += since(t0);
+                    if (!up_ok) break;
+                    if (!ok) break;
+                    up = std::thread([&, cur] {
+                        Chunk &u = ch[cur];
+                        uint32_t bad = 0;
+                        if (mk_index_import_columns_huffman(out[0], u.pb, u.pe, (const uint8_t *)stage[cur], u.bytes, u.blocks.data(), (uint32_t)u.blocks.size(),
+                                                            u.lens.data(), (uint32_t)(u.lens.size() / 257), u.crc.data(), &bad) != MK_OK) {
+                            up_err = mk_last_error(); up_ok = false; return;
+                        }
+                        if (bad) { up_err = "corrupt index columns (a block does not decode)"; up_ok = false; return; }
+                        size_t slot = 0;
+                        for (size_t i = u.m0; i < u.m1 && up_ok; ++i) {      // every member's CRC-32 from its blocks' remainders
+                            uint32_t r = 0;
+                            for (uint64_t left = mem[i].isize; left; slot += 64) {
+                                const uint64_t sbytes = std::min<uint64_t>(HuffIndex::kSuper, left);
+                                for (uint32_t q = 0; (uint64_t)q * HuffIndex::kSub < sbytes; ++q) {
+                                    const uint64_t len = std::min<uint64_t>(HuffIndex::kSub, sbytes - (uint64_t)q * HuffIndex::kSub);
+                                    r = (len == HuffIndex::kSub ? crc32_shift_by(k16, r) : crc32_shift(r, len)) ^ u.crc[slot + q];
+                                }
+                                left -= sbytes;
+                            }
+                            if (crc32_from_raw(r, mem[i].isize) != mem[i].crc) { up_err = "corrupt index columns (CRC)"; up_ok = false; }
+                        }
+                    });
+                    cur ^= 1;
+                }
+                if (up.joinable()) up.join();
+                if (ok && !up_ok) { err = up_err; ok = false; }
+                if (ok) { rows_done = P; ok = f.seek_member(K < mem.size() ? mem[K].begin : mem[K - 1].at + mem[K - 1].payload + 8); }
+                if (trace)
+                    fprintf(stderr, "[load] columns inflated on the GPU: %.2f s (%zu members; reading them %.2f s, waiting for the device %.2f s)\n", since(t_gpu), K,
+                            t_rd, t_up);
+            }
+            for (int q = 0; q < 2; ++q) if (stage[q]) mk_host_free(out[0], stage[q]);
+        }
+    }
+    if (trace) fprintf(stderr, "[load] columns start after %.2f s\n", since(t_begin));
+    const auto t_cols = now();
+    for (int k = 0; k < 2 && rows_done < P; ++k) {               // (the chunks of the host's inflate path: only when it runs)
         if (ok && !out.empty() && mk_host_alloc(out[0], chunk_bytes, &pinned[k]) != MK_OK) pinned[k] = nullptr;
         if (!pinned[k]) pageable[k].resize(chunk_bytes);
         cbuf[k] = pinned[k] ? (uint8_t *)pinned[k] : pageable[k].data();
     }
-    double t_read = 0, t_wait = 0;
-    if (trace) fprintf(stderr, "[load] contexts, matrix and page-locked chunks ready after %.2f s\n", since(t_begin));
-    const auto t_cols = now();
     std::thread importer;
     bool import_ok = true;
     std::string import_err;
     int k = 0;
-    for (uint32_t pb = 0; ok && pb < P; pb += rows, k ^= 1) {
+    for (uint32_t pb = rows_done; ok && pb < P; pb += rows, k ^= 1) {
         const uint32_t pe = std::min(P, pb + rows);
         uint8_t *const b = cbuf[k];
         auto t0 = now();

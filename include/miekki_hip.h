@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MK_ABI_VERSION 4
+#define MK_ABI_VERSION 5
 
 typedef enum {
     MK_OK = 0,
@@ -205,6 +205,28 @@ int mk_index_export_bloom(mk_ctx *ctx, uint64_t begin, uint64_t end, uint8_t *ds
 
 int mk_index_import_begin(mk_ctx *ctx, uint32_t n_genomes);    /* empties the index first */
 int mk_index_import_columns(mk_ctx *ctx, uint32_t p_begin, uint32_t p_end, const uint8_t *src);
+
+/* mk_index_import_columns for rows that are still Huffman-coded -- the form this program's own index files keep the
+ * fingerprint columns in (host/fastz.cpp, deflate_huffman_only: deflate blocks of literals only, one Huffman code of at
+ * most 12 bits per MiB, a block per 16 KiB; each gzip member's extra field lists where every block's first symbol lies).
+ * The device inflates them, one lane per block (huff.hip): the reference's `in->read` of the columns (Miekki.cpp:708-712)
+ * without an inflater on the host.  `payload`: the members' deflate streams as they lie in the file, one after the other
+ * (page-locked memory makes the copy a DMA).  `blocks`: n_blocks of them, a multiple of 64 -- every 64 consecutive entries
+ * use ONE code (entry 64 i's `code`; slots with out_len 0 fill a group up) -- that together produce exactly the bytes of
+ * rows [p_begin, p_end) in the dump's byte order.  `lens`: n_codes x 257 code lengths (literals 0 .. 255, end-of-block).
+ * Out: crc_out[i] = the CRC-32 remainder of block i's bytes (start value 0, no final complement: the caller folds them
+ * with the blocks' lengths and compares with the members' trailers); *bad_out = blocks whose code is not a complete code
+ * of at most 12 bits, that point outside the payload or the rows, hold an end-of-block code early or lack it at their
+ * end -- the index is not usable unless it is 0 and the CRCs hold. */
+typedef struct {
+    uint64_t bit;       /* where the block's first symbol starts: bits from payload[0] */
+    uint64_t out;       /* where its bytes go: bytes from the first byte of row p_begin */
+    uint32_t out_len;   /* how many bytes it holds */
+    uint32_t code;      /* which of the n_codes length tables it is coded with */
+} mk_huff_block;
+int mk_index_import_columns_huffman(mk_ctx *ctx, uint32_t p_begin, uint32_t p_end, const uint8_t *payload, uint64_t payload_bytes,
+                                    const mk_huff_block *blocks, uint32_t n_blocks, const uint8_t *lens, uint32_t n_codes,
+                                    uint32_t *crc_out, uint32_t *bad_out);
 int mk_index_import_sizes(mk_ctx *ctx, const uint64_t *genome_size, const uint32_t *sketch_size);
 int mk_index_import_bloom(mk_ctx *ctx, uint64_t begin, uint64_t end, const uint8_t *src);
 

@@ -1059,7 +1059,7 @@ void mk_destroy(mk_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)drain_timers(c);
     for (Timer &t : c->free_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
-    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom); dev_free(c->d_ratio); dev_free(c->d_colstage);
+    dev_free(c->d_M); dev_free(c->d_sketch_size); dev_free(c->d_genome_size); dev_free(c->d_bloom); dev_free(c->d_ratio); dev_free(c->d_colstage); dev_free(c->d_huff);
     if (c->h_M) (void)hipHostFree(c->h_M);
     if (c->h_Z) (void)hipHostFree(c->h_Z);
     dev_free(c->d_zoff); dev_free(c->d_zstage[0]); dev_free(c->d_zstage[1]);
@@ -1464,6 +1464,55 @@ int mk_index_import_columns(mk_ctx *c, uint32_t pb, uint32_t pe, const uint8_t *
     MK_TRY(use_device(c));
     ++c->gen;
     return staged_columns(c, true, pb, pe, const_cast<uint8_t *>(src));
+}
+
+// the same for rows that arrive Huffman-coded: inflated on the device (huff.hip)
+int mk_index_import_columns_huffman(mk_ctx *c, uint32_t pb, uint32_t pe, const uint8_t *payload, uint64_t payload_bytes,
+                                               const mk_huff_block *blocks, uint32_t n_blocks, const uint8_t *lens, uint32_t n_codes,
+                                               uint32_t *crc_out, uint32_t *bad_out)
+{
+    if (!c || !payload || !blocks || !lens || !crc_out || !bad_out) { set_error("null argument"); return MK_ERR_ARG; }
+    if (pb > pe || pe > c->P) { set_error("partition range out of bounds"); return MK_ERR_ARG; }
+    if (n_blocks % 64u) { set_error("blocks come in groups of 64 that share a code"); return MK_ERR_ARG; }
+    *bad_out = 0;
+    if (pb == pe || c->G == 0 || !n_blocks) return MK_OK;
+    MK_TRY(use_device(c));
+    MK_TRY(need_raw_cold(c));
+    ++c->gen;
+    const uint64_t row = (uint64_t)c->G * c->W, out_bytes = (uint64_t)(pe - pb) * row;
+    if (out_bytes > (2ull << 30)) { set_error("at most 2 GiB of rows per call"); return MK_ERR_ARG; }
+    if (out_bytes > c->colstage_cap) {
+        dev_free(c->d_colstage);
+        c->colstage_cap = 0;
+        MK_TRY(dev_alloc(&c->d_colstage, out_bytes));
+        c->colstage_cap = out_bytes;
+    }
+    // the coded bytes, the block list, the codes' lengths, the remainders and the count: one device buffer, kept
+    const uint64_t o_blocks = (payload_bytes + 8 + 255) / 256 * 256, o_lens = o_blocks + ((uint64_t)n_blocks * sizeof(mk_huff_block) + 255) / 256 * 256;
+    const uint64_t o_crc = o_lens + ((uint64_t)n_codes * 257u + 255) / 256 * 256, o_bad = o_crc + ((uint64_t)n_blocks * 4 + 255) / 256 * 256;
+    const uint64_t need = o_bad + 256;
+    if (need > c->huff_cap) {
+        dev_free(c->d_huff);
+        c->huff_cap = 0;
+        MK_TRY(dev_alloc(&c->d_huff, need + need / 4));
+        c->huff_cap = need + need / 4;
+    }
+    uint8_t *d = c->d_huff;
+    hipStream_t st = c->stream;
+    bool ok = hipMemcpyAsync(d, payload, payload_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemsetAsync(d + payload_bytes, 0, 8, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d + o_blocks, blocks, (size_t)n_blocks * sizeof(mk_huff_block), hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d + o_lens, lens, (size_t)n_codes * 257u, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemsetAsync(d + o_bad, 0, 4, st) == hipSuccess;
+    if (!ok) { set_error("Huffman column upload failed: %s", hipGetErrorString(hipGetLastError())); return MK_ERR_DEVICE; }
+    MK_TRY(launch_huff_decode(c, d, payload_bytes, reinterpret_cast<const mk_huff_block *>(d + o_blocks), n_blocks, d + o_lens, n_codes,
+                              c->d_colstage, out_bytes, reinterpret_cast<uint32_t *>(d + o_crc), reinterpret_cast<uint32_t *>(d + o_bad)));
+    MK_HIP(hipMemcpyAsync(crc_out, d + o_crc, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, st));
+    MK_HIP(hipMemcpyAsync(bad_out, d + o_bad, 4, hipMemcpyDeviceToHost, st));
+    // (the rows are laid out even when a block was bad: the caller fails the load on `bad_out` / the CRCs and drops the index)
+    MK_TRY(launch_convert_columns(c, true, pb, pe, c->d_colstage));
+    MK_HIP(hipStreamSynchronize(st));
+    return MK_OK;
 }
 
 int mk_index_import_sizes(mk_ctx *c, const uint64_t *genome_size, const uint32_t *sketch_size)

@@ -91,6 +91,8 @@ struct mk_ctx {
     uint64_t ratio_gen, ratio_cap;
     uint8_t *d_colstage;           // staging of mk_index_export_columns / _import_columns (kept between calls)
     uint64_t colstage_cap;
+    uint8_t *d_huff = nullptr;     // mk_index_import_columns_huffman: coded bytes, block list, code lengths, remainders (kept between calls)
+    uint64_t huff_cap = 0;
     void *exact_buf[10];           // exact mode (K7) scratch, grown on demand, freed with the context
     uint64_t exact_cap[10];
     bool exact_have_B;             // set B of the genome loaded last (mk_exact_load_genome) is resident
@@ -363,6 +365,9 @@ int launch_synth_genomes(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t len,
 int launch_synth_queries(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
                          char *d_out);
 int launch_convert_columns(mk_ctx *c, bool to_device, uint32_t p_begin, uint32_t p_end, uint8_t *d_staging);
+// huff.hip: one lane per deflate block of literals (mk_index_import_columns_huffman)
+int launch_huff_decode(mk_ctx *c, const uint8_t *d_payload, uint64_t payload_bytes, const mk_huff_block *d_blocks, uint32_t n_blocks,
+                       const uint8_t *d_lens, uint32_t n_codes, uint8_t *d_out, uint64_t out_bytes, uint32_t *d_crc, uint32_t *d_bad);
 int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t *d_dst);   // d_dst[P][n] (W bytes each, dump byte order)
 inline MatRef mat_ref(const mk_ctx *c);
 

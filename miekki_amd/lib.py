@@ -72,6 +72,7 @@ SIGNATURES = {
     "mk_index_export_bloom": (i32, [vp, u64, u64, vp]),
     "mk_index_import_begin": (i32, [vp, u32]),
     "mk_index_import_columns": (i32, [vp, u32, u32, vp]),
+    "mk_index_import_columns_huffman": (i32, [vp, u32, u32, vp, u64, vp, u32, vp, u32, vp, vp]),
     "mk_index_import_sizes": (i32, [vp, vp, vp]),
     "mk_index_import_bloom": (i32, [vp, u64, u64, vp]),
     "mk_query_scores": (i32, [vp, vp, vp, u32, vp]),

@@ -155,6 +155,59 @@ int main(int argc, char **argv)
                 if (n > 70 && crc32_fast(seed, plain.data() + 3, n - 5) != (uint32_t)crc32(seed, plain.data() + 3, n - 5)) FAIL("crc32 (unaligned) differs: kind %d n %zu", kind, n);
                 ++checks;
             }
+            // remainders of pieces put together: cut the input in three, fold, compare with zlib's value of the whole
+            if (n >= 3) {
+                const size_t a = 1 + rnd() % (n - 2), b2 = a + 1 + rnd() % (n - a - 1);
+                uint32_t r = crc32_raw(plain.data(), a);
+                r = crc32_shift(r, b2 - a) ^ crc32_raw(plain.data() + a, b2 - a);
+                r = crc32_shift(r, n - b2) ^ crc32_raw(plain.data() + b2, n - b2);
+                if (crc32_from_raw(r, n) != (uint32_t)crc32(0, plain.data(), n)) FAIL("folded CRC differs: kind %d n %zu", kind, n);
+                // ... and a plain bytewise remainder (what the GPU computes per block) is crc32_raw
+                uint32_t t = 0;
+                for (size_t i = 0; i < std::min<size_t>(n, 5000); ++i) { t ^= plain[i]; for (int k = 0; k < 8; ++k) t = (t & 1) ? (t >> 1) ^ 0xEDB88320u : t >> 1; }
+                if (t != crc32_raw(plain.data(), std::min<size_t>(n, 5000))) FAIL("bytewise remainder differs: kind %d n %zu", kind, n);
+                ++checks;
+            }
+            // the block index of the writer: every listed position is where a block's first symbol starts
+            if (n) {
+                HuffIndex hx;
+                Bytes z2(huffman_only_bound(n));
+                const size_t zn = deflate_huffman_only(plain.data(), n, z2.data(), &hx);
+                if (hx.all_coded) {
+                    const size_t nsuper = (n + HuffIndex::kSuper - 1) / HuffIndex::kSuper;
+                    size_t nsub = 0;
+                    for (size_t sp = 0; sp < nsuper; ++sp) nsub += (std::min(HuffIndex::kSuper, n - sp * HuffIndex::kSuper) + HuffIndex::kSub - 1) / HuffIndex::kSub;
+                    if (hx.lens.size() != nsuper * 257 || hx.sym_bit.size() != nsub) FAIL("block index sizes: kind %d n %zu", kind, n);
+                    for (uint8_t l : hx.lens) if (l > HuffIndex::kMaxLen) FAIL("code longer than %u bits", HuffIndex::kMaxLen);
+                    // decode the first few symbols of every block by hand with the listed lengths
+                    size_t sub = 0;
+                    for (size_t sp = 0; sp < nsuper; ++sp) {
+                        const uint8_t *lens = hx.lens.data() + sp * 257;
+                        uint32_t cnt[16] = {0}, next[16] = {0}, codes[257];
+                        for (int v = 0; v < 257; ++v) ++cnt[lens[v]];
+                        cnt[0] = 0;
+                        uint32_t c = 0;
+                        for (int l = 1; l <= 15; ++l) { c = (c + cnt[l - 1]) << 1; next[l] = c; }
+                        for (int v = 0; v < 257; ++v) codes[v] = lens[v] ? next[lens[v]]++ : 0;
+                        const size_t sbytes = std::min(HuffIndex::kSuper, n - sp * HuffIndex::kSuper);
+                        for (size_t q = 0; q * HuffIndex::kSub < sbytes; ++q, ++sub) {
+                            uint64_t bit = hx.sym_bit[sub];
+                            const size_t base = sp * HuffIndex::kSuper + q * HuffIndex::kSub, m = std::min<size_t>(8, std::min(HuffIndex::kSub, sbytes - q * HuffIndex::kSub));
+                            for (size_t i = 0; i < m; ++i) {
+                                uint32_t code = 0, len = 0;
+                                int found = -1;
+                                while (found < 0 && len < 15) {
+                                    if (bit / 8 >= zn) FAIL("block index points past the stream");
+                                    code = (code << 1) | ((z2[bit / 8] >> (bit % 8)) & 1u); ++bit; ++len;
+                                    for (int v = 0; v < 257; ++v) if (lens[v] == len && codes[v] == code) { found = v; break; }
+                                }
+                                if (found != plain[base + i]) FAIL("block index: kind %d n %zu block %zu symbol %zu: %d, not %d", kind, n, sub, i, found, plain[base + i]);
+                            }
+                        }
+                    }
+                    ++checks;
+                }
+            }
             // zlib's streams through the reader here
             struct { int level, strategy, flush; } forms[] = {{1, Z_DEFAULT_STRATEGY, 0}, {6, Z_DEFAULT_STRATEGY, 0}, {9, Z_DEFAULT_STRATEGY, 0}, {0, Z_DEFAULT_STRATEGY, 0},
                                                               {1, Z_HUFFMAN_ONLY, 0}, {6, Z_RLE, 0}, {6, Z_FIXED, 0}, {6, Z_FILTERED, 0}, {6, Z_DEFAULT_STRATEGY, 777},

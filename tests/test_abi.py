@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_layouts():
     lib = L.load_library()
-    assert lib.mk_abi_version() == 4
+    assert lib.mk_abi_version() == 5
     assert ctypes.sizeof(L.Hit) == 24          # similarity_score, Miekki.h:27-31
     assert ctypes.sizeof(L.Params) == 32
     assert ctypes.sizeof(L.PackedSeq) == 56    # mk_packed_seq: two pointers, the length, 32 head characters

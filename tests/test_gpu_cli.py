@@ -291,3 +291,39 @@ def test_multi_rank_driver_whole_file_queries(workdirs, golden_dir):
     r = subprocess.run(cmd, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     assert (d / "outA_mgpu.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["h20", "w16", "rnd3"])
+def test_index_columns_inflated_on_the_gpu(workdirs, golden_dir, name):
+    """`-i` on this program's own dump: the Huffman-coded column members go to the device as they are and are inflated there
+    (mk_index_import_columns_huffman, huff.hip) -- same answers as with MIEKKI_LOAD_INFLATE=host (the reader's threads
+    inflate) and as the reference's goldens; a flipped bit in a column member fails the load (block CRCs folded on the
+    host against the member's trailer) instead of answering from a damaged index."""
+    case, d, base = workdirs(name)
+    run(["-l", "genomes.lst", "-d", "idx_h.gz", *base], d)
+    outs = {}
+    for how in ("gpu", "host"):
+        env = dict(os.environ, MIEKKI_DEVICES="0", MIEKKI_IO_TRACE="1")
+        if how == "host":
+            env["MIEKKI_LOAD_INFLATE"] = "host"
+        r = subprocess.run([CLI, "-i", "idx_h.gz", "-a", "queries.fa", "-o", f"out_{how}.txt", "-t", "2"], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        assert (b"columns inflated on the GPU" in r.stderr) == (how == "gpu"), r.stderr.decode(errors="replace")
+        outs[how] = (d / f"out_{how}.txt").read_bytes()
+    assert outs["gpu"] == outs["host"] == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    # damage: one bit in the middle of the second member's deflate stream (the first member is the 39-byte head)
+    raw = bytearray((d / "idx_h.gz").read_bytes())
+    xlen0, pay0 = int.from_bytes(raw[10:12], "little"), int.from_bytes(raw[16:24], "little")
+    at = 12 + xlen0 + pay0 + 8
+    xlen1, pay1 = int.from_bytes(raw[at + 10:at + 12], "little"), int.from_bytes(raw[at + 16:at + 24], "little")
+    assert raw[at + 24:at + 26] == b"MH" and pay1 > 1000
+    raw[at + 12 + xlen1 + pay1 // 2] ^= 0x10
+    (d / "idx_bad.gz").write_bytes(bytes(raw))
+    for how in ("gpu", "host"):
+        env = dict(os.environ, MIEKKI_DEVICES="0")
+        if how == "host":
+            env["MIEKKI_LOAD_INFLATE"] = "host"
+        r = subprocess.run([CLI, "-i", "idx_bad.gz", "-a", "queries.fa", "-o", "out_bad.txt", "-t", "2"], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600, env=env)
+        assert r.returncode != 0 or b"orrupt" in r.stdout or b"truncated" in r.stdout, r.stdout.decode(errors="replace")

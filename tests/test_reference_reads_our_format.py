@@ -79,13 +79,15 @@ def test_index_writer_forms_are_plain_gzip_too(tmp_path, stored):
     else:
         assert len(raw) < 0.85 * len(cols)                                      # uniform over 60 values: 5.9 of 8 bits per byte
     # the 100 MiB of zeros (less what the block before them took): ready-made members (a few KB each, identical), not deflate runs
-    head = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x04\x03\x0c\x00MK\x08\x00"
-    sizes = []
-    at = raw.find(head)
-    while at >= 0:
-        nxt = raw.find(head, at + 1)
-        sizes.append((nxt if nxt >= 0 else len(raw)) - at)
-        at = nxt
+    sizes, indexed, at = [], 0, 0
+    while at < len(raw):                                                        # member by member: 12 + XLEN + stream + 8
+        assert raw[at:at + 4] == b"\x1f\x8b\x08\x04" and raw[at + 12:at + 16] == b"MK\x08\x00"
+        xlen, payload = int.from_bytes(raw[at + 10:at + 12], "little"), int.from_bytes(raw[at + 16:at + 24], "little")
+        indexed += xlen > 12 and raw[at + 24:at + 26] == b"MH"
+        sizes.append(12 + xlen + payload + 8)
+        at += sizes[-1]
+    assert at == len(raw)
+    assert (indexed == 0) if stored else (indexed >= 2)                         # Huffman-only members carry their block index
     assert sum(1 for a, b in zip(sizes, sizes[1:]) if a == b and a < 200_000) >= 1   # identical small members in a row
 
 
