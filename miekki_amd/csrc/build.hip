@@ -425,17 +425,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     constexpr uint32_t kKeyPos = KEY32 ? 24 : 40;                    // key = fingerprint << kKeyPos | position
     constexpr key_t kNoKey = (key_t)~(key_t)0;
     constexpr uint32_t kThreads = 512, kWin = (1u << kBin) / kThreads;   // winners per thread
-    __shared__ key_t table[1u << kBin];
-    __shared__ uint32_t s_act;
-    __shared__ unsigned long long s_card;
     constexpr uint32_t kMetaChunk = 1280;                             // scatter workgroups whose meta words sit in LDS at a time (5 Mb: 1,221)
-    __shared__ uint32_t s_meta[kMetaChunk];
     // flagged items seen: partition in bin << 32 | position.  More than fit: every winner of the bin gets the filter
     // looked at (that is the state of a young filter, where nearly everything is flagged anyway)
     constexpr uint32_t kNoted = KEY32 ? 2048 : 1024;                  // (64-bit keys: a 32 KiB table -- 46 KiB in all, three workgroups per CU)
-    __shared__ unsigned long long noted[kNoted];
-    __shared__ uint32_t n_noted;
-    __shared__ uint32_t to_check[(1u << kBin) / 32];                  // partitions whose winner is a flagged item
+    // (one object, the table first: at LDS address 0 the atomic minimum's address is the read's -- with the table behind the
+    // list the compiler added the table's offset once more for every item)
+    struct Shared {
+        key_t table[1u << kBin];
+        unsigned long long noted[kNoted];
+        unsigned long long card;
+        uint32_t meta[kMetaChunk];
+        uint32_t to_check[(1u << kBin) / 32];                         // partitions whose winner is a flagged item
+        uint32_t act, n_noted;
+    };
+    __shared__ Shared sh;
+    key_t (&table)[1u << kBin] = sh.table;
+    unsigned long long (&noted)[kNoted] = sh.noted;
+    uint32_t (&s_meta)[kMetaChunk] = sh.meta;
+    uint32_t (&to_check)[(1u << kBin) / 32] = sh.to_check;
+    uint32_t &s_act = sh.act, &n_noted = sh.n_noted;
+    unsigned long long &s_card = sh.card;
     // workgroups are dealt to the XCDs round robin: XCD x gets the bins x * nbins / 8 ... of a genome, i.e. neighbours
     const uint32_t g = blockIdx.y;
     const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
@@ -518,7 +528,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     }
                     // slot: the item's place in the list of flagged items, or beyond it for an item that is not flagged
                     auto fold = [&](auto with_list, uint32_t w, item_t item, uint32_t lob, uint32_t slot) {
-                        const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
+                        // the partition's table entry as a BYTE offset: one shift and one mask from the item
+                        constexpr uint32_t kKeyLog = KEY32 ? 2 : 3, kPartShift = (W == 1 ? 12 : 4) - kKeyLog;
+                        key_t *const entry = reinterpret_cast<key_t *>(reinterpret_cast<unsigned char *>(table) + ((item >> kPartShift) & ((R - 1u) << kKeyLog)));
                         key_t key;
                         if (KEY32) key = (key_t)((item & 0xff000fffu) | (w << 12));                // fingerprint << 24 | position
                         else {
@@ -529,25 +541,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                         // a later position -- again and again, and 64 lanes of an atomic minimum on ONE entry cost 620 cycles where
                         // a read of one entry is a broadcast, profiles/r3_ubench.txt; a key that cannot win is dropped here.
                         // profiles/r4_repeat_rich.txt: 20 % of a genome in tandem repeats tripled this kernel's time without it)
-                        if (key < table[part]) atomicMin(&table[part], key);
+                        if (key < *entry) atomicMin(entry, key);
                         if constexpr (decltype(with_list)::value) {
+                            const uint32_t part = W == 1 ? (item >> 12) & (R - 1u) : (item >> 4) & (R - 1u);
                             const uint32_t pos = W == 1 ? item & (kSeg - 1u) : ((item & 0xfu) << 8) | lob;
                             if (slot < kNoted) noted[slot] = ((unsigned long long)part << 32) | (uint32_t)((uint64_t)w * kSeg + pos);
                         }
                     };
+                    // (the lane's items e = 0 .. kIPL-1 lie at a0 + j0 + e: inside the run for lo <= e < hi -- compared as they are,
+                    // against two numbers per lane, instead of one more addition per item)
+                    const int lo = (int)first - (int)(a0 + j0), hi = (int)end - (int)(a0 + j0);
                     if (noting) {
 #pragma unroll
                         for (uint32_t e = 0; e < kIPL; ++e) {
                             const uint32_t at = a0 + j0 + e;
-                            if (at >= first && at < end)
+                            if ((int)e >= lo && (int)e < hi)
                                 fold(std::true_type{}, w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, at < fend ? nbase + (at - first) : ~0u);
                         }
                     } else {
 #pragma unroll
-                        for (uint32_t e = 0; e < kIPL; ++e) {
-                            const uint32_t at = a0 + j0 + e;
-                            if (at >= first && at < end) fold(std::false_type{}, w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, ~0u);
-                        }
+                        for (uint32_t e = 0; e < kIPL; ++e)
+                            if ((int)e >= lo && (int)e < hi) fold(std::false_type{}, w, q.v[u][e], W == 2 ? (q.lo[u] >> (8 * e)) & 0xffu : 0u, ~0u);
                     }
                     // Runs longer than their lanes reach.  Rare on ordinary sequence (the lanes cover mean + 4 sigma), the rule on
                     // repeat-rich sequence: a tandem repeat sends a whole stretch of k-mers into ONE partition, i.e. hundreds or
