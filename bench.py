@@ -315,6 +315,12 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints a five-line version banner on stdout from the first
+    # communicator of a process (torch's as well as the library's own), so descriptor 1 points at stderr until that line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -585,7 +591,10 @@ def main(argv=None):
                 sys.stderr.write(f"host-fed build sample skipped: {e}\n")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.h, os.cpu_count() or 1)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     lib.mk_qset_free(ix._h, qs)
     if comm:
         lib.mk_comm_destroy(comm)
