@@ -522,6 +522,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
                    o_ent_off = carve(((uint64_t)nq + 1) * 8), o_entries = carve((qs->h_ent_off[nq] + 1) * 8),
                    o_nent = carve(((uint64_t)nq + 1) * 4), o_scan_n = carve(((uint64_t)nq + 1) * 4),
                    o_dense = carve(dense_bytes), o_dense_q = carve(qs->dense_q.size() * 4),
+                   o_lut = carve(c->W == 1 ? (uint64_t)((qs->dense_q.size() / 4 + 1) / 2) * c->P * 16 : 0),
                    o_split = carve(qs->split_room ? (uint64_t)nq * (qs->split_room + 1) * 4 : 0);
     if (transient && !c->qarena_busy) {
         if (at > c->qarena_cap) {
@@ -548,6 +549,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     if (!qs->dense_q.empty()) {
         qs->d_dense = qs->d_arena + o_dense;
         qs->d_dense_q = reinterpret_cast<uint32_t *>(qs->d_arena + o_dense_q);
+        qs->d_dense_lut = c->W == 1 ? reinterpret_cast<DenseLut *>(qs->d_arena + o_lut) : nullptr;
         MK_HIP(hipMemsetAsync(qs->d_dense, 0xFF, dense_bytes, c->stream));           // every slot starts empty
         MK_HIP(hipMemcpyAsync(qs->d_dense_q, qs->dense_q.data(), qs->dense_q.size() * 4, hipMemcpyHostToDevice,
                               c->stream));
@@ -627,6 +629,8 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
                 for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_dense(c, qs, slot + j));
             slot += n;
         }
+        // one-byte fingerprints: the field tables the dense scan looks bytes up in (scan_dense_lut_kernel)
+        if (qs->d_dense_lut) MK_TRY(launch_dense_lut(c, qs->d_dense, (uint32_t)(qs->dense_q.size() / 4), qs->d_dense_lut));
     }
     MK_TRY(launch_scan_counts(c, qs));
     qs->sketched = true;
@@ -832,10 +836,11 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         DenseArgs d;
         d.M = M; d.Mc = Mc; d.P_hot = P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
         d.row_lo = row_lo; d.row_hi = row_hi;
-        d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8192);
+        d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8176);          // (below 2^13: the table kernel counts in 13 bit planes)
         d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
         d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
         d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
+        d.lut = qs->d_dense_lut; d.noctets = (d.ngroups + 1) / 2;
         d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
         ScopedTimer t(c, 1);
         return launch_scan_dense(c, d);

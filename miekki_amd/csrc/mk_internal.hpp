@@ -241,6 +241,7 @@ struct mk_ctx {
     std::vector<mk::Timer> free_timers;
 };
 
+namespace mk { struct DenseLut; }
 struct mk_qset {
     uint32_t nq;
     mk_ctx *owner;
@@ -263,6 +264,7 @@ struct mk_qset {
     std::vector<uint32_t> dense_q; // set indices, group-major; 0xffffffff pads the last group
     uint8_t *d_dense;
     uint32_t *d_dense_q;
+    mk::DenseLut *d_dense_lut = nullptr;   // one-byte fingerprints: the dense queries' field tables, [octet][P] (scan_kernel.hpp)
     uint32_t *d_scan_n;            // entries the sparse scan walks: nent for sparse queries, 0 for dense ones
     uint32_t short_max_nk;         // longest short query (k-mers)
     uint32_t *d_split;             // [nq][S + 1] entry index of each partition-range boundary
@@ -426,6 +428,7 @@ inline ScoreLayout score_layout_tiles(uint32_t W, uint32_t nq)                  
 }
 
 // dense long queries (scan_kernel.hpp: scan_dense_kernel): adds into the score rows
+struct DenseLut;
 struct DenseArgs {
     const uint8_t *M;
     const uint8_t *Mc;             // cold rows (MatRef::cold_m) or null
@@ -435,12 +438,15 @@ struct DenseArgs {
     uint32_t row_lo, row_hi;       // rows this launch walks (nchunks covers them in pieces of rows_per_item)
     const uint8_t *dense;          // [group][P][4] fingerprints (W bytes each), empty = inactive
     const uint32_t *dense_q;       // [group][4] set index of each slot or 0xffffffff
+    const DenseLut *lut;    // one-byte fingerprints: [octet = two groups][P] field tables (scan_kernel.hpp), or null
+    uint32_t noctets;
     uint32_t q0, q1;               // set range the score buffer covers
     uint32_t *scores;
     uint64_t score_tile_stride, score_q_stride;
     uint32_t empty;
 };
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a);
+int launch_dense_lut(mk_ctx *c, const uint8_t *d_dense, uint32_t ngroups, DenseLut *d_lut);
 int probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes);
 
 // ---- select.hip

@@ -434,4 +434,200 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
     }
 }
 
+// ---------------------------------------------------------------- dense queries, one-byte fingerprints: by table
+// scan_dense_kernel above tests a row piece against every query on its own -- six vector instructions per four
+// comparisons, 48 per data word for its eight queries -- and is bound by exactly those (2.97e13 comparisons/s = 3.85 TB/s x
+// 8 queries, half of what HBM would carry).  Here a data word costs about a dozen for EIGHT queries:
+//  * "which of the eight queries have this byte at this row" is a function of the byte: mask(v) = T0[v & 3] & T1[(v >> 2) & 3]
+//    & T2[(v >> 4) & 3] & T3[v >> 6], where Tf holds, per value of the 2-bit field f, the queries whose fingerprint has that
+//    value there (a byte equals a fingerprint iff all four fields do).  The four tables of a row -- four bytes each, made
+//    once per set by dense_lut_kernel -- are looked up for the four bytes of a word at once by v_perm_b32 (a four-entry
+//    byte table IS one source word, and it comes straight from a scalar register: tables of eight entries need two
+//    sources, of which only one may be scalar -- their copies into vector registers cost more than the fourth lookup);
+//    the field selectors are shared by every group of eight queries the wave carries.
+//  * the masks of successive rows are COUNTED bit by bit: every bit of the mask word (query j of genome byte b) has a
+//    counter spread over bit planes, fed by carry-save adders -- sixteen rows go in with fifteen adders of two
+//    instructions each (v_bitop3: sum and majority) and one ripple through the upper planes: three instructions per row
+//    and word for all eight queries, where the byte counters above took three per query.
+// Matches are counted directly (no "active rows minus mismatches"): a query without a fingerprint at a row is in no table.
+struct DenseLut { uint32_t t[4]; };   // 16 bytes per (octet of queries, row): four 4-entry byte tables, one per 2-bit field of a byte
+
+__global__ __launch_bounds__(256) void dense_lut_kernel(const uint8_t *__restrict__ dense, uint32_t ngroups, uint32_t P, uint32_t empty,
+                                                        DenseLut *__restrict__ lut)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x, octet = blockIdx.y;
+    if (p >= P) return;
+    DenseLut t;
+    t.t[0] = t.t[1] = t.t[2] = t.t[3] = 0;
+#pragma unroll
+    for (uint32_t half = 0; half < 2; ++half) {
+        const uint32_t group = octet * 2 + half;
+        if (group >= ngroups) break;
+        const uint32_t f4 = reinterpret_cast<const uint32_t *>(dense)[(uint64_t)group * P + p];   // four queries' fingerprints of this row
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t v = (f4 >> (8 * j)) & 0xffu, bit = 1u << (half * 4 + j);
+            if (v == empty) continue;
+#pragma unroll
+            for (uint32_t f = 0; f < 4; ++f) t.t[f] |= bit << (8 * ((v >> (2 * f)) & 3u));
+        }
+    }
+    lut[(uint64_t)octet * P + p] = t;
+}
+
+// sum and carry of three one-bit inputs per bit position
+__device__ __forceinline__ void csa(uint32_t &carry, uint32_t &sum, uint32_t a, uint32_t b, uint32_t c)
+{
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);            // majority: one instruction (v_bitop3_b32)
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);              // parity: one more
+}
+
+template <int NO>
+__global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
+{
+    constexpr uint32_t kPlanes = 13;                                 // counts up to 8,191: the host cuts chunks of at most 8,176 rows
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t work = blockIdx.x * 4u + wave;
+    const uint32_t nsets = (a.noctets + NO - 1) / NO;
+    if (work >= nsets * a.ntiles * a.nchunks) return;
+    const uint32_t chunk = work % a.nchunks, gt = work / a.nchunks;
+    const uint32_t tile = gt % a.ntiles, set = gt / a.ntiles;
+    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G) return;
+    uint32_t qidx[NO][8];
+    bool any = false;
+#pragma unroll
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t slot = (set * NO + o) * 8 + j;
+            const uint32_t qi = slot < a.ngroups * 4 ? a.dense_q[slot] : 0xffffffffu;
+            qidx[o][j] = qi;
+            any |= qi >= a.q0 && qi < a.q1;
+        }
+    if (!any) return;
+    const uint32_t row0 = a.row_lo + chunk * a.rows_per_item, row1 = min(a.row_hi, row0 + a.rows_per_item);
+    const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
+    const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
+    const uint32_t voff = lane * 16u;
+    const DenseLut *__restrict__ lut[NO];
+#pragma unroll
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P;
+    // plane[o][w][k]: bit k of the counters of mask word w (bit 8 b + j = query j of octet o against genome byte b of the word)
+    // With sixteen queries the second octet's upper planes -- touched once per sixteen rows -- live in LDS (9 KiB per wave, lane-
+    // major: no bank conflicts): both octets' counters in registers are 104 of them and left one wave per SIMD (282 registers;
+    // 188 and two waves this way.  Variants measured side by side on one box, 32 queries x 100,000 genomes: this one 55.3 ms;
+    // batches of four rows 57.4; all upper planes in LDS 55-58; three waves per SIMD forced, with 23 spilled words: 66.1).
+    constexpr uint32_t kRegOctets = NO == 2 ? 1 : NO;
+    __shared__ uint32_t s_up[NO == 2 ? 4 : 1][NO == 2 ? (kPlanes - 4) * 4 : 1][64];
+    uint32_t plane[NO][4][kPlanes];
+#pragma unroll
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w)
+#pragma unroll
+            for (uint32_t k = 0; k < kPlanes; ++k) {
+                if (o < kRegOctets || k < 4) plane[o][w][k] = 0;
+                else s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = 0;
+            }
+    constexpr uint32_t RB = 8;                                           // rows per batch of loads
+    for (uint32_t r = row0; r < row1; r += 16) {
+        uint32_t twosP[NO][4], foursP[NO][4], eightsP[NO][4];            // carries waiting for their partner
+#pragma unroll
+        for (uint32_t bt = 0; bt < 16 / RB; ++bt) {                       // a batch: its loads first (all in flight), then the work
+            uint4 d[RB];
+#pragma unroll
+            for (uint32_t u = 0; u < RB; ++u) d[u] = load_row16<false>(row_base(base, cbase, a.P_hot, r + bt * RB + u, a.ld) + voff);
+            // Two rows at a time (their tables: four scalar words per row and octet, asked for when their turn comes -- all
+            // rows' tables at once do not fit the scalar registers and end up as vector copies): masks of the pair's four words,
+            // into the ones; a carry waits for its partner of the same weight.  The fences keep the compiler from pooling the pairs.
+#pragma unroll
+            for (uint32_t pp = 0; pp < RB / 2; ++pp) {
+                const uint32_t pr = bt * (RB / 2) + pp;                   // pair 0 .. 7 of the sixteen rows
+                __builtin_amdgcn_sched_barrier(0);
+                uint4 tb[2][NO];
+#pragma unroll
+                for (uint32_t v = 0; v < 2; ++v) {
+                    const uint32_t rr = r + pr * 2 + v;                       // (inside the chunk: chunks are whole groups of sixteen rows)
+#pragma unroll
+                    for (uint32_t o = 0; o < (uint32_t)NO; ++o) tb[v][o] = *reinterpret_cast<const uint4 *>(lut[o] + rr);   // (a scalar load: rr is the wave's)
+                }
+#pragma unroll
+                for (uint32_t w = 0; w < 4; ++w) {
+                    uint32_t sel[2][4];
+#pragma unroll
+                    for (uint32_t v = 0; v < 2; ++v) {
+                        const uint4 &dd = d[pp * 2 + v];
+                        const uint32_t dw = w == 0 ? dd.x : w == 1 ? dd.y : w == 2 ? dd.z : dd.w;
+                        sel[v][0] = dw & 0x03030303u; sel[v][1] = (dw >> 2) & 0x03030303u; sel[v][2] = (dw >> 4) & 0x03030303u; sel[v][3] = (dw >> 6) & 0x03030303u;
+                    }
+#pragma unroll
+                    for (uint32_t o = 0; o < (uint32_t)NO; ++o) {
+                        uint32_t m[2];
+#pragma unroll
+                        for (uint32_t v = 0; v < 2; ++v)
+                            m[v] = __builtin_amdgcn_perm(0u, tb[v][o].x, sel[v][0]) & __builtin_amdgcn_perm(0u, tb[v][o].y, sel[v][1]) &
+                                   __builtin_amdgcn_perm(0u, tb[v][o].z, sel[v][2]) & __builtin_amdgcn_perm(0u, tb[v][o].w, sel[v][3]);
+                        uint32_t twos;
+                        csa(twos, plane[o][w][0], plane[o][w][0], m[0], m[1]);
+                        if (!(pr & 1u)) { twosP[o][w] = twos; continue; }
+                        uint32_t fours;
+                        csa(fours, plane[o][w][1], plane[o][w][1], twosP[o][w], twos);
+                        if (!(pr & 2u)) { foursP[o][w] = fours; continue; }
+                        uint32_t eights;
+                        csa(eights, plane[o][w][2], plane[o][w][2], foursP[o][w], fours);
+                        if (!(pr & 4u)) { eightsP[o][w] = eights; continue; }
+                        uint32_t carry;
+                        csa(carry, plane[o][w][3], plane[o][w][3], eightsP[o][w], eights);
+                        // one bit of weight sixteen per position: rippled through the upper planes
+#pragma unroll
+                        for (uint32_t k = 4; k < kPlanes; ++k) {
+                            if (o < kRegOctets) {
+                                const uint32_t t = plane[o][w][k];
+                                plane[o][w][k] = t ^ carry;
+                                carry &= t;
+                            } else {
+                                const uint32_t t = s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
+                                s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = t ^ carry;
+                                carry &= t;
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the counters' planes -> numbers, query by query: four genomes of a word at a time (low eight planes into byte counters,
+    // the upper planes into a second set), added to the score rows with integer atomics
+#pragma unroll
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t qi = qidx[o][j];
+            if (qi < a.q0 || qi >= a.q1) continue;                       // wave-uniform
+            uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)(qi - a.q0) * a.score_q_stride + lane * 16u;
+            const uint32_t g0 = tile * kTileBytes + lane * 16u;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t pl = (o < kRegOctets || k < 4) ? plane[o][w][k] : s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
+                    lo += ((pl >> j) & 0x01010101u) << k;
+                }
+#pragma unroll
+                for (uint32_t k = 8; k < kPlanes; ++k) {
+                    const uint32_t pl = o < kRegOctets ? plane[o][w][k] : s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
+                    hi += ((pl >> j) & 0x01010101u) << (k - 8);
+                }
+#pragma unroll
+                for (uint32_t b = 0; b < 4; ++b) {
+                    const uint32_t n = ((lo >> (8 * b)) & 0xffu) | (((hi >> (8 * b)) & 0xffu) << 8);
+                    if (n && g0 + w * 4 + b < a.G) atomicAdd(row + w * 4 + b, n);
+                }
+            }
+        }
+}
+
 }  // namespace mk

@@ -733,6 +733,53 @@ def test_runs_of_long_queries_against_oracle(hip):
         ix.close()
 
 
+@pytest.mark.parametrize("mode", ["2", "1", "0"])
+def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode):
+    """Whole-genome queries of one-byte fingerprints are scored by table lookups and bit-plane counters
+    (scan_dense_lut_kernel: sixteen queries per pass over the rows in mode 2, eight in mode 1; mode 0 is the
+    compare kernel, which two-byte fingerprints always take): 21 dense queries -- three octets, i.e. a sixteen-query wave,
+    an eight-query one and padding -- with empty partitions in some of them (sequences shorter than the sketch), a query
+    that is in no genome, short queries between them, 1,100 genomes (two row tiles, the second ragged); every score
+    against the oracle's, the hits against its filter."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("MIEKKI_DENSE_LUT", mode)
+    k, h = 31, 12
+    P = 1 << h
+    rng = np.random.default_rng(21)
+    base = [synth.genome_bases(900 + i, 0, 9_000) for i in range(24)]
+    # many genomes that share stretches with the queries, so that scores are spread over the whole range
+    seqs = []
+    for g in range(1100):
+        a, b = base[g % 24], base[(g * 7 + 3) % 24]
+        cut = int(rng.integers(0, 9000))
+        seqs.append(a[:cut] + b[cut:cut + int(rng.integers(0, 4000))])
+    seqs = [s_ if len(s_) >= k else base[0] for s_ in seqs]
+    o = orc.OracleMiekki(k, h, 8, 33, 10)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 33, 10)
+    try:
+        for i in range(0, len(seqs), 64):
+            ix.insert_sequences(seqs[i:i + 64])
+        qs = []
+        for j in range(21):
+            if j % 5 == 4:
+                qs.append(base[j][:P // 4 + k + 40 * j])              # barely dense: most partitions empty
+            else:
+                qs.append(base[j] + base[(j + 1) % 24][:3000])        # every partition active
+            if j % 7 == 0:
+                qs.append(base[j][100:900])                           # a short query in between
+        qs.append(synth.genome_bases(5000, 0, 9_000))                 # dense, matches nothing (but chance)
+        want = o.query_sequences(qs)
+        got = ix.query_sequences(qs)
+        np.testing.assert_array_equal(got, want)
+        hits, _ = ix.query(qs, 10, 5, 1.0)
+        for q in range(len(qs)):
+            w = o.filter_results(want[q], 10, 5, 1.0)
+            assert [(x.genome, x.matches) for x in hits[q]] == [(y[0], y[1]) for y in w], q
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("h,fpb,slots", [(20, 8, None), (18, 16, None), (18, 16, "300000"), (22, 8, None)])
 def test_mid_length_queries_against_oracle(hip, h, fpb, slots):
     """Long reads and contigs (more than 4,096 k-mers, fewer than 2^h / 4 and at most 2^18) are sketched through per-query

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void valu_kernel(uint32_t *out, uint32_t seed)
             // pair v_cmp + v_cndmask above costs 4.4 per instruction: the lone form is not reported)
             if (OP == 27) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
             if (OP == 28) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(w[i]) : "v"(w[(i + 1) % kChains]));
+            // the dense scan's table lookups (scan_dense_lut_kernel): an eight-entry byte table per instruction
+            if (OP == 29) asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(K));
+            if (OP == 30) asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(a[i]) : "s"(seed), "v"(K));
         }
     }
     uint32_t r = 0;
@@ -154,13 +157,14 @@ int main()
     const char *names[] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_lshlrev_b64", "v_alignbit_b32", "v_xor_b32",
                            "v_bfe_u32", "v_ffbh_u32", "v_and_or_b32", "v_cmp_lt_u64+cndmask", "v_mul_u32_u24", "v_mad_u32_u24",
                            "v_lshl_add_u32", "v_bitop3_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_and_b32", "v_or_b32", "v_mov_b32",
-                           "v_sub_u32", "v_add3_u32", "v_lshl_or_b32", "v_or3_b32", "v_min_u32", "v_cmp_ne_u32", "v_mbcnt_lo_u32_b32", "v_lshl_add_u64"};
+                           "v_sub_u32", "v_add3_u32", "v_lshl_or_b32", "v_or3_b32", "v_min_u32", "v_cmp_ne_u32", "v_mbcnt_lo_u32_b32", "v_lshl_add_u64",
+                           "v_perm_b32", "v_perm_b32 (one SGPR)"};
     void (*fn[])(int, uint32_t *) = {launch_valu<0>, launch_valu<1>, launch_valu<2>, launch_valu<3>, launch_valu<4>, launch_valu<5>, launch_valu<6>,
                                      launch_valu<7>, launch_valu<8>, launch_valu<9>, launch_valu<10>, launch_valu<11>, launch_valu<12>,
                                      launch_valu<13>, launch_valu<14>, launch_valu<15>, launch_valu<16>, launch_valu<17>, launch_valu<18>,
                                      launch_valu<19>, launch_valu<20>, launch_valu<21>, launch_valu<22>, launch_valu<23>, launch_valu<24>,
-                                     launch_valu<25>, launch_valu<27>, launch_valu<28>};
-    constexpr int kOps = 28;
+                                     launch_valu<25>, launch_valu<27>, launch_valu<28>, launch_valu<29>, launch_valu<30>};
+    constexpr int kOps = 30;
     printf("%-24s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD at 1, 2, 4, 8 waves per SIMD)\n", "op", "1", "2", "4", "8");
     for (int op = 0; op < kOps; ++op) {
         printf("%-24s", names[op]);
