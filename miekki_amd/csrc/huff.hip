@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void huff_decode_kernel(const uint8_t *__restr
     const uint64_t slot = (uint64_t)group * 64u + lane;
     if (!blk.out_len) { crc_out[slot] = 0; return; }
     // a block the table cannot serve, or one that points outside what was handed over: reported, nothing written
-    if (!table_ok || blk.out + blk.out_len > out_bytes || (blk.bit >> 3) >= payload_bytes) {
+    if (!table_ok || blk.out > out_bytes || blk.out_len > out_bytes - blk.out || (blk.bit >> 3) >= payload_bytes) {
         crc_out[slot] = 0;
         atomicAdd(bad, 1u);
         return;
