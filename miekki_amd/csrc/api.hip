@@ -522,7 +522,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
                    o_ent_off = carve(((uint64_t)nq + 1) * 8), o_entries = carve((qs->h_ent_off[nq] + 1) * 8),
                    o_nent = carve(((uint64_t)nq + 1) * 4), o_scan_n = carve(((uint64_t)nq + 1) * 4),
                    o_dense = carve(dense_bytes), o_dense_q = carve(qs->dense_q.size() * 4),
-                   o_lut = carve(c->W == 1 ? (uint64_t)((qs->dense_q.size() / 4 + 1) / 2) * c->P * 16 : 0),
+                   o_lut = carve((uint64_t)((qs->dense_q.size() / 4 + 1) / 2) * c->P * 16 * c->W),
                    o_split = carve(qs->split_room ? (uint64_t)nq * (qs->split_room + 1) * 4 : 0);
     if (transient && !c->qarena_busy) {
         if (at > c->qarena_cap) {
@@ -549,7 +549,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     if (!qs->dense_q.empty()) {
         qs->d_dense = qs->d_arena + o_dense;
         qs->d_dense_q = reinterpret_cast<uint32_t *>(qs->d_arena + o_dense_q);
-        qs->d_dense_lut = c->W == 1 ? reinterpret_cast<DenseLut *>(qs->d_arena + o_lut) : nullptr;
+        qs->d_dense_lut = reinterpret_cast<DenseLut *>(qs->d_arena + o_lut);
         MK_HIP(hipMemsetAsync(qs->d_dense, 0xFF, dense_bytes, c->stream));           // every slot starts empty
         MK_HIP(hipMemcpyAsync(qs->d_dense_q, qs->dense_q.data(), qs->dense_q.size() * 4, hipMemcpyHostToDevice,
                               c->stream));
@@ -629,7 +629,7 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
                 for (uint32_t j = 0; j < n; ++j) MK_TRY(launch_query_sketch_dense(c, qs, slot + j));
             slot += n;
         }
-        // one-byte fingerprints: the field tables the dense scan looks bytes up in (scan_dense_lut_kernel)
+        // the field tables the dense scan looks bytes up in (scan_dense_lut_kernel)
         if (qs->d_dense_lut) MK_TRY(launch_dense_lut(c, qs->d_dense, (uint32_t)(qs->dense_q.size() / 4), qs->d_dense_lut));
     }
     MK_TRY(launch_scan_counts(c, qs));

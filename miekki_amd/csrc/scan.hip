@@ -56,26 +56,31 @@ int launch_scan_slab(mk_ctx *c, const SlabArgs &a)
 int launch_dense_lut(mk_ctx *c, const uint8_t *d_dense, uint32_t ngroups, DenseLut *d_lut)
 {
     if (!ngroups) return MK_OK;
-    hipLaunchKernelGGL(dense_lut_kernel, dim3((c->P + 255) / 256, (ngroups + 1) / 2), dim3(256), 0, c->stream, d_dense, ngroups, c->P, c->empty, d_lut);
+    if (c->W == 1) hipLaunchKernelGGL(dense_lut_kernel<1>, dim3((c->P + 255) / 256, (ngroups + 1) / 2), dim3(256), 0, c->stream, d_dense, ngroups, c->P, c->empty, d_lut);
+    else           hipLaunchKernelGGL(dense_lut_kernel<2>, dim3((c->P + 255) / 256, (ngroups + 1) / 2), dim3(256), 0, c->stream, d_dense, ngroups, c->P, c->empty, d_lut);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
 {
-    // one-byte fingerprints: by table, eight or sixteen queries per pass over the matrix (MIEKKI_DENSE_LUT=0: the compare
-    // kernel below, which two-byte fingerprints always take -- a table over 65,536 values per row is no table)
+    // by table, eight or sixteen queries per pass over the matrix (MIEKKI_DENSE_LUT=0: the compare kernel below)
     const char *lut_env = getenv("MIEKKI_DENSE_LUT");          // (read per launch: the tests switch it)
     const int lut_mode = lut_env ? atoi(lut_env) : 2;
     // (the table kernel walks rows in groups of sixteen: every window and chunk of rows is a multiple of that for P >= 16)
-    if (c->W == 1 && a.lut && lut_mode > 0 && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
+    if (a.lut && lut_mode > 0 && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
         const uint32_t no = a.noctets >= 2 && lut_mode >= 2 ? 2 : 1;
         const uint64_t work = (uint64_t)((a.noctets + no - 1) / no) * a.ntiles * a.nchunks;
         if (work == 0) return MK_OK;
         if (work >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }
         const uint32_t blocks = (uint32_t)((work + 3) / 4);
-        if (no == 2) hipLaunchKernelGGL((scan_dense_lut_kernel<2>), dim3(blocks), dim3(256), 0, c->stream, a);
-        else         hipLaunchKernelGGL((scan_dense_lut_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        if (c->W == 1) {
+            if (no == 2) hipLaunchKernelGGL((scan_dense_lut_kernel<1, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
+            else         hipLaunchKernelGGL((scan_dense_lut_kernel<1, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        } else {
+            if (no == 2) hipLaunchKernelGGL((scan_dense_lut_kernel<2, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
+            else         hipLaunchKernelGGL((scan_dense_lut_kernel<2, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+        }
         MK_HIP(hipGetLastError());
         return MK_OK;
     }

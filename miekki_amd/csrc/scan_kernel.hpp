@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
     }
 }
 
-// ---------------------------------------------------------------- dense queries, one-byte fingerprints: by table
+// ---------------------------------------------------------------- dense queries by table (described for one-byte fingerprints;
+// two bytes: the last paragraph)
 // scan_dense_kernel above tests a row piece against every query on its own -- six vector instructions per four
 // comparisons, 48 per data word for its eight queries -- and is bound by exactly those (2.97e13 comparisons/s = 3.85 TB/s x
 // 8 queries, half of what HBM would carry).  Here a data word costs about a dozen for EIGHT queries:
@@ -450,29 +451,41 @@ __global__ __launch_bounds__(256) void scan_dense_kernel(const DenseArgs a)
 //    instructions each (v_bitop3: sum and majority) and one ripple through the upper planes: three instructions per row
 //    and word for all eight queries, where the byte counters above took three per query.
 // Matches are counted directly (no "active rows minus mismatches"): a query without a fingerprint at a row is in no table.
-struct DenseLut { uint32_t t[4]; };   // 16 bytes per (octet of queries, row): four 4-entry byte tables, one per 2-bit field of a byte
+// Two-byte fingerprints: a fingerprint matches where its low byte matches a query's low byte AND its high byte that query's
+// high byte -- two sets of tables per row and octet; a word's high bytes (1 and 3) select from the upper half of an eight-entry
+// table (the second source word of v_perm_b32) whose lower half is the low byte's; the byte-wise sets meet by m & (m >> 8).
+struct DenseLut { uint32_t t[4]; };   // four 4-entry byte tables, one per 2-bit field of a byte: 16 bytes per (octet of queries, row) at one
+                                      // byte per fingerprint; two of them at two bytes (the low byte's tables, then the high byte's)
 
+template <int W>
 __global__ __launch_bounds__(256) void dense_lut_kernel(const uint8_t *__restrict__ dense, uint32_t ngroups, uint32_t P, uint32_t empty,
                                                         DenseLut *__restrict__ lut)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x, octet = blockIdx.y;
     if (p >= P) return;
-    DenseLut t;
-    t.t[0] = t.t[1] = t.t[2] = t.t[3] = 0;
+    DenseLut t[W];
+#pragma unroll
+    for (uint32_t x = 0; x < (uint32_t)W; ++x) t[x].t[0] = t[x].t[1] = t[x].t[2] = t[x].t[3] = 0;
 #pragma unroll
     for (uint32_t half = 0; half < 2; ++half) {
         const uint32_t group = octet * 2 + half;
         if (group >= ngroups) break;
-        const uint32_t f4 = reinterpret_cast<const uint32_t *>(dense)[(uint64_t)group * P + p];   // four queries' fingerprints of this row
+        // four queries' fingerprints of this row
+        uint32_t f4[W];
+        if (W == 1) f4[0] = reinterpret_cast<const uint32_t *>(dense)[(uint64_t)group * P + p];
+        else { const uint2 v2 = reinterpret_cast<const uint2 *>(dense)[(uint64_t)group * P + p]; f4[0] = v2.x; f4[W - 1] = v2.y; }
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t v = (f4 >> (8 * j)) & 0xffu, bit = 1u << (half * 4 + j);
+            const uint32_t v = W == 1 ? (f4[0] >> (8 * j)) & 0xffu : (f4[j / 2] >> (16 * (j & 1u))) & 0xffffu, bit = 1u << (half * 4 + j);
             if (v == empty) continue;
 #pragma unroll
-            for (uint32_t f = 0; f < 4; ++f) t.t[f] |= bit << (8 * ((v >> (2 * f)) & 3u));
+            for (uint32_t x = 0; x < (uint32_t)W; ++x)
+#pragma unroll
+                for (uint32_t f = 0; f < 4; ++f) t[x].t[f] |= bit << (8 * ((v >> (8 * x + 2 * f)) & 3u));
         }
     }
-    lut[(uint64_t)octet * P + p] = t;
+#pragma unroll
+    for (uint32_t x = 0; x < (uint32_t)W; ++x) lut[((uint64_t)octet * P + p) * W + x] = t[x];
 }
 
 // sum and carry of three one-bit inputs per bit position
@@ -482,7 +495,7 @@ __device__ __forceinline__ void csa(uint32_t &carry, uint32_t &sum, uint32_t a, 
     sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);              // parity: one more
 }
 
-template <int NO>
+template <int W, int NO>
 __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
 {
     constexpr uint32_t kPlanes = 13;                                 // counts up to 8,191: the host cuts chunks of at most 8,176 rows
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     if (work >= nsets * a.ntiles * a.nchunks) return;
     const uint32_t chunk = work % a.nchunks, gt = work / a.nchunks;
     const uint32_t tile = gt % a.ntiles, set = gt / a.ntiles;
-    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G) return;
+    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     uint32_t qidx[NO][8];
     bool any = false;
 #pragma unroll
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     const uint32_t voff = lane * 16u;
     const DenseLut *__restrict__ lut[NO];
 #pragma unroll
-    for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P;
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P * W;
     // plane[o][w][k]: bit k of the counters of mask word w (bit 8 b + j = query j of octet o against genome byte b of the word)
     // With sixteen queries the second octet's upper planes -- touched once per sixteen rows -- live in LDS (9 KiB per wave, lane-
     // major: no bank conflicts): both octets' counters in registers are 104 of them and left one wave per SIMD (282 registers;
@@ -545,12 +558,15 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
             for (uint32_t pp = 0; pp < RB / 2; ++pp) {
                 const uint32_t pr = bt * (RB / 2) + pp;                   // pair 0 .. 7 of the sixteen rows
                 __builtin_amdgcn_sched_barrier(0);
-                uint4 tb[2][NO];
+                uint4 tb[2][NO][W];
 #pragma unroll
                 for (uint32_t v = 0; v < 2; ++v) {
                     const uint32_t rr = r + pr * 2 + v;                       // (inside the chunk: chunks are whole groups of sixteen rows)
 #pragma unroll
-                    for (uint32_t o = 0; o < (uint32_t)NO; ++o) tb[v][o] = *reinterpret_cast<const uint4 *>(lut[o] + rr);   // (a scalar load: rr is the wave's)
+                    for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+                        for (uint32_t x = 0; x < (uint32_t)W; ++x)
+                            tb[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)rr * W + x);   // (scalar loads: rr is the wave's)
                 }
 #pragma unroll
                 for (uint32_t w = 0; w < 4; ++w) {
@@ -560,14 +576,21 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                         const uint4 &dd = d[pp * 2 + v];
                         const uint32_t dw = w == 0 ? dd.x : w == 1 ? dd.y : w == 2 ? dd.z : dd.w;
                         sel[v][0] = dw & 0x03030303u; sel[v][1] = (dw >> 2) & 0x03030303u; sel[v][2] = (dw >> 4) & 0x03030303u; sel[v][3] = (dw >> 6) & 0x03030303u;
+                        // two-byte fingerprints: a word's high bytes (1 and 3) look their fields up in the high byte's tables -- the
+                        // upper half of an eight-entry table whose lower half is the low byte's
+                        if (W == 2) { sel[v][0] |= 0x04000400u; sel[v][1] |= 0x04000400u; sel[v][2] |= 0x04000400u; sel[v][3] |= 0x04000400u; }
                     }
 #pragma unroll
                     for (uint32_t o = 0; o < (uint32_t)NO; ++o) {
                         uint32_t m[2];
 #pragma unroll
-                        for (uint32_t v = 0; v < 2; ++v)
-                            m[v] = __builtin_amdgcn_perm(0u, tb[v][o].x, sel[v][0]) & __builtin_amdgcn_perm(0u, tb[v][o].y, sel[v][1]) &
-                                   __builtin_amdgcn_perm(0u, tb[v][o].z, sel[v][2]) & __builtin_amdgcn_perm(0u, tb[v][o].w, sel[v][3]);
+                        for (uint32_t v = 0; v < 2; ++v) {
+                            const uint4 lo = tb[v][o][0], hi = tb[v][o][W - 1];
+                            const uint32_t both = __builtin_amdgcn_perm(W == 2 ? hi.x : 0u, lo.x, sel[v][0]) & __builtin_amdgcn_perm(W == 2 ? hi.y : 0u, lo.y, sel[v][1]) &
+                                                  __builtin_amdgcn_perm(W == 2 ? hi.z : 0u, lo.z, sel[v][2]) & __builtin_amdgcn_perm(W == 2 ? hi.w : 0u, lo.w, sel[v][3]);
+                            // (two bytes: a fingerprint matches where its low byte's set and its high byte's meet; the result sits in the low byte's place)
+                            m[v] = W == 1 ? both : both & (both >> 8) & 0x00ff00ffu;
+                        }
                         uint32_t twos;
                         csa(twos, plane[o][w][0], plane[o][w][0], m[0], m[1]);
                         if (!(pr & 1u)) { twosP[o][w] = twos; continue; }
@@ -606,8 +629,9 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
         for (uint32_t j = 0; j < 8; ++j) {
             const uint32_t qi = qidx[o][j];
             if (qi < a.q0 || qi >= a.q1) continue;                       // wave-uniform
-            uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)(qi - a.q0) * a.score_q_stride + lane * 16u;
-            const uint32_t g0 = tile * kTileBytes + lane * 16u;
+            constexpr uint32_t NCNT = 16 / W;                             // genomes per lane
+            uint32_t *__restrict__ row = a.scores + (uint64_t)tile * a.score_tile_stride + (uint64_t)(qi - a.q0) * a.score_q_stride + lane * NCNT;
+            const uint32_t g0 = tile * (kTileBytes / W) + lane * NCNT;
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) {
                 uint32_t lo = 0, hi = 0;
@@ -622,9 +646,10 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                     hi += ((pl >> j) & 0x01010101u) << (k - 8);
                 }
 #pragma unroll
-                for (uint32_t b = 0; b < 4; ++b) {
+                for (uint32_t b = 0; b < 4; b += W) {                      // (two bytes: the counts sit in bytes 0 and 2 of the word)
                     const uint32_t n = ((lo >> (8 * b)) & 0xffu) | (((hi >> (8 * b)) & 0xffu) << 8);
-                    if (n && g0 + w * 4 + b < a.G) atomicAdd(row + w * 4 + b, n);
+                    const uint32_t gi = (w * 4 + b) / W;
+                    if (n && g0 + gi < a.G) atomicAdd(row + gi, n);
                 }
             }
         }

@@ -733,11 +733,12 @@ def test_runs_of_long_queries_against_oracle(hip):
         ix.close()
 
 
+@pytest.mark.parametrize("fpb", [8, 16])
 @pytest.mark.parametrize("mode", ["2", "1", "0"])
-def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode):
-    """Whole-genome queries of one-byte fingerprints are scored by table lookups and bit-plane counters
-    (scan_dense_lut_kernel: sixteen queries per pass over the rows in mode 2, eight in mode 1; mode 0 is the
-    compare kernel, which two-byte fingerprints always take): 21 dense queries -- three octets, i.e. a sixteen-query wave,
+def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode, fpb):
+    """Whole-genome queries are scored by table lookups and bit-plane counters (scan_dense_lut_kernel: sixteen queries
+    per pass over the rows in mode 2, eight in mode 1; mode 0 is the compare kernel; two-byte fingerprints look their low
+    and high bytes up in two sets of tables and match where both do): 21 dense queries -- three octets, i.e. a sixteen-query wave,
     an eight-query one and padding -- with empty partitions in some of them (sequences shorter than the sketch), a query
     that is in no genome, short queries between them, 1,100 genomes (two row tiles, the second ragged); every score
     against the oracle's, the hits against its filter."""
@@ -754,9 +755,9 @@ def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode):
         cut = int(rng.integers(0, 9000))
         seqs.append(a[:cut] + b[cut:cut + int(rng.integers(0, 4000))])
     seqs = [s_ if len(s_) >= k else base[0] for s_ in seqs]
-    o = orc.OracleMiekki(k, h, 8, 33, 10)
+    o = orc.OracleMiekki(k, h, fpb, 33, 10)
     o.insert_sequences(seqs)
-    ix = hip.Miekki(k, h, 8, 33, 10)
+    ix = hip.Miekki(k, h, fpb, 33, 10)
     try:
         for i in range(0, len(seqs), 64):
             ix.insert_sequences(seqs[i:i + 64])
