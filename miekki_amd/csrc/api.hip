@@ -494,13 +494,27 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr;
     qs->d_arena = nullptr; qs->split_in_arena = false; qs->split_room = 0;
     qs->h_off.assign(nq + 1, 0); qs->h_ent_off.assign(nq + 1, 0);
+    // Long queries that activate a large share of the partitions (whole genomes, -A) keep a dense fingerprint vector
+    // instead of an entry list and are scored by passes over ALL rows, sixteen queries per pass (scan_dense_lut_kernel).  From
+    // which share on that is cheaper depends on how many there are to share a pass: a pass costs what 16 x 0.115 P entries cost
+    // the sparse scan (27.7 ms per 105 GB against 7.1 TB/s of entries), i.e. a query with more than P / 8 k-mers (0.118 P
+    // active partitions) is better off dense when a pass is full, and one with P / 4 (0.22 P) even when it has a pass nearly
+    // to itself.  (MIEKKI_DENSE_DIV sets the divisor; the vectors and tables of the dense queries stay below 8 GiB.)
+    uint64_t dense_div = 4;
+    {
+        uint64_t n8 = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
+            n8 += nk > kShortMax && nk >= c->P / 8 ? 1 : 0;
+        }
+        if (n8 >= 16 && n8 * c->P * c->W * 3 <= (8ull << 30)) dense_div = 8;       // (vector: P W bytes per query; tables: 2 P W per query)
+        if (const char *e = getenv("MIEKKI_DENSE_DIV")) dense_div = (uint64_t)std::max(1, atoi(e));
+    }
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
         if (lens[q] >= (1ull << 40)) { set_error("query too long"); return MK_ERR_ARG; }
         qs->h_off[q + 1] = qs->h_off[q] + lens[q];
-        // long queries that activate a large share of the partitions (whole genomes, -A)
-        // keep a dense fingerprint vector instead of an entry list
-        const bool dense = nk > kShortMax && nk >= c->P / 4;
+        const bool dense = nk > kShortMax && nk >= c->P / dense_div;
         qs->h_ent_off[q + 1] = qs->h_ent_off[q] + (dense ? 0 : std::min<uint64_t>(nk, c->P));
         if (dense) qs->dense_q.push_back(q);
         else if (nk > kShortMax) qs->long_q.push_back(q);

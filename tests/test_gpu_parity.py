@@ -701,11 +701,16 @@ def test_compact_device_merge_is_the_host_heap(hip):
         ix.close()
 
 
-def test_runs_of_long_queries_against_oracle(hip):
+@pytest.mark.parametrize("dense_div", ["4", None])
+def test_runs_of_long_queries_against_oracle(hip, monkeypatch, dense_div):
     """Queries beyond the in-LDS sketch (more than 4,096 k-mers) that sit next to each other in a
     batch are sketched together (binned K1 + one gate-and-append launch); loners go one by one.
-    Mixed with short queries, a too-long-for-sparse (dense) one and a repetitive one."""
+    Mixed with short queries, a too-long-for-sparse (dense) one and a repetitive one.  With sixteen and more queries above
+    2^h / 8 k-mers in a set these go the dense way by default (a full pass of sixteen is cheaper than their entry lists):
+    MIEKKI_DENSE_DIV=4 keeps them on the long sparse path, which is what this test is about; the default form is compared too."""
     from oracle import oracle as orc
+    if dense_div:
+        monkeypatch.setenv("MIEKKI_DENSE_DIV", dense_div)
     k, h = 31, 15
     seqs = [synth.genome_bases(400 + i, 0, 150_000) for i in range(12)]
     o = orc.OracleMiekki(k, h, 8, 33, 10)
