@@ -312,6 +312,12 @@ def test_index_columns_inflated_on_the_gpu(workdirs, golden_dir, name):
         assert (b"columns inflated on the GPU" in r.stderr) == (how == "gpu"), r.stderr.decode(errors="replace")
         outs[how] = (d / f"out_{how}.txt").read_bytes()
     assert outs["gpu"] == outs["host"] == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    # the same into a matrix most of whose rows live in host memory (1 MiB of HBM budget): the inflated rows are laid out on both sides
+    env = dict(os.environ, MIEKKI_DEVICES="0", MIEKKI_IO_TRACE="1", MIEKKI_HBM_MATRIX_MIB="1")
+    r = subprocess.run([CLI, "-i", "idx_h.gz", "-a", "queries.fa", "-o", "out_cold.txt", "-t", "2"], cwd=d, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, env=env)
+    assert r.returncode == 0 and b"columns inflated on the GPU" in r.stderr, r.stderr.decode(errors="replace")
+    assert (d / "out_cold.txt").read_bytes() == outs["gpu"]
     # damage: one bit in the middle of the second member's deflate stream (the first member is the 39-byte head)
     raw = bytearray((d / "idx_h.gz").read_bytes())
     xlen0, pay0 = int.from_bytes(raw[10:12], "little"), int.from_bytes(raw[16:24], "little")
