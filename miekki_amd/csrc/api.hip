@@ -855,6 +855,7 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
         d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
         d.lut = qs->d_dense_lut; d.noctets = (d.ngroups + 1) / 2;
+        { const char *e = getenv("MIEKKI_DENSE_SETS_APART"); d.sets_apart = e && atoi(e) ? 1u : 0u; }
         d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
         ScopedTimer t(c, 1);
         return launch_scan_dense(c, d);

@@ -440,6 +440,7 @@ struct DenseArgs {
     const uint32_t *dense_q;       // [group][4] set index of each slot or 0xffffffff
     const DenseLut *lut;    // one-byte fingerprints: [octet = two groups][P] field tables (scan_kernel.hpp), or null
     uint32_t noctets;
+    uint32_t sets_apart;           // 1: every set of queries is a pass of its own (grid order); 0: the sets of a (tile, chunk) are neighbours
     uint32_t q0, q1;               // set range the score buffer covers
     uint32_t *scores;
     uint64_t score_tile_stride, score_q_stride;

@@ -504,8 +504,12 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     const uint32_t work = blockIdx.x * 4u + wave;
     const uint32_t nsets = (a.noctets + NO - 1) / NO;
     if (work >= nsets * a.ntiles * a.nchunks) return;
-    const uint32_t chunk = work % a.nchunks, gt = work / a.nchunks;
-    const uint32_t tile = gt % a.ntiles, set = gt / a.ntiles;
+    // the sets of one (tile, chunk of rows) are neighbours in the grid -- waves of one workgroup: they walk the same rows at the
+    // same time, and all but the first find them in the CU's cache instead of asking HBM again (MIEKKI_DENSE_SETS_APART=1: a
+    // set is a pass of its own over the matrix, as before)
+    uint32_t chunk, tile, set;
+    if (a.sets_apart) { chunk = work % a.nchunks; const uint32_t gt = work / a.nchunks; tile = gt % a.ntiles; set = gt / a.ntiles; }
+    else { set = work % nsets; const uint32_t ct = work / nsets; chunk = ct % a.nchunks; tile = ct / a.nchunks; }
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     uint32_t qidx[NO][8];
     bool any = false;
@@ -544,6 +548,13 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                 else s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = 0;
             }
     constexpr uint32_t RB = 8;                                           // rows per batch of loads
+    uint4 tbn[2][NO][W];                                                 // the tables of the pair of rows that comes next
+#pragma unroll
+    for (uint32_t v = 0; v < 2; ++v)
+#pragma unroll
+        for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+            for (uint32_t x = 0; x < (uint32_t)W; ++x) tbn[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)(row0 + v) * W + x);
     for (uint32_t r = row0; r < row1; r += 16) {
         uint32_t twosP[NO][4], foursP[NO][4], eightsP[NO][4];            // carries waiting for their partner
 #pragma unroll
@@ -558,16 +569,26 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
             for (uint32_t pp = 0; pp < RB / 2; ++pp) {
                 const uint32_t pr = bt * (RB / 2) + pp;                   // pair 0 .. 7 of the sixteen rows
                 __builtin_amdgcn_sched_barrier(0);
+                // this pair's tables were asked for a pair ago (scalar loads: a row is the wave's); the next pair's are asked for now,
+                // so that their latency passes under this pair's work (a wave that carries sixteen queries has one neighbour on its SIMD)
                 uint4 tb[2][NO][W];
 #pragma unroll
-                for (uint32_t v = 0; v < 2; ++v) {
-                    const uint32_t rr = r + pr * 2 + v;                       // (inside the chunk: chunks are whole groups of sixteen rows)
+                for (uint32_t v = 0; v < 2; ++v)
 #pragma unroll
                     for (uint32_t o = 0; o < (uint32_t)NO; ++o)
 #pragma unroll
-                        for (uint32_t x = 0; x < (uint32_t)W; ++x)
-                            tb[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)rr * W + x);   // (scalar loads: rr is the wave's)
+                        for (uint32_t x = 0; x < (uint32_t)W; ++x) tb[v][o][x] = tbn[v][o][x];
+                {
+                    const uint32_t nr = min(r + pr * 2 + 2, row1 - 2);       // (the pair after the chunk's last: the last once more, unused)
+#pragma unroll
+                    for (uint32_t v = 0; v < 2; ++v)
+#pragma unroll
+                        for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+                            for (uint32_t x = 0; x < (uint32_t)W; ++x)
+                                tbn[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)(nr + v) * W + x);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (uint32_t w = 0; w < 4; ++w) {
                     uint32_t sel[2][4];
