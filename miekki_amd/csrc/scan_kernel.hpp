@@ -505,8 +505,8 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     const uint32_t nsets = (a.noctets + NO - 1) / NO;
     if (work >= nsets * a.ntiles * a.nchunks) return;
     // the sets of one (tile, chunk of rows) are neighbours in the grid -- waves of one workgroup: they walk the same rows at the
-    // same time, and all but the first find them in the CU's cache instead of asking HBM again (MIEKKI_DENSE_SETS_APART=1: a
-    // set is a pass of its own over the matrix, as before)
+    // same time, and all but the first find them in a cache (the Infinity Cache mostly: profiles/r4_pmc_dense.txt) instead of
+    // waiting for HBM again (MIEKKI_DENSE_SETS_APART=1: a set is a pass of its own over the matrix, as before)
     uint32_t chunk, tile, set;
     if (a.sets_apart) { chunk = work % a.nchunks; const uint32_t gt = work / a.nchunks; tile = gt % a.ntiles; set = gt / a.ntiles; }
     else { set = work % nsets; const uint32_t ct = work / nsets; chunk = ct % a.nchunks; tile = ct / a.nchunks; }
