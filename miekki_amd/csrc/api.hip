@@ -891,14 +891,16 @@ static int ensure_partials(mk_ctx *c, uint64_t bytes)
 
 static int qset_scan_slab(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1)
 {
+    const uint32_t rows_per_range = qs->S ? c->P / qs->S : c->P;
+    // (ranges cut by count, or no ranges at all: cold rows are read in place below -- as they are, so unpack them BEFORE
+    // the matrix's addresses are taken: need_raw_cold gives the cold rows a new home)
+    if (has_cold(c) && (qs->chunk || qs->S < 2 || rows_per_range == 0)) MK_TRY(need_raw_cold(c));
     SlabArgs a;
     a.M = c->d_M; a.Mc = mat_ref(c).cold_m; a.P_hot = c->P_hot; a.ld = c->ld; a.G = c->G; a.ntiles = ntiles_of(c);
     a.nq = q1 - q0; a.q_begin = q0; a.S = qs->S; a.r_begin = 0; a.r_count = qs->S;
     a.entries = qs->d_entries; a.ent_off = qs->d_ent_off; a.split = qs->d_split; a.partials = c->d_partials;
     a.chunk = qs->chunk; a.nent = qs->d_scan_n;
     c->stats.scan_slab_launches++;
-    const uint32_t rows_per_range = qs->S ? c->P / qs->S : c->P;
-    if (has_cold(c) && (qs->chunk || qs->S < 2 || rows_per_range == 0)) MK_TRY(need_raw_cold(c));   // (read in place below)
     if (!has_cold(c) || qs->chunk || qs->S < 2 || rows_per_range == 0) {
         // everything in HBM -- or ranges cut by count (small sets), which do not map to partition
         // ranges: cold rows, if any, are then read in place over PCIe

@@ -207,3 +207,54 @@ def test_independent_genomes_are_left_unpacked(hip, monkeypatch):
         assert ix.compress_index() == (0, 0)
     finally:
         ix.close()
+
+
+def test_persistent_set_across_reserve_and_compress(hip, monkeypatch):
+    """a query set prepared for the small-set schedule (pieces cut by count) while every row is in HBM, then
+    mk_reserve sends rows to host memory (no new index generation: the set is not prepared again), mk_index_compress packs
+    them, and the same set runs again: the scan must unpack BEFORE it takes the matrix's addresses -- it read rows beyond
+    the hot ones out of the hot allocation.  Checked against the oracle's filter over the oracle's score rows."""
+    import ctypes as C
+    import torch
+    from oracle import oracle as orc
+    from miekki_amd import lib as L, distributed as mkd
+    k, h, G, strains, rate, L_ = 21, 10, 240, 20, 1000, 9000
+    monkeypatch.setenv("MIEKKI_HBM_MATRIX_MIB", "1")             # 1,024 rows x 1 KiB fit; at 2 KiB a row (after the reserve) 512 do
+    seqs = [synth.strain_device(g, strains, rate, 0, L_) for g in range(G)]
+    o = orc.OracleMiekki(k, h, 8, 32, 10)
+    o.insert_sequences(seqs)
+    ix = hip.Miekki(k, h, 8, 32, 10)
+    lib = L.load_library()
+    qset = C.c_void_p()
+    try:
+        ix.insert_synthetic_strains(0, G, L_, strains, rate)
+        assert ix.compress_index() == (0, 0)                       # nothing cold yet
+        qs = [seqs[(7 * q) % G][50 * q:50 * q + 700 + 20 * q] for q in range(24)]
+        rows = o.query_sequences(qs)
+        ptrs, lens = L.seq_arrays(qs)
+        L.check(lib.mk_qset_upload(ix._h, ptrs, lens, len(qs), C.byref(qset)))
+        cap, nres = 64, 10
+        d_count = torch.zeros(len(qs), dtype=torch.int32, device="cuda")
+        d_cand = torch.zeros(len(qs) * cap * 24, dtype=torch.uint8, device="cuda")
+
+        def run():
+            L.check(lib.mk_qset_run(ix._h, qset, nres, 3, 5.0, cap, d_count.data_ptr(), d_cand.data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            hits, over = mkd.merge_candidates(d_count.cpu().numpy()[None], d_cand.cpu().numpy()[None], cap, nres)
+            assert not over.any()
+            for q, row in enumerate(rows):
+                want = o.filter_results(row, nres, 3, 5.0)
+                assert [(int(x["genome"]), int(x["matches"])) for x in hits[q]] == [(w[0], w[1]) for w in want], q
+        run()
+        before = ix.stats()["scan_slab_launches"]
+        ix.reserve(1100)                                           # pitch 2 KiB: rows [512, 1024) leave for host memory
+        raw, packed = ix.compress_index()
+        assert raw > 0 and packed < raw, (raw, packed)
+        run()                                                      # the same prepared set over packed cold rows
+        assert ix.stats()["scan_slab_launches"] > before
+        assert ix.compress_index()[1] == packed                    # (the in-place read unpacked them; packing again is the same bytes)
+        run()
+    finally:
+        if qset:
+            lib.mk_qset_free(ix._h, qset)
+        ix.close()
