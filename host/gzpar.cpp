@@ -233,14 +233,8 @@ ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads
     if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && pread(fd, h, kHeader, 0) == (ssize_t)kHeader && is_mk_header(h)) {
         fd_ = fd;
         file_size_ = (uint64_t)st.st_size;
-        // MIEKKI_LOAD_IO=mmap inflates the members straight out of a mapping of the file instead of reading them into
-        // buffers first: level with pread on the GPU boxes while it runs (20 - 25 GB/s with sixteen threads), but taking a
-        // 76 GB mapping down again costs 2.5 s at the end -- not the default
-        const char *e = getenv("MIEKKI_LOAD_IO");
-        if (e && !strcmp(e, "mmap")) {
-            void *m = mmap(nullptr, (size_t)file_size_, PROT_READ, MAP_SHARED, fd, 0);
-            if (m != MAP_FAILED) map_ = (const uint8_t *)m;
-        }
+        // (members are read with pread into buffers; inflating them out of a mapping of the file was level while it ran and
+        // cost 2.5 s to take a 76 GB mapping down again: profiles/r4_cli_c3.txt)
     } else {
         close(fd);
         gz_ = gzopen(path.c_str(), "rb");                        // gzip of any make, or plain bytes
@@ -251,7 +245,6 @@ ParallelGzipReader::ParallelGzipReader(const std::string &path, unsigned threads
 ParallelGzipReader::~ParallelGzipReader()
 {
     for (auto &j : jobs_) if (j->th.joinable()) j->th.join();
-    if (map_) munmap((void *)map_, (size_t)file_size_);
     if (fd_ >= 0) close(fd_);
     if (gz_) gzclose(gz_);
 }
@@ -319,20 +312,15 @@ bool ParallelGzipReader::seek_member(uint64_t begin)
 bool ParallelGzipReader::read_raw(uint64_t at, void *dst, size_t n) const
 {
     if (fd_ < 0 || at + n > file_size_) return false;
-    if (map_) { memcpy(dst, map_ + at, n); return true; }
     return pread_all(fd_, (uint8_t *)dst, n, at);
 }
 
-void ParallelGzipReader::inflate_member(Job *j, int fd, const uint8_t *map)
+void ParallelGzipReader::inflate_member(Job *j, int fd)
 {
     const size_t payload = (size_t)j->m.payload, isize = j->m.isize;
-    std::unique_ptr<uint8_t[]> buf;
-    const uint8_t *src = map ? map + j->m.at : nullptr;
-    if (!src) {
-        buf.reset(new uint8_t[payload + 16]);
-        if (!pread_all(fd, buf.get(), payload, j->m.at)) { j->bad = true; return; }
-        src = buf.get();
-    }
+    std::unique_ptr<uint8_t[]> buf(new uint8_t[payload + 16]);
+    if (!pread_all(fd, buf.get(), payload, j->m.at)) { j->bad = true; return; }
+    const uint8_t *src = buf.get();
     size_t used = 0, got = 0;
     if (inflate_raw(src, payload, j->dst, isize, &used, &got) != FZ_OK || got != isize || used != payload) {
         // whatever fastz does not take goes to zlib, which then decides what the member is worth (one spare byte of room:
@@ -355,8 +343,7 @@ void ParallelGzipReader::start(std::unique_ptr<Job> j)
 {
     Job *raw = j.get();
     const int fd = fd_;
-    const uint8_t *map = map_;
-    raw->th = std::thread([raw, fd, map] { inflate_member(raw, fd, map); });
+    raw->th = std::thread([raw, fd] { inflate_member(raw, fd); });
     jobs_.push_back(std::move(j));
 }
 
@@ -422,8 +409,7 @@ size_t ParallelGzipReader::read_some(void *dst, size_t n)
                 done += m.isize;
                 Job *raw = j.get();
                 const int fd = fd_;
-                const uint8_t *map = map_;
-                raw->th = std::thread([raw, fd, map] { inflate_member(raw, fd, map); });
+                raw->th = std::thread([raw, fd] { inflate_member(raw, fd); });
                 direct.push_back(std::move(j));
                 if (direct.size() >= nthreads_) {
                     direct.front()->th.join();

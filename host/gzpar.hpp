@@ -123,12 +123,11 @@ private:
         std::thread th;
         bool bad = false;
     };
-    static void inflate_member(Job *j, int fd, const uint8_t *map);
+    static void inflate_member(Job *j, int fd);
     bool next_member(Member &m);         // the member at scan_; false at the clean end of the file or on error
     void prefetch();
     void start(std::unique_ptr<Job> j);
     int fd_ = -1;                        // "MK" member mode
-    const uint8_t *map_ = nullptr;       // the whole file, mapped (members are inflated from where they lie)
     gzFile gz_ = nullptr;                // generic mode
     unsigned nthreads_;
     uint64_t scan_ = 0, file_size_ = 0;

@@ -197,11 +197,9 @@ struct Driver {
         // readers parse into pinned buffers, three device batches ahead; the append of one
         // batch returns as soon as its copy is done, so parsing, copying and sketching overlap
         // ... and pack as they parse (2 bits per base, mk_index_append_packed): a quarter of the bytes to buffer and
-        // to move over PCIe, and the device skips its own packing pass.  MIEKKI_INGEST=chars keeps the characters.
-        static const bool as_chars = [] { const char *e = getenv("MIEKKI_INGEST"); return e && string(e) == "chars"; }();
+        // to move over PCIe, and the device skips its own packing pass.
         PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 3 * 64,
-                                  !as_chars);
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 3 * 64, true);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         auto flush = [&]() {

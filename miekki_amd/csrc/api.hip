@@ -499,7 +499,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
     // which share on that is cheaper depends on how many there are to share a pass: a pass costs what 16 x 0.115 P entries cost
     // the sparse scan (27.7 ms per 105 GB against 7.1 TB/s of entries), i.e. a query with more than P / 8 k-mers (0.118 P
     // active partitions) is better off dense when a pass is full, and one with P / 4 (0.22 P) even when it has a pass nearly
-    // to itself.  (MIEKKI_DENSE_DIV sets the divisor; the vectors and tables of the dense queries stay below 8 GiB.)
+    // to itself.  (The vectors and tables of the dense queries stay below 8 GiB.)
     uint64_t dense_div = 4;
     {
         uint64_t n8 = 0;
@@ -508,7 +508,6 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
             n8 += nk > kShortMax && nk >= c->P / 8 ? 1 : 0;
         }
         if (n8 >= 16 && n8 * c->P * c->W * 3 <= (8ull << 30)) dense_div = 8;       // (vector: P W bytes per query; tables: 2 P W per query)
-        if (const char *e = getenv("MIEKKI_DENSE_DIV")) dense_div = (uint64_t)std::max(1, atoi(e));
     }
     for (uint32_t q = 0; q < nq; ++q) {
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
@@ -606,12 +605,10 @@ static int qset_sketch_only(mk_ctx *c, mk_qset *qs)
         // kernels do not take (h > 22) go one by one through the atomic kernel
         MK_TRY(ensure_build_scratch(c, 0, 0, false));
         // long reads and contigs (up to 2^18 k-mers): per-query hash tables, O(length) -- no 2^h table is touched
-        // (MIEKKI_MID_SKETCH=0 keeps them on the table path: tests compare the two)
-        static const bool mid_on = [] { const char *e = getenv("MIEKKI_MID_SKETCH"); return !e || atoi(e) != 0; }();
         std::vector<uint32_t> mid, rest;
         for (uint32_t q : qs->long_q) {
             const uint64_t len = qs->h_off[q + 1] - qs->h_off[q];
-            (mid_on && query_is_mid_length(c, len - c->p.k) ? mid : rest).push_back(q);
+            (query_is_mid_length(c, len - c->p.k) ? mid : rest).push_back(q);
         }
         // (MIEKKI_MID_SLOTS: fewer slots per round than the scratch holds -- the tests make small sets take several rounds)
         static const uint64_t slot_cap = [] { const char *e = getenv("MIEKKI_MID_SLOTS"); return e ? (uint64_t)std::max(1L, atol(e)) : ~0ull; }();
@@ -855,7 +852,6 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
         d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
         d.lut = qs->d_dense_lut; d.noctets = (d.ngroups + 1) / 2;
-        { const char *e = getenv("MIEKKI_DENSE_SETS_APART"); d.sets_apart = e && atoi(e) ? 1u : 0u; }
         d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;
         ScopedTimer t(c, 1);
         return launch_scan_dense(c, d);
@@ -870,11 +866,6 @@ static uint32_t chunk_queries_slab(const mk_ctx *c, uint32_t nq, uint32_t S)
     const uint64_t budget = chunk_budget(16ull << 30, c->partials_cap);
     uint64_t per = std::max<uint64_t>(1, budget / std::max<uint64_t>(partial_bytes_per_query(c, S), 1));
     per = std::min<uint64_t>(per, 0x7ffffff0ull / std::max<uint64_t>((uint64_t)ntiles_of(c) * S, 1));   // one launch
-    // The waves in flight share one slab of the matrix AND the entry lists of the chunk's queries for that range
-    // (~0.9 KB each): with very many queries per launch those lists (90 MB for 100,000 queries) crowd the slab out
-    // of the Infinity Cache.  MIEKKI_SLAB_MAX_QUERIES bounds the chunk (tuning knob).
-    static const uint64_t max_q = [] { const char *e = getenv("MIEKKI_SLAB_MAX_QUERIES"); return e ? (uint64_t)std::max(1L, atol(e)) : (uint64_t)kSlabMaxQueries; }();
-    per = std::min<uint64_t>(per, max_q);
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 1), std::max<uint32_t>(nq, 1));
 }
 
@@ -1051,8 +1042,7 @@ int mk_create(const mk_params *p, mk_ctx **out)
     MK_HIP(hipStreamCreateWithFlags(&c->front_stream, hipStreamNonBlocking));
     MK_HIP(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     {
-        const char *e = getenv("MIEKKI_COPY_STREAMS");             // all copy streams of a packed append, this one included
-        c->n_copy_extra = std::max(0, std::min(mk_ctx::kCopyExtra, (e ? atoi(e) : kDefaultCopyStreams) - 1));
+        c->n_copy_extra = kCopyStreams - 1;                           // all copy streams of a packed append, this one included
         for (int i = 0; i < c->n_copy_extra; ++i) {
             MK_HIP(hipStreamCreateWithFlags(&c->copy_extra[i], hipStreamNonBlocking));
             MK_HIP(hipEventCreateWithFlags(&c->ev_extra[i], hipEventDisableTiming));

@@ -35,7 +35,6 @@ constexpr uint32_t kPer = 16;              // consecutive k-mers per thread
 constexpr uint32_t kBin = 12;              // log2 partitions per bin = entries of the reduce table
 constexpr uint32_t kBins = 1024;           // most bins (h <= 22)
 constexpr uint32_t kAllFlagged = 127;      // meta word: the run's flagged count when it is >= this, i.e. "all of them"
-constexpr uint32_t kScatterLdsFloor = 0;   // bytes of LDS a scatter workgroup asks for at least (0: what it needs), see launch_build_front
 }  // namespace
 
 // ---------------------------------------------------------------- characters -> packed
@@ -717,7 +716,6 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     // whatever h -- were measured at -h 17: 2^9-partition bins 47.0k sketches/s, 2^10 52.8k, 2^11 55.1k, 2^12 54.2k; and at
     // -h 20 2^10 32.4k, 2^11 40.8k against 53.5k: a reduce workgroup's LDS table wants many entries per lane.)
     bs.low_bits = std::min<uint32_t>(kBin, c->p.h);
-    if (const char *e = getenv("MIEKKI_BUILD_LOW_BITS")) bs.low_bits = std::min<uint32_t>(std::min<uint32_t>(kBin, c->p.h), (uint32_t)std::max(1, atoi(e)));   // tuning knob
     bs.nbins = c->P >> bs.low_bits;
     if (bs.nbins > kBins || max_len >= (1ULL << 35) || max_nk == 0) return MK_OK;
     bs.nwg = (uint32_t)((max_nk + kSeg - 1) / kSeg);
@@ -864,11 +862,6 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
     const size_t stage_bytes = (kSeg + 4) * 4 + (c->W == 2 ? kSeg + 16 : 0);
     size_t lds = stage_bytes + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
-    // How many scatter workgroups a CU takes decides whether the reduce kernel of the batch before (the other stream) finds
-    // room beside them: by itself the scatter kernel fills every CU with its small workgroups and the two kernels take
-    // turns.  A larger LDS request per workgroup leaves LDS -- and wave slots -- for reduce workgroups.
-    static const size_t lds_floor = [] { const char *e = getenv("MIEKKI_SCATTER_LDS_KIB"); return e ? (size_t)std::max(0, atoi(e)) << 10 : (size_t)kScatterLdsFloor; }();
-    if (!for_queries) lds = std::max(lds, std::min<size_t>(lds_floor, 64u << 10));
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, st ? st : c->front_stream, d_codes,     \
                        d_except,                                                                                                \

@@ -335,8 +335,7 @@ int mk_qset_run_compact_gather(mk_ctx *c, mk_comm *m, mk_qset *qs, uint32_t nres
     MK_HIP(hipSetDevice(c->p.device));
     const uint32_t nq = qs->nq;
     const uint64_t rstride = (uint64_t)cap + 1;
-    static const uint32_t blocks_wanted = [] { const char *e = getenv("MIEKKI_EXCHANGE_BLOCKS"); return (uint32_t)std::max(1, e ? atoi(e) : 4); }();
-    const uint32_t nblocks = nq >= 4096 ? blocks_wanted : 1;       // small sets: one ncclGather
+    const uint32_t nblocks = nq >= 4096 ? 4u : 1u;                 // small sets: one ncclGather
     const uint32_t block = std::max<uint32_t>(1, (nq + nblocks - 1) / nblocks);
     // the exchange may start once everything queued so far is done (the merge that read d_recv last, say)
     MK_HIP(hipEventRecord(m->ev_enter, c->stream));

@@ -33,9 +33,8 @@ constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batc
 constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
 constexpr uint64_t kEmptyKey = ~0ULL;
 constexpr int kPosBits = 40;                      // a minimum key in a table: fingerprint << 40 | position
-constexpr int kDefaultCopyStreams = 2;            // copy streams of a packed append (MIEKKI_COPY_STREAMS; see mk_ctx::copy_extra)
+constexpr int kCopyStreams = 2;                   // copy streams of a packed append (see mk_ctx::copy_extra; three: 30.9k sketches/s, four: 37.8k, two: 39.0k)
 constexpr uint32_t kBloomRegionLog2 = 16;          // cells per region of the Bloom sweep (bloom_sweep_kernel)
-constexpr uint32_t kSlabMaxQueries = 1u << 30;   // queries per launch of the slab schedule (no bound by default; see chunk_queries_slab)
 
 // packed query-sketch entry: partition in the low word, fingerprint in the high word
 __host__ __device__ inline uint64_t make_entry(uint32_t p, uint32_t fp) { return (uint64_t)p | ((uint64_t)fp << 32); }
@@ -136,7 +135,7 @@ struct mk_ctx {
     hipEvent_t ev_copy;
     // further copy streams for batches that arrive as many separate buffers (mk_index_append_packed: one per sequence,
     // ~1 MB each): a DMA engine spends as long on starting such a copy as on moving it, several engines overlap that
-    static constexpr int kCopyExtra = 3;
+    static constexpr int kCopyExtra = mk::kCopyStreams - 1;
     hipStream_t copy_extra[kCopyExtra];
     hipEvent_t ev_extra[kCopyExtra];
     int n_copy_extra;
@@ -440,7 +439,6 @@ struct DenseArgs {
     const uint32_t *dense_q;       // [group][4] set index of each slot or 0xffffffff
     const DenseLut *lut;    // one-byte fingerprints: [octet = two groups][P] field tables (scan_kernel.hpp), or null
     uint32_t noctets;
-    uint32_t sets_apart;           // 1: every set of queries is a pass of its own (grid order); 0: the sets of a (tile, chunk) are neighbours
     uint32_t q0, q1;               // set range the score buffer covers
     uint32_t *scores;
     uint64_t score_tile_stride, score_q_stride;

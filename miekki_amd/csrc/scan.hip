@@ -64,12 +64,11 @@ int launch_dense_lut(mk_ctx *c, const uint8_t *d_dense, uint32_t ngroups, DenseL
 
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
 {
-    // by table, eight or sixteen queries per pass over the matrix (MIEKKI_DENSE_LUT=0: the compare kernel below)
-    const char *lut_env = getenv("MIEKKI_DENSE_LUT");          // (read per launch: the tests switch it)
-    const int lut_mode = lut_env ? atoi(lut_env) : 2;
-    // (the table kernel walks rows in groups of sixteen: every window and chunk of rows is a multiple of that for P >= 16)
-    if (a.lut && lut_mode > 0 && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
-        const uint32_t no = a.noctets >= 2 && lut_mode >= 2 ? 2 : 1;
+    // by table, sixteen queries per pass over the matrix (eight when there are no more)
+    // (the table kernel walks rows in groups of sixteen: every window and chunk of rows is a multiple of that for P >= 16;
+    // sketches of fewer partitions take the compare kernel below)
+    if (a.lut && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
+        const uint32_t no = a.noctets >= 2 ? 2 : 1;
         const uint64_t work = (uint64_t)((a.noctets + no - 1) / no) * a.ntiles * a.nchunks;
         if (work == 0) return MK_OK;
         if (work >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }

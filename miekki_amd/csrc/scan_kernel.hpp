@@ -506,10 +506,8 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     if (work >= nsets * a.ntiles * a.nchunks) return;
     // the sets of one (tile, chunk of rows) are neighbours in the grid -- waves of one workgroup: they walk the same rows at the
     // same time, and all but the first find them in a cache (the Infinity Cache mostly: profiles/r4_pmc_dense.txt) instead of
-    // waiting for HBM again (MIEKKI_DENSE_SETS_APART=1: a set is a pass of its own over the matrix, as before)
-    uint32_t chunk, tile, set;
-    if (a.sets_apart) { chunk = work % a.nchunks; const uint32_t gt = work / a.nchunks; tile = gt % a.ntiles; set = gt / a.ntiles; }
-    else { set = work % nsets; const uint32_t ct = work / nsets; chunk = ct % a.nchunks; tile = ct / a.nchunks; }
+    // waiting for HBM again
+    const uint32_t set = work % nsets, ct = work / nsets, chunk = ct % a.nchunks, tile = ct / a.nchunks;
     if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
     uint32_t qidx[NO][8];
     bool any = false;

@@ -43,18 +43,13 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-// SRC 0: u32 scores (plain schedule); 1 / 2: per-range mismatch counts, 1 / 2 bytes each.
-// PF: ranges whose counter words are requested one step ahead (8 for the default slab shape, 16 for sets of
-// 2-4 kb queries, which get twice the ranges)
-template <int SRC, uint32_t PF = 8>
+// The selection over u32 scores (plain schedule: long queries, mk_qset_scores' layout), four genomes per lane.
 __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (q >= a.nq) return;
-    const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;      // entries (SRC 0)
-    const uint64_t range_stride = (uint64_t)a.nq * kTileBytes;          // bytes (SRC 1, 2)
-    const uint32_t n_active = SRC == 0 ? 0u : a.nent[q];
+    const uint64_t tile_stride = (uint64_t)a.nq * a.tile_genomes;      // entries
     const uint32_t N = a.nresults;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double topv = inf;               // lane i < cnt: i-th value of the current top-N multiset
@@ -64,65 +59,18 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     mk_hit *__restrict__ out = a.cand ? a.cand + (uint64_t)q * a.cap : nullptr;
     // compact form (multi-GPU exchange): row = [count][cap x (genome | matches << 32)]
     uint64_t *__restrict__ crow = a.rows ? a.rows + (uint64_t)q * (a.cap + 1u) : nullptr;
-
-    // A step is a dependent load -> test -> ballot chain, and the kernel spends three
-    // quarters of its wave cycles waiting for the loads (PMC).  With at most eight ranges of
-    // byte counters (the default slab shape) the RAW words of a step are therefore
-    // requested one step ahead and only summed when their turn comes.
-    const bool prefetch = SRC == 1 && a.S <= PF;
-    uint32_t raw[PF];
-    auto request = [&](uint32_t g0) {
-        const uint32_t gl = g0 + lane * 4u;
-#pragma unroll
-        for (uint32_t r = 0; r < PF; ++r) raw[r] = 0;
-        if (gl >= a.G) return;
-        const uint32_t t = gl / a.tile_genomes, wi = gl - t * a.tile_genomes;
-        const uint8_t *__restrict__ p = a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + wi;
-#pragma unroll
-        for (uint32_t r = 0; r < PF; ++r)
-            if (r < a.S) raw[r] = *reinterpret_cast<const uint32_t *>(p + (uint64_t)r * range_stride);
-    };
-    if (prefetch) request(0);
     for (uint32_t g0 = 0; g0 < a.G; g0 += 256) {
         const uint32_t gl = g0 + lane * 4u;                            // this lane's four genomes
         uint32_t s[4] = {0, 0, 0, 0};
         double jac[4] = {0, 0, 0, 0}, inter[4] = {0, 0, 0, 0};
         uint32_t pot = 0;
-        if (prefetch) {
-            // byte-wise sums of up to eight words, two bytes per 16-bit lane: no carry between counters
-            uint32_t even = 0, odd = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < PF; ++r) { even += raw[r] & 0x00ff00ffu; odd += (raw[r] >> 8) & 0x00ff00ffu; }
-            s[0] = n_active - (even & 0xffffu); s[1] = n_active - (odd & 0xffffu);
-            s[2] = n_active - (even >> 16);     s[3] = n_active - (odd >> 16);
-        }
         uint32_t ss[4] = {1, 1, 1, 1};
         uint64_t gs[4] = {0, 0, 0, 0};
         bool any = false;
         if (gl < a.G) {
             const uint32_t t = gl / a.tile_genomes, wi = gl - t * a.tile_genomes;   // 256 | tile_genomes
-            if (prefetch) {
-                // scores are in s already
-            } else if (SRC == 0) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(a.scores + (uint64_t)t * tile_stride +
-                                                                 (uint64_t)q * a.tile_genomes + wi);
-                s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
-            } else {                                                   // shared = active - sum of mismatches
-                const uint8_t *__restrict__ p =
-                    a.partials + ((uint64_t)t * a.S * a.nq + q) * kTileBytes + (uint64_t)wi * SRC;
-                uint32_t ne[4] = {0, 0, 0, 0};
-                for (uint32_t r = 0; r < a.S; ++r, p += range_stride) {
-                    if (SRC == 1) {
-                        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
-                        ne[0] += w & 0xffu; ne[1] += (w >> 8) & 0xffu; ne[2] += (w >> 16) & 0xffu; ne[3] += w >> 24;
-                    } else {
-                        const uint2 w = *reinterpret_cast<const uint2 *>(p);
-                        ne[0] += w.x & 0xffffu; ne[1] += w.x >> 16; ne[2] += w.y & 0xffffu; ne[3] += w.y >> 16;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] = n_active - ne[j];
-            }
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.scores + (uint64_t)t * tile_stride + (uint64_t)q * a.tile_genomes + wi);
+            s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) any |= (gl + j < a.G) && s[j] >= a.min_score;     // Miekki.cpp:381
             if (any) {
@@ -134,11 +82,6 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
                 gs[0] = gsa.x; gs[1] = gsa.y; gs[2] = gsb.x; gs[3] = gsb.y;
             }
         }
-        // the next step's words are requested AFTER this step's size loads: loads return in
-        // order, so waiting for the sizes must not mean waiting for the prefetch as well
-        __builtin_amdgcn_sched_barrier(0);
-        if (prefetch && g0 + 256 < a.G) request(g0 + 256);
-        __builtin_amdgcn_sched_barrier(0);
         if (gl < a.G) {
             if (any) {
 #pragma unroll
@@ -200,7 +143,7 @@ __global__ __launch_bounds__(256) void select_kernel(const SelectArgs a)
     }
 }
 
-// The same selection over the slab schedule's partials, EIGHT genomes per lane (round 4).  select_kernel<1> above asks for
+// The same selection over the slab schedule's partials, EIGHT genomes per lane (round 4).  Its predecessor asked for
 // four bytes per lane and range -- 256 bytes per wave-load, two half-used cache lines -- plus three 16-byte loads of the
 // genomes' sizes per step: 2.75 load instructions per genome for a kernel that waits on loads three quarters of its time
 // (20.7 ms per step of 100,000 queries x 100,000 genomes: 8 bytes of partials per (query, genome) = 80 GB at 3.9 TB/s).
@@ -377,17 +320,13 @@ int launch_select(mk_ctx *c, const SelectArgs &a)
     if (!a.nq) return MK_OK;
     if (a.nresults > kSelectMaxResults) { set_error("device selection supports nresults <= 64"); return MK_ERR_ARG; }
     const dim3 grid((a.nq + 3) / 4), block(256);
-    static const bool old_form = [] { const char *e = getenv("MIEKKI_SELECT_OLD"); return e && atoi(e) != 0; }();   // A/B timing knob
-    if (a.partials && a.ratio && !old_form && a.S <= 64) {
+    if (a.partials) {                                                // the slab schedule's per-range counts (S <= 64 by construction)
+        if (!a.ratio || a.S > 64) { set_error("selection over partial counts needs the ratio array and at most 64 ranges"); return MK_ERR_ARG; }
         if (a.W == 1) hipLaunchKernelGGL(select_ranges_kernel<1>, grid, block, 0, c->stream, a, a.ratio);
         else hipLaunchKernelGGL(select_ranges_kernel<2>, grid, block, 0, c->stream, a, a.ratio);
-        MK_HIP(hipGetLastError());
-        return MK_OK;
+    } else {
+        hipLaunchKernelGGL(select_kernel, grid, block, 0, c->stream, a);
     }
-    if (!a.partials)     hipLaunchKernelGGL(select_kernel<0>, grid, block, 0, c->stream, a);
-    else if (a.W == 1 && a.S > 8 && a.S <= 16) hipLaunchKernelGGL((select_kernel<1, 16>), grid, block, 0, c->stream, a);
-    else if (a.W == 1)   hipLaunchKernelGGL(select_kernel<1>, grid, block, 0, c->stream, a);
-    else                 hipLaunchKernelGGL(select_kernel<2>, grid, block, 0, c->stream, a);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

@@ -701,17 +701,15 @@ def test_compact_device_merge_is_the_host_heap(hip):
         ix.close()
 
 
-@pytest.mark.parametrize("dense_div", ["4", None])
-def test_runs_of_long_queries_against_oracle(hip, monkeypatch, dense_div):
-    """Queries beyond the in-LDS sketch (more than 4,096 k-mers) that sit next to each other in a
-    batch are sketched together (binned K1 + one gate-and-append launch); loners go one by one.
-    Mixed with short queries, a too-long-for-sparse (dense) one and a repetitive one.  With sixteen and more queries above
-    2^h / 8 k-mers in a set these go the dense way by default (a full pass of sixteen is cheaper than their entry lists):
-    MIEKKI_DENSE_DIV=4 keeps them on the long sparse path, which is what this test is about; the default form is compared too."""
+@pytest.mark.parametrize("h", [15, 16])
+def test_runs_of_long_queries_against_oracle(hip, h):
+    """Queries beyond the in-LDS sketch (more than 4,096 k-mers) that sit next to each other in a batch, mixed with short
+    queries, a whole-genome (dense) one, loners and a repetitive one.  At -h 15 the 70 long ones lie above 2^h / 8 k-mers and,
+    being sixteen and more, go the dense way (a full pass of sixteen is cheaper than their entry lists: they are sketched
+    together through the build's packed kernels, launch_query_sketch_dense_batch); at -h 16 they stay below it and take the
+    O(length) sketches and the plain scan over their entry lists."""
     from oracle import oracle as orc
-    if dense_div:
-        monkeypatch.setenv("MIEKKI_DENSE_DIV", dense_div)
-    k, h = 31, 15
+    k = 31
     seqs = [synth.genome_bases(400 + i, 0, 150_000) for i in range(12)]
     o = orc.OracleMiekki(k, h, 8, 33, 10)
     o.insert_sequences(seqs)
@@ -723,7 +721,7 @@ def test_runs_of_long_queries_against_oracle(hip, monkeypatch, dense_div):
             g = j % 12
             qs.append(seqs[g][1000 * j:1000 * j + 4200 + 731 * (j % 9)])
         qs.append(seqs[3][500:1500])                                    # short
-        qs.append(seqs[5][:70_000])                                     # dense at h=15 (>= 2^h / 4 k-mers)
+        qs.append(seqs[5][:70_000])                                     # dense at either h (>= 2^h / 4 k-mers)
         qs.append(seqs[7][100:9100])                                    # a loner
         qs.append(seqs[1][200:900])
         qs.append((b"ACGTTGCA" * 2000)[:12_000])                        # repetitive long query
@@ -739,17 +737,17 @@ def test_runs_of_long_queries_against_oracle(hip, monkeypatch, dense_div):
 
 
 @pytest.mark.parametrize("fpb", [8, 16])
-@pytest.mark.parametrize("mode", ["2", "1", "0"])
-def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode, fpb):
+@pytest.mark.parametrize("form", ["sixteen", "eight", "compare"])
+def test_dense_queries_by_table_against_oracle(hip, form, fpb):
     """Whole-genome queries are scored by table lookups and bit-plane counters (scan_dense_lut_kernel: sixteen queries
-    per pass over the rows in mode 2, eight in mode 1; mode 0 is the compare kernel; two-byte fingerprints look their low
-    and high bytes up in two sets of tables and match where both do): 21 dense queries -- three octets, i.e. a sixteen-query wave,
-    an eight-query one and padding -- with empty partitions in some of them (sequences shorter than the sketch), a query
+    per pass over the rows, eight when a set has no more -- form "eight": seven dense queries; two-byte fingerprints look
+    their low and high bytes up in two sets of tables and match where both do); sketches of fewer than sixteen partitions
+    take the compare kernel (form "compare": -h 3).  21 dense queries -- three octets, i.e. a sixteen-query wave, an
+    eight-query one and padding -- with empty partitions in some of them (sequences shorter than the sketch), a query
     that is in no genome, short queries between them, 1,100 genomes (two row tiles, the second ragged); every score
     against the oracle's, the hits against its filter."""
     from oracle import oracle as orc
-    monkeypatch.setenv("MIEKKI_DENSE_LUT", mode)
-    k, h = 31, 12
+    k, h = 31, (3 if form == "compare" else 12)
     P = 1 << h
     rng = np.random.default_rng(21)
     base = [synth.genome_bases(900 + i, 0, 9_000) for i in range(24)]
@@ -767,7 +765,7 @@ def test_dense_queries_by_table_against_oracle(hip, monkeypatch, mode, fpb):
         for i in range(0, len(seqs), 64):
             ix.insert_sequences(seqs[i:i + 64])
         qs = []
-        for j in range(21):
+        for j in range(7 if form == "eight" else 21):
             if j % 5 == 4:
                 qs.append(base[j][:P // 4 + k + 40 * j])              # barely dense: most partitions empty
             else:
@@ -813,6 +811,8 @@ def test_mid_length_queries_against_oracle(hip, h, fpb, slots):
         ix.insert_sequences(seqs)
         top = min((1 << h) // 4 - 1, 1 << 18)                           # most k-mers the path takes
         lens = [4096 + k + 1, 4096 + k + 2, 8192 + k, 8192 + k + 1, 12_345, 20_000, 20_000, 50_001, top + k, top + k - 1, 30_000]
+        if h >= 21:                                                     # beyond the O(length) sketches, below 2^h / 4: the 2^h-table path
+            lens += [(1 << 18) + 5000 + k, (1 << 18) + 1 + k]           # (a run of two: launch_query_sketch_long_batch)
         qs = []
         for j, n in enumerate(lens):
             g = j % 6

@@ -47,15 +47,14 @@ def test_parallel_gzip_round_trips_and_is_plain_gzip(tmp_path, size):
         assert mkgz(["d", other, "4"]) == data
 
 
-@pytest.mark.parametrize("io", ["mmap", "pread"])
-def test_reader_io_paths(tmp_path, io):
-    """The reader inflates members out of a mapping of the file, or out of buffers it preads (MIEKKI_LOAD_IO): same bytes."""
+def test_reader_reads_members_in_parallel(tmp_path):
+    """The reader inflates members out of buffers it preads, several at a time: same bytes."""
     rng = np.random.default_rng(11)
     data = (rng.integers(0, 50, (70 << 20) + 4321, dtype=np.uint8) + 100).tobytes()
     path = str(tmp_path / "x.gz")
     mkgz(["c", path, "6"], data)
     assert gzip.decompress(open(path, "rb").read()) == data
-    assert mkgz(["d", path, "5"], env=dict(os.environ, MIEKKI_LOAD_IO=io)) == data
+    assert mkgz(["d", path, "5"]) == data
 
 
 @pytest.mark.parametrize("stored", [False, True])

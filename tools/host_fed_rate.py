@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-fed build rate on its own (the `sketch.host_fed_*` figures of bench.py, more rounds): 64 synthetic 5 Mb genomes
 in page-locked host buffers, appended `rounds` times packed (mk_index_append_packed) and as characters (mk_index_append).
-    python tools/host_fed_rate.py [rounds]        MIEKKI_COPY_STREAMS=1..4 chooses the copy streams of the packed form"""
+    python tools/host_fed_rate.py [rounds]"""
 import os
 import sys
 
