@@ -187,6 +187,32 @@ int mk_index_append_synthetic(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64
 int mk_index_append_synthetic_strains(mk_ctx *ctx, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains,
                                       uint32_t rate_ppm);
 
+/* ---- gzip'd input on the device.  The reference reads every genome file through zstr::ifstream (Miekki.cpp:559-567;
+ * zstr.hpp:78: inflateInit2(15 + 32), i.e. gzip members or plain text); these calls take the FILES' bytes as they are.
+ * A file is decoded only if it is nothing but well-formed gzip members from its first byte to its last, every member's
+ * CRC-32 and ISIZE included; anything else gets a status and is left to the caller's own inflater. */
+typedef enum {
+    MK_GZ_OK = 0,
+    MK_GZ_EMPTY = 1,          /* no stream */
+    MK_GZ_NOT_GZIP = 2,       /* no gzip header where one must be (magic, method, reserved flags) */
+    MK_GZ_TRUNCATED = 3,      /* the input ends inside a member */
+    MK_GZ_BAD_BLOCK = 4,      /* block type 3 */
+    MK_GZ_BAD_STORED = 5,     /* a stored block's length and its complement disagree */
+    MK_GZ_BAD_LENGTHS = 6,    /* a block's code lengths: over-subscribed, incomplete, bad repeat, no end-of-block code */
+    MK_GZ_BAD_CODE = 7,       /* bits that are no code of the block's code */
+    MK_GZ_BAD_DISTANCE = 8,   /* a match that reaches back beyond the member's first byte */
+    MK_GZ_TOKEN_ROOM = 9,     /* more symbols than the call provided for (about one per two bytes of text) */
+    MK_GZ_OUTPUT_ROOM = 10,   /* more text than the room given */
+    MK_GZ_TRAILING = 11,      /* bytes behind the last member that are not another member */
+    MK_GZ_BAD_CRC = 12,
+    MK_GZ_BAD_SIZE = 13,
+    MK_GZ_INTERNAL = 14       /* the decoder disagrees with itself (never expected; the file goes to the host like any other failure) */
+} mk_gz_status;
+
+/* n whole files -> their text in out[i] (room out_room[i] bytes): out_bytes[i] and status[i] (mk_gz_status) per file. */
+int mk_gz_inflate(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, uint8_t *const *out,
+                  const uint64_t *out_room, uint64_t *out_bytes, int32_t *status);
+
 /* ---- persistence: the payload of dump_disk / the loading constructor
  * (Miekki.cpp:649-719), streamed in ranges so that the host never
  * needs the whole matrix at once. --------------------------------------------- */

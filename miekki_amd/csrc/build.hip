@@ -409,6 +409,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // items are noted in an LDS list while they pass, and those that turn out to be their partition's minimum get the
 // filter looked at.  Once the filter has filled up nothing is flagged and a winner costs no memory request at all
 // (before: its codes, 16 bytes from a random place of the genome -- 67 M L2 requests per 64 x 5 Mb batch).
+#ifndef MK_REDUCE_STAGES
+#define MK_REDUCE_STAGES 4
+#define MK_REDUCE_UN 1
+#endif
 template <int W, bool KEY32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && KEY32) ? 8 : 6, 8))) void build_reduce_kernel(
     const typename ItemOf<W>::type *__restrict__ items, const uint8_t *__restrict__ low, const uint32_t *__restrict__ meta,
@@ -449,10 +453,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
     const uint32_t g = blockIdx.y;
     const uint32_t bin = (bs.nbins & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (bs.nbins >> 3) + (blockIdx.x >> 3);
     const uint32_t R = 1u << bs.low_bits;
-    for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
-    if (threadIdx.x < (1u << kBin) / 32) to_check[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_act = 0; s_card = 0; n_noted = 0; }
-    __syncthreads();
+    // (the table and the counters are set up while the first meta words are on their way: below)
+    auto init_shared = [&] {
+        for (uint32_t i = threadIdx.x; i < R; i += kThreads) table[i] = kNoKey;
+        if (threadIdx.x < (1u << kBin) / 32) to_check[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { s_act = 0; s_card = 0; n_noted = 0; }
+    };
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     {
         // lpr lanes per run, 16 bytes (kIPL items) per lane.  A run starts wherever the bin's items start in their
@@ -462,8 +468,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         const uint32_t lpr = bs.lpr, per_wave = 64u / lpr;            // runs per wave-instruction
         const uint32_t sub = lane / lpr, j0 = (lane % lpr) * kIPL;
         const uint32_t nwg = (bs.tune & 2u) ? 0u : bs.nwg;
-        constexpr uint32_t NW = kThreads / 64, UN = 2;
+        // KR stages of UN wave-loads each are in flight per wave (see the loop at the end of this block)
+        constexpr uint32_t NW = kThreads / 64, UN = MK_REDUCE_UN, KR = MK_REDUCE_STAGES;
         constexpr uint32_t kMetaPer = (kMetaChunk + kThreads - 1) / kThreads;
+        if (!nwg) init_shared();
         for (uint32_t c0 = 0; c0 < nwg; c0 += kMetaChunk) {
             const uint32_t cn = min(kMetaChunk, nwg - c0);
             if (c0) __syncthreads();                                  // the previous chunk's words have been used
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                 const uint32_t i = threadIdx.x + u * kThreads;
                 mw[u] = meta[((uint64_t)g * bs.nwg + c0 + min(i, cn - 1u)) * bs.nbins + bin];   // (no branch: see the item loads below)
             }
+            if (!c0) init_shared();                                   // (under the loads' latency)
 #pragma unroll
             for (uint32_t u = 0; u < kMetaPer; ++u) {
                 const uint32_t i = threadIdx.x + u * kThreads;
@@ -585,16 +594,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     }
                 }
             };
+            // A ring of KR stages: while one stage's items go to the table the loads of the KR - 1 after it are in flight, and a
+            // stage is requested again the moment it has been consumed.  (Round 4 had two stages of two wave-loads: the loads a
+            // consume waited for had been requested ONE consume earlier, and half the kernel's wave-cycles were such waits,
+            // profiles/r5_pmc_build_sq.txt; with four stages of one wave-load -- the same registers -- they are three
+            // consumes old.)  A stage past the chunk's end holds no items.
             constexpr uint32_t kStep = NW * UN;                       // wave-loads a stage of the whole workgroup covers
             const uint32_t step = kStep * per_wave;
-            Stage A, B;
+            Stage S[KR];
             uint32_t r0 = wave * per_wave;
-            fetch(r0, A);
-            for (; r0 < cn; r0 += 2 * step) {                         // (a stage past the chunk's end holds no items)
-                fetch(r0 + step, B);
-                consume(r0, A);
-                fetch(r0 + 2 * step, A);
-                consume(r0 + step, B);
+#pragma unroll
+            for (uint32_t i = 0; i + 1 < KR; ++i) fetch(r0 + i * step, S[i]);
+            for (; r0 < cn; r0 += KR * step) {
+#pragma unroll
+                for (uint32_t i = 0; i < KR; ++i) {
+                    fetch(r0 + (i + KR - 1) * step, S[(i + KR - 1) % KR]);
+                    consume(r0 + i * step, S[i]);
+                }
             }
         }
     }

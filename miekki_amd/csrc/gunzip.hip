@@ -1,0 +1,737 @@
+// gzip'd FASTA on the GPU (the reference's normal input: index_file_of_file reads every genome
+// through zstr::ifstream, Miekki.cpp:559-567, zstr.hpp:78 inflateInit2(15 + 32)).
+//
+// A deflate stream is serial -- a symbol's first bit is known only when the symbol before it has been decoded -- but a
+// collection is thousands of streams, and decoding splits into a serial part that needs no history and a copying part
+// that needs no bit reading:
+//   gz_tokens_kernel   ONE LANE PER STREAM walks the bits: gzip member headers, stored / fixed / dynamic blocks, Huffman
+//                      codes through per-lane lookup tables in LDS (9 bits for literals and lengths, 8 for distances:
+//                      99.9 % / 99.2 % of the codes of gzip'd DNA; longer ones bit by bit from the codes' counts), and
+//                      writes TOKENS -- a literal, or (length, distance), 4 bytes each.  No window: a token does not
+//                      depend on earlier output.  Streams written by one compressor change tables at the same token
+//                      counts (zlib: every 16,383 symbols), so the lanes of a wave stay in step.
+//   gz_resolve_kernel  ONE WAVE PER STREAM executes the tokens, 64 at a time, in a 36 KiB window in LDS (32 KiB of
+//                      history + 4 KiB being written): places from a prefix sum of the lengths, copies byte by byte
+//                      inside LDS -- a token whose source lies among the bytes the same step writes waits for a later
+//                      round of the step -- finished 4 KiB blocks leave for the text buffer in 16-byte stores, and
+//                      their CRC-32 (each lane a 64-byte slice by table, the slices joined by multiplication with
+//                      powers of x modulo the CRC polynomial) is held against every member's trailer, as is ISIZE.
+// Every loop is bounded by the stream's input length, its token room or its output room, and whatever is not a sequence
+// of well-formed gzip members from the first byte to the last -- truncated input, an over-subscribed or incomplete code,
+// a distance beyond the output so far, a stored block whose length check fails, trailing bytes -- ends that stream with
+// a status and nothing else: the caller (host/fasta_reader.cpp) hands such a file to the host's own inflater, which
+// then says what the file is worth.  Behind it, fasta.hip strips header lines and line ends and packs the sequences.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "mk_internal.hpp"
+
+namespace mk {
+
+namespace {
+
+constexpr uint32_t kLitRoot = 9, kDistRoot = 8, kLitSize = 1u << kLitRoot, kDistSize = 1u << kDistRoot;
+constexpr uint32_t kTokMatch = 0x80000000u;    // | length << 16 | distance - 1
+constexpr uint32_t kTokMember = 0x40000000u;   // a member ends here: the next two words are its CRC-32 and ISIZE
+constexpr uint32_t kTokStored = 0x20000000u;   // | n (16 bits): n bytes of a stored block; the next word is where they lie in the stream
+constexpr uint32_t kWin = 36u << 10, kHist = 32u << 10, kFlush = 4u << 10;
+
+enum : uint32_t { ST_MEMBER = 0, ST_BLOCK = 1, ST_TOKENS = 2, ST_TRAILER = 4, ST_DONE = 5 };
+
+// ---------------------------------------------------------------- phase 1: bits -> tokens
+// LDS of a wave (64 streams), every per-lane array interleaved [index][lane]:
+//   lit 512 x u16 (64 KiB), dist 256 x u16 (32 KiB): code length | kind | value, 0 = not in the table
+//   cnt_l / cnt_d 16 x u16: codes per length (the bit-by-bit path); nxt / ofs 16 x u16: scratch of the table build
+//   sym_d 32 x u8: distance symbols in code order; lens 352 x u8: the block's code lengths (the code length
+//   code's table borrows the lane's column of dist).  The literal / length symbols in code order live in global memory (aux: 288 x u16 per lane).
+constexpr uint32_t kInWords = 48, kInPitch = 52, kTokRing = 64, kTokPitch = 68;
+struct TokLds {
+    uint16_t lit[kLitSize][64];
+    uint16_t dist[kDistSize][64];              // (its first 128 rows also serve as the code length code's table while a header is read:
+                                               // the lane's own column -- done with before the distance table is built)
+    uint16_t cnt_l[16][64], cnt_d[16][64], nxt[16][64], ofs[16][64];
+    uint8_t sym_d[32][64];
+    uint8_t lens[352][64];                     // [0, 19): the code length code's own; [32, 32 + 316): the two alphabets' (fixed code: [0, 320))
+    // The bit loop touches no global memory: a lane reads its stream from its row of `in` (the next kInWords words of it)
+    // and leaves its tokens in its row of `tok`; every few dozen steps each lane refills its row with 16-byte loads and
+    // writes its ring out with 16-byte stores (round(), below).  With a load or a store per lane and token in the loop --
+    // 64 cache lines per instruction, and every wait for an input word a wait for the token stores before it -- and the
+    // rows moved by the whole wave through lane shuffles, a token took 3,100 cycles (profiles/r5_gunzip.txt).
+    uint32_t in[64][kInPitch];
+    uint32_t tok[64][kTokPitch];
+};
+
+struct BitReader {
+    const uint32_t *in32;          // the stream's words (16-byte aligned, zero padding behind the last byte)
+    const TokLds *lds;             // (its `in` row `lane` holds words [base, base + kInWords) of the stream)
+    uint32_t lane;
+    uint64_t bb;
+    uint32_t bc, wi, wmax, base;   // words [0, wi) are in bb
+    bool over;                     // asked for words beyond the padding: the stream is truncated
+    __device__ __forceinline__ void start(const uint8_t *p, uint32_t in_len, const TokLds *l, uint32_t ln)
+    {
+        in32 = reinterpret_cast<const uint32_t *>(p);
+        lds = l; lane = ln;
+        wmax = (in_len + 3u) / 4u + 3u;                            // (the upload pads 16 zero bytes)
+        bb = 0; bc = 0; wi = 0; over = false;
+        base = 0xffffffffu - kInWords;                             // (nothing buffered yet)
+    }
+    __device__ __forceinline__ void refill()                       // bc <= 32 on entry
+    {
+        uint32_t w = 0;
+        if (wi >= wmax) over = true;
+        else if (wi - base < kInWords) w = lds->in[lane][wi - base];
+        else w = in32[wi];                                         // beyond the buffered words (a block's header, a skip): from memory
+        bb |= (uint64_t)w << bc;
+        bc += 32u;
+        ++wi;
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n)           // n <= 32
+    {
+        if (bc < n) refill();
+        return (uint32_t)bb & (n >= 32u ? 0xffffffffu : ((1u << n) - 1u));
+    }
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint32_t get(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+    __device__ __forceinline__ uint64_t consumed_bits() const { return (uint64_t)wi * 32u - bc; }
+    __device__ __forceinline__ void align_byte() { drop(bc & 7u); }
+    __device__ void seek_byte(uint64_t at)                          // continue at byte `at` of the stream
+    {
+        bb = 0; bc = 0;
+        const uint64_t w = at / 4u;
+        if (w >= wmax) { over = true; wi = wmax; return; }
+        wi = (uint32_t)w;
+        refill();
+        drop((uint32_t)(at % 4u) * 8u);
+    }
+};
+
+// canonical code of `n` symbols (lengths in L.lens[base ...]) into a root table and the counts of the bit-by-bit path.
+// kind: 0 literal / length alphabet, 1 distance alphabet, 2 the code length code (complete codes only).
+// Returns false for what zlib's inflate_table refuses: an over-subscribed set, an incomplete one unless it is a single
+// code of one bit (or, for the two data alphabets, no code at all).
+__device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, int kind, uint32_t *aux_sorted)
+{
+    uint16_t (*cnt)[64] = kind == 1 ? L.cnt_d : L.cnt_l;
+    for (uint32_t l = 0; l < 16; ++l) cnt[l][lane] = 0;
+    uint32_t maxlen = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t l = L.lens[base + s][lane];
+        if (l) { cnt[l][lane] = (uint16_t)(cnt[l][lane] + 1u); maxlen = max(maxlen, l); }
+    }
+    int left = 1;
+    uint32_t code = 0, off = 0;
+    for (uint32_t l = 1; l < 16; ++l) {
+        const uint32_t c = cnt[l][lane];
+        left = (left << 1) - (int)c;
+        if (left < 0) return false;                                // over-subscribed
+        L.nxt[l][lane] = (uint16_t)code;                           // first code of this length
+        L.ofs[l][lane] = (uint16_t)off;
+        code = (code + c) << 1;
+        off += c;
+    }
+    if (left > 0 && (kind == 2 || maxlen > 1u)) return false;      // incomplete (inftrees.c: only a lone one-bit code may be)
+    if (kind == 2 && maxlen == 0) return false;
+    const uint32_t root = kind == 0 ? kLitRoot : kind == 1 ? kDistRoot : 7u, size = 1u << root;
+    if (kind == 0) for (uint32_t i = 0; i < size; ++i) L.lit[i][lane] = 0;
+    else if (kind == 1) for (uint32_t i = 0; i < size; ++i) L.dist[i][lane] = 0;
+    else for (uint32_t i = 0; i < size; ++i) L.dist[i][lane] = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t l = L.lens[base + s][lane];
+        if (!l) continue;
+        const uint32_t c = L.nxt[l][lane];
+        L.nxt[l][lane] = (uint16_t)(c + 1u);
+        const uint32_t o = L.ofs[l][lane];
+        L.ofs[l][lane] = (uint16_t)(o + 1u);
+        if (kind == 0) aux_sorted[o] = s;
+        else if (kind == 1) L.sym_d[o & 31u][lane] = (uint8_t)s;
+        if (l > root) continue;                                    // (the code length code has no longer ones)
+        uint32_t e;
+        if (kind == 0) {
+            // code length | kind << 4 | value << 7: kind 7 a literal (value = the byte), 6 end of block, 0..5 a match
+            // length with that many extra bits (value = its base, RFC 1951 3.2.5)
+            if (s < 256u) e = l | (7u << 4) | (s << 7);
+            else if (s == 256u) e = l | (6u << 4);
+            else if (s > 285u) continue;                           // (286, 287: in the fixed code, never valid -- left to the slow path's check)
+            else {
+                const uint32_t c2 = s - 257u;
+                const uint32_t ex = c2 < 8u || c2 == 28u ? 0u : (c2 >> 2) - 1u;
+                const uint32_t lb = c2 < 8u ? 3u + c2 : c2 == 28u ? 258u : 3u + ((4u + (c2 & 3u)) << ex);
+                e = l | (ex << 4) | (lb << 7);
+            }
+        } else if (kind == 1) {
+            if (s > 29u) continue;
+            e = l | (s << 4);
+        } else {
+            e = s | (l << 5);
+        }
+        const uint32_t r = __brev(c) >> (32u - l);
+        if (kind == 0) for (uint32_t i = r; i < size; i += 1u << l) L.lit[i][lane] = (uint16_t)e;
+        else if (kind == 1) for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][lane] = (uint16_t)e;
+        else for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][lane] = (uint16_t)e;
+    }
+    return true;
+}
+
+// a symbol the root table does not hold: bit by bit against the counts (the canonical walk of RFC 1951 3.2.2); ~0u: no
+// such code
+__device__ uint32_t slow_symbol(TokLds &L, uint32_t lane, BitReader &br, bool dist_code, uint32_t *aux_sorted)
+{
+    uint16_t (*cnt)[64] = dist_code ? L.cnt_d : L.cnt_l;
+    const uint32_t bits = br.peek(15);
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l <= 15; ++l) {
+        code |= (bits >> (l - 1u)) & 1u;
+        const uint32_t c = cnt[l][lane];
+        if (code - first < c) {                                    // (code >= first always holds here)
+            br.drop(l);
+            const uint32_t at = index + (code - first);
+            // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
+            return dist_code ? (uint32_t)L.sym_d[at & 31u][lane] : __hip_atomic_load(&aux_sorted[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return ~0u;
+}
+
+__global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
+                                                       uint32_t *__restrict__ tokens, uint32_t *__restrict__ aux)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TokLds &L = *reinterpret_cast<TokLds *>(smem);
+    const uint32_t lane = threadIdx.x, s = blockIdx.x * 64u + lane;
+    const bool live = s < n;
+    mk_gz_stream job = live ? jobs[s] : mk_gz_stream{};
+    uint32_t *const sorted = aux + (uint64_t)(live ? s : 0u) * 288u;
+    BitReader br;
+    br.start(gz + job.in_off, live ? job.in_len : 0u, &L, lane);
+    uint32_t state = live ? ST_MEMBER : ST_DONE, status = live ? MK_GZ_OK : MK_GZ_EMPTY;
+    uint32_t n_tok = 0, n_out = 0, out_len = 0, member_out = 0, members = 0;      // n_out: tokens already in memory (the rest: the lane's ring)
+    bool final_block = false;
+    if (live && job.in_len < 18u) { state = ST_DONE; status = MK_GZ_NOT_GZIP; }
+    auto fail = [&](uint32_t why) { status = why; state = ST_DONE; };
+    auto emit = [&](uint32_t t) {                                   // (the passes below emit at most three; round() keeps that much room)
+        if (n_tok < job.tok_cap) { L.tok[lane][n_tok - n_out] = t; ++n_tok; }
+        else fail(MK_GZ_TOKEN_ROOM);
+    };
+    // A lane's ring out to memory, four tokens per store (what is left over moves to the ring's start), and its row of
+    // input refilled from the word it reads next, four words per load.  Every lane its own stream: 64 cache lines per
+    // instruction, but only a few dozen instructions per round and a round every few dozen tokens.
+    const uint4 *__restrict__ in16 = reinterpret_cast<const uint4 *>(gz + job.in_off);
+    uint4 *__restrict__ tok16 = reinterpret_cast<uint4 *>(tokens + job.tok_off);      // (tok_off is a multiple of four)
+    auto round = [&]() {
+        const uint32_t have = n_tok - n_out, whole = have & ~3u;
+        for (uint32_t i = 0; __any(i < whole); i += 4u)
+            if (i < whole) tok16[(n_out + i) >> 2] = *reinterpret_cast<const uint4 *>(&L.tok[lane][i]);
+        if (whole) for (uint32_t i = 0; i < (have & 3u); ++i) L.tok[lane][i] = L.tok[lane][whole + i];
+        n_out += whole;
+        br.base = br.wi & ~3u;
+        uint4 v[kInWords / 4u];
+#pragma unroll
+        for (uint32_t i = 0; i < kInWords / 4u; ++i) {
+            const uint32_t at = br.base + 4u * i;
+            // (a stream's room is a multiple of 16 bytes beyond wmax words: a whole piece)
+            v[i] = at < br.wmax ? in16[at >> 2] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kInWords / 4u; ++i) *reinterpret_cast<uint4 *>(&L.in[lane][4u * i]) = v[i];
+    };
+    round();
+    // every pass of this loop consumes input bits, emits a token or ends a lane: bounded by the streams' bits and rooms
+    while (__any(state != ST_DONE)) {
+        // a round when some ring may not take another pass's tokens, or some lane has used most of its buffered words
+        if (__any(n_tok - n_out + 4u > kTokRing || (state != ST_DONE && br.wi - br.base + 4u > kInWords))) round();
+        if (__all(state == ST_TOKENS || state == ST_DONE)) {
+            // ---- the loop the time goes into: one symbol (a literal, a match or a block's end) per lane and pass, without a
+            // branch but for the rare ones -- a code longer than the table's index, an error, a block's end, a round.  Lanes
+            // that are done idle along.
+            uint32_t pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];     // the word the next refill takes
+            for (;;) {
+                const bool act = state == ST_TOKENS;
+                uint32_t err = 0;
+                auto refill = [&](bool want) {
+                    const bool need = want && br.bc <= 32u;
+                    if (need && br.wi >= br.wmax) err = MK_GZ_TRUNCATED;
+                    br.bb |= need ? (uint64_t)pre << br.bc : 0ull;
+                    br.bc += need ? 32u : 0u;
+                    br.wi += need ? 1u : 0u;
+                    pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];
+                };
+                refill(act);
+                const uint32_t e = L.lit[(uint32_t)br.bb & (kLitSize - 1u)][lane];
+                uint32_t kind = (e >> 4) & 7u, value = e >> 7, cl = e & 15u;
+                if (act && e == 0u) {                                  // a code of more than nine bits (one symbol in a thousand)
+                    const uint32_t sym = slow_symbol(L, lane, br, false, sorted);
+                    cl = 0;
+                    if (sym < 256u) { kind = 7; value = sym; }
+                    else if (sym == 256u) { kind = 6; value = 0; }
+                    else if (sym <= 285u) {
+                        const uint32_t c2 = sym - 257u;
+                        kind = c2 < 8u || c2 == 28u ? 0u : (c2 >> 2) - 1u;
+                        value = c2 < 8u ? 3u + c2 : c2 == 28u ? 258u : 3u + ((4u + (c2 & 3u)) << kind);
+                    } else { kind = 7; value = 0; err = MK_GZ_BAD_CODE; }
+                    pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];
+                }
+                br.bb >>= (act ? cl : 0u); br.bc -= (act ? cl : 0u);
+                const bool is_len = act && kind < 6u, is_lit = act && kind == 7u, is_eob = act && kind == 6u;
+                const uint32_t ex = is_len ? kind : 0u;
+                const uint32_t len = value + ((uint32_t)br.bb & ((1u << ex) - 1u));
+                br.bb >>= ex; br.bc -= ex;
+                refill(is_len);
+                const uint32_t d = L.dist[(uint32_t)br.bb & (kDistSize - 1u)][lane];
+                uint32_t dsym = d >> 4, dcl = d & 15u;
+                if (is_len && d == 0u) {                               // a distance code of more than eight bits
+                    dsym = slow_symbol(L, lane, br, true, sorted);
+                    dcl = 0;
+                    pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];
+                }
+                if (is_len && dsym > 29u) { err = MK_GZ_BAD_CODE; dsym = 0; }
+                br.bb >>= (is_len ? dcl : 0u); br.bc -= (is_len ? dcl : 0u);
+                const uint32_t dex = !is_len || dsym < 4u ? 0u : (dsym >> 1) - 1u;
+                const uint32_t dist = (dsym < 4u ? dsym + 1u : 1u + ((2u + (dsym & 1u)) << dex)) + ((uint32_t)br.bb & ((1u << dex) - 1u));
+                br.bb >>= dex; br.bc -= dex;
+                const uint32_t grow = is_len ? len : is_lit ? 1u : 0u;
+                if (is_len && dist > out_len - member_out) err = err ? err : MK_GZ_BAD_DISTANCE;
+                if (grow > job.out_cap - out_len) err = err ? err : MK_GZ_OUTPUT_ROOM;
+                if (grow && n_tok >= job.tok_cap) err = err ? err : MK_GZ_TOKEN_ROOM;
+                const bool put = grow != 0u && err == 0u;
+                L.tok[lane][put ? n_tok - n_out : kTokRing] = is_len ? kTokMatch | (len << 16) | (dist - 1u) : value;   // (column kTokRing: nobody reads it)
+                n_tok += put ? 1u : 0u;
+                out_len += put ? grow : 0u;
+                if (err) { status = err; state = ST_DONE; }
+                else if (is_eob) state = final_block ? ST_TRAILER : ST_BLOCK;
+                // leave the loop for a block's end or an error somewhere, and for a round
+                if (__any(state != (act ? ST_TOKENS : ST_DONE) || n_tok - n_out + 4u > kTokRing || (act && br.wi - br.base + 4u > kInWords))) break;
+            }
+            continue;
+        }
+        if (state == ST_TOKENS) {
+            // (some other lane reads a header or a trailer in this pass: the symbol loop waits for it)
+        } else if (state == ST_BLOCK) {
+            final_block = br.get(1) != 0;
+            const uint32_t type = br.get(2);
+            if (type == 0u) {
+                br.align_byte();
+                const uint32_t len = br.get(16), nlen = br.get(16);
+                const uint64_t at = br.consumed_bits() >> 3;        // (byte-aligned: the block's bytes lie here as they are)
+                if ((len ^ nlen) != 0xffffu) fail(MK_GZ_BAD_STORED);
+                else if (br.over || at + len > job.in_len) fail(MK_GZ_TRUNCATED);
+                else if (len > job.out_cap - out_len) fail(MK_GZ_OUTPUT_ROOM);
+                else {
+                    if (len) { emit(kTokStored | len); emit((uint32_t)at); out_len += len; }
+                    if (state != ST_DONE) { br.seek_byte(at + len); state = final_block ? ST_TRAILER : ST_BLOCK; }
+                }
+            } else if (type == 1u) {
+                for (uint32_t i = 0; i < 288u; ++i) L.lens[i][lane] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8);
+                for (uint32_t i = 0; i < 32u; ++i) L.lens[288u + i][lane] = 5;
+                (void)build_code(L, lane, 0, 288, 0, sorted);
+                (void)build_code(L, lane, 288, 32, 1, sorted);      // (codes 30 and 31 decode to an error, as in zlib's fixed table)
+                state = ST_TOKENS;
+            } else if (type == 2u) {
+                const uint32_t hlit = br.get(5) + 257u, hdist = br.get(5) + 1u, hclen = br.get(4) + 4u;
+                bool ok = hlit <= 286u && hdist <= 30u;
+                for (uint32_t i = 0; i < 19u; ++i) L.lens[i][lane] = 0;
+                for (uint32_t i = 0; i < hclen; ++i) {
+                    // whose length comes i-th (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                    const uint32_t j = i - 4u;
+                    const uint32_t which = i < 3u ? 16u + i : i == 3u ? 0u : (j & 1u) ? 7u - (j >> 1) : 8u + (j >> 1);
+                    L.lens[which][lane] = (uint8_t)br.get(3);
+                }
+                ok = ok && build_code(L, lane, 0, 19, 2, sorted);
+                uint32_t i = 0, prev = 0;
+                const uint32_t total = hlit + hdist;
+                // the lengths of both alphabets, run-length coded (at most `total` passes: every pass writes a length)
+                while (ok && i < total) {
+                    const uint32_t ce = L.dist[br.peek(7)][lane];
+                    if (!ce) { ok = false; break; }
+                    br.drop(ce >> 5);
+                    const uint32_t sym = ce & 31u;
+                    if (sym < 16u) { L.lens[32u + i][lane] = (uint8_t)sym; prev = sym; ++i; }
+                    else {
+                        uint32_t rep, val = 0;
+                        if (sym == 16u) { if (!i) { ok = false; break; } val = prev; rep = 3u + br.get(2); }
+                        else if (sym == 17u) rep = 3u + br.get(3);
+                        else rep = 11u + br.get(7);
+                        if (i + rep > total) { ok = false; break; }
+                        for (uint32_t r = 0; r < rep; ++r) L.lens[32u + i + r][lane] = (uint8_t)val;
+                        i += rep; prev = val;
+                    }
+                    if (br.over) ok = false;
+                }
+                // (the lengths lie at lens[32 ...]: the code length code's own nineteen stay below them)
+                ok = ok && L.lens[32u + 256u][lane] != 0;             // no end-of-block code: inflate.c "missing end-of-block"
+                ok = ok && build_code(L, lane, 32, hlit, 0, sorted);
+                ok = ok && build_code(L, lane, 32u + hlit, hdist, 1, sorted);
+                if (!ok) fail(br.over ? MK_GZ_TRUNCATED : MK_GZ_BAD_LENGTHS);
+                else state = ST_TOKENS;
+            } else {
+                fail(MK_GZ_BAD_BLOCK);
+            }
+            if (br.over && state != ST_DONE) fail(MK_GZ_TRUNCATED);
+        } else if (state == ST_TRAILER) {
+            br.align_byte();
+            const uint32_t crc = br.get(32), isize = br.get(32);
+            emit(kTokMember);
+            emit(crc);
+            emit(isize);
+            ++members;
+            member_out = out_len;
+            const uint64_t used = br.consumed_bits() >> 3;          // whole bytes: the reader is byte-aligned here
+            if (br.over || used > job.in_len) fail(MK_GZ_TRUNCATED);
+            else if (state != ST_DONE) {
+                if (used == job.in_len) state = ST_DONE;              // the stream ends with this member: status stays OK
+                else state = ST_MEMBER;                               // another member must follow (anything else: a status)
+            }
+        } else if (state == ST_MEMBER) {
+            // RFC 1952 2.3: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16]
+            const uint64_t left = (uint64_t)job.in_len - (br.consumed_bits() >> 3);
+            if (left < 18u) fail(members ? MK_GZ_TRAILING : MK_GZ_NOT_GZIP);
+            else {
+                const uint32_t id = br.get(16), cm = br.get(8), flg = br.get(8);
+                (void)br.get(32); (void)br.get(16);
+                if (id != 0x8b1fu || cm != 8u || (flg & 0xe0u)) fail(members ? MK_GZ_TRAILING : MK_GZ_NOT_GZIP);
+                else {
+                    uint64_t budget = job.in_len;                     // bytes these loops may skip at most
+                    if (flg & 4u) {
+                        uint32_t xlen = br.get(16);
+                        while (xlen && budget && !br.over) { (void)br.get(8); --xlen; --budget; }
+                    }
+                    for (uint32_t f = 8u; f <= 16u; f <<= 1)          // name, comment: zero-terminated
+                        if (flg & f) while (budget && !br.over && br.get(8) != 0u) --budget;
+                    if (flg & 2u) (void)br.get(16);
+                    if (br.over || !budget || (br.consumed_bits() >> 3) + 8u > job.in_len) fail(MK_GZ_TRUNCATED);
+                    else state = ST_BLOCK;
+                }
+            }
+        }
+    }
+    round();                                                         // what is left in the rings: whole fours, then the rest
+    for (uint32_t i = 0; i < n_tok - n_out; ++i) tokens[job.tok_off + n_out + i] = L.tok[lane][i];
+    if (live) {
+        jobs[s].n_tok = n_tok;
+        jobs[s].out_len = out_len;
+        jobs[s].status = status;
+        jobs[s].members = members;
+    }
+}
+
+// ---------------------------------------------------------------- phase 2: tokens -> text
+// x^(8 n) mod P for the reflected CRC-32 polynomial, as multiplication operands: a(x) * b(x) mod P in the reflected bit
+// order (bit 31 = x^0), the shift-and-add of zlib's crc32_combine (multmodp)
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+#pragma unroll 8
+    for (uint32_t i = 0; i < 32; ++i) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t byte_shift; };   // x^(512 (63 - lane)), x^(8 * 4096), x^8
+
+// Four streams per workgroup (a wave each, its own window; the CRC tables are shared).
+__global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
+                                                         const uint32_t *__restrict__ tokens, uint8_t *__restrict__ text, ResolveConsts K)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsmem[];
+    uint32_t (*crc_tab)[256] = reinterpret_cast<uint32_t (*)[256]>(rsmem);           // slice-by-4 tables (reflected 0xEDB88320)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, s = blockIdx.x * 4u + wave;
+    uint8_t *const win = rsmem + 4096u + wave * kWin;
+    {
+        uint32_t c = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        crc_tab[0][threadIdx.x] = c;
+        __syncthreads();
+        uint32_t v = c;
+        for (uint32_t t = 1; t < 4u; ++t) { v = crc_tab[0][v & 0xffu] ^ (v >> 8); crc_tab[t][threadIdx.x] = v; }
+    }
+    __syncthreads();
+    if (s >= n) return;
+    const mk_gz_stream job = jobs[s];
+    if (job.status != MK_GZ_OK) return;
+    const uint32_t *__restrict__ tok = tokens + job.tok_off;
+    uint8_t *__restrict__ out = text + job.out_off;
+    const uint32_t ntok = job.n_tok;
+    uint32_t t0 = 0, pos = 0, flushed = 0;          // pos: bytes produced so far; [0, flushed) are in `out` (flushed % kFlush == 0)
+    uint32_t crc_raw = 0;                             // remainder of the member's bytes [member_pos, crc_from) (start 0, no complement)
+    uint32_t member_pos = 0, crc_from = 0;
+    uint32_t status = MK_GZ_OK;
+    auto x_pow = [&](uint32_t nbytes) {              // x^(8 n) mod P by square-and-multiply
+        uint32_t r = 0x80000000u, sq = K.byte_shift;
+        for (uint32_t e = nbytes; e; e >>= 1) { if (e & 1u) r = gf_mul(r, sq); sq = gf_mul(sq, sq); }
+        return r;
+    };
+    // bytes [a, b) of the output (inside the window, b - a <= kFlush) into crc_raw: every lane a slice of 64, four bytes per
+    // table step, the slices joined by powers of x
+    auto crc_span = [&](uint32_t a, uint32_t b) {
+        const uint32_t len = b - a;
+        if (!len) return;
+        const uint32_t lo = min(a + lane * 64u, b), hi = min(lo + 64u, b);
+        uint32_t r = 0, p = lo;
+        if (len == kFlush && (a % kFlush) == 0u) {                    // a whole aligned block: sixteen aligned words per lane
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(win + (lo % kWin));
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+                const uint32_t x = r ^ w[i];
+                r = crc_tab[3][x & 0xffu] ^ crc_tab[2][(x >> 8) & 0xffu] ^ crc_tab[1][(x >> 16) & 0xffu] ^ crc_tab[0][x >> 24];
+            }
+            p = hi;
+        }
+        for (; p < hi; ++p) r = crc_tab[0][(r ^ win[p % kWin]) & 0xffu] ^ (r >> 8);
+        const uint32_t after = b - hi;
+        const uint32_t m = len == kFlush ? K.lane_shift[lane] : x_pow(after);
+        r = hi > lo ? (after ? gf_mul(r, m) : r) : 0u;
+        for (int o = 32; o > 0; o >>= 1) r ^= (uint32_t)__shfl_xor((int)r, o);
+        crc_raw = gf_mul(crc_raw, len == kFlush ? K.block_shift : x_pow(len)) ^ r;
+    };
+    auto crc_to = [&](uint32_t upto) {
+        while (crc_from < upto) {
+            const uint32_t end = min(upto, (crc_from / kFlush + 1u) * kFlush);
+            crc_span(crc_from, end);
+            crc_from = end;
+        }
+    };
+    // bytes [flushed, upto) -> out (upto a multiple of kFlush, or the very end)
+    auto flush_to = [&](uint32_t upto) {
+        while (flushed < upto) {
+            const uint32_t end = min(upto, flushed + kFlush), len = end - flushed;
+            const uint32_t w0 = flushed % kWin;                     // (a flush block never wraps: kWin is a multiple of kFlush)
+            if (len == kFlush) {                                    // (out is 16-byte aligned, flushed a multiple of kFlush)
+#pragma unroll
+                for (uint32_t i = 0; i < kFlush / 1024u; ++i) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&win[w0 + i * 1024u + lane * 16u]);
+                    *reinterpret_cast<uint4 *>(out + flushed + i * 1024u + lane * 16u) = v;
+                }
+            } else {
+                for (uint32_t i = lane; i < len; i += 64u) out[flushed + i] = win[w0 + i];
+            }
+            flushed = end;
+        }
+    };
+    auto leave = [&]() {                                             // whole blocks leave the window, their CRC first
+        const uint32_t whole = pos / kFlush * kFlush;
+        if (whole > flushed) { crc_to(whole); flush_to(whole); }
+    };
+    uint32_t t_next = lane < ntok ? tok[lane] : kTokMember;          // the step's tokens, requested a step ahead
+    uint32_t t_next_at = 0;
+    while (t0 < ntok && status == MK_GZ_OK) {                        // (every pass takes at least one token)
+        const uint32_t idx = t0 + lane;
+        uint32_t t = t_next_at == t0 ? t_next : (idx < ntok ? tok[idx] : kTokMember);
+        t_next_at = t0 + 64u;                                        // (the usual step takes all 64)
+        t_next = t_next_at + lane < ntok ? tok[t_next_at + lane] : kTokMember;
+        // a stored block or a member's end among these tokens: the tokens before it first, then the special itself
+        const unsigned long long special = __ballot((t & (kTokMember | kTokStored)) && !(t & kTokMatch));
+        const uint32_t upto_lane = special ? (uint32_t)__ffsll((long long)special) - 1u : 64u;
+        if (upto_lane == 0u) {
+            const uint32_t head = (uint32_t)__shfl((int)t, 0);
+            if (head & kTokStored) {
+                // the bytes of a stored block: from the stream into the window, a window's slack at a time
+                if (t0 + 1u >= ntok) { status = MK_GZ_INTERNAL; break; }
+                uint32_t left = head & 0xffffu;
+                const uint8_t *__restrict__ from = gz + job.in_off + tok[t0 + 1u];
+                while (left) {
+                    const uint32_t m = min(left, kWin - kHist);
+                    for (uint32_t i = lane; i < m; i += 64u) win[(pos + i) % kWin] = from[i];
+                    pos += m; from += m; left -= m;
+                    leave();
+                }
+                t0 += 2u;
+            } else {
+                // a member's end: its CRC-32 and length against the trailer's, then the next member starts
+                if (t0 + 2u >= ntok) { status = MK_GZ_INTERNAL; break; }
+                const uint32_t want_crc = tok[t0 + 1u], want_size = tok[t0 + 2u];
+                crc_to(pos);
+                // crc32(M) = remainder(M, start 0) ^ (0xffffffff moved up by |M| bytes) ^ 0xffffffff
+                const uint32_t nbytes = pos - member_pos;
+                const uint32_t crc = crc_raw ^ gf_mul(0xffffffffu, x_pow(nbytes)) ^ 0xffffffffu;
+                if (crc != want_crc) status = MK_GZ_BAD_CRC;
+                else if (nbytes != want_size) status = MK_GZ_BAD_SIZE;     // (ISIZE is the length mod 2^32; a stream's output is below that here)
+                crc_raw = 0; member_pos = pos; crc_from = pos;
+                t0 += 3u;
+            }
+            continue;
+        }
+        const bool mine = lane < upto_lane;
+        const bool is_match = mine && (t & kTokMatch);
+        const uint32_t len = !mine ? 0u : is_match ? (t >> 16) & 0x1ffu : 1u;
+        // places: inclusive prefix sum of the lengths
+        uint32_t incl = len;
+#pragma unroll
+        for (uint32_t o = 1; o < 64u; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += v;
+        }
+        // only as many tokens as fit the window's slack beyond the history
+        const unsigned long long fits = __ballot(mine && incl <= kWin - kHist);
+        const uint32_t take = (uint32_t)__popcll(fits);              // (prefix sums are monotone: the fitting lanes are the first `take`)
+        if (take == 0u) { status = MK_GZ_INTERNAL; break; }          // (a token is at most 258 bytes: cannot happen)
+        const bool act = lane < take;
+        const uint32_t dst = pos + incl - len;
+        const uint32_t dist = is_match ? (t & 0x7fffu) + 1u : 0u;
+        const uint32_t src = dst - dist;                             // (phase 1 checked dist <= bytes of this member so far)
+        const uint32_t total = (uint32_t)__shfl((int)incl, (int)(take - 1u));
+        // rounds: a token is ready when its source bytes lie below the first unfinished token's place -- or when it IS that
+        // token (its own bytes may overlap its source: such a copy runs byte by byte in order)
+        bool done = !act;
+        if (act && !is_match) { win[dst % kWin] = (uint8_t)t; done = true; }
+        unsigned long long todo = __ballot(!done);
+        while (todo) {                                               // (each round finishes at least the lowest unfinished lane)
+            const uint32_t low = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t frontier = (uint32_t)__shfl((int)dst, (int)low);
+            const bool ready = !done && (lane == low || src + len <= frontier);
+            uint32_t j = 0, d = dst % kWin, f = src % kWin;
+            // eight bytes at a time where the source does not reach into what the eight writes (distance >= 8) and neither
+            // run wraps around the window's end: the reads of a piece are independent of each other
+            const bool wide = ready && dist >= 8u;
+            while (__any(wide && j + 8u <= len && d + 8u <= kWin && f + 8u <= kWin)) {
+                if (wide && j + 8u <= len && d + 8u <= kWin && f + 8u <= kWin) {
+                    uint8_t b[8];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8u; ++i) b[i] = win[f + i];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8u; ++i) win[d + i] = b[i];
+                    j += 8u; d += 8u; f += 8u;
+                    d = d == kWin ? 0u : d;
+                    f = f == kWin ? 0u : f;
+                }
+            }
+            // ... the rest (and short distances, and runs across the window's end) byte by byte; with a distance of four and
+            // more, four reads before their writes
+            while (__any(ready && j < len)) {
+                if (ready && j < len) {
+                    if (dist >= 4u && j + 4u <= len && d + 4u <= kWin && f + 4u <= kWin) {
+                        uint8_t b[4];
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i) b[i] = win[f + i];
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i) win[d + i] = b[i];
+                        j += 4u; d += 4u; f += 4u;
+                        d = d == kWin ? 0u : d;
+                        f = f == kWin ? 0u : f;
+                    } else {
+                        win[d] = win[f];
+                        ++j;
+                        d = d + 1u == kWin ? 0u : d + 1u;
+                        f = f + 1u == kWin ? 0u : f + 1u;
+                    }
+                }
+            }
+            if (ready) done = true;
+            todo = __ballot(!done);
+        }
+        pos += total;
+        t0 += take;
+        leave();
+    }
+    if (status == MK_GZ_OK) {
+        if (pos != job.out_len || member_pos != pos) status = MK_GZ_INTERNAL;      // (the last token is a member's end)
+        flush_to(pos);
+    }
+    if (lane == 0) jobs[s].status = status;
+}
+
+}  // namespace
+
+uint32_t gf_mul_host(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < 32; ++i) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+static uint32_t x_pow_bytes(uint64_t nbytes)                          // x^(8 n) mod P
+{
+    uint32_t r = 0x80000000u, sq = 0x00800000u;                       // x^0; x^8 (bit 31 - 8)
+    for (uint64_t e = nbytes; e; e >>= 1) { if (e & 1u) r = gf_mul_host(r, sq); sq = gf_mul_host(sq, sq); }
+    return r;
+}
+
+// ---- the two phases over a batch of streams already on the device (gz: their bytes; jobs: where each lies and how much
+// room its tokens and text have).  Queued on `st`; the jobs' results are in d_jobs when the stream gets there.
+int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t n, uint32_t *d_tokens, uint32_t *d_aux, uint8_t *d_text,
+                  hipStream_t st)
+{
+    if (!n) return MK_OK;
+    static_assert(sizeof(TokLds) <= 160u << 10, "phase 1's tables and buffers fit one wave per CU");
+    MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
+    hipLaunchKernelGGL(gz_tokens_kernel, dim3((n + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_jobs, n, d_tokens, d_aux);
+    MK_HIP(hipGetLastError());
+    ResolveConsts K;
+    for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
+    K.block_shift = x_pow_bytes(kFlush);
+    K.byte_shift = x_pow_bytes(1);
+    const size_t lds2 = 4096u + 4u * kWin;
+    MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, d_jobs, n, d_tokens, d_text, K);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+// Whole gzip files -> their text, inflated on the device (the two kernels above); status[i] != MK_GZ_OK: that file is for
+// the host's inflater (nothing of it is returned).
+int mk_gz_inflate(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, uint8_t *const *out, const uint64_t *out_room,
+                  uint64_t *out_bytes, int32_t *status)
+{
+    if (!c || (n && (!gz || !gz_bytes || !out || !out_room || !out_bytes || !status))) { set_error("null argument"); return MK_ERR_ARG; }
+    if (!n) return MK_OK;
+    MK_HIP(hipSetDevice(c->p.device));
+    std::vector<mk_gz_stream> jobs(n);
+    uint64_t in_at = 0, tok_at = 0, out_at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        mk_gz_stream &j = jobs[i];
+        memset(&j, 0, sizeof j);
+        if (gz_bytes[i] >= 0xfffffff0ull) { set_error("stream %u: more than 4 GiB", i); return MK_ERR_ARG; }
+        j.in_off = in_at; j.in_len = (uint32_t)gz_bytes[i];
+        in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
+        j.out_cap = (uint32_t)std::min<uint64_t>(out_room[i], 0xfffffff0ull);
+        // (a token yields at least a byte, a member's end is three words per >= 18 bytes of input, a stored block two per >= 5: this room always suffices)
+        j.tok_cap = (uint32_t)std::min<uint64_t>((uint64_t)j.out_cap + j.in_len / 4u + 16u, 0xfffffff0ull);
+        j.tok_off = tok_at; tok_at += ((uint64_t)j.tok_cap + 3u) / 4u * 4u;
+        j.out_off = out_at; out_at += ((uint64_t)j.out_cap + 15u) / 16u * 16u;
+    }
+    uint8_t *d_gz = nullptr, *d_text = nullptr;
+    uint32_t *d_tok = nullptr;
+    uint32_t *d_aux = nullptr;
+    mk_gz_stream *d_jobs = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_gz); (void)hipFree(d_text); (void)hipFree(d_tok); (void)hipFree(d_aux); (void)hipFree(d_jobs); };
+    hipStream_t st = c->stream;
+    bool ok = hipMalloc((void **)&d_gz, in_at + 16) == hipSuccess && hipMalloc((void **)&d_text, out_at + 16) == hipSuccess &&
+              hipMalloc((void **)&d_tok, (tok_at + 1) * 4) == hipSuccess && hipMalloc((void **)&d_aux, (uint64_t)n * 288u * 4u) == hipSuccess &&
+              hipMalloc((void **)&d_jobs, (uint64_t)n * sizeof(mk_gz_stream)) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); cleanup(); set_error("no device memory for %u streams", n); return MK_ERR_NOMEM; }
+    ok = hipMemsetAsync(d_gz, 0, in_at + 16, st) == hipSuccess;
+    for (uint32_t i = 0; i < n && ok; ++i)
+        if (jobs[i].in_len) ok = hipMemcpyAsync(d_gz + jobs[i].in_off, gz[i], jobs[i].in_len, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st) == hipSuccess;
+    int rc = ok ? launch_gunzip(c, d_gz, d_jobs, n, d_tok, d_aux, d_text, st) : MK_ERR_DEVICE;
+    if (rc == MK_OK && hipMemcpyAsync(jobs.data(), d_jobs, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
+    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
+    for (uint32_t i = 0; i < n && rc == MK_OK; ++i) {
+        status[i] = (int32_t)jobs[i].status;
+        out_bytes[i] = jobs[i].status == MK_GZ_OK ? jobs[i].out_len : 0;
+        if (jobs[i].status == MK_GZ_OK && jobs[i].out_len &&
+            hipMemcpyAsync(out[i], d_text + jobs[i].out_off, jobs[i].out_len, hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
+    }
+    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
+    if (rc == MK_ERR_DEVICE) set_error("gzip inflate on the device failed: %s", hipGetErrorString(hipGetLastError()));
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

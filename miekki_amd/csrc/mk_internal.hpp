@@ -240,7 +240,7 @@ struct mk_ctx {
     std::vector<mk::Timer> free_timers;
 };
 
-namespace mk { struct DenseLut; }
+namespace mk { struct DenseLut; struct mk_gz_stream; }
 struct mk_qset {
     uint32_t nq;
     mk_ctx *owner;
@@ -371,6 +371,18 @@ int launch_huff_decode(mk_ctx *c, const uint8_t *d_payload, uint64_t payload_byt
                        const uint8_t *d_lens, uint32_t n_codes, uint8_t *d_out, uint64_t out_bytes, uint32_t *d_crc, uint32_t *d_bad);
 int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t *d_dst);   // d_dst[P][n] (W bytes each, dump byte order)
 inline MatRef mat_ref(const mk_ctx *c);
+
+// ---- gunzip.hip: gzip streams inflated on the device
+struct mk_gz_stream {
+    uint64_t in_off;               // the stream's bytes at gz + in_off (16-byte aligned, >= 16 zero bytes behind them)
+    uint64_t tok_off;              // its tokens at tokens + tok_off (32-bit words)
+    uint64_t out_off;              // its text at text + out_off (16-byte aligned)
+    uint32_t in_len, tok_cap, out_cap;
+    uint32_t n_tok, out_len, status, members;      // results (mk_gz_status)
+    uint32_t pad;
+};
+int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t n, uint32_t *d_tokens, uint32_t *d_aux, uint8_t *d_text,
+                  hipStream_t st);
 
 // ---- cold.hip: the cold rows packed (delta vs the genome before + bit packing)
 int pack_cold(mk_ctx *c, uint64_t *raw_bytes, uint64_t *packed_bytes);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "mk_qset_scores": (i32, [vp, vp, u32, u32, vp]),
     "mk_qset_active": (i32, [vp, vp, vp]),
     "mk_sync": (i32, [vp]),
+    "mk_gz_inflate": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
     "mk_exact": (i32, [vp, vp, vp, u32, vp, vp, u32, vp, vp]),
     "mk_exact_load_genome": (i32, [vp, vp, vp, u32]),
     "mk_exact_query": (i32, [vp, vp, vp, u32, vp, vp]),
@@ -169,6 +170,21 @@ def load_library():
 def check(status: int):
     if status != 0:
         raise MiekkiHipError(status, load_library().mk_last_error().decode(errors="replace"))
+
+
+def gz_inflate(ctx_handle, blobs, rooms):
+    """mk_gz_inflate: whole gzip files (bytes) -> (texts, statuses); a text is None where the status is not MK_GZ_OK."""
+    import numpy as np
+    lib = load_library()
+    n = len(blobs)
+    ptrs, lens = seq_arrays(blobs)
+    outs = [np.empty(max(int(r), 1), np.uint8) for r in rooms]
+    out_ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    room = (C.c_uint64 * n)(*[int(r) for r in rooms])
+    got = (C.c_uint64 * n)()
+    status = (C.c_int32 * n)()
+    check(lib.mk_gz_inflate(ctx_handle, ptrs, lens, n, out_ptrs, room, got, status))
+    return [bytes(outs[i][:got[i]]) if status[i] == 0 else None for i in range(n)], list(status)
 
 
 def seq_arrays(seqs):
