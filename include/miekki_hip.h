@@ -213,6 +213,16 @@ typedef enum {
 int mk_gz_inflate(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, uint8_t *const *out,
                   const uint64_t *out_room, uint64_t *out_bytes, int32_t *status);
 
+/* n genome FILES (gzip'd FASTA) -> their sequences as index_file_of_file reads them (Miekki.cpp:559-567: every line
+ * that does not start with '>' appended, line feeds dropped), inflated, stripped and kept ON THE DEVICE: mk_gz_sequence
+ * hands out a device pointer that mk_index_append takes like a host pointer (the copy then never leaves the GPU).
+ * A file whose status is not MK_GZ_OK has no sequence here: inflate it on the host.  The batch's memory (about twice
+ * the files' text) stays allocated until mk_gz_free; the appends that read it must have returned by then. */
+typedef struct mk_gz_batch mk_gz_batch;
+int mk_gz_unpack(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out);
+int mk_gz_sequence(const mk_gz_batch *batch, uint32_t i, const char **d_seq, uint64_t *len, int32_t *status);
+void mk_gz_free(mk_gz_batch *batch);
+
 /* ---- persistence: the payload of dump_disk / the loading constructor
  * (Miekki.cpp:649-719), streamed in ranges so that the host never
  * needs the whole matrix at once. --------------------------------------------- */

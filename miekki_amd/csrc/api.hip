@@ -1198,7 +1198,7 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
         const int buf = c->seq_cur ^ 1;
         MK_TRY(ensure_build_scratch(c, off[nb], buf));
         for (uint32_t g = 0; g < nb; ++g)
-            MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice,
+            MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyDefault,   // (host memory, or the device's: mk_gz_sequence)
                                   c->copy_stream));
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));

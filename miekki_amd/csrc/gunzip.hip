@@ -114,6 +114,7 @@ struct BitReader {
 // code of one bit (or, for the two data alphabets, no code at all).
 __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, int kind, uint32_t *aux_sorted)
 {
+    const uint32_t col = ((lane & 31u) << 1) | (lane >> 5);       // (the lane's column of the two-byte tables, see the kernel)
     uint16_t (*cnt)[64] = kind == 1 ? L.cnt_d : L.cnt_l;
     for (uint32_t l = 0; l < 16; ++l) cnt[l][lane] = 0;
     uint32_t maxlen = 0;
@@ -135,9 +136,9 @@ __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, 
     if (left > 0 && (kind == 2 || maxlen > 1u)) return false;      // incomplete (inftrees.c: only a lone one-bit code may be)
     if (kind == 2 && maxlen == 0) return false;
     const uint32_t root = kind == 0 ? kLitRoot : kind == 1 ? kDistRoot : 7u, size = 1u << root;
-    if (kind == 0) for (uint32_t i = 0; i < size; ++i) L.lit[i][lane] = 0;
-    else if (kind == 1) for (uint32_t i = 0; i < size; ++i) L.dist[i][lane] = 0;
-    else for (uint32_t i = 0; i < size; ++i) L.dist[i][lane] = 0;
+    if (kind == 0) for (uint32_t i = 0; i < size; ++i) L.lit[i][col] = 0;
+    else if (kind == 1) for (uint32_t i = 0; i < size; ++i) L.dist[i][col] = 0;
+    else for (uint32_t i = 0; i < size; ++i) L.dist[i][col] = 0;
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t l = L.lens[base + s][lane];
         if (!l) continue;
@@ -168,9 +169,9 @@ __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, 
             e = s | (l << 5);
         }
         const uint32_t r = __brev(c) >> (32u - l);
-        if (kind == 0) for (uint32_t i = r; i < size; i += 1u << l) L.lit[i][lane] = (uint16_t)e;
-        else if (kind == 1) for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][lane] = (uint16_t)e;
-        else for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][lane] = (uint16_t)e;
+        if (kind == 0) for (uint32_t i = r; i < size; i += 1u << l) L.lit[i][col] = (uint16_t)e;
+        else if (kind == 1) for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][col] = (uint16_t)e;
+        else for (uint32_t i = r; i < size; i += 1u << l) L.dist[i][col] = (uint16_t)e;
     }
     return true;
 }
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TokLds &L = *reinterpret_cast<TokLds *>(smem);
     const uint32_t lane = threadIdx.x, s = blockIdx.x * 64u + lane;
+    // a lane's column in the two-byte tables: lanes l and l + 32 share a word -- they are served in different halves of a wave's
+    // access, so 32 lanes looking 32 different rows up meet on no bank (with columns in lane order neighbours always did: 64 % of
+    // the LDS cycles were conflicts)
+    const uint32_t col = ((lane & 31u) << 1) | (lane >> 5);
     const bool live = s < n;
     mk_gz_stream job = live ? jobs[s] : mk_gz_stream{};
     uint32_t *const sorted = aux + (uint64_t)(live ? s : 0u) * 288u;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                     pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];
                 };
                 refill(act);
-                const uint32_t e = L.lit[(uint32_t)br.bb & (kLitSize - 1u)][lane];
+                const uint32_t e = L.lit[(uint32_t)br.bb & (kLitSize - 1u)][col];
                 uint32_t kind = (e >> 4) & 7u, value = e >> 7, cl = e & 15u;
                 if (act && e == 0u) {                                  // a code of more than nine bits (one symbol in a thousand)
                     const uint32_t sym = slow_symbol(L, lane, br, false, sorted);
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 const uint32_t len = value + ((uint32_t)br.bb & ((1u << ex) - 1u));
                 br.bb >>= ex; br.bc -= ex;
                 refill(is_len);
-                const uint32_t d = L.dist[(uint32_t)br.bb & (kDistSize - 1u)][lane];
+                const uint32_t d = L.dist[(uint32_t)br.bb & (kDistSize - 1u)][col];
                 uint32_t dsym = d >> 4, dcl = d & 15u;
                 if (is_len && d == 0u) {                               // a distance code of more than eight bits
                     dsym = slow_symbol(L, lane, br, true, sorted);
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 const uint32_t total = hlit + hdist;
                 // the lengths of both alphabets, run-length coded (at most `total` passes: every pass writes a length)
                 while (ok && i < total) {
-                    const uint32_t ce = L.dist[br.peek(7)][lane];
+                    const uint32_t ce = L.dist[br.peek(7)][col];
                     if (!ce) { ok = false; break; }
                     br.drop(ce >> 5);
                     const uint32_t sym = ce & 31u;
@@ -430,6 +435,19 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
         b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
     }
     return p;
+}
+
+// inclusive prefix sum over the wave's 64 lanes by data-parallel-primitive moves (no LDS round trips: __shfl_up is one each)
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x)
+{
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1 (rows of 16 lanes)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
 struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t byte_shift; };   // x^(512 (63 - lane)), x^(8 * 4096), x^8
@@ -560,13 +578,7 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restri
         const bool mine = lane < upto_lane;
         const bool is_match = mine && (t & kTokMatch);
         const uint32_t len = !mine ? 0u : is_match ? (t >> 16) & 0x1ffu : 1u;
-        // places: inclusive prefix sum of the lengths
-        uint32_t incl = len;
-#pragma unroll
-        for (uint32_t o = 1; o < 64u; o <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-            if (lane >= o) incl += v;
-        }
+        const uint32_t incl = wave_prefix_sum(len);                  // places: inclusive prefix sum of the lengths
         // only as many tokens as fit the window's slack beyond the history
         const unsigned long long fits = __ballot(mine && incl <= kWin - kHist);
         const uint32_t take = (uint32_t)__popcll(fits);              // (prefix sums are monotone: the fitting lanes are the first `take`)
@@ -575,51 +587,43 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restri
         const uint32_t dst = pos + incl - len;
         const uint32_t dist = is_match ? (t & 0x7fffu) + 1u : 0u;
         const uint32_t src = dst - dist;                             // (phase 1 checked dist <= bytes of this member so far)
-        const uint32_t total = (uint32_t)__shfl((int)incl, (int)(take - 1u));
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(take - 1u));
         // rounds: a token is ready when its source bytes lie below the first unfinished token's place -- or when it IS that
         // token (its own bytes may overlap its source: such a copy runs byte by byte in order)
         bool done = !act;
         if (act && !is_match) { win[dst % kWin] = (uint8_t)t; done = true; }
         unsigned long long todo = __ballot(!done);
+        uint8_t *const sink = rsmem + 4096u + 4u * kWin + wave * 64u + lane;     // where the bytes of a piece beyond a token's end go
         while (todo) {                                               // (each round finishes at least the lowest unfinished lane)
             const uint32_t low = (uint32_t)__ffsll((long long)todo) - 1u;
-            const uint32_t frontier = (uint32_t)__shfl((int)dst, (int)low);
+            const uint32_t frontier = (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)low);
             const bool ready = !done && (lane == low || src + len <= frontier);
             uint32_t j = 0, d = dst % kWin, f = src % kWin;
             // eight bytes at a time where the source does not reach into what the eight writes (distance >= 8) and neither
-            // run wraps around the window's end: the reads of a piece are independent of each other
+            // run crosses the window's end: the reads of a piece are independent of each other, and a write beyond the
+            // token's end goes to the lane's sink instead of under a branch (most matches of gzip'd DNA are one piece)
             const bool wide = ready && dist >= 8u;
-            while (__any(wide && j + 8u <= len && d + 8u <= kWin && f + 8u <= kWin)) {
-                if (wide && j + 8u <= len && d + 8u <= kWin && f + 8u <= kWin) {
-                    uint8_t b[8];
+            while (__any(wide && j < len && d + 8u <= kWin && f + 8u <= kWin)) {
+                const bool go = wide && j < len && d + 8u <= kWin && f + 8u <= kWin;
+                uint8_t b8[8];
 #pragma unroll
-                    for (uint32_t i = 0; i < 8u; ++i) b[i] = win[f + i];
+                for (uint32_t i = 0; i < 8u; ++i) b8[i] = win[go ? f + i : 0u];
 #pragma unroll
-                    for (uint32_t i = 0; i < 8u; ++i) win[d + i] = b[i];
-                    j += 8u; d += 8u; f += 8u;
+                for (uint32_t i = 0; i < 8u; ++i) *(go && j + i < len ? win + d + i : sink) = b8[i];
+                if (go) {
+                    const uint32_t adv = min(8u, len - j);
+                    j += adv; d += adv; f += adv;
                     d = d == kWin ? 0u : d;
                     f = f == kWin ? 0u : f;
                 }
             }
-            // ... the rest (and short distances, and runs across the window's end) byte by byte; with a distance of four and
-            // more, four reads before their writes
+            // ... the rest (short distances, runs across the window's end) byte by byte
             while (__any(ready && j < len)) {
                 if (ready && j < len) {
-                    if (dist >= 4u && j + 4u <= len && d + 4u <= kWin && f + 4u <= kWin) {
-                        uint8_t b[4];
-#pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i) b[i] = win[f + i];
-#pragma unroll
-                        for (uint32_t i = 0; i < 4u; ++i) win[d + i] = b[i];
-                        j += 4u; d += 4u; f += 4u;
-                        d = d == kWin ? 0u : d;
-                        f = f == kWin ? 0u : f;
-                    } else {
-                        win[d] = win[f];
-                        ++j;
-                        d = d + 1u == kWin ? 0u : d + 1u;
-                        f = f + 1u == kWin ? 0u : f + 1u;
-                    }
+                    win[d] = win[f];
+                    ++j;
+                    d = d + 1u == kWin ? 0u : d + 1u;
+                    f = f + 1u == kWin ? 0u : f + 1u;
                 }
             }
             if (ready) done = true;
@@ -670,7 +674,7 @@ int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t
     for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
     K.block_shift = x_pow_bytes(kFlush);
     K.byte_shift = x_pow_bytes(1);
-    const size_t lds2 = 4096u + 4u * kWin;
+    const size_t lds2 = 4096u + 4u * kWin + 256u;                     // CRC tables, four windows, the lanes' sinks
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, d_jobs, n, d_tokens, d_text, K);
     MK_HIP(hipGetLastError());
@@ -732,6 +736,116 @@ int mk_gz_inflate(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes,
     if (rc == MK_ERR_DEVICE) set_error("gzip inflate on the device failed: %s", hipGetErrorString(hipGetLastError()));
     cleanup();
     return rc;
+}
+
+// A batch of genome FILES (gzip members holding FASTA text) -> their sequences as index_file_of_file would read them
+// (Miekki.cpp:559-567), resident on the device: inflate, then fasta.hip.  The sequences take the place of the tokens (a
+// token buffer has twice the text's room); everything else of the batch's scratch is freed before the call returns.
+struct mk_gz_batch {
+    mk_ctx *owner;
+    uint32_t n;
+    std::vector<mk_gz_stream> jobs;
+    std::vector<uint64_t> seq_off, seq_len;
+    uint8_t *d_seqs;
+};
+
+int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out)
+{
+    if (!c || !out || (n && (!gz || !gz_bytes))) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = nullptr;
+    MK_HIP(hipSetDevice(c->p.device));
+    std::unique_ptr<mk_gz_batch> b(new mk_gz_batch());
+    b->owner = c; b->n = n; b->d_seqs = nullptr;
+    b->jobs.resize(n); b->seq_off.assign(n, 0); b->seq_len.assign(n, 0);
+    if (!n) { *out = b.release(); return MK_OK; }
+    uint64_t in_at = 0, tok_at = 0, out_at = 0;
+    constexpr uint64_t kMaxText = 1ull << 30;                        // a larger file is the host's
+    for (uint32_t i = 0; i < n; ++i) {
+        mk_gz_stream &j = b->jobs[i];
+        memset(&j, 0, sizeof j);
+        j.in_off = in_at;
+        j.in_len = gz_bytes[i] < 0xfffffff0ull ? (uint32_t)gz_bytes[i] : 0u;
+        in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
+        // room for the text: what the last member's trailer says (ISIZE, RFC 1952 2.3.1) -- all of it when the file is one
+        // member -- and never less than four times the file (DNA is two bits a base at best: files of many members fit that too)
+        uint64_t isize = 0;
+        if (j.in_len >= 18u) for (int k = 0; k < 4; ++k) isize |= (uint64_t)gz[i][j.in_len - 4u + k] << (8 * k);
+        const uint64_t room = std::min<uint64_t>(std::max<uint64_t>(isize + 64u, 4ull * j.in_len + 4096u), kMaxText);
+        j.out_cap = (uint32_t)room;
+        j.tok_cap = (uint32_t)(room / 2u + j.in_len / 4u + 1024u);
+        j.tok_off = tok_at; tok_at += ((uint64_t)j.tok_cap + 3u) / 4u * 4u;
+        j.out_off = out_at; out_at += (room + 15u) / 16u * 16u;
+    }
+    uint8_t *d_gz = nullptr, *d_text = nullptr, *d_scratch = nullptr;
+    uint32_t *d_tok = nullptr, *d_aux = nullptr, *d_first = nullptr;
+    uint64_t *d_seq_off = nullptr, *d_seq_len = nullptr;
+    mk_gz_stream *d_jobs = nullptr;
+    auto release = [&](bool all) {
+        (void)hipFree(d_gz); (void)hipFree(d_text); (void)hipFree(d_aux); (void)hipFree(d_jobs); (void)hipFree(d_scratch); (void)hipFree(d_first);
+        (void)hipFree(d_seq_off); (void)hipFree(d_seq_len);
+        if (all) (void)hipFree(d_tok);
+    };
+    hipStream_t st = c->stream;
+    bool ok = hipMalloc((void **)&d_gz, in_at + 16) == hipSuccess && hipMalloc((void **)&d_text, out_at + 16) == hipSuccess &&
+              hipMalloc((void **)&d_tok, (tok_at + 4) * 4) == hipSuccess && hipMalloc((void **)&d_aux, (uint64_t)n * 288u * 4u) == hipSuccess &&
+              hipMalloc((void **)&d_jobs, (uint64_t)n * sizeof(mk_gz_stream)) == hipSuccess &&
+              hipMalloc((void **)&d_first, ((uint64_t)n + 1) * 4) == hipSuccess && hipMalloc((void **)&d_seq_off, (uint64_t)n * 8) == hipSuccess &&
+              hipMalloc((void **)&d_seq_len, (uint64_t)n * 8) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError(); release(true);
+        set_error("no device memory to unpack %u files (%.1f GB of text): take fewer at a time", n, out_at / 1e9);
+        return MK_ERR_NOMEM;
+    }
+    ok = hipMemsetAsync(d_gz, 0, in_at + 16, st) == hipSuccess;
+    for (uint32_t i = 0; i < n && ok; ++i)
+        if (b->jobs[i].in_len) ok = hipMemcpyAsync(d_gz + b->jobs[i].in_off, gz[i], b->jobs[i].in_len, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_jobs, b->jobs.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st) == hipSuccess;
+    int rc = ok ? launch_gunzip(c, d_gz, d_jobs, n, d_tok, d_aux, d_text, st) : MK_ERR_DEVICE;
+    if (rc == MK_OK && hipMemcpyAsync(b->jobs.data(), d_jobs, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
+    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
+    // the texts' chunks, the sequences' places (each in its own stream's token room), then the strip
+    std::vector<uint32_t> first(n + 1, 0);
+    if (rc == MK_OK) {
+        for (uint32_t i = 0; i < n; ++i) {
+            const mk_gz_stream &j = b->jobs[i];
+            first[i + 1] = first[i] + (j.status == MK_GZ_OK ? (j.out_len + 4095u) / 4096u : 0u);
+            b->seq_off[i] = j.tok_off * 4u;
+        }
+        if (hipMalloc((void **)&d_scratch, fasta_scratch_bytes(first[n])) != hipSuccess) { (void)hipGetLastError(); rc = MK_ERR_NOMEM; set_error("no device memory for the FASTA scan"); }
+    }
+    if (rc == MK_OK) {
+        ok = hipMemcpyAsync(d_first, first.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+             hipMemcpyAsync(d_seq_off, b->seq_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+        rc = ok ? launch_fasta_strip(c, d_text, d_jobs, n, d_first, first[n], d_scratch, reinterpret_cast<uint8_t *>(d_tok), d_seq_off, d_seq_len, st) : MK_ERR_DEVICE;
+        if (rc == MK_OK && hipMemcpyAsync(b->seq_len.data(), d_seq_len, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
+        if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
+    }
+    if (rc == MK_ERR_DEVICE) set_error("unpacking gzip'd FASTA on the device failed: %s", hipGetErrorString(hipGetLastError()));
+    release(rc != MK_OK);
+    if (rc != MK_OK) return rc;
+    b->d_seqs = reinterpret_cast<uint8_t *>(d_tok);
+    *out = b.release();
+    return MK_OK;
+}
+
+int mk_gz_sequence(const mk_gz_batch *b, uint32_t i, const char **d_seq, uint64_t *len, int32_t *status)
+{
+    if (!b || i >= b->n || !d_seq || !len || !status) { set_error("bad argument"); return MK_ERR_ARG; }
+    *status = (int32_t)b->jobs[i].status;
+    const bool ok = b->jobs[i].status == MK_GZ_OK;
+    *d_seq = ok ? reinterpret_cast<const char *>(b->d_seqs + b->seq_off[i]) : nullptr;
+    *len = ok ? b->seq_len[i] : 0;
+    return MK_OK;
+}
+
+void mk_gz_free(mk_gz_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->owner->p.device);
+    (void)hipStreamSynchronize(b->owner->stream);
+    (void)hipStreamSynchronize(b->owner->copy_stream);
+    if (b->d_seqs) (void)hipFree(b->d_seqs);
+    delete b;
 }
 
 }  // extern "C"

@@ -383,6 +383,10 @@ struct mk_gz_stream {
 };
 int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t n, uint32_t *d_tokens, uint32_t *d_aux, uint8_t *d_text,
                   hipStream_t st);
+// ---- fasta.hip: text -> sequence (header lines and line feeds removed)
+int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first,
+                       uint32_t n_chunks, void *d_scratch, uint8_t *d_seqs, const uint64_t *d_seq_off, uint64_t *d_seq_len, hipStream_t st);
+uint64_t fasta_scratch_bytes(uint32_t n_chunks);
 
 // ---- cold.hip: the cold rows packed (delta vs the genome before + bit packing)
 int pack_cold(mk_ctx *c, uint64_t *raw_bytes, uint64_t *packed_bytes);

@@ -137,6 +137,44 @@ class Miekki:
         L.check(self._lib.mk_index_append_packed(self._h, arr, len(packed)))
         self.file_names += list(names) if names else [""] * len(packed)
 
+    def insert_gz_files(self, blobs, names=None, fallback=True):
+        """index_file_of_file's loop (Miekki.cpp:559-573) over gzip'd genome files whose BYTES are handed over: inflated,
+        stripped of header lines and line feeds and appended on the device (mk_gz_unpack; the sequences never visit the
+        host); a file the device refuses is inflated here (zstr's semantics: every member) when `fallback` is set.
+        Returns the files' statuses (mk_gz_status).  Sequences shorter than k are skipped like the reference's."""
+        blobs = [bytes(b) for b in blobs]
+        n = len(blobs)
+        if not n:
+            return []
+        ptrs, lens = L.seq_arrays(blobs)
+        batch = C.c_void_p()
+        L.check(self._lib.mk_gz_unpack(self._h, ptrs, lens, n, C.byref(batch)))
+        status, keep = [], []                  # keep: host-side sequences that must outlive the appends
+        try:
+            seq_p, seq_l, kept_names = [], [], []
+            for i in range(n):
+                d, ln, st = C.c_void_p(), C.c_uint64(), C.c_int32()
+                L.check(self._lib.mk_gz_sequence(batch, i, C.byref(d), C.byref(ln), C.byref(st)))
+                status.append(st.value)
+                if st.value == 0:
+                    ptr, length = d.value, ln.value
+                elif fallback:
+                    ref = b"".join(l for l in _gunzip_members(blobs[i]).split(b"\n") if not l.startswith(b">"))
+                    keep.append(C.create_string_buffer(ref, len(ref)))
+                    ptr, length = C.addressof(keep[-1]), len(ref)
+                else:
+                    continue
+                if length >= self.kmer_size:
+                    seq_p.append(ptr); seq_l.append(length); kept_names.append(names[i] if names else "")
+            for g0 in range(0, len(seq_p), 64):
+                m = len(seq_p[g0:g0 + 64])
+                L.check(self._lib.mk_index_append(self._h, (C.c_void_p * m)(*seq_p[g0:g0 + 64]), (C.c_uint64 * m)(*seq_l[g0:g0 + 64]), m))
+            L.check(self._lib.mk_sync(self._h))
+            self.file_names += kept_names
+        finally:
+            self._lib.mk_gz_free(batch)
+        return status
+
     def insert_synthetic(self, first_id, n, length):
         L.check(self._lib.mk_index_append_synthetic(self._h, first_id, n, length))
         self.file_names += [f"synthetic:{first_id + i}" for i in range(n)]
@@ -341,6 +379,22 @@ def _readn(f, n):
     if len(b) != n:
         raise EOFError("truncated index stream")
     return b
+
+
+def _gunzip_members(data: bytes) -> bytes:
+    """every gzip member from the start; what follows the last whole member is ignored (zlib's gzread does the same)"""
+    import zlib
+    out = []
+    while data[:2] == b"\x1f\x8b":
+        d = zlib.decompressobj(31)
+        try:
+            out.append(d.decompress(data))
+        except zlib.error:
+            break
+        if not d.eof:
+            break
+        data = d.unused_data
+    return b"".join(out)
 
 
 def _read_text(path) -> bytes:

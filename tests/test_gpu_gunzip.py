@@ -160,3 +160,84 @@ def test_many_streams_of_uneven_length(ctx):
     got, status = inflate(ctx, blobs)
     assert status == [OK] * len(texts)
     assert got == texts
+
+
+# ---- gzip'd genome FILES -> the index (mk_gz_unpack: inflate + strip on the device, the sequences never visit the host)
+import hashlib
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd0", "rnd2", "rnd3", "rnd4", "rnd5"])
+@pytest.mark.parametrize("level", [6, 1])
+def test_index_from_gzipped_files_equals_the_reference(name, level):
+    """Every genome file of a reference-pinned case handed over gzip'd (whatever it was on disk): the index stream -- columns,
+    sizes, Bloom bytes -- must be the one the real reference built from the same files (tests/golden/*.npz)."""
+    import miekki_amd
+    case = synth.CASES[name]()
+    gold = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    ix = miekki_amd.Miekki(case.k, case.h, case.fp_bits, case.b, case.threshold)
+    try:
+        blobs = []
+        for _, text, _ in case.genome_files:
+            blobs.append(gz(text, level) if len(text) % 3 else gz(text[:len(text) // 2], level) + gz(text[len(text) // 2:], 9))   # (some as two members)
+        status = ix.insert_gz_files(blobs, fallback=True)
+        # (a file of several members has room for four times its size -- the trailer only tells the last member's length:
+        # a repeat-rich text that packs better than that is the host's)
+        two = [len(text) % 3 == 0 for _, text, _ in case.genome_files]
+        assert all(s_ == OK or (s_ == OUTPUT_ROOM and t_) for s_, t_ in zip(status, two)), status
+        assert sum(s_ == OK for s_ in status) >= len(status) - 2
+        assert ix.index_size == int(gold["G"])
+        np.testing.assert_array_equal(ix.sketch_size, gold["sketch_size"])
+        np.testing.assert_array_equal(ix.genome_size, gold["genome_size"])
+        raw = bytearray(b"".join(ix.serialize()))
+        raw[32] = 0; raw[38] = 0
+        assert hashlib.sha256(bytes(raw)).hexdigest() == str(gold["stream_sha_masked"])
+    finally:
+        ix.close()
+
+
+def test_fasta_shapes_and_fallback_against_oracle():
+    """Texts that stress the strip: no trailing line feed, empty lines, header-only files, a header as the last line without
+    a line feed, '>' inside a line, carriage returns, lines longer than a chunk, a line feed exactly at a chunk's edge, a
+    header line across a chunk's edge -- and files the device refuses among them (their sequences come from the host)."""
+    import miekki_amd
+    from oracle import oracle as orc
+    k, h = 15, 10
+    rng = np.random.default_rng(17)
+    base = [synth.genome_bases(700 + i, 0, 30_000) for i in range(6)]
+    texts = [
+        b">a\n" + base[0],                                                            # no line feed at the end
+        b">a\n\n\n" + base[1][:9000] + b"\n\n>b desc\n" + base[1][9000:] + b"\n\n",   # empty lines, two records
+        b">only a header\n",
+        b">h\n" + base[2][:5000] + b"\n>last header without line feed",
+        base[3][:100] + b">notaheader" + base[3][100:4000] + b"\n" + b"ACGT>ACGT\n",   # '>' inside lines
+        b">crlf\r\n" + b"\r\n".join(base[4][i:i + 60] for i in range(0, 12_000, 60)) + b"\r\n",
+        b">long line\n" + base[5] + b"\n",                                            # a 30,000-byte line
+        b">edge\n" + base[0][:4096 - 6 - 1] + b"\n" + base[0][5000:9000] + b"\n",    # line feed is the chunk's last byte
+        b">edge2\n" + base[1][:4096 - 7 - 3] + b"\n" + b">" + b"x" * 50 + b"\n" + base[1][:3000] + b"\n",   # a header across the edge
+        b"".join((b">c%d\n" % i) + base[i % 6][i * 10:i * 10 + int(rng.integers(1, 200))] + b"\n" for i in range(300)),   # 300 tiny records
+        b"",
+        b"\n\n\n",
+    ]
+    blobs = [gz(t, 6) for t in texts]
+    blobs[1] = blobs[1] + b"trailing bytes"                                          # refused (trailing): the host's inflater takes it
+    texts[1] = texts[1]
+    blobs.append(b"not gzip at all, but a long enough run of bytes"); texts.append(None)
+    seqs = [b"".join(l for l in t.split(b"\n") if not l.startswith(b">")) for t in texts if t is not None]
+    o = orc.OracleMiekki(k, h, 8, 32, 10)
+    o.insert_sequences([s_ for s_ in seqs if len(s_) >= k])
+    ix = miekki_amd.Miekki(k, h, 8, 32, 10)
+    try:
+        status = ix.insert_gz_files(blobs[:-1], fallback=True)
+        assert status[1] == TRAILING and all(s_ == OK for i, s_ in enumerate(status) if i != 1), status
+        assert ix.insert_gz_files([blobs[-1]], fallback=False) == [NOT_GZIP]
+        assert ix.index_size == o.index_size
+        np.testing.assert_array_equal(ix.sketch_size, o.sketch_size)
+        np.testing.assert_array_equal(ix.genome_size, o.genome_size)
+        a = bytearray(b"".join(ix.serialize())); a[32] = 0
+        b = bytearray(o.serialize().tobytes()); b[32] = 0
+        assert bytes(a) == bytes(b)
+    finally:
+        ix.close()
