@@ -147,7 +147,9 @@ static bool gunzip_members(const uint8_t *in, size_t in_size, std::vector<char> 
     if (in_size < 18) return false;
     uint32_t isize_last;
     memcpy(&isize_last, in + in_size - 4, 4);                     // right for the usual file of ONE member below 4 GiB
-    out.resize(std::max<size_t>((size_t)isize_last + 64, 1 << 16));
+    // (the trailer's word is a guess until the member has been inflated: never more room up front than a text that packed
+    // 64 : 1 would need -- a corrupt or many-member file must not make every reader thread clear gigabytes)
+    out.resize(std::max<size_t>(std::min<size_t>((size_t)isize_last + 64, in_size * 64 + (1 << 16)), 1 << 16));
     size_t at = 0, produced = 0;
     while (at < in_size) {
         size_t used = 0, got = 0;
@@ -194,6 +196,15 @@ static bool gunzip_all(const char *in, size_t in_size, std::vector<char> &out)
     inflateEnd(&zs);
     out.resize(produced);
     return ok;
+}
+
+bool inflate_fasta(const char *gz, size_t n, std::vector<char> &seq)
+{
+    std::vector<char> text;
+    if (!gunzip_all(gz, n, text)) return false;
+    seq.resize(text.size() + 1);
+    seq.resize(strip_fasta(text.data(), text.size(), seq.data()));
+    return true;
 }
 
 bool read_file(const std::string &path, std::vector<char> &out, std::vector<char> &scratch)
@@ -291,9 +302,11 @@ FileText::~FileText()
     if (map_) munmap(map_, maplen_);
 }
 
-OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed)
-    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed)
+OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed,
+                                       bool raw_gz)
+    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed), raw_gz_(raw_gz)
 {
+    if (raw_gz_) ahead_limit_ = 16ull << 30;                        // (a device batch is thousands of files: their bytes wait here)
     for (auto &r : ready_) r.store(0);
     const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
     window_ = std::max<size_t>(window, 2 * n + 8);
@@ -354,6 +367,7 @@ void OrderedFastaReader::pool_release(char *p)
 void OrderedFastaReader::recycle(Item &it)
 {
     if (!it.data) return;
+    if (it.raw) { munmap(it.data, it.len); it.data = nullptr; it.len = 0; it.raw = false; return; }
     std::lock_guard<std::mutex> g(pool_m_);
     pool_.emplace_back(it.data, it.cap);
     it.data = nullptr; it.len = it.cap = 0;
@@ -382,13 +396,33 @@ void OrderedFastaReader::work()
         {
             std::unique_lock<std::mutex> lk(m_);
             // bounded read-ahead, in files and in bytes (the file the consumer waits for always goes)
-            cv_.wait(lk, [&] { return stop_ || (i < consumed_ + window_ && (ahead_bytes_ < kAheadBytes || i == consumed_)); });
+            cv_.wait(lk, [&] { return stop_ || (i < consumed_ + window_ && (ahead_bytes_ < ahead_limit_ || i == consumed_)); });
             if (stop_) return;                                          // destroyed before every item was taken
         }
         Item it;
         struct stat st;
         it.exists = stat(files_[i].c_str(), &st) == 0;
-        if (it.exists) {
+        bool raw_done = false;
+        if (it.exists && raw_gz_ && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
+            // a gzip'd file as it is, for the device's inflater: mapped (the upload reads the page cache; a copy into page-locked
+            // buffers first cost more than the upload)
+            const int fd = ::open(files_[i].c_str(), O_RDONLY);
+            if (fd >= 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                close(fd);
+                if (m != MAP_FAILED) {
+                    const unsigned char *u = (const unsigned char *)m;
+                    if (u[0] == 0x1f && u[1] == 0x8b) {
+                        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+                        it.data = (char *)m; it.len = (size_t)st.st_size; it.cap = 0; it.raw = true;
+                        raw_done = true;
+                    } else {
+                        munmap(m, (size_t)st.st_size);
+                    }
+                }
+            }
+        }
+        if (it.exists && !raw_done) {
             FileText ft;                                               // mapped, or inflated into `text`
             if (!ft.open(files_[i], text)) {
                 it.failed = true;

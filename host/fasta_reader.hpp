@@ -44,6 +44,10 @@ inline size_t packed_except_words(size_t len) { return (len + 63) / 64 + 2; }
 // returns the sequence's length; *dirty = it holds characters other than A, C, G, T.  text[0..n) must be readable.
 size_t pack_fasta(const char *text, size_t n, uint64_t *codes, uint64_t *except, char head[32], bool *dirty);
 
+// the sequence of a gzip'd FASTA file whose bytes are at hand (every member, then strip_fasta): what a raw item becomes
+// when the device does not take it
+bool inflate_fasta(const char *gz, size_t n, std::vector<char> &seq);
+
 // whole file into `out`, gunzipped when it starts with the gzip magic (any number of members)
 bool read_file(const std::string &path, std::vector<char> &out, std::vector<char> &scratch);
 
@@ -68,12 +72,17 @@ public:
         size_t len = 0, cap = 0;
         // packed items (a reader made with a PackAppendFn): `data` holds the two arrays, no characters
         bool packed = false, dirty = false;
+        // raw items (a reader made with raw_gz): `data` is the FILE as it is -- gzip members, for the device to inflate
+        // (mk_gz_unpack) -- mapped, not copied (len bytes; recycle() takes the mapping down)
+        bool raw = false;
         uint64_t *codes = nullptr, *except = nullptr;
         char head[32] = {0};
     };
     // window = how many files may be parsed ahead of the consumer (each holds one buffer);
     // packed: items come packed (a quarter of the bytes to buffer and to copy to the GPU)
-    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed = false);
+    // raw_gz: files that start with the gzip magic are handed over as they are (Item::raw), everything else as before
+    OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed = false,
+                       bool raw_gz = false);
     ~OrderedFastaReader();
     // blocks until file i (called with i = 0, 1, 2, ...) has been read
     Item take(size_t i);
@@ -89,11 +98,11 @@ private:
     std::atomic<size_t> next_{0};
     size_t consumed_ = 0, window_ = 8, ahead_bytes_ = 0;
     bool stop_ = false;                            // set by the destructor: parked workers leave
-    static constexpr size_t kAheadBytes = 4ull << 30;
+    size_t ahead_limit_ = 4ull << 30;
     std::mutex m_;
     std::condition_variable cv_;
     HostAllocator a_;
-    bool pack_ = false;
+    bool pack_ = false, raw_gz_ = false;
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
     std::unordered_set<char *> plain_;              // buffers that came from malloc although an allocator was given

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <future>
 #include <iostream>
@@ -186,7 +187,7 @@ struct Driver {
     // one shard's share of index_file_of_file: files [f0, f1) of the list into ctx, in order.
     // `log` collects what the reference prints meanwhile (one '-' per genome kept, the
     // "Missed file" lines) so that several shards' output can be shown in list order.
-    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0; };
+    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0; size_t gz_on_device = 0, gz_on_host = 0; };
     void build_shard(mk_ctx *ctx, const vector<string> &files, unsigned nthreads, bool live, ShardBuild &sb)
     {
         vector<OrderedFastaReader::Item> seqs;
@@ -198,8 +199,14 @@ struct Driver {
         // batch returns as soon as its copy is done, so parsing, copying and sketching overlap
         // ... and pack as they parse (2 bits per base, mk_index_append_packed): a quarter of the bytes to buffer and
         // to move over PCIe, and the device skips its own packing pass.
+        // gzip'd files -- the reference's normal input (zstr, Miekki.cpp:559) -- arrive as their bytes and are inflated,
+        // stripped and appended on the device, a few thousand at a time (a deflate stream is decoded by one lane, so it is
+        // the number of streams in flight that makes the rate; MIEKKI_GZ_BATCH sets it, 0 = the readers inflate);
+        // whatever the device refuses is inflated here
+        static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)1024; }();
         PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, 3 * 64, true);
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, 4 * gz_batch + 64), true,
+                                  gz_batch != 0);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         auto flush = [&]() {
@@ -229,13 +236,110 @@ struct Driver {
             seqs.clear(); names.clear(); bytes = 0;
             return true;
         };
+        // Runs of raw (gzip'd) files: a batch is unpacked on the device by a thread of its own (mk_gz_unpack works on a
+        // stream of its own) while this thread takes the next files from the readers and appends the batch before -- a
+        // stream is decoded by ONE lane, half a second for a 5 Mb genome whatever the batch's size, so batches overlap:
+        // up to three in flight.  Appended in list order, sixty-four at a time.
+        struct RawBatch {
+            vector<OrderedFastaReader::Item> items;
+            vector<string> names;
+            std::future<mk_gz_batch *> unpacked;
+            string error;
+        };
+        std::deque<std::unique_ptr<RawBatch>> in_flight;
+        vector<OrderedFastaReader::Item> raw;
+        vector<string> raw_names;
+        auto start_raw = [&]() {
+            if (raw.empty()) return;
+            std::unique_ptr<RawBatch> rb(new RawBatch());
+            rb->items.swap(raw); rb->names.swap(raw_names);
+            RawBatch *r = rb.get();
+            r->unpacked = std::async(std::launch::async, [r, ctx]() -> mk_gz_batch * {
+                vector<const uint8_t *> gp;
+                vector<uint64_t> gl;
+                for (auto &it : r->items) { gp.push_back((const uint8_t *)it.data); gl.push_back(it.len); }
+                mk_gz_batch *gzb = nullptr;
+                if (mk_gz_unpack(ctx, gp.data(), gl.data(), (uint32_t)gp.size(), &gzb) != MK_OK) { r->error = mk_last_error(); return nullptr; }
+                return gzb;
+            });
+            in_flight.push_back(std::move(rb));
+        };
+        // the oldest batches until at most `leave` are in flight: their sequences into the index
+        auto drain_raw = [&](size_t leave) {
+            while (in_flight.size() > leave) {
+                std::unique_ptr<RawBatch> rb = std::move(in_flight.front());
+                in_flight.pop_front();
+                const double t0 = now();
+                mk_gz_batch *gzb = rb->unpacked.get();
+                sb.t_unpack_wait += now() - t0;
+                if (!gzb) { sb.error = "index build failed: " + rb->error; return false; }
+                vector<uint32_t> which;                                // files of the batch waiting to be appended together
+                vector<string> kept;
+                bool ok = true;
+                auto append = [&]() {
+                    if (which.empty()) return true;
+                    const double ta = now();
+                    if (mk_index_append_gz(ctx, gzb, which.data(), (uint32_t)which.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
+                    sb.t_append += now() - ta;
+                    sb.names.insert(sb.names.end(), kept.begin(), kept.end());
+                    which.clear(); kept.clear();
+                    return true;
+                };
+                for (size_t i = 0; i < rb->items.size() && ok; ++i) {
+                    uint64_t len = 0;
+                    int32_t st = 0;
+                    mk_gz_sequence(gzb, (uint32_t)i, &len, &st);
+                    if (st != MK_GZ_OK) {
+                        // the device refused the file: inflated here, appended in its place
+                        vector<char> seq;
+                        if (!mkhost::inflate_fasta(rb->items[i].data, rb->items[i].len, seq)) { sb.error = "cannot read " + rb->names[i]; ok = false; break; }
+                        ++sb.gz_on_host;
+                        if (seq.size() >= k) {
+                            ok = append();
+                            const char *p = seq.data();
+                            const uint64_t l = seq.size();
+                            if (ok && mk_index_append(ctx, &p, &l, 1) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); ok = false; }
+                            if (ok) { sb.names.push_back(rb->names[i]); sb.log += '-'; }
+                        }
+                        continue;
+                    }
+                    if (len >= k) {
+                        which.push_back((uint32_t)i); kept.push_back(rb->names[i]);
+                        sb.log += '-';
+                        if (which.size() >= 64) { ok = append(); show(); }
+                    }
+                }
+                ok = ok && append();
+                // (mk_gz_free waits for the strip kernels that read the batch's text)
+                mk_gz_free(gzb);
+                sb.gz_on_device += rb->items.size();
+                for (auto &it : rb->items) reader.recycle(it);
+                show();
+                if (!ok) return false;
+            }
+            return true;
+        };
+        // everything raw so far into the index (before anything that must come after it in list order)
+        auto flush_raw = [&]() {
+            if (raw.empty() && in_flight.empty()) return true;
+            if (!flush()) return false;                                // (list order: what came before the run goes first)
+            start_raw();
+            return drain_raw(0);
+        };
         for (size_t i = 0; i < files.size(); ++i) {
             const string &fn = files[i];
             const double t0 = now();
             OrderedFastaReader::Item item = reader.take(i);
             sb.t_wait += now() - t0;
-            if (!item.exists) { sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
+            if (!item.exists) { if (!flush_raw()) return; sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
             if (item.failed) { sb.error = "cannot read " + fn; return; }
+            if (item.raw) {
+                if (raw.empty() && in_flight.empty() && !flush()) return;      // (a run starts: what came before it goes first)
+                raw.push_back(item); raw_names.push_back(fn);
+                if (raw.size() >= gz_batch) { start_raw(); if (!drain_raw(2)) return; }
+                continue;
+            }
+            if (!flush_raw()) return;
             if (item.len >= k) {
                 bytes += item.len;
                 seqs.push_back(item); names.push_back(fn);
@@ -245,7 +349,8 @@ struct Driver {
                 reader.recycle(item);
             }
         }
-        if (!flush()) return;
+        if (!flush_raw() || !flush()) return;
+        mk_gz_trim(ctx);                                           // (the inflater's blocks: the queries' buffers want the memory)
         if (mk_index_size(ctx) != sb.names.size()) sb.error = string("index build failed: ") + mk_last_error();   // settles the last batch
     }
 
@@ -299,7 +404,8 @@ struct Driver {
         if (getenv("MIEKKI_VERBOSE"))
             for (size_t d = 0; d < D; ++d)
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
-                     << "s, in mk_index_append " << sb[d].t_append << "s" << endl;
+                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s; gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
+                     << ", on the host " << sb[d].gz_on_host << endl;
         finish_index(true);
         compress_cold();
         cout << "Reference indexed: " << group.total() << endl;

@@ -213,15 +213,23 @@ typedef enum {
 int mk_gz_inflate(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, uint8_t *const *out,
                   const uint64_t *out_room, uint64_t *out_bytes, int32_t *status);
 
-/* n genome FILES (gzip'd FASTA) -> their sequences as index_file_of_file reads them (Miekki.cpp:559-567: every line
- * that does not start with '>' appended, line feeds dropped), inflated, stripped and kept ON THE DEVICE: mk_gz_sequence
- * hands out a device pointer that mk_index_append takes like a host pointer (the copy then never leaves the GPU).
- * A file whose status is not MK_GZ_OK has no sequence here: inflate it on the host.  The batch's memory (about twice
- * the files' text) stays allocated until mk_gz_free; the appends that read it must have returned by then. */
+/* n genome FILES (gzip'd FASTA) inflated and kept as text ON THE DEVICE, their sequences as index_file_of_file reads them
+ * (Miekki.cpp:559-567: every line that does not start with '>' appended, line feeds dropped) measured: mk_gz_sequence says
+ * how long file i's is, mk_index_append_gz appends files of the batch -- their sequences are stripped out of the text straight
+ * into the build's buffers, nothing crosses PCIe again.  A file whose status is not MK_GZ_OK has no sequence here: inflate it
+ * on the host.  The batch's memory (the files, their text and about as much again) is the context's until mk_gz_free -- the
+ * appends that read it must have returned -- and stays with the context for the next batch until mk_gz_trim or mk_destroy.
+ * mk_gz_unpack works on a stream of its own and touches nothing of the context but its device and its list of spare memory:
+ * it may run on a thread of its own while other calls use the context (the driver inflates the next batch while it appends
+ * the one before). */
 typedef struct mk_gz_batch mk_gz_batch;
 int mk_gz_unpack(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out);
-int mk_gz_sequence(const mk_gz_batch *batch, uint32_t i, const char **d_seq, uint64_t *len, int32_t *status);
+int mk_gz_sequence(const mk_gz_batch *batch, uint32_t i, uint64_t *len, int32_t *status);
+/* insert_sequences (Miekki.cpp:277-314) for files which[0 .. n) of the batch, in that order (each must have status MK_GZ_OK and
+ * at least k characters); pipelined like mk_index_append. */
+int mk_index_append_gz(mk_ctx *ctx, const mk_gz_batch *batch, const uint32_t *which, uint32_t n);
 void mk_gz_free(mk_gz_batch *batch);
+void mk_gz_trim(mk_ctx *ctx);                /* give the device memory kept between batches back (after a build) */
 
 /* ---- persistence: the payload of dump_disk / the loading constructor
  * (Miekki.cpp:649-719), streamed in ranges so that the host never

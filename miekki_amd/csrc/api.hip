@@ -541,6 +541,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         if (at > c->qarena_cap) {
             MK_HIP(hipStreamSynchronize(c->stream));
             dev_free(c->d_qarena);
+    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
             c->qarena_cap = 0;
             const uint64_t cap = std::max<uint64_t>(at + at / 2, 4ull << 20);
             MK_TRY(dev_alloc(&c->d_qarena, cap));
@@ -1198,14 +1199,46 @@ int mk_index_append(mk_ctx *c, const char *const *seqs, const uint64_t *lens, ui
         const int buf = c->seq_cur ^ 1;
         MK_TRY(ensure_build_scratch(c, off[nb], buf));
         for (uint32_t g = 0; g < nb; ++g)
-            MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyDefault,   // (host memory, or the device's: mk_gz_sequence)
-                                  c->copy_stream));
+            MK_HIP(hipMemcpyAsync(c->d_seq[buf] + off[g], seqs[g0 + g], lens[g0 + g], hipMemcpyHostToDevice, c->copy_stream));
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));
         MK_TRY(enqueue_back(c));
         MK_TRY(settle_older(c));
         c->seq_cur = buf;
         MK_HIP(hipEventSynchronize(c->ev_copy));
+        g0 += nb;
+    }
+    return MK_OK;
+}
+
+// insert_sequences for files of an inflated batch (mk_gz_unpack): their sequences are stripped out of the batch's text
+// straight into the build's sequence buffer -- no copy, nothing crosses PCIe -- and take the same kernels as characters.
+int mk_index_append_gz(mk_ctx *c, const mk_gz_batch *batch, const uint32_t *which, uint32_t n)
+{
+    if (!c || !batch || (n && !which)) { set_error("null argument"); return MK_ERR_ARG; }
+    if (gz_batch_owner(batch) != c) { set_error("the batch belongs to another context"); return MK_ERR_ARG; }
+    MK_TRY(use_device(c, false));
+    for (uint32_t g = 0; g < n; ++g) {
+        if (which[g] >= gz_batch_size(batch) || !gz_batch_ok(batch, which[g])) { set_error("file %u of the batch has no sequence", which[g]); return MK_ERR_ARG; }
+        if (gz_batch_len(batch, which[g]) < c->p.k) { set_error("sequence %u shorter than k", g); return MK_ERR_ARG; }
+    }
+    MK_TRY(ensure_build_scratch(c, 0, c->seq_cur ^ 1));
+    for (uint32_t g0 = 0; g0 < n;) {
+        uint64_t off[kBuildBatch + 1];
+        off[0] = 0;
+        uint32_t nb = 0;
+        while (nb < c->build_batch && g0 + nb < n && (nb == 0 || off[nb] + gz_batch_len(batch, which[g0 + nb]) <= (2ull << 30))) {
+            off[nb + 1] = off[nb] + gz_batch_len(batch, which[g0 + nb]);
+            ++nb;
+        }
+        const int buf = c->seq_cur ^ 1;
+        MK_TRY(ensure_build_scratch(c, off[nb], buf));
+        MK_TRY(gz_batch_strip(c, batch, which + g0, nb, reinterpret_cast<uint8_t *>(c->d_seq[buf]), off, c->copy_stream));
+        MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
+        MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));
+        MK_TRY(enqueue_back(c));
+        MK_TRY(settle_older(c));
+        c->seq_cur = buf;
         g0 += nb;
     }
     return MK_OK;

@@ -118,31 +118,40 @@ __global__ void fasta_offsets_kernel(const mk_gz_stream *__restrict__ jobs, cons
     seq_len[s] = jobs[s].status == MK_GZ_OK ? off : 0u;
 }
 
-__global__ __launch_bounds__(256) void fasta_strip_kernel(const uint8_t *__restrict__ text, const mk_gz_stream *__restrict__ jobs,
-                                                          const uint32_t *__restrict__ chunk_first, uint32_t n,
-                                                          const ChunkPlace *__restrict__ places, uint8_t *__restrict__ seqs,
-                                                          const uint64_t *__restrict__ seq_off)
+// the kept bytes of up to 64 texts to where the build wants them (its sequence buffer): a call's chunks are the chunks of
+// its texts, one text after the other
+struct StripCall {
+    uint32_t stream[kBuildBatch];          // which texts
+    uint32_t chunk0[kBuildBatch];          // each one's first chunk in the batch's numbering (sums / places)
+    uint32_t first[kBuildBatch + 1];       // each one's first chunk in the call's numbering
+    uint64_t dst_off[kBuildBatch];         // where each sequence starts in dst
+    uint32_t n;
+};
+
+__global__ __launch_bounds__(256) void fasta_strip_kernel(const uint8_t *__restrict__ text, const mk_gz_stream *__restrict__ jobs, StripCall call,
+                                                          const ChunkPlace *__restrict__ places, uint8_t *__restrict__ dst)
 {
     __shared__ Sum buf[2][256];
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (chunk_first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const mk_gz_stream job = jobs[lo];
+    uint32_t lo = 0, hi = call.n;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (call.first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const mk_gz_stream job = jobs[call.stream[lo]];
     if (job.status != MK_GZ_OK) return;
-    const uint32_t at = (blockIdx.x - chunk_first[lo]) * kChunk + threadIdx.x * kPiece;
+    const uint32_t local = blockIdx.x - call.first[lo];
+    const uint32_t at = local * kChunk + threadIdx.x * kPiece;
     const Piece p = load_piece(text + job.out_off, job.out_len, at);
-    const ChunkPlace place = places[blockIdx.x];
+    const ChunkPlace place = places[call.chunk0[lo] + local];
     Sum total;
     const Sum ex = block_scan(summarise(p), buf, &total);
     // what came before this piece in the chunk: the line it starts in, and how many kept bytes
     uint32_t header = ex.has ? ex.st : place.in_header;
-    uint8_t *__restrict__ dst = seqs + seq_off[lo] + place.seq_off + (place.in_header ? 0u : ex.head) + ex.body;
+    uint8_t *__restrict__ out = dst + call.dst_off[lo] + place.seq_off + (place.in_header ? 0u : ex.head) + ex.body;
     uint8_t prev = p.prev;
 #pragma unroll
     for (uint32_t j = 0; j < kPiece; ++j) {
         if (j < p.n) {
             const uint8_t c = p.b[j];
             if (prev == '\n') header = c == '>' ? 1u : 0u;
-            if (c != '\n' && !header) *dst++ = c;
+            if (c != '\n' && !header) *out++ = c;
             prev = c;
         }
     }
@@ -150,11 +159,10 @@ __global__ __launch_bounds__(256) void fasta_strip_kernel(const uint8_t *__restr
 
 }  // namespace
 
-// The sequences of the batch's texts (streams whose status is not MK_GZ_OK: length 0): h_first[n + 1] = the streams' first
-// chunks (prefix sums of ceil(out_len / 4 KiB), made by the caller from the jobs it has read back), d_seq_off[n] = where
-// each sequence goes in d_seqs (bytes), d_seq_len[n] out.  Queued on st.
-int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first,
-                       uint32_t n_chunks, void *d_scratch, uint8_t *d_seqs, const uint64_t *d_seq_off, uint64_t *d_seq_len, hipStream_t st)
+// The sequences' lengths (streams whose status is not MK_GZ_OK: 0) and every chunk's place: d_chunk_first[n + 1] = the streams'
+// first chunks (prefix sums of ceil(out_len / 4 KiB), made by the caller from the streams it has read back).  Queued on st.
+int launch_fasta_count(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first, uint32_t n_chunks,
+                       void *d_scratch, uint64_t *d_seq_len, hipStream_t st)
 {
     (void)c;
     if (!n) return MK_OK;
@@ -166,10 +174,30 @@ int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_j
     }
     hipLaunchKernelGGL(fasta_offsets_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, d_jobs, d_chunk_first, n, sums, places, d_seq_len);
     MK_HIP(hipGetLastError());
-    if (n_chunks) {
-        hipLaunchKernelGGL(fasta_strip_kernel, dim3(n_chunks), dim3(256), 0, st, d_text, d_jobs, d_chunk_first, n, places, d_seqs, d_seq_off);
-        MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+// m <= 64 of the batch's sequences (streams which[0 .. m), whose first chunks are h_chunk_first[which[i]]) into d_dst at
+// dst_off[i]
+int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, const uint32_t *which, uint32_t m, const uint32_t *h_chunk_first,
+                       uint32_t n_chunks, const void *d_scratch, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st)
+{
+    (void)c;
+    if (!m) return MK_OK;
+    if (m > kBuildBatch) { set_error("at most %u sequences per call", kBuildBatch); return MK_ERR_ARG; }
+    StripCall call;
+    call.n = m;
+    call.first[0] = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        call.stream[i] = which[i];
+        call.chunk0[i] = h_chunk_first[which[i]];
+        call.first[i + 1] = call.first[i] + (h_chunk_first[which[i] + 1] - h_chunk_first[which[i]]);
+        call.dst_off[i] = dst_off[i];
     }
+    if (!call.first[m]) return MK_OK;
+    const ChunkPlace *places = reinterpret_cast<const ChunkPlace *>(reinterpret_cast<const ChunkSum *>(d_scratch) + n_chunks);
+    hipLaunchKernelGGL(fasta_strip_kernel, dim3(call.first[m]), dim3(256), 0, st, d_text, d_jobs, call, places, d_dst);
+    MK_HIP(hipGetLastError());
     return MK_OK;
 }
 

@@ -22,6 +22,9 @@
 // a status and nothing else: the caller (host/fasta_reader.cpp) hands such a file to the host's own inflater, which
 // then says what the file is worth.  Behind it, fasta.hip strips header lines and line ends and packs the sequences.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -197,8 +200,13 @@ __device__ uint32_t slow_symbol(TokLds &L, uint32_t lane, BitReader &br, bool di
     return ~0u;
 }
 
-__global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
-                                                       uint32_t *__restrict__ tokens, uint32_t *__restrict__ aux)
+// One lane per SEGMENT of a stream: from the stream's first byte, or from a block's first bit that the finder (below) has
+// vouched for, up to the next such bit that the decoding ARRIVES at between two blocks (or to the stream's end).  A segment
+// whose start was no block's start decodes noise until an error or until it falls into step with the real blocks: nobody
+// follows the chain through it.  write = 0: nothing is stored -- the pass that measures every segment (tokens, bytes, where
+// it ends), so that the pass that writes knows every segment's place.
+__global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict__ gz, mk_gz_seg *__restrict__ jobs, uint32_t n,
+                                                       const uint64_t *__restrict__ cands, uint32_t *__restrict__ tokens, uint32_t *__restrict__ aux)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TokLds &L = *reinterpret_cast<TokLds *>(smem);
@@ -208,14 +216,24 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
     // the LDS cycles were conflicts)
     const uint32_t col = ((lane & 31u) << 1) | (lane >> 5);
     const bool live = s < n;
-    mk_gz_stream job = live ? jobs[s] : mk_gz_stream{};
+    mk_gz_seg job = live ? jobs[s] : mk_gz_seg{};
     uint32_t *const sorted = aux + (uint64_t)(live ? s : 0u) * 288u;
     BitReader br;
     br.start(gz + job.in_off, live ? job.in_len : 0u, &L, lane);
     uint32_t state = live ? ST_MEMBER : ST_DONE, status = live ? MK_GZ_OK : MK_GZ_EMPTY;
-    uint32_t n_tok = 0, n_out = 0, out_len = 0, member_out = 0, members = 0;      // n_out: tokens already in memory (the rest: the lane's ring)
+    uint32_t n_tok = 0, n_out = 0, out_len = 0, members = 0;        // n_out: tokens already in memory (the rest: the lane's ring)
+    uint32_t member_bytes = job.member_out0;                         // bytes of the member being decoded so far (what a match may reach back into)
+    uint32_t link = 0xffffffffu, ci = job.cand_next;                 // the candidate this segment stops at; the next one to look at
+    const uint64_t *__restrict__ my_cands = cands + job.cand_off;    // (ascending, ends with ~0)
+    const bool writing = job.write != 0u;
     bool final_block = false;
-    if (live && job.in_len < 18u) { state = ST_DONE; status = MK_GZ_NOT_GZIP; }
+    if (live && job.start_bit == 0ull && job.in_len < 18u) { state = ST_DONE; status = MK_GZ_NOT_GZIP; }
+    if (live && job.start_bit != 0ull) {
+        br.seek_byte(job.start_bit >> 3);
+        br.drop((uint32_t)(job.start_bit & 7u));
+        state = br.over ? ST_DONE : ST_BLOCK;
+        if (br.over) status = MK_GZ_TRUNCATED;
+    }
     auto fail = [&](uint32_t why) { status = why; state = ST_DONE; };
     auto emit = [&](uint32_t t) {                                   // (the passes below emit at most three; round() keeps that much room)
         if (n_tok < job.tok_cap) { L.tok[lane][n_tok - n_out] = t; ++n_tok; }
@@ -225,13 +243,24 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
     // input refilled from the word it reads next, four words per load.  Every lane its own stream: 64 cache lines per
     // instruction, but only a few dozen instructions per round and a round every few dozen tokens.
     const uint4 *__restrict__ in16 = reinterpret_cast<const uint4 *>(gz + job.in_off);
-    uint4 *__restrict__ tok16 = reinterpret_cast<uint4 *>(tokens + job.tok_off);      // (tok_off is a multiple of four)
+    // (a segment's tokens start wherever the segment before it ended: the ring is written out in 16-byte pieces from the
+    // first multiple of four on -- n_out starts at the few tokens before it, which are stored one by one)
+    uint32_t *__restrict__ tok_base = tokens + job.tok_off;
+    const uint32_t lead = writing ? (uint32_t)((4u - (job.tok_off & 3u)) & 3u) : 0u;       // tokens before the first aligned one
     auto round = [&]() {
-        const uint32_t have = n_tok - n_out, whole = have & ~3u;
-        for (uint32_t i = 0; __any(i < whole); i += 4u)
-            if (i < whole) tok16[(n_out + i) >> 2] = *reinterpret_cast<const uint4 *>(&L.tok[lane][i]);
-        if (whole) for (uint32_t i = 0; i < (have & 3u); ++i) L.tok[lane][i] = L.tok[lane][whole + i];
-        n_out += whole;
+        uint32_t have = n_tok - n_out, done = 0;
+        // (the first tokens of a segment up to the 16-byte boundary of its place, one by one; then whole fours)
+        if (writing && n_out < lead) { done = min(lead - n_out, have); for (uint32_t i = 0; i < done; ++i) tok_base[n_out + i] = L.tok[lane][i]; }
+        const uint32_t whole = (have - done) & ~3u;
+        for (uint32_t i = 0; __any(writing && i < whole); i += 4u)
+            if (writing && i < whole) {
+                uint4 v;
+                v.x = L.tok[lane][done + i]; v.y = L.tok[lane][done + i + 1u]; v.z = L.tok[lane][done + i + 2u]; v.w = L.tok[lane][done + i + 3u];
+                *reinterpret_cast<uint4 *>(tok_base + n_out + done + i) = v;
+            }
+        const uint32_t gone = writing ? done + whole : have & ~3u;
+        if (gone) for (uint32_t i = 0; i < have - gone; ++i) L.tok[lane][i] = L.tok[lane][gone + i];
+        n_out += gone;
         br.base = br.wi & ~3u;
         uint4 v[kInWords / 4u];
 #pragma unroll
@@ -298,13 +327,14 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 const uint32_t dist = (dsym < 4u ? dsym + 1u : 1u + ((2u + (dsym & 1u)) << dex)) + ((uint32_t)br.bb & ((1u << dex) - 1u));
                 br.bb >>= dex; br.bc -= dex;
                 const uint32_t grow = is_len ? len : is_lit ? 1u : 0u;
-                if (is_len && dist > out_len - member_out) err = err ? err : MK_GZ_BAD_DISTANCE;
+                if (is_len && dist > member_bytes) err = err ? err : MK_GZ_BAD_DISTANCE;
                 if (grow > job.out_cap - out_len) err = err ? err : MK_GZ_OUTPUT_ROOM;
                 if (grow && n_tok >= job.tok_cap) err = err ? err : MK_GZ_TOKEN_ROOM;
                 const bool put = grow != 0u && err == 0u;
                 L.tok[lane][put ? n_tok - n_out : kTokRing] = is_len ? kTokMatch | (len << 16) | (dist - 1u) : value;   // (column kTokRing: nobody reads it)
                 n_tok += put ? 1u : 0u;
                 out_len += put ? grow : 0u;
+                member_bytes += put ? grow : 0u;
                 if (err) { status = err; state = ST_DONE; }
                 else if (is_eob) state = final_block ? ST_TRAILER : ST_BLOCK;
                 // leave the loop for a block's end or an error somewhere, and for a round
@@ -314,6 +344,15 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
         }
         if (state == ST_TOKENS) {
             // (some other lane reads a header or a trailer in this pass: the symbol loop waits for it)
+        } else if (state == ST_BLOCK && [&] {
+                       // between two blocks: has the decoding arrived at a start that another segment decodes from?
+                       const uint64_t here = br.consumed_bits();
+                       if (here == job.start_bit) return false;
+                       while (my_cands[ci] < here) ++ci;
+                       return my_cands[ci] == here;
+                   }()) {
+            link = ci;
+            state = ST_DONE;                                         // (status stays OK: the chain goes on in that segment)
         } else if (state == ST_BLOCK) {
             final_block = br.get(1) != 0;
             const uint32_t type = br.get(2);
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 else if (br.over || at + len > job.in_len) fail(MK_GZ_TRUNCATED);
                 else if (len > job.out_cap - out_len) fail(MK_GZ_OUTPUT_ROOM);
                 else {
-                    if (len) { emit(kTokStored | len); emit((uint32_t)at); out_len += len; }
+                    if (len) { emit(kTokStored | len); emit((uint32_t)at); out_len += len; member_bytes += len; }
                     if (state != ST_DONE) { br.seek_byte(at + len); state = final_block ? ST_TRAILER : ST_BLOCK; }
                 }
             } else if (type == 1u) {
@@ -382,7 +421,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
             emit(crc);
             emit(isize);
             ++members;
-            member_out = out_len;
+            member_bytes = 0;
             const uint64_t used = br.consumed_bits() >> 3;          // whole bytes: the reader is byte-aligned here
             if (br.over || used > job.in_len) fail(MK_GZ_TRUNCATED);
             else if (state != ST_DONE) {
@@ -413,12 +452,145 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
         }
     }
     round();                                                         // what is left in the rings: whole fours, then the rest
-    for (uint32_t i = 0; i < n_tok - n_out; ++i) tokens[job.tok_off + n_out + i] = L.tok[lane][i];
+    if (writing) for (uint32_t i = 0; i < n_tok - n_out; ++i) tok_base[n_out + i] = L.tok[lane][i];
     if (live) {
         jobs[s].n_tok = n_tok;
         jobs[s].out_len = out_len;
         jobs[s].status = status;
         jobs[s].members = members;
+        jobs[s].link = link;
+        jobs[s].member_tail = member_bytes;
+    }
+}
+
+// ---------------------------------------------------------------- where blocks start
+// A deflate stream says nowhere where its blocks start, but a dynamic block's header is hard to imitate: the type bits, at
+// most 286 + 30 codes, a COMPLETE code length code, code lengths that decode without a repeat before the first length or
+// across the end, an end-of-block code, and two complete codes (or a single distance code).  Random bits pass the first part
+// (gz_find_kernel: type, counts, the code length code's Kraft sum) at one offset in a thousand and the second
+// (gz_check_kernel) practically never: on gzip'd genomes exactly the blocks' real starts are left (59 of 59, no other offset
+// of 12.4 million).  A start that is missed -- a fixed or stored block, a file this test is too strict for -- only means that
+// the segment before it decodes on through it; a false one only costs a lane that decodes noise.
+__device__ __forceinline__ uint64_t bits_at(const uint8_t *__restrict__ p, uint64_t bit)       // 57 bits from `bit` on
+{
+    const uint64_t b = bit >> 3;
+    uint64_t v;
+    __builtin_memcpy(&v, p + b, 8);                                 // (the streams have 16 bytes of padding behind them)
+    return v >> (bit & 7u);
+}
+
+__global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict__ gz, const mk_gz_stream *__restrict__ streams, const uint64_t *__restrict__ word_first,
+                                                      uint32_t n, uint64_t *__restrict__ hits, uint32_t *__restrict__ n_hits, uint32_t cap)
+{
+    // a thread: the 32 bit offsets of one 4-byte word of one stream
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (w >= word_first[n]) return;
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (word_first[mid] <= w) lo = mid; else hi = mid; }
+    const mk_gz_stream st = streams[lo];
+    const uint8_t *__restrict__ p = gz + st.in_off;
+    const uint64_t bit0 = (w - word_first[lo]) * 32u, nbits = (uint64_t)st.in_len * 8u;
+    for (uint32_t o = 0; o < 32u; ++o) {
+        const uint64_t bit = bit0 + o;
+        if (bit + 80u > nbits) break;                               // (a block and a trailer need more than that)
+        const uint64_t v = bits_at(p, bit);
+        if (((v >> 1) & 3u) != 2u) continue;                        // BTYPE: dynamic Huffman codes
+        if (((v >> 3) & 31u) > 29u || ((v >> 8) & 31u) > 29u) continue;   // HLIT, HDIST
+        const uint32_t hclen = (uint32_t)((v >> 13) & 15u) + 4u;
+        // the code length code's lengths, three bits each from bit 17 on: complete iff the sum of 2^(7 - length) is 2^7
+        uint32_t kraft = 0;
+        uint64_t x = v >> 17;                                        // 40 bits = 13 lengths; the rest from a second look
+        for (uint32_t i = 0; i < hclen; ++i) {
+            if (i == 13u) x = bits_at(p, bit + 17u + 39u);
+            const uint32_t l = (uint32_t)x & 7u;
+            x >>= 3;
+            kraft += l ? 128u >> l : 0u;
+        }
+        if (kraft != 128u) continue;
+        const uint32_t at = atomicAdd(n_hits, 1u);
+        if (at < cap) hits[at] = ((uint64_t)lo << 40) | bit;
+    }
+}
+
+// the second part of the test, one thread per offset that passed the first; the offsets that pass this one too are appended
+// to `good`
+__global__ __launch_bounds__(64) void gz_check_kernel(const uint8_t *__restrict__ gz, const mk_gz_stream *__restrict__ streams, const uint64_t *__restrict__ hits,
+                                                      const uint32_t *__restrict__ n_hits, uint32_t cap, uint64_t *__restrict__ good, uint32_t *__restrict__ n_good,
+                                                      uint32_t good_cap)
+{
+    __shared__ uint8_t cl_tab[128][64];                              // the code length code's table, a column per lane: symbol | length << 5
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane, total = min(*n_hits, cap);
+    if (i >= total) return;
+    const uint64_t h = hits[i];
+    const uint32_t s = (uint32_t)(h >> 40);
+    const uint64_t bit = h & ((1ull << 40) - 1ull);
+    const mk_gz_stream st = streams[s];
+    const uint8_t *__restrict__ p = gz + st.in_off;
+    const uint64_t nbits = (uint64_t)st.in_len * 8u;
+    uint64_t v = bits_at(p, bit);
+    const uint32_t hlit = (uint32_t)((v >> 3) & 31u) + 257u, hdist = (uint32_t)((v >> 8) & 31u) + 1u, hclen = (uint32_t)((v >> 13) & 15u) + 4u;
+    uint32_t cl[19];
+#pragma unroll
+    for (uint32_t j = 0; j < 19u; ++j) cl[j] = 0;
+    uint64_t q = bit + 17u;
+    // (cl[] is indexed by constants only: the order of RFC 1951 3.2.7 unrolled)
+    uint32_t got[19];
+#pragma unroll
+    for (uint32_t j = 0; j < 19u; ++j) { got[j] = j < hclen ? (uint32_t)bits_at(p, q) & 7u : 0u; q += j < hclen ? 3u : 0u; }
+    cl[16] = got[0]; cl[17] = got[1]; cl[18] = got[2]; cl[0] = got[3]; cl[8] = got[4]; cl[7] = got[5]; cl[9] = got[6]; cl[6] = got[7]; cl[10] = got[8];
+    cl[5] = got[9]; cl[11] = got[10]; cl[4] = got[11]; cl[12] = got[12]; cl[3] = got[13]; cl[13] = got[14]; cl[2] = got[15]; cl[14] = got[16]; cl[1] = got[17];
+    cl[15] = got[18];
+    // canonical codes of the (complete) code length code into the table
+    uint32_t cnt[8];
+#pragma unroll
+    for (uint32_t l = 0; l < 8u; ++l) cnt[l] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 19u; ++j)
+#pragma unroll
+        for (uint32_t l = 1; l < 8u; ++l) cnt[l] += cl[j] == l ? 1u : 0u;
+    uint32_t next[8], code = 0;
+    next[0] = 0;
+#pragma unroll
+    for (uint32_t l = 1; l < 8u; ++l) { code = (code + (l > 1u ? cnt[l - 1u] : 0u)) << 1; next[l] = code; }
+#pragma unroll
+    for (uint32_t j = 0; j < 19u; ++j) {
+        const uint32_t l = cl[j];
+        if (!l) continue;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < 8u; ++k) if (l == k) { c = next[k]; next[k] = c + 1u; }
+        const uint32_t r = __brev(c) >> (32u - l);
+        for (uint32_t e = r; e < 128u; e += 1u << l) cl_tab[e][lane] = (uint8_t)(j | (l << 5));
+    }
+    // the lengths of both alphabets: nothing is kept but each alphabet's Kraft sum (in units of 2^-15), its longest code and
+    // whether symbol 256 has one
+    const uint32_t total_syms = hlit + hdist;
+    uint32_t k = 0, prev = 0, kraft_l = 0, kraft_d = 0, max_l = 0, max_d = 0, eob = 0;
+    bool ok = true;
+    auto take = [&](uint32_t len, uint32_t rep) {                    // `rep` symbols of length `len` from symbol k on
+        for (uint32_t r = 0; r < rep; ++r, ++k) {
+            if (!len) continue;
+            if (k < hlit) { kraft_l += 32768u >> len; max_l = max(max_l, len); if (k == 256u) eob = 1; }
+            else { kraft_d += 32768u >> len; max_d = max(max_d, len); }
+        }
+    };
+    while (ok && k < total_syms) {                                   // (every pass takes at least one symbol's length)
+        if (q + 64u > nbits + 64u) { ok = false; break; }
+        v = bits_at(p, q);
+        const uint32_t e = cl_tab[(uint32_t)v & 127u][lane];
+        const uint32_t sym = e & 31u, l = e >> 5;                    // (the code is complete: every index holds an entry)
+        q += l; v >>= l;
+        if (sym < 16u) { take(sym, 1); prev = sym; }
+        else if (sym == 16u) { if (!k) { ok = false; break; } const uint32_t rep = 3u + ((uint32_t)v & 3u); q += 2u; if (k + rep > total_syms) { ok = false; break; } take(prev, rep); }
+        else if (sym == 17u) { const uint32_t rep = 3u + ((uint32_t)v & 7u); q += 3u; if (k + rep > total_syms) { ok = false; break; } take(0, rep); prev = 0; }
+        else { const uint32_t rep = 11u + ((uint32_t)v & 127u); q += 7u; if (k + rep > total_syms) { ok = false; break; } take(0, rep); prev = 0; }
+        if (q > nbits) ok = false;
+    }
+    // what inflate_table takes: not over-subscribed; incomplete only as a single one-bit code (or, the distances, none at all)
+    ok = ok && eob && kraft_l <= 32768u && (kraft_l == 32768u || max_l <= 1u) && kraft_d <= 32768u && (kraft_d == 32768u || max_d <= 1u);
+    if (ok) {
+        const uint32_t at = atomicAdd(n_good, 1u);
+        if (at < good_cap) good[at] = h;
     }
 }
 
@@ -642,7 +814,7 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restri
 
 }  // namespace
 
-uint32_t gf_mul_host(uint32_t a, uint32_t b)
+static uint32_t gf_mul_host(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
     for (uint32_t i = 0; i < 32; ++i) {
@@ -660,24 +832,270 @@ static uint32_t x_pow_bytes(uint64_t nbytes)                          // x^(8 n)
     return r;
 }
 
-// ---- the two phases over a batch of streams already on the device (gz: their bytes; jobs: where each lies and how much
-// room its tokens and text have).  Queued on `st`; the jobs' results are in d_jobs when the stream gets there.
-int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t n, uint32_t *d_tokens, uint32_t *d_aux, uint8_t *d_text,
-                  hipStream_t st)
+// ---- device memory of the inflater: blocks kept by the context between batches (allocating and freeing tens of gigabytes
+// per batch cost a second each)
+static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got)
 {
+    {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        size_t best = c->gz_blocks.size();
+        for (size_t i = 0; i < c->gz_blocks.size(); ++i)
+            if (c->gz_blocks[i].second >= need && c->gz_blocks[i].second <= 2 * need + (64ull << 20) &&
+                (best == c->gz_blocks.size() || c->gz_blocks[i].second < c->gz_blocks[best].second)) best = i;
+        if (best != c->gz_blocks.size()) {
+            uint8_t *p = (uint8_t *)c->gz_blocks[best].first;
+            *got = c->gz_blocks[best].second;
+            c->gz_blocks.erase(c->gz_blocks.begin() + (long)best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    const uint64_t want = need + need / 8 + 4096;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        {                                                            // what is kept and does not fit makes room
+            std::lock_guard<std::mutex> g(c->gz_m);
+            for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
+            c->gz_blocks.clear();
+        }
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    *got = want;
+    return (uint8_t *)p;
+}
+
+static void gz_block_put(mk_ctx *c, uint8_t *p, uint64_t bytes)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(c->gz_m);
+    c->gz_blocks.emplace_back(p, bytes);
+}
+
+// One batch of streams through the inflater: the files' bytes up, where their blocks start (gz_find / gz_check), every
+// segment measured (gz_tokens, write = 0), the chain of segments from each stream's first byte to its last followed on the
+// host -- which gives every stream's token count and text length exactly --, then the pass that writes the tokens and the
+// pass that turns them into text (gz_resolve).  The text stays on the device (blk_out) with the streams' results in
+// `streams`; a stream whose status is not MK_GZ_OK has no text.
+struct GzRun {
+    mk_ctx *c = nullptr;
+    hipStream_t st = nullptr;
+    uint32_t n = 0;
+    std::vector<mk_gz_stream> streams;
+    uint8_t *blk_in = nullptr, *blk_seg = nullptr, *blk_out = nullptr;
+    uint64_t in_bytes = 0, seg_bytes = 0, out_bytes = 0;
+    uint8_t *d_text = nullptr;
+    mk_gz_stream *d_streams = nullptr;
+    uint8_t *d_extra = nullptr;                                       // `extra` bytes of the out block for the caller (256-byte aligned)
+    uint32_t n_segs = 0, n_cands = 0;
+    double t_up = 0, t_find = 0, t_measure = 0, t_write = 0, t_text = 0;
+    ~GzRun()
+    {
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (c) { gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_seg, seg_bytes); gz_block_put(c, blk_out, out_bytes); }
+    }
+};
+
+static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, const uint64_t *out_room,
+                  const std::function<uint64_t(const std::vector<mk_gz_stream> &)> &extra_bytes)
+{
+    r.c = c; r.n = n;
+    r.streams.assign(n, mk_gz_stream{});
     if (!n) return MK_OK;
+    MK_HIP(hipSetDevice(c->p.device));
+    MK_HIP(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));  // (a stream of its own: the call may run beside others on the context)
+    hipStream_t st = r.st;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    // ---- the input block: the files, the streams, the finder's lists
+    uint64_t in_at = 0;
+    std::vector<uint64_t> word_first(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        mk_gz_stream &j = r.streams[i];
+        j.in_off = in_at;
+        j.in_len = gz_bytes[i] < 0xfffffff0ull ? (uint32_t)gz_bytes[i] : 0u;
+        j.status = gz_bytes[i] < 0xfffffff0ull ? MK_GZ_OK : MK_GZ_OUTPUT_ROOM;
+        in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
+        word_first[i + 1] = word_first[i] + ((uint64_t)j.in_len + 3u) / 4u;
+    }
+    const uint64_t total_words = word_first[n];
+    const uint32_t hit_cap = (uint32_t)std::min<uint64_t>(total_words / 8u + 65536u, 1u << 30);       // (0.1 % of the bit offsets pass the first test: room for 0.4 %)
+    const uint32_t good_cap = (uint32_t)std::min<uint64_t>(in_at / 2048u + 64ull * n + 4096u, 1u << 28);   // (a block per 26 KB of gzip'd DNA)
+    uint64_t at = 0;
+    auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
+    const uint64_t o_gz = carve(in_at + 16), o_streams = carve((uint64_t)n * sizeof(mk_gz_stream)), o_wf = carve(((uint64_t)n + 1) * 8),
+                   o_hits = carve((uint64_t)hit_cap * 8), o_good = carve((uint64_t)good_cap * 8), o_cnt = carve(64);
+    r.blk_in = gz_block_get(c, at, &r.in_bytes);
+    if (!r.blk_in) { set_error("no device memory for %u gzip'd files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
+    uint8_t *d_gz = r.blk_in + o_gz;
+    r.d_streams = reinterpret_cast<mk_gz_stream *>(r.blk_in + o_streams);
+    uint64_t *d_wf = reinterpret_cast<uint64_t *>(r.blk_in + o_wf), *d_hits = reinterpret_cast<uint64_t *>(r.blk_in + o_hits),
+             *d_good = reinterpret_cast<uint64_t *>(r.blk_in + o_good);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(r.blk_in + o_cnt);
+    for (uint32_t i = 0; i < n; ++i) {
+        const mk_gz_stream &j = r.streams[i];
+        if (j.in_len) MK_HIP(hipMemcpyAsync(d_gz + j.in_off, gz[i], j.in_len, hipMemcpyHostToDevice, st));
+        const uint64_t end = j.in_off + j.in_len, next = i + 1 < n ? r.streams[i + 1].in_off : in_at + 16;
+        MK_HIP(hipMemsetAsync(d_gz + end, 0, next - end, st));      // (the bit reader may look 16 bytes past a stream's end)
+    }
+    MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
+    MK_HIP(hipMemcpyAsync(d_wf, word_first.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+    MK_HIP(hipMemsetAsync(d_cnt, 0, 64, st));
+    MK_HIP(hipStreamSynchronize(st));
+    r.t_up = now() - t0;
+    // ---- where blocks start
+    const double t1 = now();
+    uint32_t cnt[2] = {0, 0};
+    if (total_words) {
+        hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((total_words + 255u) / 256u)), dim3(256), 0, st, d_gz, r.d_streams, d_wf, n, d_hits, d_cnt, hit_cap);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipMemcpyAsync(cnt, d_cnt, 4, hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        const uint32_t nh = std::min(cnt[0], hit_cap);
+        if (nh) {
+            hipLaunchKernelGGL(gz_check_kernel, dim3((nh + 63u) / 64u), dim3(64), 0, st, d_gz, r.d_streams, d_hits, d_cnt, hit_cap, d_good, d_cnt + 1, good_cap);
+            MK_HIP(hipGetLastError());
+        }
+        MK_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+    }
+    const uint32_t ng = std::min(cnt[1], good_cap);
+    std::vector<uint64_t> good(ng);
+    if (ng) { MK_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)ng * 8, hipMemcpyDeviceToHost, st)); MK_HIP(hipStreamSynchronize(st)); }
+    std::sort(good.begin(), good.end());                              // (stream << 40 | bit: by stream, then by place)
+    good.erase(std::unique(good.begin(), good.end()), good.end());
+    r.t_find = now() - t1;
+    // ---- the segments: every stream's first byte and every candidate start; a stream's candidates end with ~0
+    const double t2 = now();
+    std::vector<uint64_t> cands;
+    std::vector<mk_gz_seg> segs;
+    std::vector<uint32_t> seg_first(n + 1, 0);
+    cands.reserve(good.size() + n);
+    segs.reserve(good.size() + n);
+    size_t gi = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const mk_gz_stream &j = r.streams[i];
+        const uint64_t c_off = cands.size();
+        while (gi < good.size() && (uint32_t)(good[gi] >> 40) < i) ++gi;
+        size_t ge = gi;
+        while (ge < good.size() && (uint32_t)(good[ge] >> 40) == i) ++ge;
+        seg_first[i] = (uint32_t)segs.size();
+        if (j.status == MK_GZ_OK) {
+            mk_gz_seg sg;
+            memset(&sg, 0, sizeof sg);
+            sg.in_off = j.in_off; sg.in_len = j.in_len; sg.stream = i; sg.cand_off = c_off;
+            sg.tok_cap = sg.out_cap = 0xffffffffu; sg.member_out0 = 1u << 30;
+            sg.start_bit = 0; sg.cand_next = 0;
+            segs.push_back(sg);
+            for (size_t g = gi; g < ge; ++g) {
+                sg.start_bit = good[g] & ((1ull << 40) - 1ull);
+                sg.cand_next = (uint32_t)(g - gi) + 1u;
+                segs.push_back(sg);
+                cands.push_back(sg.start_bit);
+            }
+        }
+        cands.push_back(~0ull);
+        gi = ge;
+    }
+    seg_first[n] = (uint32_t)segs.size();
+    r.n_segs = (uint32_t)segs.size(); r.n_cands = (uint32_t)cands.size();
+    at = 0;
+    const uint64_t o_cands = carve(cands.size() * 8), o_segs = carve(segs.size() * sizeof(mk_gz_seg)), o_aux = carve((uint64_t)segs.size() * 288u * 4u);
+    r.blk_seg = gz_block_get(c, at + 256, &r.seg_bytes);
+    if (!r.blk_seg) { set_error("no device memory for %zu segments", segs.size()); return MK_ERR_NOMEM; }
+    uint64_t *d_cands = reinterpret_cast<uint64_t *>(r.blk_seg + o_cands);
+    mk_gz_seg *d_segs = reinterpret_cast<mk_gz_seg *>(r.blk_seg + o_segs);
+    uint32_t *d_aux = reinterpret_cast<uint32_t *>(r.blk_seg + o_aux);
     static_assert(sizeof(TokLds) <= 160u << 10, "phase 1's tables and buffers fit one wave per CU");
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
-    hipLaunchKernelGGL(gz_tokens_kernel, dim3((n + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_jobs, n, d_tokens, d_aux);
-    MK_HIP(hipGetLastError());
+    if (!segs.empty()) {
+        MK_HIP(hipMemcpyAsync(d_cands, cands.data(), cands.size() * 8, hipMemcpyHostToDevice, st));
+        MK_HIP(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(mk_gz_seg), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gz_tokens_kernel, dim3((r.n_segs + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, r.n_segs, d_cands, (uint32_t *)nullptr, d_aux);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipMemcpyAsync(segs.data(), d_segs, segs.size() * sizeof(mk_gz_seg), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+    }
+    // ---- the chain of every stream: from its first byte from link to link to its end
+    std::vector<mk_gz_seg> chain;                                     // the segments that are on a chain, with their places: the writing pass
+    uint64_t tok_at = 0, out_at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        mk_gz_stream &j = r.streams[i];
+        if (j.status != MK_GZ_OK) continue;
+        const uint32_t s0 = seg_first[i], ns = seg_first[i + 1] - s0;
+        uint64_t ntok = 0, nout = 0;
+        uint32_t member_bytes = 0, members = 0, status = MK_GZ_OK, cur = 0, steps = 0;
+        const size_t chain0 = chain.size();
+        for (;;) {
+            const mk_gz_seg &sg = segs[s0 + cur];
+            if (sg.status != MK_GZ_OK) { status = sg.status; break; }
+            if (++steps > ns) { status = MK_GZ_INTERNAL; break; }   // (links only lead forward: cannot happen)
+            mk_gz_seg w = sg;
+            w.write = 1; w.tok_cap = sg.n_tok; w.out_cap = sg.out_len; w.member_out0 = member_bytes;
+            w.tok_off = ntok;                                          // (within the stream: its base is added below)
+            chain.push_back(w);
+            ntok += sg.n_tok; nout += sg.out_len;
+            members += sg.members;
+            member_bytes = sg.members ? sg.member_tail : member_bytes + sg.out_len;
+            if (nout >= 0xfffffff0ull || ntok >= 0xfffffff0ull) { status = MK_GZ_OUTPUT_ROOM; break; }
+            if (sg.link == 0xffffffffu) break;                        // the stream's end
+            cur = sg.link + 1u;                                        // candidate k is segment k + 1 of the stream
+            if (cur >= ns) { status = MK_GZ_INTERNAL; break; }
+        }
+        if (status == MK_GZ_OK && out_room && nout > out_room[i]) status = MK_GZ_OUTPUT_ROOM;
+        if (status == MK_GZ_OK && nout > (1ull << 30)) status = MK_GZ_OUTPUT_ROOM;          // (a larger text is the host's)
+        j.status = status; j.members = members;
+        if (status != MK_GZ_OK) { chain.resize(chain0); continue; }
+        j.n_tok = (uint32_t)ntok; j.out_len = (uint32_t)nout;
+        j.tok_off = tok_at; j.out_off = out_at;
+        // (a token's distance is checked against the bytes of its member so far, the first segment's member starts with it)
+        for (size_t k = chain0; k < chain.size(); ++k) chain[k].tok_off += tok_at;
+        tok_at += (ntok + 3u) / 4u * 4u;
+        out_at += (nout + 15u) / 16u * 16u;
+    }
+    r.t_measure = now() - t2;
+    // ---- the out block: tokens, text, whatever the caller wants behind them
+    const double t3 = now();
+    const uint64_t extra = extra_bytes ? extra_bytes(r.streams) : 0;
+    at = 0;
+    const uint64_t o_tok = carve((tok_at + 8) * 4), o_text = carve(out_at + 32), o_extra = carve(extra);
+    r.blk_out = gz_block_get(c, at + 256, &r.out_bytes);
+    if (!r.blk_out) { set_error("no device memory for the text of %u files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
+    uint32_t *d_tok = reinterpret_cast<uint32_t *>(r.blk_out + o_tok);
+    r.d_text = r.blk_out + o_text;
+    r.d_extra = r.blk_out + o_extra;
+    MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
+    if (!chain.empty()) {
+        const uint32_t nc = (uint32_t)chain.size();
+        MK_HIP(hipMemcpyAsync(d_segs, chain.data(), chain.size() * sizeof(mk_gz_seg), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gz_tokens_kernel, dim3((nc + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, nc, d_cands, d_tok, d_aux);
+        MK_HIP(hipGetLastError());
+        MK_HIP(hipMemcpyAsync(chain.data(), d_segs, chain.size() * sizeof(mk_gz_seg), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        // the writing pass must have seen what the measuring pass saw
+        for (const mk_gz_seg &w : chain)
+            if (w.status != MK_GZ_OK || w.n_tok != w.tok_cap || w.out_len != w.out_cap) {
+                mk_gz_stream &j = r.streams[w.stream];
+                if (j.status == MK_GZ_OK) j.status = w.status != MK_GZ_OK ? w.status : MK_GZ_INTERNAL;
+            }
+        MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
+    }
+    r.t_write = now() - t3;
+    // ---- tokens -> text
+    const double t4 = now();
     ResolveConsts K;
     for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
     K.block_shift = x_pow_bytes(kFlush);
     K.byte_shift = x_pow_bytes(1);
     const size_t lds2 = 4096u + 4u * kWin + 256u;                     // CRC tables, four windows, the lanes' sinks
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, d_jobs, n, d_tokens, d_text, K);
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, r.d_streams, n, d_tok, r.d_text, K);
     MK_HIP(hipGetLastError());
+    MK_HIP(hipMemcpyAsync(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    r.t_text = now() - t4;
+    if (getenv("MIEKKI_VERBOSE"))
+        fprintf(stderr, "[gz] %u files, %.2f GB: %u segments; upload %.3f s, block starts %.3f s, measuring pass %.3f s, writing pass %.3f s, text %.3f s (%.2f GB)\n", n,
+                in_at / 1e9, r.n_segs, r.t_up, r.t_find, r.t_measure, r.t_write, r.t_text, out_at / 1e9);
     return MK_OK;
 }
 
@@ -687,165 +1105,106 @@ using namespace mk;
 
 extern "C" {
 
-// Whole gzip files -> their text, inflated on the device (the two kernels above); status[i] != MK_GZ_OK: that file is for
-// the host's inflater (nothing of it is returned).
+// Whole gzip files -> their text, inflated on the device; status[i] != MK_GZ_OK: that file is for the host's inflater
+// (nothing of it is returned).
 int mk_gz_inflate(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, uint8_t *const *out, const uint64_t *out_room,
                   uint64_t *out_bytes, int32_t *status)
 {
     if (!c || (n && (!gz || !gz_bytes || !out || !out_room || !out_bytes || !status))) { set_error("null argument"); return MK_ERR_ARG; }
     if (!n) return MK_OK;
-    MK_HIP(hipSetDevice(c->p.device));
-    std::vector<mk_gz_stream> jobs(n);
-    uint64_t in_at = 0, tok_at = 0, out_at = 0;
+    GzRun r;
+    MK_TRY(gz_run(r, c, gz, gz_bytes, n, out_room, nullptr));
     for (uint32_t i = 0; i < n; ++i) {
-        mk_gz_stream &j = jobs[i];
-        memset(&j, 0, sizeof j);
-        if (gz_bytes[i] >= 0xfffffff0ull) { set_error("stream %u: more than 4 GiB", i); return MK_ERR_ARG; }
-        j.in_off = in_at; j.in_len = (uint32_t)gz_bytes[i];
-        in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
-        j.out_cap = (uint32_t)std::min<uint64_t>(out_room[i], 0xfffffff0ull);
-        // (a token yields at least a byte, a member's end is three words per >= 18 bytes of input, a stored block two per >= 5: this room always suffices)
-        j.tok_cap = (uint32_t)std::min<uint64_t>((uint64_t)j.out_cap + j.in_len / 4u + 16u, 0xfffffff0ull);
-        j.tok_off = tok_at; tok_at += ((uint64_t)j.tok_cap + 3u) / 4u * 4u;
-        j.out_off = out_at; out_at += ((uint64_t)j.out_cap + 15u) / 16u * 16u;
+        const mk_gz_stream &j = r.streams[i];
+        status[i] = (int32_t)j.status;
+        out_bytes[i] = j.status == MK_GZ_OK ? j.out_len : 0;
+        if (j.status == MK_GZ_OK && j.out_len) MK_HIP(hipMemcpyAsync(out[i], r.d_text + j.out_off, j.out_len, hipMemcpyDeviceToHost, r.st));
     }
-    uint8_t *d_gz = nullptr, *d_text = nullptr;
-    uint32_t *d_tok = nullptr;
-    uint32_t *d_aux = nullptr;
-    mk_gz_stream *d_jobs = nullptr;
-    auto cleanup = [&] { (void)hipFree(d_gz); (void)hipFree(d_text); (void)hipFree(d_tok); (void)hipFree(d_aux); (void)hipFree(d_jobs); };
-    hipStream_t st = c->stream;
-    bool ok = hipMalloc((void **)&d_gz, in_at + 16) == hipSuccess && hipMalloc((void **)&d_text, out_at + 16) == hipSuccess &&
-              hipMalloc((void **)&d_tok, (tok_at + 1) * 4) == hipSuccess && hipMalloc((void **)&d_aux, (uint64_t)n * 288u * 4u) == hipSuccess &&
-              hipMalloc((void **)&d_jobs, (uint64_t)n * sizeof(mk_gz_stream)) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); cleanup(); set_error("no device memory for %u streams", n); return MK_ERR_NOMEM; }
-    ok = hipMemsetAsync(d_gz, 0, in_at + 16, st) == hipSuccess;
-    for (uint32_t i = 0; i < n && ok; ++i)
-        if (jobs[i].in_len) ok = hipMemcpyAsync(d_gz + jobs[i].in_off, gz[i], jobs[i].in_len, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st) == hipSuccess;
-    int rc = ok ? launch_gunzip(c, d_gz, d_jobs, n, d_tok, d_aux, d_text, st) : MK_ERR_DEVICE;
-    if (rc == MK_OK && hipMemcpyAsync(jobs.data(), d_jobs, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
-    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
-    for (uint32_t i = 0; i < n && rc == MK_OK; ++i) {
-        status[i] = (int32_t)jobs[i].status;
-        out_bytes[i] = jobs[i].status == MK_GZ_OK ? jobs[i].out_len : 0;
-        if (jobs[i].status == MK_GZ_OK && jobs[i].out_len &&
-            hipMemcpyAsync(out[i], d_text + jobs[i].out_off, jobs[i].out_len, hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
-    }
-    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
-    if (rc == MK_ERR_DEVICE) set_error("gzip inflate on the device failed: %s", hipGetErrorString(hipGetLastError()));
-    cleanup();
-    return rc;
+    MK_HIP(hipStreamSynchronize(r.st));
+    return MK_OK;
 }
 
-// A batch of genome FILES (gzip members holding FASTA text) -> their sequences as index_file_of_file would read them
-// (Miekki.cpp:559-567), resident on the device: inflate, then fasta.hip.  The sequences take the place of the tokens (a
-// token buffer has twice the text's room); everything else of the batch's scratch is freed before the call returns.
+// A batch of genome FILES (gzip members holding FASTA text): inflated, their sequences as index_file_of_file would read
+// them (Miekki.cpp:559-567) measured (fasta.hip) -- the text stays on the device until mk_gz_free; mk_index_append_gz strips
+// it straight into the build's sequence buffer, sixty-four genomes a call.
 struct mk_gz_batch {
-    mk_ctx *owner;
-    uint32_t n;
-    std::vector<mk_gz_stream> jobs;
-    std::vector<uint64_t> seq_off, seq_len;
-    uint8_t *d_seqs;
+    GzRun run;
+    std::vector<uint32_t> chunk_first;
+    std::vector<uint64_t> seq_len;
+    uint32_t n_chunks = 0;
+    void *d_scratch = nullptr;
 };
 
 int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out)
 {
     if (!c || !out || (n && (!gz || !gz_bytes))) { set_error("null argument"); return MK_ERR_ARG; }
     *out = nullptr;
-    MK_HIP(hipSetDevice(c->p.device));
     std::unique_ptr<mk_gz_batch> b(new mk_gz_batch());
-    b->owner = c; b->n = n; b->d_seqs = nullptr;
-    b->jobs.resize(n); b->seq_off.assign(n, 0); b->seq_len.assign(n, 0);
-    if (!n) { *out = b.release(); return MK_OK; }
-    uint64_t in_at = 0, tok_at = 0, out_at = 0;
-    constexpr uint64_t kMaxText = 1ull << 30;                        // a larger file is the host's
-    for (uint32_t i = 0; i < n; ++i) {
-        mk_gz_stream &j = b->jobs[i];
-        memset(&j, 0, sizeof j);
-        j.in_off = in_at;
-        j.in_len = gz_bytes[i] < 0xfffffff0ull ? (uint32_t)gz_bytes[i] : 0u;
-        in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
-        // room for the text: what the last member's trailer says (ISIZE, RFC 1952 2.3.1) -- all of it when the file is one
-        // member -- and never less than four times the file (DNA is two bits a base at best: files of many members fit that too)
-        uint64_t isize = 0;
-        if (j.in_len >= 18u) for (int k = 0; k < 4; ++k) isize |= (uint64_t)gz[i][j.in_len - 4u + k] << (8 * k);
-        const uint64_t room = std::min<uint64_t>(std::max<uint64_t>(isize + 64u, 4ull * j.in_len + 4096u), kMaxText);
-        j.out_cap = (uint32_t)room;
-        j.tok_cap = (uint32_t)(room / 2u + j.in_len / 4u + 1024u);
-        j.tok_off = tok_at; tok_at += ((uint64_t)j.tok_cap + 3u) / 4u * 4u;
-        j.out_off = out_at; out_at += (room + 15u) / 16u * 16u;
-    }
-    uint8_t *d_gz = nullptr, *d_text = nullptr, *d_scratch = nullptr;
-    uint32_t *d_tok = nullptr, *d_aux = nullptr, *d_first = nullptr;
-    uint64_t *d_seq_off = nullptr, *d_seq_len = nullptr;
-    mk_gz_stream *d_jobs = nullptr;
-    auto release = [&](bool all) {
-        (void)hipFree(d_gz); (void)hipFree(d_text); (void)hipFree(d_aux); (void)hipFree(d_jobs); (void)hipFree(d_scratch); (void)hipFree(d_first);
-        (void)hipFree(d_seq_off); (void)hipFree(d_seq_len);
-        if (all) (void)hipFree(d_tok);
+    b->chunk_first.assign(n + 1, 0); b->seq_len.assign(n, 0);
+    uint64_t o_first = 0, o_len = 0, o_scratch = 0;
+    auto extra = [&](const std::vector<mk_gz_stream> &streams) {      // behind the text: the chunks' table, the lengths, the scan's scratch
+        for (uint32_t i = 0; i < n; ++i) b->chunk_first[i + 1] = b->chunk_first[i] + (streams[i].status == MK_GZ_OK ? (streams[i].out_len + 4095u) / 4096u : 0u);
+        b->n_chunks = b->chunk_first[n];
+        o_first = 0; o_len = (((uint64_t)n + 1) * 4 + 255u) / 256u * 256u; o_scratch = o_len + ((uint64_t)n * 8 + 255u) / 256u * 256u;
+        return o_scratch + fasta_scratch_bytes(b->n_chunks);
     };
-    hipStream_t st = c->stream;
-    bool ok = hipMalloc((void **)&d_gz, in_at + 16) == hipSuccess && hipMalloc((void **)&d_text, out_at + 16) == hipSuccess &&
-              hipMalloc((void **)&d_tok, (tok_at + 4) * 4) == hipSuccess && hipMalloc((void **)&d_aux, (uint64_t)n * 288u * 4u) == hipSuccess &&
-              hipMalloc((void **)&d_jobs, (uint64_t)n * sizeof(mk_gz_stream)) == hipSuccess &&
-              hipMalloc((void **)&d_first, ((uint64_t)n + 1) * 4) == hipSuccess && hipMalloc((void **)&d_seq_off, (uint64_t)n * 8) == hipSuccess &&
-              hipMalloc((void **)&d_seq_len, (uint64_t)n * 8) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError(); release(true);
-        set_error("no device memory to unpack %u files (%.1f GB of text): take fewer at a time", n, out_at / 1e9);
-        return MK_ERR_NOMEM;
-    }
-    ok = hipMemsetAsync(d_gz, 0, in_at + 16, st) == hipSuccess;
-    for (uint32_t i = 0; i < n && ok; ++i)
-        if (b->jobs[i].in_len) ok = hipMemcpyAsync(d_gz + b->jobs[i].in_off, gz[i], b->jobs[i].in_len, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_jobs, b->jobs.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st) == hipSuccess;
-    int rc = ok ? launch_gunzip(c, d_gz, d_jobs, n, d_tok, d_aux, d_text, st) : MK_ERR_DEVICE;
-    if (rc == MK_OK && hipMemcpyAsync(b->jobs.data(), d_jobs, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
-    if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
-    // the texts' chunks, the sequences' places (each in its own stream's token room), then the strip
-    std::vector<uint32_t> first(n + 1, 0);
-    if (rc == MK_OK) {
-        for (uint32_t i = 0; i < n; ++i) {
-            const mk_gz_stream &j = b->jobs[i];
-            first[i + 1] = first[i] + (j.status == MK_GZ_OK ? (j.out_len + 4095u) / 4096u : 0u);
-            b->seq_off[i] = j.tok_off * 4u;
-        }
-        if (hipMalloc((void **)&d_scratch, fasta_scratch_bytes(first[n])) != hipSuccess) { (void)hipGetLastError(); rc = MK_ERR_NOMEM; set_error("no device memory for the FASTA scan"); }
-    }
-    if (rc == MK_OK) {
-        ok = hipMemcpyAsync(d_first, first.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
-             hipMemcpyAsync(d_seq_off, b->seq_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-        rc = ok ? launch_fasta_strip(c, d_text, d_jobs, n, d_first, first[n], d_scratch, reinterpret_cast<uint8_t *>(d_tok), d_seq_off, d_seq_len, st) : MK_ERR_DEVICE;
-        if (rc == MK_OK && hipMemcpyAsync(b->seq_len.data(), d_seq_len, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = MK_ERR_DEVICE;
-        if (rc == MK_OK && hipStreamSynchronize(st) != hipSuccess) rc = MK_ERR_DEVICE;
-    }
-    if (rc == MK_ERR_DEVICE) set_error("unpacking gzip'd FASTA on the device failed: %s", hipGetErrorString(hipGetLastError()));
-    release(rc != MK_OK);
-    if (rc != MK_OK) return rc;
-    b->d_seqs = reinterpret_cast<uint8_t *>(d_tok);
+    MK_TRY(gz_run(b->run, c, gz, gz_bytes, n, nullptr, extra));
+    if (!n) { *out = b.release(); return MK_OK; }
+    GzRun &r = b->run;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(r.d_extra + o_first);
+    uint64_t *d_len = reinterpret_cast<uint64_t *>(r.d_extra + o_len);
+    b->d_scratch = r.d_extra + o_scratch;
+    // (a stream that failed in the text pass -- a CRC -- keeps its chunks in the table: the kernels skip them by its status)
+    MK_HIP(hipMemcpyAsync(d_first, b->chunk_first.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, r.st));
+    MK_TRY(launch_fasta_count(c, r.d_text, r.d_streams, n, d_first, b->n_chunks, b->d_scratch, d_len, r.st));
+    MK_HIP(hipMemcpyAsync(b->seq_len.data(), d_len, (size_t)n * 8, hipMemcpyDeviceToHost, r.st));
+    MK_HIP(hipStreamSynchronize(r.st));
+    if (getenv("MIEKKI_VERBOSE"))
+        fprintf(stderr, "[gz] sequences measured in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
     *out = b.release();
     return MK_OK;
 }
 
-int mk_gz_sequence(const mk_gz_batch *b, uint32_t i, const char **d_seq, uint64_t *len, int32_t *status)
+int mk_gz_sequence(const mk_gz_batch *b, uint32_t i, uint64_t *len, int32_t *status)
 {
-    if (!b || i >= b->n || !d_seq || !len || !status) { set_error("bad argument"); return MK_ERR_ARG; }
-    *status = (int32_t)b->jobs[i].status;
-    const bool ok = b->jobs[i].status == MK_GZ_OK;
-    *d_seq = ok ? reinterpret_cast<const char *>(b->d_seqs + b->seq_off[i]) : nullptr;
-    *len = ok ? b->seq_len[i] : 0;
+    if (!b || i >= b->run.n || !len || !status) { set_error("bad argument"); return MK_ERR_ARG; }
+    *status = (int32_t)b->run.streams[i].status;
+    *len = b->run.streams[i].status == MK_GZ_OK ? b->seq_len[i] : 0;
     return MK_OK;
 }
 
 void mk_gz_free(mk_gz_batch *b)
 {
     if (!b) return;
-    (void)hipSetDevice(b->owner->p.device);
-    (void)hipStreamSynchronize(b->owner->stream);
-    (void)hipStreamSynchronize(b->owner->copy_stream);
-    if (b->d_seqs) (void)hipFree(b->d_seqs);
-    delete b;
+    if (b->run.c) {
+        (void)hipSetDevice(b->run.c->p.device);
+        (void)hipStreamSynchronize(b->run.c->front_stream);          // (the appends' strip kernels read the batch's text)
+        (void)hipStreamSynchronize(b->run.c->copy_stream);
+    }
+    delete b;                                                        // (the blocks go back to the context's list)
+}
+
+// the blocks kept between batches go back to the device (after a build, before the queries' buffers are sized)
+void mk_gz_trim(mk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    std::lock_guard<std::mutex> g(c->gz_m);
+    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
+    c->gz_blocks.clear();
 }
 
 }  // extern "C"
+
+// the batch's text for the strip kernels of mk_index_append_gz (api.hip)
+namespace mk {
+int gz_batch_strip(mk_ctx *c, const mk_gz_batch *b, const uint32_t *which, uint32_t m, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st)
+{
+    return launch_fasta_strip(c, b->run.d_text, b->run.d_streams, which, m, b->chunk_first.data(), b->n_chunks, b->d_scratch, d_dst, dst_off, st);
+}
+uint32_t gz_batch_size(const mk_gz_batch *b) { return b->run.n; }
+bool gz_batch_ok(const mk_gz_batch *b, uint32_t i) { return b->run.streams[i].status == MK_GZ_OK; }
+uint64_t gz_batch_len(const mk_gz_batch *b, uint32_t i) { return b->seq_len[i]; }
+const mk_ctx *gz_batch_owner(const mk_gz_batch *b) { return b->run.c; }
+}  // namespace mk

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -238,9 +239,13 @@ struct mk_ctx {
     mk_stats stats;
     std::vector<mk::Timer> pending;
     std::vector<mk::Timer> free_timers;
+    // device blocks of finished mk_gz_unpack batches, kept for the next ones (allocating and freeing tens of gigabytes per
+    // batch cost half a second each): (pointer, bytes); mk_gz_trim and mk_destroy free them
+    std::vector<std::pair<void *, uint64_t>> gz_blocks;
+    std::mutex gz_m;
 };
 
-namespace mk { struct DenseLut; struct mk_gz_stream; }
+namespace mk { struct DenseLut; struct mk_gz_stream; struct mk_gz_seg; }
 struct mk_qset {
     uint32_t nq;
     mk_ctx *owner;
@@ -373,20 +378,36 @@ int launch_export_genomes(mk_ctx *c, const uint32_t *d_ids, uint32_t n, uint8_t 
 inline MatRef mat_ref(const mk_ctx *c);
 
 // ---- gunzip.hip: gzip streams inflated on the device
-struct mk_gz_stream {
-    uint64_t in_off;               // the stream's bytes at gz + in_off (16-byte aligned, >= 16 zero bytes behind them)
-    uint64_t tok_off;              // its tokens at tokens + tok_off (32-bit words)
+struct mk_gz_stream {              // a stream (a file) of a batch
+    uint64_t in_off;               // its bytes at gz + in_off (16-byte aligned, >= 16 zero bytes behind them)
+    uint64_t tok_off;              // its tokens at tokens + tok_off (32-bit words; a multiple of four)
     uint64_t out_off;              // its text at text + out_off (16-byte aligned)
-    uint32_t in_len, tok_cap, out_cap;
-    uint32_t n_tok, out_len, status, members;      // results (mk_gz_status)
-    uint32_t pad;
+    uint32_t in_len, n_tok, out_len, status, members, pad;      // status: mk_gz_status
 };
-int launch_gunzip(mk_ctx *c, const uint8_t *d_gz, mk_gz_stream *d_jobs, uint32_t n, uint32_t *d_tokens, uint32_t *d_aux, uint8_t *d_text,
-                  hipStream_t st);
-// ---- fasta.hip: text -> sequence (header lines and line feeds removed)
-int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first,
-                       uint32_t n_chunks, void *d_scratch, uint8_t *d_seqs, const uint64_t *d_seq_off, uint64_t *d_seq_len, hipStream_t st);
+struct mk_gz_seg {                 // a lane's work in gz_tokens_kernel: a stretch of a stream from a block's first bit on
+    uint64_t in_off;               // the stream's bytes
+    uint64_t start_bit;            // 0: the stream's first byte (a member's header comes first)
+    uint64_t cand_off;             // the stream's candidate starts at cands + cand_off (ascending bit offsets, then ~0)
+    uint64_t tok_off;              // (write) where this segment's tokens go
+    uint32_t in_len, stream, cand_next, write;     // cand_next: the first candidate behind start_bit
+    uint32_t tok_cap, out_cap, member_out0, pad;   // rooms (all ones while measuring); bytes of the open member before this segment
+    uint32_t n_tok, out_len, status, members;      // results ...
+    uint32_t link, member_tail;                    // ... the candidate it arrived at (all ones: the stream's end), bytes of the member open at its end
+    uint64_t pad2;
+};
+int launch_fasta_count(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first, uint32_t n_chunks,
+                       void *d_scratch, uint64_t *d_seq_len, hipStream_t st);
+int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, const uint32_t *which, uint32_t m, const uint32_t *h_chunk_first,
+                       uint32_t n_chunks, const void *d_scratch, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st);
 uint64_t fasta_scratch_bytes(uint32_t n_chunks);
+}  // namespace mk
+struct mk_gz_batch;
+namespace mk {
+int gz_batch_strip(mk_ctx *c, const mk_gz_batch *b, const uint32_t *which, uint32_t m, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st);
+uint32_t gz_batch_size(const mk_gz_batch *b);
+bool gz_batch_ok(const mk_gz_batch *b, uint32_t i);
+uint64_t gz_batch_len(const mk_gz_batch *b, uint32_t i);
+const mk_ctx *gz_batch_owner(const mk_gz_batch *b);
 
 // ---- cold.hip: the cold rows packed (delta vs the genome before + bit packing)
 int pack_cold(mk_ctx *c, uint64_t *raw_bytes, uint64_t *packed_bytes);

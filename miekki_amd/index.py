@@ -149,26 +149,28 @@ class Miekki:
         ptrs, lens = L.seq_arrays(blobs)
         batch = C.c_void_p()
         L.check(self._lib.mk_gz_unpack(self._h, ptrs, lens, n, C.byref(batch)))
-        status, keep = [], []                  # keep: host-side sequences that must outlive the appends
+        status = []
         try:
-            seq_p, seq_l, kept_names = [], [], []
+            run, kept_names = [], []          # run: files of the batch waiting to be appended together
+            def flush_run():
+                for g0 in range(0, len(run), 64):
+                    part = run[g0:g0 + 64]
+                    L.check(self._lib.mk_index_append_gz(self._h, batch, (C.c_uint32 * len(part))(*part), len(part)))
+                del run[:]
             for i in range(n):
-                d, ln, st = C.c_void_p(), C.c_uint64(), C.c_int32()
-                L.check(self._lib.mk_gz_sequence(batch, i, C.byref(d), C.byref(ln), C.byref(st)))
+                ln, st = C.c_uint64(), C.c_int32()
+                L.check(self._lib.mk_gz_sequence(batch, i, C.byref(ln), C.byref(st)))
                 status.append(st.value)
                 if st.value == 0:
-                    ptr, length = d.value, ln.value
+                    if ln.value >= self.kmer_size:
+                        run.append(i); kept_names.append(names[i] if names else "")
                 elif fallback:
                     ref = b"".join(l for l in _gunzip_members(blobs[i]).split(b"\n") if not l.startswith(b">"))
-                    keep.append(C.create_string_buffer(ref, len(ref)))
-                    ptr, length = C.addressof(keep[-1]), len(ref)
-                else:
-                    continue
-                if length >= self.kmer_size:
-                    seq_p.append(ptr); seq_l.append(length); kept_names.append(names[i] if names else "")
-            for g0 in range(0, len(seq_p), 64):
-                m = len(seq_p[g0:g0 + 64])
-                L.check(self._lib.mk_index_append(self._h, (C.c_void_p * m)(*seq_p[g0:g0 + 64]), (C.c_uint64 * m)(*seq_l[g0:g0 + 64]), m))
+                    if len(ref) >= self.kmer_size:
+                        flush_run()                       # (list order: the files before it first)
+                        L.check(self._lib.mk_index_append(self._h, (C.c_char_p * 1)(ref), (C.c_uint64 * 1)(len(ref)), 1))
+                        kept_names.append(names[i] if names else "")
+            flush_run()
             L.check(self._lib.mk_sync(self._h))
             self.file_names += kept_names
         finally:

@@ -118,8 +118,10 @@ SIGNATURES = {
     "mk_sync": (i32, [vp]),
     "mk_gz_inflate": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
     "mk_gz_unpack": (i32, [vp, vp, vp, u32, PP(vp)]),
-    "mk_gz_sequence": (i32, [vp, u32, PP(vp), PP(u64), PP(C.c_int32)]),
+    "mk_gz_sequence": (i32, [vp, u32, PP(u64), PP(C.c_int32)]),
+    "mk_index_append_gz": (i32, [vp, vp, vp, u32]),
     "mk_gz_free": (None, [vp]),
+    "mk_gz_trim": (None, [vp]),
     "mk_exact": (i32, [vp, vp, vp, u32, vp, vp, u32, vp, vp]),
     "mk_exact_load_genome": (i32, [vp, vp, vp, u32]),
     "mk_exact_query": (i32, [vp, vp, vp, u32, vp, vp]),

@@ -41,5 +41,5 @@ with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
         idx = float(el[0]) if el else float("nan")
         print(f"run {rep}: wall {wall:.2f}s; index phase {idx:.2f}s = {G / idx:.0f} genomes/s, {G * L / idx / 1e9:.2f} GB/s of sequence", flush=True)
         for line in out.splitlines():
-            if line.startswith("[ingest]"):
+            if line.startswith("[ingest]") or line.startswith("[gz]"):
                 print("   ", line)
