@@ -204,8 +204,9 @@ struct Driver {
         // the number of streams in flight that makes the rate; MIEKKI_GZ_BATCH sets it, 0 = the readers inflate);
         // whatever the device refuses is inflated here
         static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)1024; }();
+        static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)3; }();
         PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, 4 * gz_batch + 64), true,
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, (gz_in_flight + 1) * gz_batch + 64), true,
                                   gz_batch != 0);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
@@ -336,7 +337,7 @@ struct Driver {
             if (item.raw) {
                 if (raw.empty() && in_flight.empty() && !flush()) return;      // (a run starts: what came before it goes first)
                 raw.push_back(item); raw_names.push_back(fn);
-                if (raw.size() >= gz_batch) { start_raw(); if (!drain_raw(2)) return; }
+                if (raw.size() >= gz_batch) { start_raw(); if (!drain_raw(gz_in_flight - 1)) return; }
                 continue;
             }
             if (!flush_raw()) return;
