@@ -303,9 +303,11 @@ FileText::~FileText()
 }
 
 OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed,
-                                       bool raw_gz)
-    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed), raw_gz_(raw_gz)
+                                       bool raw_gz, size_t raw_unit, size_t raw_units_ahead)
+    : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed), raw_gz_(raw_gz),
+      raw_unit_(raw_gz ? raw_unit : 0), raw_limit_((long)(raw_unit * raw_units_ahead)), umode_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0)
 {
+    for (auto &u : umode_) u.store(0);
     if (raw_gz_) ahead_limit_ = 16ull << 30;                        // (a device batch is thousands of files: their bytes wait here)
     for (auto &r : ready_) r.store(0);
     const unsigned n = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(files_.size(), 1)));
@@ -367,10 +369,9 @@ void OrderedFastaReader::pool_release(char *p)
 void OrderedFastaReader::recycle(Item &it)
 {
     if (!it.data) return;
-    if (it.raw) { munmap(it.data, it.len); it.data = nullptr; it.len = 0; it.raw = false; return; }
     std::lock_guard<std::mutex> g(pool_m_);
     pool_.emplace_back(it.data, it.cap);
-    it.data = nullptr; it.len = it.cap = 0;
+    it.data = nullptr; it.len = it.cap = 0; it.raw = false;
     it.codes = it.except = nullptr;
 }
 
@@ -403,23 +404,44 @@ void OrderedFastaReader::work()
         struct stat st;
         it.exists = stat(files_[i].c_str(), &st) == 0;
         bool raw_done = false;
-        if (it.exists && raw_gz_ && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
-            // a gzip'd file as it is, for the device's inflater: mapped (the upload reads the page cache; a copy into page-locked
-            // buffers first cost more than the upload)
+        // whose unit is this file's: the device's while it has room for one more (the first reader to touch a unit says)
+        bool to_device = raw_gz_;
+        if (raw_unit_) {
+            std::atomic<int> &mode = umode_[i / raw_unit_];
+            int m = mode.load();
+            if (!m) {
+                const size_t u0 = i / raw_unit_ * raw_unit_;
+                const long in_unit = (long)(std::min(files_.size(), u0 + raw_unit_) - u0);
+                const int want = raw_out_.load() < raw_limit_ ? 1 : 2;
+                if (mode.compare_exchange_strong(m, want)) { m = want; if (want == 1) raw_out_.fetch_add(in_unit); }
+            }
+            to_device = m == 1;
+        }
+        if (it.exists && to_device && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
+            // a gzip'd file as it is, for the device's inflater: read into a pooled buffer (page-locked while the allocator
+            // has room: the upload is then a plain DMA).  Not mapped: thousands of mappings made and taken down while
+            // sixteen threads fault pages in spent more time on the address space's lock than on the files.
             const int fd = ::open(files_[i].c_str(), O_RDONLY);
             if (fd >= 0) {
-                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-                close(fd);
-                if (m != MAP_FAILED) {
-                    const unsigned char *u = (const unsigned char *)m;
-                    if (u[0] == 0x1f && u[1] == 0x8b) {
-                        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
-                        it.data = (char *)m; it.len = (size_t)st.st_size; it.cap = 0; it.raw = true;
+                unsigned char magic[2] = {0, 0};
+                if (pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+                    it.data = pool_get((size_t)st.st_size + 16, it.cap);
+                    size_t got = 0;
+                    while (it.data && got < (size_t)st.st_size) {
+                        const ssize_t r = pread(fd, it.data + got, (size_t)st.st_size - got, (off_t)got);
+                        if (r <= 0) break;
+                        got += (size_t)r;
+                    }
+                    if (it.data && got == (size_t)st.st_size) {
+                        it.len = got; it.raw = true;
                         raw_done = true;
-                    } else {
-                        munmap(m, (size_t)st.st_size);
+                    } else if (it.data) {                          // short read: the ordinary path says what is wrong with the file
+                        std::lock_guard<std::mutex> g(pool_m_);
+                        pool_.emplace_back(it.data, it.cap);
+                        it.data = nullptr; it.cap = 0;
                     }
                 }
+                close(fd);
             }
         }
         if (it.exists && !raw_done) {
@@ -444,6 +466,7 @@ void OrderedFastaReader::work()
                 else it.failed = true;
             }
         }
+        if (raw_unit_ && to_device && !raw_done) raw_out_.fetch_sub(1);     // (a file of a device unit that does not go there)
         { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
         cv_.notify_all();
     }

@@ -73,7 +73,7 @@ public:
         // packed items (a reader made with a PackAppendFn): `data` holds the two arrays, no characters
         bool packed = false, dirty = false;
         // raw items (a reader made with raw_gz): `data` is the FILE as it is -- gzip members, for the device to inflate
-        // (mk_gz_unpack) -- mapped, not copied (len bytes; recycle() takes the mapping down)
+        // (mk_gz_unpack) -- len bytes in a pooled buffer like any other item's
         bool raw = false;
         uint64_t *codes = nullptr, *except = nullptr;
         char head[32] = {0};
@@ -81,8 +81,14 @@ public:
     // window = how many files may be parsed ahead of the consumer (each holds one buffer);
     // packed: items come packed (a quarter of the bytes to buffer and to copy to the GPU)
     // raw_gz: files that start with the gzip magic are handed over as they are (Item::raw), everything else as before
+    // raw_unit / raw_units_ahead: the gzip'd files are SHARED between the device's inflater and the readers' own zlib --
+    // the list is cut into units of raw_unit files; a unit goes to the device (its files come raw) while fewer than
+    // raw_units_ahead units' worth of raw files are waiting for the consumer's raw_consumed(), and is inflated here
+    // otherwise.  raw_unit 0: every gzip'd file raw.
     OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed = false,
-                       bool raw_gz = false);
+                       bool raw_gz = false, size_t raw_unit = 0, size_t raw_units_ahead = 0);
+    // the consumer is done with n raw items (appended or given up)
+    void raw_consumed(size_t n) { raw_out_.fetch_sub((long)n); }
     ~OrderedFastaReader();
     // blocks until file i (called with i = 0, 1, 2, ...) has been read
     Item take(size_t i);
@@ -103,6 +109,10 @@ private:
     std::condition_variable cv_;
     HostAllocator a_;
     bool pack_ = false, raw_gz_ = false;
+    size_t raw_unit_ = 0;
+    long raw_limit_ = 0;
+    std::vector<std::atomic<int>> umode_;          // per unit: 0 undecided, 1 to the device, 2 inflated here
+    std::atomic<long> raw_out_{0};                 // files of device units handed out or still to come, not yet consumed
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)
     std::unordered_set<char *> plain_;              // buffers that came from malloc although an allocator was given

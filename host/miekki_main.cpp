@@ -187,12 +187,9 @@ struct Driver {
     // one shard's share of index_file_of_file: files [f0, f1) of the list into ctx, in order.
     // `log` collects what the reference prints meanwhile (one '-' per genome kept, the
     // "Missed file" lines) so that several shards' output can be shown in list order.
-    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0; size_t gz_on_device = 0, gz_on_host = 0; };
+    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0, t_free = 0, t_recycle = 0, t_start = 0, t_total = 0; size_t gz_on_device = 0, gz_on_host = 0, from_readers = 0; };
     void build_shard(mk_ctx *ctx, const vector<string> &files, unsigned nthreads, bool live, ShardBuild &sb)
     {
-        vector<OrderedFastaReader::Item> seqs;
-        vector<string> names;
-        uint64_t bytes = 0;
         // a doubling matrix would hold old and new copy at once: size it for the whole list up front
         if (!files.empty() && mk_reserve(ctx, (uint32_t)files.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return; }
         // readers parse into pinned buffers, three device batches ahead; the append of one
@@ -203,154 +200,168 @@ struct Driver {
         // stripped and appended on the device, a few thousand at a time (a deflate stream is decoded by one lane, so it is
         // the number of streams in flight that makes the rate; MIEKKI_GZ_BATCH sets it, 0 = the readers inflate);
         // whatever the device refuses is inflated here
-        static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)1024; }();
-        static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)3; }();
+        static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)128; }();
+        static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)6; }();
+        // ... and the readers' own zlib takes what the device has no room for: the list goes in units of one device batch, a
+        // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
+        // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.
+        static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return !e || atoi(e) != 0; }();
         PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, (gz_in_flight + 1) * gz_batch + 64), true,
-                                  gz_batch != 0);
+        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, (gz_in_flight + 2) * gz_batch + 64), true,
+                                  gz_batch != 0, gz_share ? gz_batch : 0, gz_in_flight);
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
-        auto flush = [&]() {
-            if (seqs.empty()) return true;
+        // What has been taken from the readers and waits for its turn, in list order: runs of up to 64 sequences the readers
+        // made (packed), and batches of raw gzip'd files the device is unpacking -- by a thread of its own each (mk_gz_unpack
+        // works on a stream of its own; a deflate stream is decoded by few lanes, so it is batches side by side that fill
+        // the device).  Everything is appended in list order, sixty-four at a time.
+        struct Pending {
+            vector<OrderedFastaReader::Item> items;
+            vector<string> names;
+            bool raw = false;
+            std::future<mk_gz_batch *> unpacked;
+            string error;
+        };
+        std::deque<std::unique_ptr<Pending>> pending;
+        size_t raw_in_flight = 0, host_waiting = 0;
+        std::unique_ptr<Pending> cur;                               // the run being collected
+        uint64_t cur_bytes = 0;
+        auto close_run = [&]() {
+            if (!cur) return;
+            if (cur->raw) {
+                const double ts = now();
+                Pending *r = cur.get();
+                r->unpacked = std::async(std::launch::async, [r, ctx]() -> mk_gz_batch * {
+                    vector<const uint8_t *> gp;
+                    vector<uint64_t> gl;
+                    for (auto &it : r->items) { gp.push_back((const uint8_t *)it.data); gl.push_back(it.len); }
+                    mk_gz_batch *gzb = nullptr;
+                    if (mk_gz_unpack(ctx, gp.data(), gl.data(), (uint32_t)gp.size(), &gzb) != MK_OK) { r->error = mk_last_error(); return nullptr; }
+                    return gzb;
+                });
+                ++raw_in_flight;
+                sb.t_start += now() - ts;
+            } else {
+                host_waiting += cur->items.size();
+            }
+            pending.push_back(std::move(cur));
+            cur_bytes = 0;
+        };
+        auto append_host_run = [&](Pending &run) {
             const double t0 = now();
             int rc;
-            if (seqs[0].packed) {
-                vector<mk_packed_seq> p(seqs.size());
-                for (size_t i = 0; i < seqs.size(); ++i) {
-                    p[i].codes = seqs[i].codes; p[i].except = seqs[i].dirty ? seqs[i].except : nullptr; p[i].len = seqs[i].len;
-                    memcpy(p[i].head, seqs[i].head, 32);
+            if (run.items[0].packed) {
+                vector<mk_packed_seq> p(run.items.size());
+                for (size_t i = 0; i < run.items.size(); ++i) {
+                    p[i].codes = run.items[i].codes; p[i].except = run.items[i].dirty ? run.items[i].except : nullptr; p[i].len = run.items[i].len;
+                    memcpy(p[i].head, run.items[i].head, 32);
                 }
                 rc = mk_index_append_packed(ctx, p.data(), (uint32_t)p.size());
             } else {
                 vector<const char *> p;
                 vector<uint64_t> l;
-                for (auto &s : seqs) { p.push_back(s.data); l.push_back(s.len); }
-                rc = mk_index_append(ctx, p.data(), l.data(), (uint32_t)seqs.size());
+                for (auto &s : run.items) { p.push_back(s.data); l.push_back(s.len); }
+                rc = mk_index_append(ctx, p.data(), l.data(), (uint32_t)run.items.size());
             }
-            if (rc != MK_OK) {
-                sb.error = string("index build failed: ") + mk_last_error();
-                return false;
-            }
+            if (rc != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
             sb.t_append += now() - t0;
-            sb.names.insert(sb.names.end(), names.begin(), names.end());
-            for (auto &s : seqs) reader.recycle(s);
-            seqs.clear(); names.clear(); bytes = 0;
+            sb.names.insert(sb.names.end(), run.names.begin(), run.names.end());
+            sb.log.append(run.items.size(), '-');
+            host_waiting -= run.items.size();
+            sb.from_readers += run.items.size();
+            for (auto &s : run.items) reader.recycle(s);
             return true;
         };
-        // Runs of raw (gzip'd) files: a batch is unpacked on the device by a thread of its own (mk_gz_unpack works on a
-        // stream of its own) while this thread takes the next files from the readers and appends the batch before -- a
-        // stream is decoded by ONE lane, half a second for a 5 Mb genome whatever the batch's size, so batches overlap:
-        // up to three in flight.  Appended in list order, sixty-four at a time.
-        struct RawBatch {
-            vector<OrderedFastaReader::Item> items;
-            vector<string> names;
-            std::future<mk_gz_batch *> unpacked;
-            string error;
-        };
-        std::deque<std::unique_ptr<RawBatch>> in_flight;
-        vector<OrderedFastaReader::Item> raw;
-        vector<string> raw_names;
-        auto start_raw = [&]() {
-            if (raw.empty()) return;
-            std::unique_ptr<RawBatch> rb(new RawBatch());
-            rb->items.swap(raw); rb->names.swap(raw_names);
-            RawBatch *r = rb.get();
-            r->unpacked = std::async(std::launch::async, [r, ctx]() -> mk_gz_batch * {
-                vector<const uint8_t *> gp;
-                vector<uint64_t> gl;
-                for (auto &it : r->items) { gp.push_back((const uint8_t *)it.data); gl.push_back(it.len); }
-                mk_gz_batch *gzb = nullptr;
-                if (mk_gz_unpack(ctx, gp.data(), gl.data(), (uint32_t)gp.size(), &gzb) != MK_OK) { r->error = mk_last_error(); return nullptr; }
-                return gzb;
-            });
-            in_flight.push_back(std::move(rb));
-        };
-        // the oldest batches until at most `leave` are in flight: their sequences into the index
-        auto drain_raw = [&](size_t leave) {
-            while (in_flight.size() > leave) {
-                std::unique_ptr<RawBatch> rb = std::move(in_flight.front());
-                in_flight.pop_front();
-                const double t0 = now();
-                mk_gz_batch *gzb = rb->unpacked.get();
-                sb.t_unpack_wait += now() - t0;
-                if (!gzb) { sb.error = "index build failed: " + rb->error; return false; }
-                vector<uint32_t> which;                                // files of the batch waiting to be appended together
-                vector<string> kept;
-                bool ok = true;
-                auto append = [&]() {
-                    if (which.empty()) return true;
-                    const double ta = now();
-                    if (mk_index_append_gz(ctx, gzb, which.data(), (uint32_t)which.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
-                    sb.t_append += now() - ta;
-                    sb.names.insert(sb.names.end(), kept.begin(), kept.end());
-                    which.clear(); kept.clear();
-                    return true;
-                };
-                for (size_t i = 0; i < rb->items.size() && ok; ++i) {
-                    uint64_t len = 0;
-                    int32_t st = 0;
-                    mk_gz_sequence(gzb, (uint32_t)i, &len, &st);
-                    if (st != MK_GZ_OK) {
-                        // the device refused the file: inflated here, appended in its place
-                        vector<char> seq;
-                        if (!mkhost::inflate_fasta(rb->items[i].data, rb->items[i].len, seq)) { sb.error = "cannot read " + rb->names[i]; ok = false; break; }
-                        ++sb.gz_on_host;
-                        if (seq.size() >= k) {
-                            ok = append();
-                            const char *p = seq.data();
-                            const uint64_t l = seq.size();
-                            if (ok && mk_index_append(ctx, &p, &l, 1) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); ok = false; }
-                            if (ok) { sb.names.push_back(rb->names[i]); sb.log += '-'; }
-                        }
-                        continue;
+        auto append_raw_batch = [&](Pending &rb) {
+            const double t0 = now();
+            mk_gz_batch *gzb = rb.unpacked.get();
+            sb.t_unpack_wait += now() - t0;
+            --raw_in_flight;
+            if (!gzb) { sb.error = "index build failed: " + rb.error; reader.raw_consumed(rb.items.size()); return false; }
+            vector<uint32_t> which;                                // files of the batch waiting to be appended together
+            vector<string> kept;
+            bool ok = true;
+            auto append = [&]() {
+                if (which.empty()) return true;
+                const double ta = now();
+                if (mk_index_append_gz(ctx, gzb, which.data(), (uint32_t)which.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
+                sb.t_append += now() - ta;
+                sb.names.insert(sb.names.end(), kept.begin(), kept.end());
+                which.clear(); kept.clear();
+                return true;
+            };
+            for (size_t i = 0; i < rb.items.size() && ok; ++i) {
+                uint64_t len = 0;
+                int32_t st = 0;
+                mk_gz_sequence(gzb, (uint32_t)i, &len, &st);
+                if (st != MK_GZ_OK) {
+                    // the device refused the file: inflated here, appended in its place
+                    vector<char> seq;
+                    if (!mkhost::inflate_fasta(rb.items[i].data, rb.items[i].len, seq)) { sb.error = "cannot read " + rb.names[i]; ok = false; break; }
+                    ++sb.gz_on_host;
+                    if (seq.size() >= k) {
+                        ok = append();
+                        const char *p = seq.data();
+                        const uint64_t l = seq.size();
+                        if (ok && mk_index_append(ctx, &p, &l, 1) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); ok = false; }
+                        if (ok) { sb.names.push_back(rb.names[i]); sb.log += '-'; }
                     }
-                    if (len >= k) {
-                        which.push_back((uint32_t)i); kept.push_back(rb->names[i]);
-                        sb.log += '-';
-                        if (which.size() >= 64) { ok = append(); show(); }
-                    }
+                    continue;
                 }
-                ok = ok && append();
-                // (mk_gz_free waits for the strip kernels that read the batch's text)
-                mk_gz_free(gzb);
-                sb.gz_on_device += rb->items.size();
-                for (auto &it : rb->items) reader.recycle(it);
+                if (len >= k) {
+                    which.push_back((uint32_t)i); kept.push_back(rb.names[i]);
+                    sb.log += '-';
+                    if (which.size() >= 64) { ok = append(); show(); }
+                }
+            }
+            ok = ok && append();
+            const double tf = now();
+            mk_gz_free(gzb);                                           // (waits for the strip kernels that read the batch's text)
+            sb.t_free += now() - tf;
+            sb.gz_on_device += rb.items.size();
+            const double tr = now();
+            for (auto &it : rb.items) reader.recycle(it);
+            sb.t_recycle += now() - tr;
+            reader.raw_consumed(rb.items.size());
+            return ok;
+        };
+        // the front of the queue into the index: everything (all), or whatever is ready now -- and more, waiting for the
+        // device, while too much is held back behind it
+        auto drain = [&](bool all) {
+            while (!pending.empty()) {
+                Pending &f = *pending.front();
+                if (f.raw && !all && raw_in_flight <= gz_in_flight && host_waiting < 4096 &&
+                    f.unpacked.wait_for(chrono::seconds(0)) != std::future_status::ready) break;
+                const bool ok = f.raw ? append_raw_batch(f) : append_host_run(f);
+                pending.pop_front();
                 show();
                 if (!ok) return false;
             }
             return true;
         };
-        // everything raw so far into the index (before anything that must come after it in list order)
-        auto flush_raw = [&]() {
-            if (raw.empty() && in_flight.empty()) return true;
-            if (!flush()) return false;                                // (list order: what came before the run goes first)
-            start_raw();
-            return drain_raw(0);
-        };
+        const double t_loop = now();
         for (size_t i = 0; i < files.size(); ++i) {
             const string &fn = files[i];
             const double t0 = now();
             OrderedFastaReader::Item item = reader.take(i);
             sb.t_wait += now() - t0;
-            if (!item.exists) { if (!flush_raw()) return; sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
-            if (item.failed) { sb.error = "cannot read " + fn; return; }
+            if (!item.exists) { close_run(); if (!drain(true)) return; sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
+            if (item.failed) { close_run(); (void)drain(true); if (sb.error.empty()) sb.error = "cannot read " + fn; return; }
+            if (!item.raw && item.len < k) { reader.recycle(item); continue; }
+            if (cur && cur->raw != item.raw) close_run();
+            if (!cur) { cur.reset(new Pending()); cur->raw = item.raw; }
+            cur->items.push_back(item); cur->names.push_back(fn);
             if (item.raw) {
-                if (raw.empty() && in_flight.empty() && !flush()) return;      // (a run starts: what came before it goes first)
-                raw.push_back(item); raw_names.push_back(fn);
-                if (raw.size() >= gz_batch) { start_raw(); if (!drain_raw(gz_in_flight - 1)) return; }
-                continue;
-            }
-            if (!flush_raw()) return;
-            if (item.len >= k) {
-                bytes += item.len;
-                seqs.push_back(item); names.push_back(fn);
-                if (seqs.size() >= 64 || bytes > (1ull << 30)) { if (!flush()) return; show(); }
-                sb.log += '-';
+                if (cur->items.size() >= gz_batch) close_run();
             } else {
-                reader.recycle(item);
+                cur_bytes += item.len;
+                if (cur->items.size() >= 64 || cur_bytes > (1ull << 30)) close_run();
             }
+            if (!drain(false)) return;
         }
-        if (!flush_raw() || !flush()) return;
+        close_run();
+        if (!drain(true)) return;
+        sb.t_total = now() - t_loop;
         mk_gz_trim(ctx);                                           // (the inflater's blocks: the queries' buffers want the memory)
         if (mk_index_size(ctx) != sb.names.size()) sb.error = string("index build failed: ") + mk_last_error();   // settles the last batch
     }
@@ -405,8 +416,8 @@ struct Driver {
         if (getenv("MIEKKI_VERBOSE"))
             for (size_t d = 0; d < D; ++d)
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
-                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s; gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
-                     << ", on the host " << sb[d].gz_on_host << endl;
+                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s and for its batches' last kernels " << sb[d].t_free << "s (unmapping files " << sb[d].t_recycle << "s, starting batches " << sb[d].t_start << "s, the whole loop " << sb[d].t_total << "s); gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
+                     << ", refused by it and inflated here " << sb[d].gz_on_host << "; sequences that came from the readers " << sb[d].from_readers << endl;
         finish_index(true);
         compress_cold();
         cout << "Reference indexed: " << group.total() << endl;

@@ -769,7 +769,10 @@ int ensure_build_side(mk_ctx *c, int b)
     mk_ctx::BuildSide &sd = c->side[b];
     if (!sd.d_counters) {
         MK_HIP(hipMalloc((void **)&sd.d_counters, sizeof *sd.d_counters));
-        MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, c->stream));
+        // (done before this returns: queued on c->stream it could run -- behind the Bloom arrays' gigabytes of memset -- AFTER a
+        // front stage on the front stream had set the batch's exception flags, and wipe them)
+        MK_HIP(hipMemsetAsync(sd.d_counters, 0, sizeof *sd.d_counters, c->front_stream));
+        MK_HIP(hipStreamSynchronize(c->front_stream));
     }
     if (!sd.h_back) MK_HIP(hipHostMalloc((void **)&sd.h_back, sizeof *sd.h_back, hipHostMallocDefault));
     if (!sd.d_seq_off) MK_HIP(hipMalloc((void **)&sd.d_seq_off, (kBuildBatch + 1) * 8));

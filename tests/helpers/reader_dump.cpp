@@ -3,6 +3,9 @@
 //   reader_dump <list> <threads> [window] [allocator budget in bytes, 0 = no allocator] [take only the first N] [packed]
 // With "packed" the reader packs while it parses (2-bit codes + exception bits, unpacked again here) and the line is
 // "<exists> <length> <fnv1a64 of the sequence with every non-ACGT character as '?'> <failed> <dirty> <head as hex>".
+// With "share:<unit>:<ahead>" instead of "packed" the reader packs AND shares gzip'd files with the device in units of <unit>
+// files (fasta_reader.hpp): a raw item's line is "raw <length> <fnv1a64 of the file's bytes>"; raw items are given back
+// (raw_consumed) only when <unit> of them have been seen, as a device batch would.
 // With a budget the reader gets an allocator that hands out at most that many bytes and then
 // fails (the page-lock limit of pinned memory); with "take only N" the reader is destroyed
 // while workers are still parked on the read-ahead bound (must not hang).
@@ -38,12 +41,23 @@ int main(int argc, char **argv)
     {
         mkhost::HostAllocator a{nullptr, nullptr, nullptr};
         if (budget > 0) a = mkhost::HostAllocator{budget_alloc, budget_free, nullptr};
-        const bool packed = argc > 6 && std::string(argv[6]) == "packed";
+        const std::string mode = argc > 6 ? argv[6] : "";
+        size_t unit = 0, ahead = 0;
+        const bool share = sscanf(mode.c_str(), "share:%zu:%zu", &unit, &ahead) == 2;
+        const bool packed = share || mode == "packed";
         mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), a, argc > 3 ? (size_t)atoi(argv[3]) : 4,
-                                          packed);
+                                          packed, share, unit, ahead);
+        size_t raw_held = 0;
         for (size_t i = 0; i < files.size() && i < only; ++i) {
             mkhost::OrderedFastaReader::Item it = reader.take(i);
             uint64_t h = 1469598103934665603ull;
+            if (it.raw) {
+                for (size_t j = 0; j < it.len; ++j) { h ^= (unsigned char)it.data[j]; h *= 1099511628211ull; }
+                printf("raw %zu %016llx\n", it.len, (unsigned long long)h);
+                reader.recycle(it);
+                if (++raw_held >= unit) { reader.raw_consumed(raw_held); raw_held = 0; }
+                continue;
+            }
             if (packed && it.exists && !it.failed) {
                 for (size_t j = 0; j < it.len; ++j) {
                     const bool bad = (it.except[j / 64] >> (j % 64)) & 1u;

@@ -134,3 +134,44 @@ def test_unreadable_and_truncated_files_are_flagged_not_read_as_empty(dumper, tm
     assert out[0].split()[3] == "0" and out[3].split()[3] == "0" and int(out[0].split()[1]) == 10
     assert out[1].split()[0] == "1" and out[1].split()[3] == "1"             # truncated gzip: failed, not empty
     assert out[2].split()[0] == "1" and out[2].split()[3] == "1"             # a directory: failed
+
+
+def test_gzipd_files_are_shared_between_the_device_and_the_readers_in_whole_units(dumper, tmp_path):
+    """host/fasta_reader.hpp raw_unit / raw_units_ahead: a unit of the list goes raw (for mk_gz_unpack) while the device has
+    room, to the readers' zlib otherwise; a unit is never split between the two (a plain file in a device unit is parsed
+    here and does not use up the device's room), raw items are the files' bytes, the others the packed sequences."""
+    rng = np.random.default_rng(11)
+    texts, names = [], []
+    for i in range(60):
+        body = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(100, 5000))))
+        t = b">g%d\n" % i + b"\n".join(body[j:j + 70] for j in range(0, len(body), 70)) + b"\n"
+        plain = i in (5, 6, 23)
+        fn = tmp_path / ("g%d.fa" % i if plain else "g%d.fa.gz" % i)
+        fn.write_bytes(t if plain else gzip.compress(t, 6))
+        texts.append(t); names.append(str(fn))
+    (tmp_path / "l.txt").write_text("\n".join(names) + "\n")
+    unit = 4
+    for threads, ahead in ((1, 2), (4, 2), (8, 1), (3, 1000)):
+        out = subprocess.run([dumper, str(tmp_path / "l.txt"), str(threads), "16", "0", str(len(names)), f"share:{unit}:{ahead}"],
+                             check=True, stdout=subprocess.PIPE, timeout=120).stdout.decode().splitlines()
+        assert out[-1].startswith("done")
+        kinds = []
+        for i, line in enumerate(out[:-1]):
+            f = line.split()
+            if f[0] == "raw":
+                blob = open(names[i], "rb").read()
+                assert (int(f[1]), int(f[2], 16)) == (len(blob), fnv1a(blob)), (threads, ahead, i)
+                kinds.append("raw")
+            else:
+                seq = reference_sequence(texts[i])
+                assert int(f[1]) == len(seq) and int(f[2], 16) == fnv1a(seq), (threads, ahead, i)
+                kinds.append("plain" if names[i].endswith(".fa") else "host")
+        for u in range(0, len(names), unit):
+            ks = {k for k in kinds[u:u + unit] if k != "plain"}
+            assert len(ks) <= 1, (threads, ahead, u, kinds[u:u + unit])       # never split
+        assert kinds[0] == "raw"                                               # the device is empty at the start
+        if ahead == 1000:
+            assert "host" not in kinds                                         # room for everything: all raw
+        else:
+            # (the helper gives raw items back a unit at a time, so the device's room comes back: raw units keep coming)
+            assert "raw" in kinds[len(kinds) // 2:], (threads, ahead, kinds)
