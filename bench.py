@@ -481,21 +481,27 @@ def main(argv=None):
     comparisons_step = a_sum * G_total                # every rank has the same queries and the same (global) gate
     value = comparisons_step * args.steps / dt
 
-    merged_ok = host_heap_ok = n_over = n_hit = None
-    if rank == 0:                                     # the step's hits, checked on a sample
-        ns = min(Q, 2000)
+    merged_ok = host_heap_ok = n_over = n_hit = top_all = None
+    ns = 0
+    if rank == 0:                                     # the step's hits: every query's top hit, the heap on a strided sample
         nh = d_nhits.cpu().numpy().view(np.uint32)
         n_over = int((nh == mkd.MERGE_OVERFLOW).sum())
         n_hit = int(((nh > 0) & (nh != mkd.MERGE_OVERFLOW)).sum())
-        hits_dev = d_hits[:ns].cpu().numpy().view(mkd.HIT_DTYPE).reshape(ns, nres)
-        # query q was cut from genome q mod G_total: it must come out on top
-        merged_ok = sum(1 for q in range(ns) if 0 < nh[q] <= nres and int(hits_dev[q, 0]["genome"]) == q % G_total)
-        # and the device heap must be the host's std:: heap over the same rows
+        hits_all = d_hits[:Q].cpu().numpy().view(mkd.HIT_DTYPE).reshape(Q, nres)
+        # query q was cut from genome q mod G_total: it must come out on top -- for ALL queries of the step
+        good = (nh > 0) & (nh <= nres) & (hits_all[:, 0]["genome"] == (np.arange(Q, dtype=np.uint64) % G_total).astype(np.uint32))
+        top_all = int(good.sum())
+        # and the device heap must be the host's std:: heap over the same rows: 2,000 queries spread over the whole set
+        # (every chunk of the slab schedule, every workgroup's share of the selection), not its first 2,000
+        ns = min(Q, 2000)
+        pick = (np.arange(ns, dtype=np.int64) * Q) // ns
+        merged_ok = int(good[pick].sum())
         src = g_rows if multi else d_rows.view(1, -1)
-        rows_h = src.view(world, Q, rw)[:, :ns].cpu().numpy().view(np.uint64).reshape(world, ns * rw)
+        pick_d = torch.from_numpy(pick).to(src.device)
+        rows_h = src.view(world, Q, rw)[:, pick_d].cpu().numpy().view(np.uint64).reshape(world, ns * rw)
         hits, overflow = mkd.merge_compact_host(rows_h, ns, cap, nres, ss_all, gs_all)
-        host_heap_ok = sum(1 for q in range(ns) if overflow[q] or
-                           (nh[q] == len(hits[q]) and hits_dev[q, :nh[q]].tobytes() == hits[q].tobytes()))
+        host_heap_ok = sum(1 for i, q in enumerate(pick) if overflow[i] or
+                           (nh[q] == len(hits[i]) and hits_all[q, :nh[q]].tobytes() == hits[i].tobytes()))
 
     if rank == 0:
         launches = max(1, int(st["scan_launches"]))
@@ -573,8 +579,9 @@ def main(argv=None):
                                      if native else "torch.distributed.gather over %s" % dist.get_backend()),
                       "per_rank_ms_per_step": rank_ms,
                       "note": "rank 0: filter_results heap over the (gathered) 8-byte entrant rows, inside the timed step"},
-            "check": {"queries_with_hits": n_hit, "top_hit_is_source_genome_of_first_2000": merged_ok,
-                      "device_heap_equals_host_heap_of_first_2000": host_heap_ok},
+            "check": {"queries": Q, "queries_with_hits": n_hit, "top_hit_is_source_genome_of_all_queries": top_all,
+                      "strided_sample": ns, "top_hit_is_source_genome_of_strided_sample": merged_ok,
+                      "device_heap_equals_host_heap_of_strided_sample": host_heap_ok},
         }
         if world == 1:
             try:                                       # outside the timed region, a context of its own

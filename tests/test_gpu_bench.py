@@ -33,8 +33,8 @@ def test_one_gpu_line_and_two_rank_rehearsal_agree():
         assert r["roofline"]["hbm_floor_bytes"] == (1 << 20) * r["config"]["genomes_per_gpu"]
         assert r["merge"]["overflowed_queries"] == 0
         # every query comes out with its source genome on top, and the device heap is the host heap
-        assert r["check"]["top_hit_is_source_genome_of_first_2000"] == 2000
-        assert r["check"]["device_heap_equals_host_heap_of_first_2000"] == 2000
+        assert r["check"]["top_hit_is_source_genome_of_all_queries"] == r["check"]["queries"] == 2000
+        assert r["check"]["device_heap_equals_host_heap_of_strided_sample"] == r["check"]["strided_sample"] == 2000
     assert two["config"]["genomes_per_gpu"] == 96
     # same problem, same gate: identical active partitions, hence identical comparisons per step
     assert one["config"]["active_partitions_per_query"] == two["config"]["active_partitions_per_query"]

@@ -189,8 +189,8 @@ def test_bench_forced_collective_path_equals_the_plain_line(exchange):
     assert forced["merge"]["forced_collective_path"] and forced["merge"]["backend"] == "nccl" and forced["merge"]["ranks"] == 1
     assert ("mk_qset_run_compact_gather" in forced["merge"]["collective"]) == (exchange == "rccl")
     for r in (plain, forced):
-        assert r["check"]["top_hit_is_source_genome_of_first_2000"] == 2000
-        assert r["check"]["device_heap_equals_host_heap_of_first_2000"] == 2000
+        assert r["check"]["top_hit_is_source_genome_of_all_queries"] == r["check"]["queries"] == 20000
+        assert r["check"]["device_heap_equals_host_heap_of_strided_sample"] == r["check"]["strided_sample"] == 2000
         assert r["merge"]["overflowed_queries"] == 0
     assert forced["config"]["active_partitions_per_query"] == plain["config"]["active_partitions_per_query"]
     assert forced["merge"]["gather_bytes_per_rank"] == 20000 * (forced["merge"]["cap"] + 1) * 8

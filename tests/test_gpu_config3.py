@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import synth
-from gpu_checks import oracle_sample_check
+from gpu_checks import oracle_sample_check, oracle_slab_check
 
 pytestmark = pytest.mark.gpu
 
@@ -65,9 +65,12 @@ def single(tmp_path_factory):
             assert all(abs(a.intersection - b.intersection) <= 1e-6 * abs(b.intersection) for a, b in zip(hits[q], want))
             assert scores[q, q % G] == hits[q][0].matches
         # eight genomes' columns SHA-equal to the oracle's sketches, eight dense rows equal under the collection's own gate
-        sample = oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
-                                                                     synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
+        sample, o8 = oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                                         synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)],
+                                         with_oracle=True)
         assert len(sample) == 8
+        # ... and the SLAB path next to the oracle: sixteen queries from those genomes inside a 616-query set (mk_qset_run)
+        assert oracle_slab_check(ix, o8, sample, L_, qs[:600]) == 16
         flat = np.zeros((NQ, 10), HIT)
         nh = np.zeros(NQ, np.uint32)
         for q, h in enumerate(hits):

@@ -343,7 +343,7 @@ def test_sharded_contexts_merge_equals_single_context(hip):
             ix.close()
 
 
-from gpu_checks import oracle_sample_check  # noqa: E402
+from gpu_checks import oracle_sample_check, oracle_slab_check  # noqa: E402
 
 
 @pytest.mark.parametrize("name", ["h20", "w16", "messy", "rnd4"])
@@ -395,8 +395,10 @@ def test_config3_shard_scale_properties(hip):
             assert a.shape == b.shape and (b >= a).all()
         finally:
             small.close()
-        oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
-                                                            synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
+        sample, o8 = oracle_sample_check(ix, 31, 20, 8, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                                         synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)],
+                                         with_oracle=True)
+        assert oracle_slab_check(ix, o8, sample, L_, qs[:600]) == 16     # the slab path's hits next to the oracle's numbers
     finally:
         ix.close()
 
@@ -452,8 +454,10 @@ def test_config4_full_size_properties(hip):
             assert np.delete(scores[q], src).max() <= 8                 # 16-bit fingerprints: chance matches ~ 900 / 2^11 / 3
             want = ix.filter_results(scores[q], 10, 10, 100.0)
             assert [(a.genome, a.matches) for a in hits[q]] == [(b.genome, b.matches) for b in want], q
-        oracle_sample_check(ix, 31, 20, 16, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
-                                                             synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)])
+        sample, o8 = oracle_sample_check(ix, 31, 20, 16, G, L_, qs[:4] + [synth.genome_bases(G // 2, 777, 1000), synth.genome_bases(1, 5, 1000),
+                                                                          synth.genome_bases(G - 1, 4_000_000, 1000), synth.genome_bases(G + 5, 0, 1000)],
+                                         with_oracle=True)
+        assert oracle_slab_check(ix, o8, sample, L_, qs[:600]) == 16
     finally:
         ix.close()
 
