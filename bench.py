@@ -381,6 +381,7 @@ def main(argv=None):
             L.check(lib.mk_comm_unique_id(buf))
             ident = [bytes(buf)]
         dist.broadcast_object_list(ident, src=0)
+        os.environ["MIEKKI_COMM_BANNER_TO_STDERR"] = "1"          # (stdout is one JSON line: RCCL's version banner to stderr)
         L.check(lib.mk_comm_create(ix._h, rank, world, ident[0], C.byref(comm)))
         L.check(lib.mk_comm_sync_bloom(comm))          # MIN all-reduce of rank-keyed cells (ncclAllReduce)
         base_, total_ = C.c_uint32(0), C.c_uint32(0)

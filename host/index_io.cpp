@@ -147,8 +147,134 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
     return ok ? 0 : -1;
 }
 
+// ---- -d with one process per GPU
+namespace {
+
+// every rank's `bytes` bytes -> all ranks (host to host through the communicator's device buffers)
+bool allgather_host(mk_ctx *ctx, mk_comm *comm, const void *mine, uint64_t bytes, std::vector<uint8_t> &all, std::string &err)
+{
+    const int W = mk_comm_world(comm);
+    all.assign((size_t)bytes * W, 0);
+    void *d = nullptr;
+    if (mk_dev_alloc(ctx, bytes * (W + 1), &d) != MK_OK) { err = mk_last_error(); return false; }
+    bool ok = mk_dev_upload(ctx, (uint8_t *)d + bytes * W, mine, bytes) == MK_OK && mk_comm_allgather(comm, (uint8_t *)d + bytes * W, bytes, d) == MK_OK &&
+              mk_dev_download(ctx, all.data(), d, bytes * W) == MK_OK;
+    if (!ok) err = mk_last_error();
+    mk_dev_free(ctx, d);
+    return ok;
+}
+
+}  // namespace
+
+int dump_index_ranked(mk_ctx *ctx, mk_comm *comm, const std::string &path, std::string &err, unsigned threads)
+{
+    mk_params p;
+    if (!ctx || !comm || mk_get_params(ctx, &p) != MK_OK) { err = "no context"; return -1; }
+    const int world = mk_comm_world(comm), rank = mk_comm_rank(comm);
+    const uint32_t W = p.fp_bits / 8, P = 1u << p.h, Gm = mk_index_size(ctx);
+    std::vector<uint8_t> all;
+    if (!allgather_host(ctx, comm, &Gm, 4, all, err)) return -1;
+    std::vector<uint32_t> Gd(world), at(world + 1, 0);
+    uint32_t maxG = 0;
+    for (int r = 0; r < world; ++r) { memcpy(&Gd[r], all.data() + 4 * r, 4); at[r + 1] = at[r] + Gd[r]; maxG = std::max(maxG, Gd[r]); }
+    const uint32_t G = at[world];
+    const uint64_t row = (uint64_t)G * W, mrow = (uint64_t)maxG * W;
+    const uint32_t rows = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, mrow ? kChunk / mrow : P));
+    const uint64_t blk = std::max<uint64_t>(16, (rows * mrow + 15) / 16 * 16);          // every rank's share of a block of rows, padded alike
+    std::string my_err;                                            // (a rank that fails keeps standing in the collectives: all leave together)
+    void *d_send = nullptr, *d_recv = nullptr;
+    if (mk_dev_alloc(ctx, blk, &d_send) != MK_OK || (rank == 0 && mk_dev_alloc(ctx, blk * world, &d_recv) != MK_OK)) my_err = mk_last_error();
+    std::unique_ptr<ParallelGzipWriter> w;
+    if (rank == 0) {
+        w.reset(new ParallelGzipWriter(path, threads));
+        if (!w->ok()) { my_err = "cannot open " + path; w.reset(); }
+    }
+    if (w) {
+        Header hd{p.k, p.h, p.fp_bits, 5, G, p.bloom_log2, p.bloom_log2 ? 1ull << p.bloom_log2 : 0, 0, 0, p.threshold, 1};
+        w->write(&hd, sizeof hd);
+        w->flush_block();
+        w->set_strategy(Z_HUFFMAN_ONLY);
+        if (const char *e = getenv("MIEKKI_DUMP_LEVEL")) w->set_level(atoi(e) == 0 ? 0 : 1);
+    }
+    std::vector<uint8_t> mine((size_t)blk), got(rank == 0 ? (size_t)(blk * world) : 0), buf((size_t)std::max<uint64_t>(rows * row, 1));
+    bool coll_ok = true;
+    auto exchange = [&]() {                                        // mine -> rank 0's got[world][blk]
+        if (mk_dev_upload(ctx, d_send, mine.data(), blk) != MK_OK && my_err.empty()) my_err = mk_last_error();
+        if (mk_comm_gather(comm, d_send, blk, d_recv, 0) != MK_OK) { coll_ok = false; return; }
+        if (rank == 0 && mk_dev_download(ctx, got.data(), d_recv, blk * world) != MK_OK && my_err.empty()) my_err = mk_last_error();
+    };
+    // (a rank without buffers cannot take part in a gather of blk bytes: that failure is settled first)
+    std::string first;
+    {
+        char msg[256] = {0};
+        snprintf(msg, sizeof msg, "%s", my_err.c_str());
+        if (!allgather_host(ctx, comm, msg, sizeof msg, all, err)) return -1;
+        for (int r = 0; r < world && first.empty(); ++r) first = std::string((const char *)all.data() + 256 * r, strnlen((const char *)all.data() + 256 * r, 255));
+    }
+    for (uint32_t pb = 0; first.empty() && coll_ok && pb < P; pb += rows) {
+        const uint32_t pe = std::min(P, pb + rows);
+        if (Gm && my_err.empty() && mk_index_export_columns(ctx, pb, pe, mine.data()) != MK_OK) my_err = mk_last_error();
+        exchange();
+        if (!coll_ok) break;
+        if (w && my_err.empty()) {
+            for (int r = 0; r < world; ++r) {
+                const uint64_t prow = (uint64_t)Gd[r] * W;
+                if (!prow) continue;
+                const uint8_t *src = got.data() + (uint64_t)r * blk;
+                for (uint32_t i = 0; i < pe - pb; ++i) memcpy(buf.data() + (uint64_t)i * row + (uint64_t)at[r] * W, src + (uint64_t)i * prow, prow);
+            }
+            w->write(buf.data(), (size_t)(pe - pb) * row);
+        }
+    }
+    // the sizes: every rank's genome sizes and sketch sizes, in blocks of what fits
+    std::vector<uint64_t> gs(G), gs_m(Gm);
+    std::vector<uint32_t> ss(G), ss_m(Gm);
+    if (first.empty() && coll_ok) {
+        if (Gm && my_err.empty() && mk_index_export_sizes(ctx, gs_m.data(), ss_m.data()) != MK_OK) my_err = mk_last_error();
+        const uint32_t per = (uint32_t)std::max<uint64_t>(1, (blk - 0) / 12);
+        for (uint32_t g0 = 0; coll_ok && g0 < maxG; g0 += per) {
+            const uint32_t n_m = Gm > g0 ? std::min(per, Gm - g0) : 0;
+            if (n_m) { memcpy(mine.data(), gs_m.data() + g0, (size_t)n_m * 8); memcpy(mine.data() + (size_t)per * 8, ss_m.data() + g0, (size_t)n_m * 4); }
+            exchange();
+            if (!coll_ok || rank != 0) continue;
+            for (int r = 0; r < world; ++r) {
+                const uint32_t n_r = Gd[r] > g0 ? std::min(per, Gd[r] - g0) : 0;
+                if (!n_r) continue;
+                memcpy(gs.data() + at[r] + g0, got.data() + (uint64_t)r * blk, (size_t)n_r * 8);
+                memcpy(ss.data() + at[r] + g0, got.data() + (uint64_t)r * blk + (size_t)per * 8, (size_t)n_r * 4);
+            }
+        }
+    }
+    if (w && first.empty() && coll_ok && my_err.empty()) {
+        w->set_strategy(Z_DEFAULT_STRATEGY);
+        w->set_level(1);
+        w->write(gs.data(), (size_t)G * 8);
+        const uint64_t nb = (p.bloom_log2 ? 1ull << p.bloom_log2 : 0) / 8, reach = std::min<uint64_t>(nb, mk_bloom_reachable_bytes(ctx));
+        std::vector<uint8_t> bb((size_t)std::min<uint64_t>(kChunk, std::max<uint64_t>(reach, 1)));
+        for (uint64_t o = 0; my_err.empty() && o < reach; o += kChunk) {        // (every rank holds the global filter: rank 0's own)
+            const uint64_t e = std::min(reach, o + kChunk);
+            if (mk_index_export_bloom(ctx, o, e, bb.data()) != MK_OK) { my_err = mk_last_error(); break; }
+            w->write(bb.data(), (size_t)(e - o));
+        }
+        w->write_zeros((size_t)(nb - reach));
+        w->write(ss.data(), (size_t)G * 4);
+    }
+    if (w && !w->finish() && my_err.empty()) my_err = "write error on " + path;
+    if (d_send) mk_dev_free(ctx, d_send);
+    if (d_recv) mk_dev_free(ctx, d_recv);
+    if (!coll_ok) { err = std::string("exchange failed: ") + mk_last_error(); if (rank == 0) remove(path.c_str()); return -1; }
+    if (first.empty()) {                                           // how everybody fared: the same answer on every rank
+        char msg[256] = {0};
+        snprintf(msg, sizeof msg, "%s", my_err.c_str());
+        if (!allgather_host(ctx, comm, msg, sizeof msg, all, err)) return -1;
+        for (int r = 0; r < world && first.empty(); ++r) first = std::string((const char *)all.data() + 256 * r, strnlen((const char *)all.data() + 256 * r, 255));
+    }
+    if (!first.empty()) { err = first; if (rank == 0) remove(path.c_str()); return -1; }
+    return 0;
+}
+
 int load_index(const std::string &path, const std::vector<int> &devices, std::vector<mk_ctx *> &out, std::string &err,
-               unsigned threads)
+               unsigned threads, int slice_rank, int slice_world)
 {
     out.clear();
     // MIEKKI_IO_TRACE=1: where a load spends its time (stderr)
@@ -170,15 +296,23 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
         return -1;
     }
     const uint32_t G = hd.index_size, W = hd.fp_bits / 8;
-    // genomes split over the devices in id order; never more shards than genomes
-    const size_t D = std::max<size_t>(1, std::min<size_t>(devices.size(), std::max<uint32_t>(G, 1)));
+    // genomes split over the devices in id order; never more shards than genomes -- or, one process per GPU (slice_world
+    // ranks, this one slice_rank): over the RANKS, every one of which reads the file and keeps the columns of its own run
+    // of genomes (a rank beyond the genomes keeps none: it still needs a context to stand in the communicator)
+    const bool sliced = slice_world > 0;
+    if (sliced && (slice_rank < 0 || slice_rank >= slice_world)) { err = "rank " + std::to_string(slice_rank) + " of " + std::to_string(slice_world); return -1; }
+    const size_t D = sliced ? (size_t)slice_world : std::max<size_t>(1, std::min<size_t>(devices.size(), std::max<uint32_t>(G, 1)));
     std::vector<uint32_t> at(D + 1, 0);
     for (size_t d = 0; d < D; ++d) {
         const uint64_t base = G / D, rem = G % D;
         at[d + 1] = at[d] + (uint32_t)(base + (d < rem ? 1 : 0));
     }
-    for (size_t d = 0; ok && d < D; ++d) {
-        mk_params p{hd.kmer_size, hd.h, hd.fp_bits, hd.bloom_log2, hd.threshold, devices[d], at[d], 0};
+    std::vector<size_t> mine;                                      // out[i] holds shard mine[i]
+    if (sliced) mine.push_back((size_t)slice_rank);
+    else for (size_t d = 0; d < D; ++d) mine.push_back(d);
+    for (size_t i = 0; ok && i < mine.size(); ++i) {
+        const size_t d = mine[i];
+        mk_params p{hd.kmer_size, hd.h, hd.fp_bits, hd.bloom_log2, hd.threshold, devices[sliced ? 0 : d], at[d], 0};
         mk_ctx *ctx = nullptr;
         if (mk_create(&p, &ctx) != MK_OK) { err = mk_last_error(); ok = false; break; }
         out.push_back(ctx);
@@ -356,13 +490,14 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
                 return;
             }
             std::vector<uint8_t> part;
-            for (size_t d = 0; import_ok && d < D; ++d) {
+            for (size_t i = 0; import_ok && i < mine.size(); ++i) {
+                const size_t d = mine[i];
                 const uint64_t prow = (uint64_t)(at[d + 1] - at[d]) * W;
                 if (!prow) continue;
                 part.resize((size_t)(pe - pb) * prow);
                 for (uint32_t r = 0; r < pe - pb; ++r)
                     memcpy(part.data() + (uint64_t)r * prow, b + (uint64_t)r * row + (uint64_t)at[d] * W, prow);
-                if (mk_index_import_columns(out[d], pb, pe, part.data()) != MK_OK) { import_err = mk_last_error(); import_ok = false; }
+                if (mk_index_import_columns(out[i], pb, pe, part.data()) != MK_OK) { import_err = mk_last_error(); import_ok = false; }
             }
         });
     }
@@ -383,16 +518,18 @@ int load_index(const std::string &path, const std::vector<int> &devices, std::ve
         const uint64_t e = std::min(nb, o + bchunk);
         ok = f.read(buf.data(), (size_t)(e - o));
         if (!ok) { err = "truncated Bloom filter"; break; }
-        for (size_t d = 0; ok && d < D; ++d)                        // the one global filter, on every shard
-            if (mk_index_import_bloom(out[d], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
+        for (size_t i = 0; ok && i < out.size(); ++i)               // the one global filter, on every shard
+            if (mk_index_import_bloom(out[i], o, e, buf.data()) != MK_OK) { err = mk_last_error(); ok = false; }
     }
     if (ok && !(ok = f.read(ss.data(), (size_t)G * 4))) err = "truncated sketch sizes";
     if (trace) fprintf(stderr, "[load] sizes and Bloom filter read after %.2f s\n", since(t_begin));
-    for (size_t d = 0; ok && d < D; ++d)
-        if (at[d + 1] > at[d] && mk_index_import_sizes(out[d], gs.data() + at[d], ss.data() + at[d]) != MK_OK) {
+    for (size_t i = 0; ok && i < mine.size(); ++i) {
+        const size_t d = mine[i];
+        if (at[d + 1] > at[d] && mk_index_import_sizes(out[i], gs.data() + at[d], ss.data() + at[d]) != MK_OK) {
             err = mk_last_error();
             ok = false;
         }
+    }
     if (!ok) {
         for (mk_ctx *c : out) mk_destroy(c);
         out.clear();

@@ -54,6 +54,7 @@
 #include "index_io.hpp"
 #include "miekki_hip.h"
 #include "multi_gpu.hpp"
+#include "rendezvous.hpp"
 
 using namespace std;
 
@@ -429,34 +430,41 @@ struct Driver {
     // ---- one process per GPU (RCCL): this process builds the rank_id-th contiguous run of the list
     int rank_id = 0, rank_world = 1, rank_local = 0;
     bool forced_rank_mode = false;                // a world of one was asked for explicitly (tests: RCCL on one GPU)
-    string comm_file;
 
-    // rank 0 draws the communicator's id and leaves it in a file the launcher's other children find
-    // (MIEKKI_COMM_FILE, or a name made of the launcher's pid and port): no network code in here
+    // rank 0 draws the communicator's id and leaves it where the launcher's other children find it (rendezvous.hpp: a file
+    // that carries the run's nonce, made exclusively, checked by its readers, gone when everybody has joined)
+    mkhost::Rendezvous meet;
     mk_comm *make_comm(mk_ctx *ctx)
     {
         uint8_t id[MK_COMM_ID_BYTES];
+        string err;
         if (rank_id == 0) {
             if (mk_comm_unique_id(id) != MK_OK) die("cannot start RCCL");
-            const string tmp = comm_file + ".tmp";
-            FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { cout << "cannot write " << tmp << endl; exit(1); }
-            fclose(f);
-            if (rename(tmp.c_str(), comm_file.c_str()) != 0) { cout << "cannot write " << comm_file << endl; exit(1); }
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 60000 && !got; ++tries) {      // up to ten minutes: rank 0 may still be starting
-                FILE *f = fopen(comm_file.c_str(), "rb");
-                if (f) { got = fread(id, 1, sizeof id, f) == sizeof id; fclose(f); }
-                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            }
-            if (!got) { cerr << "rank " << rank_id << ": no communicator id in " << comm_file << endl; exit(1); }
+            static string to_remove;                                   // (whatever ends this process: the file goes)
+            to_remove = meet.path;
+            atexit([] { if (!to_remove.empty()) unlink(to_remove.c_str()); });
+            if (!mkhost::rendezvous_publish(meet, id, sizeof id, err)) { cout << err << endl; exit(1); }
+        } else if (!mkhost::rendezvous_fetch(meet, id, sizeof id, 600000, err)) {   // up to ten minutes: rank 0 may still be starting
+            cerr << "rank " << rank_id << ": " << err << endl;
+            exit(1);
         }
         mk_comm *comm = nullptr;
         if (mk_comm_create(ctx, rank_id, rank_world, id, &comm) != MK_OK) die("cannot create the communicator");
         if (mk_comm_barrier(comm) != MK_OK) die("communicator barrier failed");
-        if (rank_id == 0) remove(comm_file.c_str());                   // everybody has read it
+        if (rank_id == 0) mkhost::rendezvous_remove(meet);             // everybody has read it
         return comm;
+    }
+
+    // Every rank says how it fared (empty = well) before the next collective: if any rank failed, ALL leave here, with the
+    // first failure's words on rank 0's stdout -- nobody is left waiting in a collective the failed rank will never enter.
+    void agree(const string &mine, const char *what)
+    {
+        if (!group.ranked()) { if (!mine.empty()) { cout << what << mine << endl; exit(1); } return; }
+        vector<string> all;
+        string err;
+        if (group.all_gather_text(mine, all, err)) { cout << "multi-GPU setup failed: " << err << endl; exit(1); }
+        for (const string &e : all)
+            if (!e.empty()) { cout << what << e << endl; exit(1); }
     }
 
     template <typename MakeCtx>
@@ -927,16 +935,9 @@ int main(int argc, char **argv)
     drv.threads = reader_threads;
     drv.threads_given = threads_given;
     if (rank_mode) {
-        if (!index_file.empty() || !index_dump.empty()) {
-            cout << "-i and -d are not available with one process per GPU: run them as a single process (it uses every visible GPU)" << endl;
-            return 1;
-        }
         drv.rank_id = rank_id; drv.rank_world = rank_world; drv.rank_local = rank_local; drv.forced_rank_mode = true;
-        if (const char *e = getenv("MIEKKI_COMM_FILE")) drv.comm_file = e;
-        else {
-            const char *port = getenv("MASTER_PORT");
-            drv.comm_file = "/tmp/miekki_comm_" + to_string((long)getppid()) + "_" + (port ? port : "0");
-        }
+        drv.meet = mkhost::rendezvous_from_env();
+        setenv("MIEKKI_COMM_BANNER_TO_STDERR", "1", 1);              // (stdout is compared with the reference's: mk_comm_create)
     }
     if (!index_file.empty()) {
         if (!mkhost::file_exists(index_file)) {
@@ -945,13 +946,30 @@ int main(int argc, char **argv)
         }
         string err;
         vector<mk_ctx *> ctxs;
-        if (mkhost::load_index(index_file, devices, ctxs, err, reader_threads) != 0) { cout << "Index load failed: " << err << endl; return 1; }
-        drv.group.adopt(ctxs);
+        if (rank_mode) {
+            // one process per GPU: every rank reads the file and keeps the columns of its run of genomes (main.cpp:189-194,
+            // Miekki.cpp:687-719 per rank).  A rank that cannot load still joins the communicator -- on a context of its
+            // own making -- so that all ranks hear of it and leave together.
+            const int device = rank_local < (int)devices.size() ? devices[rank_local] : rank_local;
+            const bool loaded = mkhost::load_index(index_file, {device}, ctxs, err, reader_threads, rank_id, rank_world) == 0;
+            if (!loaded) {
+                mk_params p{31, 10, 8, 0, 0, device, 0, 0};
+                mk_ctx *ctx = nullptr;
+                if (mk_create(&p, &ctx) != MK_OK) die("cannot create a context");
+                ctxs.assign(1, ctx);
+            }
+            drv.group.adopt(ctxs);
+            drv.group.set_comm(drv.make_comm(ctxs[0]));
+            drv.agree(loaded ? string() : (err.empty() ? string("unknown error") : err), "Index load failed: ");
+        } else {
+            if (mkhost::load_index(index_file, devices, ctxs, err, reader_threads) != 0) { cout << "Index load failed: " << err << endl; return 1; }
+            drv.group.adopt(ctxs);
+        }
         drv.finish_index(false);                            // the file holds the global Bloom filter already
         mk_params p;
         mk_get_params(drv.ctx0(), &p);
         drv.k = p.k; drv.threshold = p.threshold;          // -k -h -f -b -s come from the file (main.cpp:189-194)
-        drv.out.open(output_file.c_str());
+        if (!rank_mode || rank_id == 0) drv.out.open(output_file.c_str());
         cout << "I output results in " << output_file << endl;
         cout << "Load sucessful" << endl;
     } else if (!list_file.empty()) {
@@ -974,7 +992,9 @@ int main(int argc, char **argv)
     if (!index_dump.empty()) {
         cout << "I write this index on the disk for later" << endl;
         string err;
-        if (mkhost::dump_index(drv.group.contexts(), index_dump, err, reader_threads) != 0) { cout << "Index dump failed: " << err << endl; return 1; }
+        const int rc = rank_mode ? mkhost::dump_index_ranked(drv.ctx0(), drv.group.comm(), index_dump, err, reader_threads)
+                                 : mkhost::dump_index(drv.group.contexts(), index_dump, err, reader_threads);
+        if (rc != 0) { cout << "Index dump failed: " << err << endl; return 1; }
     }
     auto end_index = chrono::system_clock::now();
     cout << "elapsed time: " << chrono::duration<double>(end_index - start).count() << "s\n";

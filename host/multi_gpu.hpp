@@ -61,6 +61,7 @@ public:
     // the same arguments; the merged hits arrive on rank 0 (the other ranks' hit arrays stay empty).
     void set_comm(mk_comm *comm) { comm_ = comm; }
     bool ranked() const { return comm_ != nullptr; }
+    mk_comm *comm() const { return comm_; }
     int rank() const { return comm_ ? mk_comm_rank(comm_) : 0; }
     int world() const { return comm_ ? mk_comm_world(comm_) : 1; }
     bool root() const { return rank() == 0; }

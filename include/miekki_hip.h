@@ -405,6 +405,10 @@ typedef struct mk_comm mk_comm;
 /* rank 0 draws the id (ncclGetUniqueId) and hands it to the other ranks by any means (a file, the launcher's
  * store, an environment variable); then every rank creates its communicator (ncclCommInitRank). */
 int mk_comm_unique_id(uint8_t *id /* MK_COMM_ID_BYTES */);
+/* (This RCCL build prints a version banner on stdout from rank 0's first communicator.  With MIEKKI_COMM_BANNER_TO_STDERR=1
+ * in the environment mk_comm_create points descriptor 1 at descriptor 2 while the communicator initialises -- process-wide,
+ * for as long as the slowest rank takes to arrive: only for programs that own their stdout, like the `miekki` binary and
+ * bench.py, which set it themselves.  Without it nothing is redirected.) */
 int mk_comm_create(mk_ctx *ctx, int rank, int world, const uint8_t *id, mk_comm **out);
 void mk_comm_destroy(mk_comm *comm);
 int mk_comm_rank(const mk_comm *comm);

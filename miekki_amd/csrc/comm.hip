@@ -144,14 +144,19 @@ int mk_comm_create(mk_ctx *c, int rank, int world, const uint8_t *id, mk_comm **
     ncclComm_t nc = nullptr;
     // This RCCL build prints a version banner ("RCCL version : ...", five lines) on STDOUT from rank 0's first
     // communicator -- into the middle of whatever the host program reports there (the `miekki` binary's banners are
-    // compared byte for byte with the reference's; bench.py's stdout is one JSON line).  It goes to stderr instead:
-    // descriptor 1 points at descriptor 2 while the communicator initialises.
-    fflush(stdout);
-    const int saved = dup(1);
-    if (saved >= 0) (void)dup2(2, 1);
+    // compared byte for byte with the reference's; bench.py's stdout is one JSON line).  A program that owns its
+    // stdout asks for it to go to stderr instead (MIEKKI_COMM_BANNER_TO_STDERR=1, set by those two before they call
+    // this): descriptor 1 then points at descriptor 2 while the communicator initialises -- for the whole PROCESS and
+    // for as long as the slowest rank takes to arrive, which is why a library caller has to opt in.
+    const char *quiet = getenv("MIEKKI_COMM_BANNER_TO_STDERR");
+    int saved = -1;
+    if (quiet && *quiet && *quiet != '0') {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
     const ncclResult_t init = g_rccl.CommInitRank(&nc, world, u, rank);   // (collective: returns when every rank has called it)
-    fflush(stdout);
-    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    if (saved >= 0) { fflush(stdout); (void)dup2(saved, 1); (void)close(saved); }
     MK_NCCL(init);
     mk_comm *m = new mk_comm();
     m->ctx = c; m->rank = rank; m->world = world; m->comm = nc; m->d_keys = nullptr; m->keys_cap = 0;

@@ -145,8 +145,50 @@ def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name)
     if os.path.exists(exa):
         run_ranked(["-l", "qfiles.lst", "-A", "qfiles.lst", "-e", "-o", "exactA_r.txt", *base], d)
         assert (d / "exactA_r.txt").read_bytes() == open(exa, "rb").read()
-    r = subprocess.run([CLI, "-i", "x.gz", "-a", "queries.fa"], cwd=d, stdout=subprocess.PIPE, env=dict(os.environ, MIEKKI_WORLD="1", MIEKKI_RANK="0"))
-    assert r.returncode == 1 and b"single process" in r.stdout
+    # -d and -i per rank (main.cpp:189-206, Miekki.cpp:649-719): the dump is the single process's stream (masked SHA of the
+    # reference's), the load keeps this rank's slice of the columns and answers like the reference
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    so_d = run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_rd.txt", "-d", "idx_r.gz", *base], d)
+    assert norm(so_d).replace(b"out_rd.txt", b"out.txt") == open(os.path.join(golden_dir, f"{name}_stdout_l.txt"), "rb").read()
+    raw = bytearray(gzip.decompress((d / "idx_r.gz").read_bytes()))
+    assert len(raw) == int(gold["stream_len"])
+    raw[32] = 0; raw[38] = 0
+    assert hashlib.sha256(bytes(raw)).hexdigest() == str(gold["stream_sha_masked"])
+    so_i = run_ranked(["-i", "idx_r.gz", "-a", "queries.fa", "-o", "out_ri.txt", "-t", "1"], d)
+    assert (d / "out_ri.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_out.txt"), "rb").read()
+    assert norm(so_i).replace(b"out_ri.txt", b"out_i.txt") == open(os.path.join(golden_dir, f"{name}_stdout_i.txt"), "rb").read()
+    run_ranked(["-i", "idx_r.gz", "-A", "qfiles.lst", "-o", "outA_ri.txt", "-t", "1"], d)
+    assert (d / "outA_ri.txt").read_bytes() == open(os.path.join(golden_dir, f"{name}_outA.txt"), "rb").read()
+    # a rank that cannot load says so and leaves (with every other rank: Driver::agree) instead of hanging in a collective
+    (d / "broken.gz").write_bytes((d / "idx_r.gz").read_bytes()[:200])
+    env = dict(os.environ, MIEKKI_DEVICES="0", MIEKKI_WORLD="1", MIEKKI_RANK="0", MIEKKI_COMM_FILE=str(d / "comm.id"))
+    r = subprocess.run([CLI, "-i", "broken.gz", "-a", "queries.fa"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert r.returncode == 1 and b"Index load failed" in r.stdout and not (d / "comm.id").exists()
+    # a file a crashed run left behind under the same name (its writer is gone) is replaced, not read
+    (d / "comm.id").write_bytes(b"MKCOMM2\n" + bytes(200))
+    run_ranked(["-i", "idx_r.gz", "-a", "queries.fa", "-o", "out_ri2.txt", "-t", "1"], d)
+    assert (d / "out_ri2.txt").read_bytes() == (d / "out_ri.txt").read_bytes()
+
+
+@pytest.mark.parametrize("name,world", [("messy", 3), ("w16", 2), ("rnd1", 5), ("h20", 64)])
+def test_an_index_loads_in_slices_as_the_ranks_take_it(workdirs, golden_dir, tmp_path_factory, name, world):
+    """-i with one process per GPU at a world of MORE than one, without the communicator (two ranks cannot share a GPU under
+    RCCL): load_index(slice_rank, slice_world) for every rank of the world -- ranks beyond the genomes keep none -- and the
+    slices side by side, dumped again, are the stream that was loaded (Miekki.cpp:687-719 per rank)."""
+    case, d, base = workdirs(name)
+    exe = str(tmp_path_factory.mktemp("sl") / "slice_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "helpers", "slice_check.cpp"), os.path.join(ROOT, "host", "index_io.cpp"), os.path.join(ROOT, "host", "gzpar.cpp"),
+                    os.path.join(ROOT, "host", "fastz.cpp"), "-L", os.path.join(ROOT, "miekki_amd"), "-lmiekki_hip", "-lz", "-lpthread",
+                    "-Wl,-rpath," + os.path.join(ROOT, "miekki_amd")], check=True)
+    run(["-l", "genomes.lst", "-d", "idx_s.gz", *base], d)
+    r = subprocess.run([exe, "idx_s.gz", str(world), "idx_s2.gz"], cwd=d, stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout
+    counts = [int(x) for x in r.stdout.split()]
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    assert len(counts) == world and max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
+    a, b = gzip.decompress((d / "idx_s.gz").read_bytes()), gzip.decompress((d / "idx_s2.gz").read_bytes())
+    assert len(a) == int(gold["stream_len"]) and a == b
 
 
 @pytest.mark.parametrize("wide", ["1", "0"])
