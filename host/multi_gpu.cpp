@@ -374,19 +374,32 @@ int DeviceGroup::query_ranked(const std::vector<uint32_t> &idx, const char *cons
         mk_dev_free(c, d_rows); mk_dev_free(c, d_recv); mk_dev_free(c, d_hits); mk_dev_free(c, d_nh); mk_dev_free(c, d_over);
     };
     auto fail = [&] { err = mk_last_error(); cleanup(); return -1; };
-    if (mk_dev_alloc(c, words * 8, &d_rows) != MK_OK || mk_dev_alloc(c, (uint64_t)(n + 1) * 4, &d_over) != MK_OK) return fail();
-    if (root() && (mk_dev_alloc(c, words * 8 * W, &d_recv) != MK_OK || mk_dev_alloc(c, (uint64_t)n * 4, &d_nh) != MK_OK ||
-                   mk_dev_alloc(c, (uint64_t)n * std::max(nresults, 1u) * sizeof(mk_hit), &d_hits) != MK_OK)) return fail();
-    if (mk_qset_upload(c, s.data(), l.data(), n, &qs) != MK_OK) return fail();
+    // what only this rank does -- buffers, the upload and sketch of the queries -- may fail on this rank alone: every rank
+    // says how it fared BEFORE the gather, and all leave together if one could not (nobody waits in a collective the failed
+    // rank never enters)
+    bool ready = mk_dev_alloc(c, words * 8, &d_rows) == MK_OK && mk_dev_alloc(c, (uint64_t)(n + 1) * 4, &d_over) == MK_OK;
+    if (ready && root())
+        ready = mk_dev_alloc(c, words * 8 * W, &d_recv) == MK_OK && mk_dev_alloc(c, (uint64_t)n * 4, &d_nh) == MK_OK &&
+                mk_dev_alloc(c, (uint64_t)n * std::max(nresults, 1u) * sizeof(mk_hit), &d_hits) == MK_OK;
+    ready = ready && mk_qset_upload(c, s.data(), l.data(), n, &qs) == MK_OK;
+    {
+        const std::string mine = ready ? std::string() : std::string("rank ") + std::to_string(rank()) + ": " + mk_last_error();
+        std::vector<std::string> all;
+        if (all_gather_text(mine, all, err)) { cleanup(); return -1; }
+        for (const std::string &e : all)
+            if (!e.empty()) { err = e; cleanup(); return -1; }
+    }
     if (mk_qset_run_compact_gather(c, comm_, qs, nresults, min_score, min_inter, cap, (uint64_t *)d_rows, (uint64_t *)d_recv, 0) != MK_OK) return fail();
+    constexpr uint32_t kRootFailed = 0xFFFFFFFFu;                     // (rank 0's own failure travels in the message everybody waits for)
     if (root()) {
         gather_bytes_ += (uint64_t)(W - 1) * words * 8;
-        if (mk_merge_compact(c, (const uint64_t *)d_recv, (uint32_t)W, n, cap, nresults, (mk_hit *)d_hits, (uint32_t *)d_nh) != MK_OK) return fail();
         std::vector<uint32_t> nh(n);
         std::vector<mk_hit> hh((size_t)n * std::max(nresults, 1u));
-        if (mk_dev_download(c, nh.data(), d_nh, (uint64_t)n * 4) != MK_OK ||
-            (nresults && mk_dev_download(c, hh.data(), d_hits, (uint64_t)n * nresults * sizeof(mk_hit)) != MK_OK)) return fail();
-        for (uint32_t i = 0; i < n; ++i) {
+        const bool merged = mk_merge_compact(c, (const uint64_t *)d_recv, (uint32_t)W, n, cap, nresults, (mk_hit *)d_hits, (uint32_t *)d_nh) == MK_OK &&
+                            mk_dev_download(c, nh.data(), d_nh, (uint64_t)n * 4) == MK_OK &&
+                            (!nresults || mk_dev_download(c, hh.data(), d_hits, (uint64_t)n * nresults * sizeof(mk_hit)) == MK_OK);
+        if (!merged) { err = mk_last_error(); over_msg[0] = kRootFailed; }
+        for (uint32_t i = 0; merged && i < n; ++i) {
             if (nh[i] == MK_MERGE_OVERFLOW) { over_msg[++over_msg[0]] = i; continue; }
             nhits[idx[i]] = nh[i];
             std::copy(hh.begin() + (size_t)i * nresults, hh.begin() + (size_t)i * nresults + nh[i], hits + (size_t)idx[i] * nresults);
@@ -395,6 +408,7 @@ int DeviceGroup::query_ranked(const std::vector<uint32_t> &idx, const char *cons
     }
     if (mk_comm_broadcast(comm_, d_over, (uint64_t)(n + 1) * 4, 0) != MK_OK ||
         mk_dev_download(c, over_msg.data(), d_over, (uint64_t)(n + 1) * 4) != MK_OK) return fail();
+    if (over_msg[0] == kRootFailed) { if (err.empty()) err = "rank 0 could not merge the rows"; cleanup(); return -1; }
     cleanup();
     qs = nullptr; d_rows = d_recv = d_hits = d_nh = d_over = nullptr;
     if (!over_msg[0]) return 0;

@@ -20,7 +20,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char **argv)
 {
-    if (argc < 6) { fprintf(stderr, "usage: index_io_bench <genomes> <h> <fp_bits> <threads> <path>\n"); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: index_io_bench <genomes> <h> <fp_bits> <threads> <path> [keep]\n"); return 2; }
     const uint32_t G = (uint32_t)atol(argv[1]);
     mk_params p;
     memset(&p, 0, sizeof p);
@@ -67,6 +67,6 @@ int main(int argc, char **argv)
     printf("the loaded index answers 64 probe queries like the built one: %s (first query: %u hits, top genome %u, %u matches)\n", same ? "yes" : "NO",
            n1[0], n1[0] ? h1[0].genome : 0, n1[0] ? h1[0].matches : 0);
     mk_destroy(loaded[0]);
-    remove(path.c_str());
+    if (!(argc > 6 && std::string(argv[6]) == "keep")) remove(path.c_str());
     return same ? 0 : 1;
 }
