@@ -308,6 +308,33 @@ inline SketchParams make_sp(const mk_ctx *c)
 int timer_begin(mk_ctx *c, int kind, Timer &t, hipStream_t stream = nullptr);
 int timer_end(mk_ctx *c, Timer &t, hipStream_t stream = nullptr);
 int drain_timers(mk_ctx *c);
+struct ScopedTimer {
+    mk_ctx *c; Timer t; bool on; hipStream_t stream;
+    ScopedTimer(mk_ctx *ctx, int kind, hipStream_t st = nullptr) : c(ctx), on(false), stream(st) { on = timer_begin(c, kind, t, stream) == MK_OK; }
+    ~ScopedTimer() { if (on) (void)timer_end(c, t, stream); }
+};
+
+// ---- api.hip, for its sister files (api_query.hip, api_multi.hip)
+template <typename T>
+inline int dev_alloc(T **p, uint64_t count)
+{
+    *p = nullptr;
+    if (!count) return MK_OK;
+    MK_HIP(hipMalloc((void **)p, count * sizeof(T)));
+    return MK_OK;
+}
+template <typename T>
+inline void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+// Every entry point starts here: bind the device and, unless the caller is an append that wants to overlap with it, fold
+// the build batches still in flight into the index.
+int use_device(const mk_ctx *c, bool settle = true);
+int settle_build(mk_ctx *c);
+// for_append = false: the long-query sketches borrow the tables / slots only
+int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf = 0, bool for_append = true);
 
 // ---- sketch.hip
 int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, const uint64_t *h_off,
