@@ -26,9 +26,35 @@ static bool nan_candidates_possible(const mk_ctx *c, uint32_t min_score)
 }
 
 // ---- query sets ------------------------------------------------------------------
+// rows of a part of a mixed set to their places in the whole set's output: row i -> dst[idx[i]] (row_bytes a multiple of 8),
+// and, when there are separate counts, cnt[i] -> dst_cnt[idx[i]]
+__global__ __launch_bounds__(256) void place_rows_kernel(const uint8_t *__restrict__ rows, uint64_t row_bytes, const uint32_t *__restrict__ idx, uint32_t n,
+                                                         uint8_t *__restrict__ dst, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ dst_cnt)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t q = idx[i];
+    const uint64_t *__restrict__ s = reinterpret_cast<const uint64_t *>(rows + (uint64_t)i * row_bytes);
+    uint64_t *__restrict__ d = reinterpret_cast<uint64_t *>(dst + (uint64_t)q * row_bytes);
+    // (a count form's row is only as full as its count says -- 24 bytes per hit -- but copying the slots is cheaper than asking)
+    for (uint64_t w = threadIdx.x; w < row_bytes / 8; w += blockDim.x) d[w] = s[w];
+    if (cnt && threadIdx.x == 0) dst_cnt[q] = cnt[i];
+}
+
+static int launch_place_rows(mk_ctx *c, const uint8_t *rows, uint64_t row_bytes, const uint32_t *d_idx, uint32_t n, uint8_t *dst, const uint32_t *cnt,
+                             uint32_t *dst_cnt)
+{
+    if (!n) return MK_OK;
+    hipLaunchKernelGGL(place_rows_kernel, dim3(n), dim3(256), 0, c->stream, rows, row_bytes, d_idx, n, dst, cnt, dst_cnt);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 static void qset_release(mk_qset *qs)
 {
     if (!qs) return;
+    for (int i = 0; i < 2; ++i) { qset_release(qs->part[i]); dev_free(qs->d_part_q[i]); }
+    dev_free(qs->d_part_out);
     if (!qs->split_in_arena) dev_free(qs->d_split);
     if (qs->arena_borrowed) qs->owner->qarena_busy = false;      // the context keeps its arena for the next call
     else dev_free(qs->d_arena);                  // every other device array of the set lives in it
@@ -585,7 +611,29 @@ int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uin
 {
     if (!c || !out || (nq && (!seqs || !lens))) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
-    return qset_upload(c, seqs, lens, nq, out, false);
+    // a set that mixes short queries with longer ones: a shell over two sets (mk_internal.hpp), so that the short ones keep
+    // the slab schedule inside ONE mk_qset_run
+    std::vector<uint32_t> idx[2];
+    for (uint32_t q = 0; q < nq; ++q) idx[lens[q] > (uint64_t)c->p.k + kShortMax ? 1 : 0].push_back(q);
+    if (idx[0].empty() || idx[1].empty()) return qset_upload(c, seqs, lens, nq, out, false);
+    std::unique_ptr<mk_qset, void (*)(mk_qset *)> shell(new mk_qset(), qset_release);
+    mk_qset *qs = shell.get();
+    qs->owner = c; qs->nq = nq; qs->arena_borrowed = false; qs->split_in_arena = false; qs->d_split = nullptr; qs->d_arena = nullptr;
+    qs->d_seq = nullptr; qs->d_off = nullptr; qs->d_ent_off = nullptr; qs->d_entries = nullptr; qs->d_nent = nullptr;
+    qs->d_dense = nullptr; qs->d_dense_q = nullptr; qs->d_scan_n = nullptr; qs->S = 0; qs->chunk = 0; qs->slab_ok = false;
+    qs->sketched = false; qs->gen = 0; qs->short_max_nk = 0; qs->head_bytes = 0; qs->total_len = 0;
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t n = (uint32_t)idx[i].size();
+        std::vector<const char *> s(n);
+        std::vector<uint64_t> l(n);
+        for (uint32_t j = 0; j < n; ++j) { s[j] = seqs[idx[i][j]]; l[j] = lens[idx[i][j]]; }
+        MK_TRY(qset_upload(c, s.data(), l.data(), n, &qs->part[i], false));
+        MK_TRY(dev_alloc(&qs->d_part_q[i], n));
+        MK_HIP(hipMemcpy(qs->d_part_q[i], idx[i].data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        qs->part_q[i] = std::move(idx[i]);
+    }
+    *out = shell.release();
+    return MK_OK;
 }
 
 int mk_qset_synthetic(mk_ctx *c, uint64_t first_id, uint32_t nq, uint64_t G, uint64_t L, uint64_t qlen,
@@ -608,6 +656,7 @@ int mk_qset_invalidate(mk_ctx *c, mk_qset *qs)
 {
     if (!c || !qs) { set_error("null argument"); return MK_ERR_ARG; }
     qs->sketched = false;
+    for (int i = 0; i < 2; ++i) if (qs->part[i]) qs->part[i]->sketched = false;
     return MK_OK;
 }
 
@@ -632,6 +681,30 @@ int qset_run(mk_ctx *c, mk_qset *qs, uint32_t nresults, uint32_t min_score, doub
     if (nan_candidates_possible(c, min_score)) {
         set_error("min_score 0 over an index with empty sketches yields NaN intersections: use mk_query");
         return MK_ERR_UNSUPPORTED;
+    }
+    if (qs->part[0]) {
+        // a mixed set: each part runs as a set with its own schedule into a buffer of the shell, and a copy kernel puts its
+        // rows in their places; the exchange of a sharded run follows the whole set (its blocks are ranges of queries)
+        const uint64_t row_bytes = d_rows ? ((uint64_t)cap + 1) * 8 : (uint64_t)cap * sizeof(mk_hit);
+        const uint32_t most = (uint32_t)std::max(qs->part_q[0].size(), qs->part_q[1].size());
+        const uint64_t need = (uint64_t)most * (row_bytes + 4) + 256;
+        if (need > qs->part_out_bytes) {
+            dev_free(qs->d_part_out);
+            qs->part_out_bytes = 0;
+            MK_TRY(dev_alloc(&qs->d_part_out, need));
+            qs->part_out_bytes = need;
+        }
+        for (int i = 0; i < 2; ++i) {
+            mk_qset *p = qs->part[i];
+            uint8_t *rows = qs->d_part_out;                            // [n][row_bytes], then (count form) [n] counts
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(qs->d_part_out + (((uint64_t)p->nq * row_bytes + 255) & ~255ull));
+            MK_TRY(qset_run(c, p, nresults, min_score, min_inter, cap, d_rows ? nullptr : cnt, d_rows ? nullptr : reinterpret_cast<mk_hit *>(rows),
+                            d_rows ? reinterpret_cast<uint64_t *>(rows) : nullptr, nullptr, 1));
+            MK_TRY(launch_place_rows(c, rows, row_bytes, qs->d_part_q[i], p->nq, d_rows ? reinterpret_cast<uint8_t *>(d_rows) : reinterpret_cast<uint8_t *>(d_cand),
+                                     d_rows ? nullptr : cnt, d_count));
+        }
+        if (after_chunk) MK_TRY((*after_chunk)(0, qs->nq));
+        return MK_OK;
     }
     MK_TRY(qset_sketch(c, qs));
     const uint64_t rstride = (uint64_t)cap + 1;
@@ -686,6 +759,16 @@ int mk_qset_scores(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t *d
     if (!c || !qs || !d_scores) { set_error("null argument"); return MK_ERR_ARG; }
     if (q0 > q1 || q1 > qs->nq) { set_error("query range out of bounds"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
+    if (qs->part[0]) {                                           // a mixed set: query by query from the part that holds it
+        for (uint32_t q = q0; q < q1; ++q)
+            for (int i = 0; i < 2; ++i) {
+                const auto it = std::lower_bound(qs->part_q[i].begin(), qs->part_q[i].end(), q);
+                if (it == qs->part_q[i].end() || *it != q) continue;
+                const uint32_t at = (uint32_t)(it - qs->part_q[i].begin());
+                MK_TRY(mk_qset_scores(c, qs->part[i], at, at + 1, d_scores + (uint64_t)(q - q0) * c->G));
+            }
+        return MK_OK;
+    }
     MK_TRY(qset_sketch(c, qs));
     return qset_scan(c, qs, q0, q1, d_scores, score_layout_rows(c->W, c->G, c->G));   // dense rows for the caller
 }
@@ -694,6 +777,14 @@ int mk_qset_active(mk_ctx *c, mk_qset *qs, uint32_t *active)
 {
     if (!c || !qs || !active) { set_error("null argument"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
+    if (qs->part[0]) {
+        for (int i = 0; i < 2; ++i) {
+            std::vector<uint32_t> a(qs->part[i]->nq);
+            MK_TRY(mk_qset_active(c, qs->part[i], a.data()));
+            for (uint32_t j = 0; j < qs->part[i]->nq; ++j) active[qs->part_q[i][j]] = a[j];
+        }
+        return MK_OK;
+    }
     MK_TRY(qset_sketch(c, qs));
     MK_HIP(hipStreamSynchronize(c->stream));
     if (qs->nq) MK_HIP(hipMemcpy(active, qs->d_nent, (size_t)qs->nq * 4, hipMemcpyDeviceToHost));

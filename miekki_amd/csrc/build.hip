@@ -185,19 +185,12 @@ struct BuildShape {
 // too many only costs the reduce kernel a look at the filter).
 template <int W> struct ItemOf { using type = uint32_t; };          // the main word in memory, either width
 
-// HyperMinHash fingerprint of anc's low 64 - h bits (Miekki::mantis, Miekki.cpp:91-113), for the
-// common case in one count-leading-zeros: v = the top 32 of those 64 - h bits.  When v >= 2^f the
-// leading one and the f bits below it all lie in v, the exponent max(prefix - 32 + h, 0) is v's own
-// bit index and the suffix the f bits below it.  (v < 2^f: one k-mer in 2^(32 - f); the general form.)
+// HyperMinHash fingerprint of anc's low 64 - h bits (Miekki::mantis, Miekki.cpp:91-113): the float-conversion form of
+// mk_device.hpp for all but one k-mer in 2^(24 - f), the general form for those.
 __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, uint32_t h, uint32_t f, uint32_t empty)
 {
     const uint32_t v = __builtin_amdgcn_alignbit(ahi, alo, 32u - h);
-    if (__builtin_expect(v >> f, 1)) {
-        uint32_t lz;
-        asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(v));               // v != 0 here: no clamp needed
-        const uint32_t top = v << lz;
-        return ((31u - lz) << f) | ((top >> (31u - f)) & ((1u << f) - 1u));       // <= 31 << f | 2^f - 1 = empty
-    }
+    if (__builtin_expect(fingerprint_top32_ok(v, f), 1)) return fingerprint_from_top32(v, f);
     return mantis_halves(ahi & ((1u << (32u - h)) - 1u), alo, h, f, empty);
 }
 
@@ -259,14 +252,15 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
         // (no branch here: without a summary the shift leaves group 0 and the one word there says "nothing is settled", or,
         // for an index without a filter, "everything is")
         const uint32_t s3 = (uint32_t)(canon >> 32) >> sumshift;                  // cell >> 11
-        const uint32_t settled = (sum32[s3 >> 5] >> (s3 & 31u)) & ((uint32_t)canon <= 0xFFFFFC00u ? 1u : 0u);
+        const uint32_t sword = (uint32_t)canon <= 0xFFFFFC00u ? sum32[s3 >> 5] : 0u;
+        const uint32_t settled = __builtin_amdgcn_ubfe(sword, s3, 1u);            // bit s3 & 31 of the word (v_bfe_u32 takes the offset's low five bits)
         const uint64_t anc = revhash64(canon);                                    // Miekki.cpp:167-168
         const uint32_t ahi = (uint32_t)(anc >> 32);
         const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
         if (fp == sp.empty || (!FULL && i0 + u >= cnt)) continue;    // (past the segment's end only in a sequence's last workgroup)
         const uint32_t bucket = ahi >> bshift;
         const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
-        const uint32_t binoff = ((bucket >> bs.low_bits) << 3) | (settled << 2);   // byte offset of the bin's counter: flagged, settled
+        const uint32_t binoff = (((bucket >> bs.low_bits) << 1) | settled) << 2;   // byte offset of the bin's counter: flagged, settled
         const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
         // (W == 2: the low eight position bits are (i0 + u) & 255, known to whoever stores the item: they are not kept here)
         it[u] = W == 1 ? (fp << 24) | (part << kBin) | (i0 + u) : (fp << 16) | (part << 4) | ((i0 + u) >> 8);

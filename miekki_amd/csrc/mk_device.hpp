@@ -99,6 +99,26 @@ MK_HD uint32_t mantis_halves(uint32_t nhi, uint32_t nlo, uint32_t h, uint32_t f,
     return (suffix + ((uint32_t)(e < 0 ? 0 : e) << f)) & empty;
 }
 
+// The common case of the same fingerprint in ONE conversion (the build's hash loop, build.hip: fingerprint_of): v = the top
+// 32 of n's 64 - h bits.  When v >= 2^f the leading one and the f bits below it all lie in v, the exponent
+// max(prefix - 32 + h, 0) is v's own bit index e and the suffix the f bits below it -- which is what a float's exponent
+// field and the top of its mantissa hold: float(v) = 1.mantissa x 2^e, bits = (127 + e) << 23 | mantissa, so the
+// fingerprint e << f | suffix is (bits >> (23 - f)) - (127 << f).  The conversion must not round up into the next power of
+// two: with the low eight bits cleared v has at most 24 significant bits and converts exactly, and the f suffix bits are
+// untouched by that as long as e >= 8 + f.  fingerprint_top32_ok says whether v qualifies (all but one k-mer in 2^(24 - f)).
+MK_HD bool fingerprint_top32_ok(uint32_t v, uint32_t f) { return v >= (256u << f); }
+MK_HD uint32_t fingerprint_from_top32(uint32_t v, uint32_t f)
+{
+    const float x = (float)(v & 0xFFFFFF00u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t bits = __float_as_uint(x);
+#else
+    uint32_t bits;
+    __builtin_memcpy(&bits, &x, 4);
+#endif
+    return (bits >> (23u - f)) - (127u << f);                      // <= 31 << f | 2^f - 1 = empty
+}
+
 // anc -> (bucket, fingerprint)  (Miekki.cpp:169-171)
 MK_HD void bucket_fp(uint64_t anc, uint32_t h, uint32_t f, uint32_t empty, uint32_t &bucket,
                      uint32_t &fp)

@@ -277,6 +277,15 @@ struct mk_qset {
     bool slab_ok;                  // every (query, range) fits the packed counters
     bool sketched;
     uint64_t gen;                  // index generation the sketch / range table were made against
+    // A MIXED set (short queries next to long reads / contigs / whole genomes; query_file batches whatever the file holds,
+    // Miekki.cpp:465-471) is a shell over two sets of its own -- the short queries, which keep the slab schedule, and the
+    // others, which take the plain / dense kernels: part[i] runs as a set, part_q[i] = its queries' places in this set
+    // (ascending), d_part_q[i] the same on the device, and the parts' rows are put in their places behind the parts' runs.
+    mk_qset *part[2] = {nullptr, nullptr};
+    std::vector<uint32_t> part_q[2];
+    uint32_t *d_part_q[2] = {nullptr, nullptr};
+    uint8_t *d_part_out = nullptr;  // a part's output rows before they go to their places
+    uint64_t part_out_bytes = 0;
 };
 
 namespace mk {

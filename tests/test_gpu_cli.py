@@ -147,6 +147,8 @@ def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name)
         assert (d / "exactA_r.txt").read_bytes() == open(exa, "rb").read()
     # -d and -i per rank (main.cpp:189-206, Miekki.cpp:649-719): the dump is the single process's stream (masked SHA of the
     # reference's), the load keeps this rank's slice of the columns and answers like the reference
+    if name not in ("messy", "w16"):                             # (every run starts RCCL: two cases, both widths, keep the suite short)
+        return
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     so_d = run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_rd.txt", "-d", "idx_r.gz", *base], d)
     assert norm(so_d).replace(b"out_rd.txt", b"out.txt") == open(os.path.join(golden_dir, f"{name}_stdout_l.txt"), "rb").read()
@@ -170,7 +172,7 @@ def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name)
     assert (d / "out_ri2.txt").read_bytes() == (d / "out_ri.txt").read_bytes()
 
 
-@pytest.mark.parametrize("name,world", [("messy", 3), ("w16", 2), ("rnd1", 5), ("h20", 64)])
+@pytest.mark.parametrize("name,world", [("messy", 3), ("w16", 2), ("rnd1", 5), ("h20", 13)])
 def test_an_index_loads_in_slices_as_the_ranks_take_it(workdirs, golden_dir, tmp_path_factory, name, world):
     """-i with one process per GPU at a world of MORE than one, without the communicator (two ranks cannot share a GPU under
     RCCL): load_index(slice_rank, slice_world) for every rank of the world -- ranks beyond the genomes keep none -- and the

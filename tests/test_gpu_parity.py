@@ -1065,3 +1065,75 @@ def test_random_operation_sequences_against_oracle(hip, seed, tmp_path):
         assert raw.size == want.size and sha(raw.tobytes()) == sha(want.tobytes())
     finally:
         ix.close()
+
+
+def test_mixed_set_in_one_qset_run_against_oracle(hip, monkeypatch):
+    """query_file batches whatever the file holds (Miekki.cpp:465-471): a prepared set that mixes 1 kb queries with long
+    reads, contigs and whole genomes runs in ONE mk_qset_run / mk_qset_run_compact -- the short queries on the slab schedule
+    (asserted by the context's counters), the others on the plain and dense kernels -- and every query's hits, exchange
+    row, dense score row and active partitions are the oracle's, wherever in the set the query stands."""
+    import ctypes as C
+    import torch
+    from miekki_amd import distributed as mkd
+    from miekki_amd import lib as L
+    from oracle import oracle as orc
+    monkeypatch.delenv("MIEKKI_SLAB_MIN_QUERIES", raising=False)     # (the default: small sets cut their entry lists by count)
+    k, h, thr = 21, 14, 10
+    G, L_ = 48, 60_000
+    seqs = [synth.genome_bases(7000 + g, 0, L_) for g in range(G)]
+    o = orc.OracleMiekki(k, h, 8, 32, thr)
+    o.insert_sequences(seqs)
+    rng = np.random.default_rng(77)
+    qs = []
+    for q in range(400):                                               # (fewer than 512 short ones: at -h 14 that is the slab kernel's small-set form)
+        g = int(rng.integers(0, G)); off = int(rng.integers(0, L_ - 1500))
+        qs.append(seqs[g][off:off + int(rng.integers(40, 1400))])
+    for q, n in ((3, 20_000), (4, 9_000), (255, 45_000), (256, L_), (311, L_), (312, 5_000), (350, 30_000), (399, L_)):
+        g = q % G
+        qs[q] = seqs[g][:n] if n == L_ else seqs[g][100:100 + n]          # whole genomes: dense; the rest: long sparse
+    qs.insert(0, seqs[5])                                              # a whole genome first, a long read last
+    qs.append(seqs[9][2000:26_000])
+    want_rows = o.query_sequences(qs)
+    ix = hip.Miekki(k, h, 8, 32, thr)
+    lib = L.load_library()
+    qset = C.c_void_p()
+    try:
+        ix.insert_sequences(seqs)
+        ptrs, lens = L.seq_arrays(qs)
+        L.check(lib.mk_qset_upload(ix._h, ptrs, lens, len(qs), C.byref(qset)))
+        cap, nres, ms, mi = 64, 10, 3, 5.0
+        d_count = torch.zeros(len(qs), dtype=torch.int32, device="cuda")
+        d_cand = torch.zeros(len(qs) * cap * 24, dtype=torch.uint8, device="cuda")
+        before = ix.stats()
+        L.check(lib.mk_qset_run(ix._h, qset, nres, ms, mi, cap, d_count.data_ptr(), d_cand.data_ptr()))
+        L.check(lib.mk_sync(ix._h))
+        after = ix.stats()
+        assert after["scan_slab_launches"] > before["scan_slab_launches"]               # the short queries kept the slab schedule
+        assert after["scan_launches"] - before["scan_launches"] > after["scan_slab_launches"] - before["scan_slab_launches"]
+        hits, over = mkd.merge_candidates(d_count.cpu().numpy()[None], d_cand.cpu().numpy()[None], cap, nres)
+        assert not over.any()
+        for q, row in enumerate(want_rows):
+            want = o.filter_results(row, nres, ms, mi)
+            assert [(int(x["genome"]), int(x["matches"]), float(x["jaccard"]), float(x["intersection"])) for x in hits[q]] == [tuple(w) for w in want], q
+        # the 8-byte exchange rows of the same set (what a shard sends), through the host statement of the merge
+        rows = torch.zeros(len(qs) * (cap + 1), dtype=torch.int64, device="cuda")
+        L.check(lib.mk_qset_run_compact(ix._h, qset, nres, ms, mi, cap, rows.data_ptr()))
+        L.check(lib.mk_sync(ix._h))
+        hits2, over2 = mkd.merge_compact_host(rows.cpu().numpy().view(np.uint64)[None], len(qs), cap, nres, ix.sketch_size, ix.genome_size)
+        assert not over2.any()
+        for q in range(len(qs)):
+            assert hits2[q].tobytes() == hits[q].tobytes(), q
+        # dense rows and active partitions by place in the set
+        d_scores = torch.zeros(3 * G, dtype=torch.int32, device="cuda")
+        for q0 in (0, 3, 255, 310, 399):
+            L.check(lib.mk_qset_scores(ix._h, qset, q0, q0 + 3, d_scores.data_ptr()))
+            L.check(lib.mk_sync(ix._h))
+            np.testing.assert_array_equal(d_scores.cpu().numpy().view(np.uint32).reshape(3, G), want_rows[q0:q0 + 3])
+        act = np.zeros(len(qs), np.uint32)
+        L.check(lib.mk_qset_active(ix._h, qset, act.ctypes.data))
+        for q in (0, 1, 4, 256, 257, 400, 401):
+            assert act[q] == o.query_sequence(qs[q])[1], q
+    finally:
+        if qset:
+            lib.mk_qset_free(ix._h, qset)
+        ix.close()
