@@ -545,6 +545,10 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_cold_stage);
     for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]);
     dev_free(c->d_hits); dev_free(c->d_nhits);
+    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);        // (the inflater's blocks and staging: gunzip.hip)
+    c->gz_blocks.clear();
+    for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
+    c->gz_pins.clear();
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     for (int b = 0; b < 2; ++b) {                                  // (d_counters, h_back, d_seq_off, d_seed_valid, d_ovf alias one of these)
         mk_ctx::BuildSide &sd = c->side[b];

@@ -118,7 +118,6 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         if (at > c->qarena_cap) {
             MK_HIP(hipStreamSynchronize(c->stream));
             dev_free(c->d_qarena);
-    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
             c->qarena_cap = 0;
             const uint64_t cap = std::max<uint64_t>(at + at / 2, 4ull << 20);
             MK_TRY(dev_alloc(&c->d_qarena, cap));

@@ -888,6 +888,37 @@ static void gz_block_put(mk_ctx *c, uint8_t *p, uint64_t bytes)
     c->gz_blocks.emplace_back(p, bytes);
 }
 
+// Page-locked staging for the run's small copies (stream tables, block starts, segments): a copy to or from ordinary memory
+// is a synchronous call inside the runtime -- it waits for everything queued on its stream -- and several batches unpacked
+// by threads of their own then take turns instead of running side by side (measured: six batches of 128 files in flight
+// finished no faster than one after the other).  Pieces of at least 1 MiB, powers of two, kept by the context.
+static void *gz_pin_get(mk_ctx *c, uint64_t need, uint64_t *got)
+{
+    uint64_t want = 1ull << 20;
+    while (want < need) want <<= 1;
+    {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        for (size_t i = 0; i < c->gz_pins.size(); ++i)
+            if (c->gz_pins[i].second == want) {
+                void *p = c->gz_pins[i].first;
+                c->gz_pins.erase(c->gz_pins.begin() + (long)i);
+                *got = want;
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = want;
+    return p;
+}
+
+static void gz_pin_put(mk_ctx *c, void *p, uint64_t bytes)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(c->gz_m);
+    c->gz_pins.emplace_back(p, bytes);
+}
+
 // One batch of streams through the inflater: the files' bytes up, where their blocks start (gz_find / gz_check), every
 // segment measured (gz_tokens, write = 0), the chain of segments from each stream's first byte to its last followed on the
 // host -- which gives every stream's token count and text length exactly --, then the pass that writes the tokens and the
@@ -905,10 +936,60 @@ struct GzRun {
     uint8_t *d_extra = nullptr;                                       // `extra` bytes of the out block for the caller (256-byte aligned)
     uint32_t n_segs = 0, n_cands = 0;
     double t_up = 0, t_find = 0, t_measure = 0, t_write = 0, t_text = 0;
+    // page-locked staging: pieces in use, and the downloads that wait for the stream (staging -> the caller's memory)
+    struct Pin { uint8_t *p; uint64_t size, used; };
+    std::vector<Pin> pins;
+    struct Down { void *dst; const void *src; size_t bytes; };
+    std::vector<Down> downs;
+    uint8_t *stage(uint64_t bytes)
+    {
+        bytes = (bytes + 63u) & ~63ull;
+        if (pins.empty() || pins.back().size - pins.back().used < bytes) {
+            uint64_t got = 0;
+            void *p = gz_pin_get(c, bytes, &got);
+            if (!p) return nullptr;
+            pins.push_back(Pin{(uint8_t *)p, got, 0});
+        }
+        uint8_t *at = pins.back().p + pins.back().used;
+        pins.back().used += bytes;
+        return at;
+    }
+    // host -> device through staging (the caller's memory is free again at once)
+    int up(void *d_dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return MK_OK;
+        uint8_t *s = stage(bytes);
+        if (!s) { set_error("no page-locked memory for the inflater's tables"); return MK_ERR_NOMEM; }
+        memcpy(s, src, bytes);
+        MK_HIP(hipMemcpyAsync(d_dst, s, bytes, hipMemcpyHostToDevice, st));
+        return MK_OK;
+    }
+    // device -> host: lands in dst at the next settle()
+    int down(void *dst, const void *d_src, size_t bytes)
+    {
+        if (!bytes) return MK_OK;
+        uint8_t *s = stage(bytes);
+        if (!s) { set_error("no page-locked memory for the inflater's tables"); return MK_ERR_NOMEM; }
+        MK_HIP(hipMemcpyAsync(s, d_src, bytes, hipMemcpyDeviceToHost, st));
+        downs.push_back(Down{dst, s, bytes});
+        return MK_OK;
+    }
+    int settle()
+    {
+        MK_HIP(hipStreamSynchronize(st));
+        for (const Down &d : downs) memcpy(d.dst, d.src, d.bytes);
+        downs.clear();
+        for (Pin &p : pins) p.used = 0;                              // (everything staged so far has been consumed)
+        while (pins.size() > 1) { gz_pin_put(c, pins.back().p, pins.back().size); pins.pop_back(); }
+        return MK_OK;
+    }
     ~GzRun()
     {
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-        if (c) { gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_seg, seg_bytes); gz_block_put(c, blk_out, out_bytes); }
+        if (c) {
+            gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_seg, seg_bytes); gz_block_put(c, blk_out, out_bytes);
+            for (Pin &p : pins) gz_pin_put(c, p.p, p.size);
+        }
     }
 };
 
@@ -954,10 +1035,10 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
         const uint64_t end = j.in_off + j.in_len, next = i + 1 < n ? r.streams[i + 1].in_off : in_at + 16;
         MK_HIP(hipMemsetAsync(d_gz + end, 0, next - end, st));      // (the bit reader may look 16 bytes past a stream's end)
     }
-    MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
-    MK_HIP(hipMemcpyAsync(d_wf, word_first.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+    MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
+    MK_TRY(r.up(d_wf, word_first.data(), ((size_t)n + 1) * 8));
     MK_HIP(hipMemsetAsync(d_cnt, 0, 64, st));
-    MK_HIP(hipStreamSynchronize(st));
+    MK_TRY(r.settle());
     r.t_up = now() - t0;
     // ---- where blocks start
     const double t1 = now();
@@ -965,19 +1046,19 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     if (total_words) {
         hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((total_words + 255u) / 256u)), dim3(256), 0, st, d_gz, r.d_streams, d_wf, n, d_hits, d_cnt, hit_cap);
         MK_HIP(hipGetLastError());
-        MK_HIP(hipMemcpyAsync(cnt, d_cnt, 4, hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TRY(r.down(cnt, d_cnt, 4));
+        MK_TRY(r.settle());
         const uint32_t nh = std::min(cnt[0], hit_cap);
         if (nh) {
             hipLaunchKernelGGL(gz_check_kernel, dim3((nh + 63u) / 64u), dim3(64), 0, st, d_gz, r.d_streams, d_hits, d_cnt, hit_cap, d_good, d_cnt + 1, good_cap);
             MK_HIP(hipGetLastError());
         }
-        MK_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TRY(r.down(cnt, d_cnt, 8));
+        MK_TRY(r.settle());
     }
     const uint32_t ng = std::min(cnt[1], good_cap);
     std::vector<uint64_t> good(ng);
-    if (ng) { MK_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)ng * 8, hipMemcpyDeviceToHost, st)); MK_HIP(hipStreamSynchronize(st)); }
+    if (ng) { MK_TRY(r.down(good.data(), d_good, (size_t)ng * 8)); MK_TRY(r.settle()); }
     std::sort(good.begin(), good.end());                              // (stream << 40 | bit: by stream, then by place)
     good.erase(std::unique(good.begin(), good.end()), good.end());
     r.t_find = now() - t1;
@@ -1025,12 +1106,12 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     static_assert(sizeof(TokLds) <= 160u << 10, "phase 1's tables and buffers fit one wave per CU");
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
     if (!segs.empty()) {
-        MK_HIP(hipMemcpyAsync(d_cands, cands.data(), cands.size() * 8, hipMemcpyHostToDevice, st));
-        MK_HIP(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(mk_gz_seg), hipMemcpyHostToDevice, st));
+        MK_TRY(r.up(d_cands, cands.data(), cands.size() * 8));
+        MK_TRY(r.up(d_segs, segs.data(), segs.size() * sizeof(mk_gz_seg)));
         hipLaunchKernelGGL(gz_tokens_kernel, dim3((r.n_segs + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, r.n_segs, d_cands, (uint32_t *)nullptr, d_aux);
         MK_HIP(hipGetLastError());
-        MK_HIP(hipMemcpyAsync(segs.data(), d_segs, segs.size() * sizeof(mk_gz_seg), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TRY(r.down(segs.data(), d_segs, segs.size() * sizeof(mk_gz_seg)));
+        MK_TRY(r.settle());
     }
     // ---- the chain of every stream: from its first byte from link to link to its end
     std::vector<mk_gz_seg> chain;                                     // the segments that are on a chain, with their places: the writing pass
@@ -1080,21 +1161,21 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     uint32_t *d_tok = reinterpret_cast<uint32_t *>(r.blk_out + o_tok);
     r.d_text = r.blk_out + o_text;
     r.d_extra = r.blk_out + o_extra;
-    MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
+    MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
     if (!chain.empty()) {
         const uint32_t nc = (uint32_t)chain.size();
-        MK_HIP(hipMemcpyAsync(d_segs, chain.data(), chain.size() * sizeof(mk_gz_seg), hipMemcpyHostToDevice, st));
+        MK_TRY(r.up(d_segs, chain.data(), chain.size() * sizeof(mk_gz_seg)));
         hipLaunchKernelGGL(gz_tokens_kernel, dim3((nc + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, nc, d_cands, d_tok, d_aux);
         MK_HIP(hipGetLastError());
-        MK_HIP(hipMemcpyAsync(chain.data(), d_segs, chain.size() * sizeof(mk_gz_seg), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TRY(r.down(chain.data(), d_segs, chain.size() * sizeof(mk_gz_seg)));
+        MK_TRY(r.settle());
         // the writing pass must have seen what the measuring pass saw
         for (const mk_gz_seg &w : chain)
             if (w.status != MK_GZ_OK || w.n_tok != w.tok_cap || w.out_len != w.out_cap) {
                 mk_gz_stream &j = r.streams[w.stream];
                 if (j.status == MK_GZ_OK) j.status = w.status != MK_GZ_OK ? w.status : MK_GZ_INTERNAL;
             }
-        MK_HIP(hipMemcpyAsync(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream), hipMemcpyHostToDevice, st));
+        MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
     }
     r.t_write = now() - t3;
     // ---- tokens -> text
@@ -1107,8 +1188,8 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, r.d_streams, n, d_tok, r.d_text, K);
     MK_HIP(hipGetLastError());
-    MK_HIP(hipMemcpyAsync(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream), hipMemcpyDeviceToHost, st));
-    MK_HIP(hipStreamSynchronize(st));
+    MK_TRY(r.down(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream)));
+    MK_TRY(r.settle());
     r.t_text = now() - t4;
     if (getenv("MIEKKI_VERBOSE"))
         fprintf(stderr, "[gz] %u files, %.2f GB: %u segments; upload %.3f s, block starts %.3f s, measuring pass %.3f s, writing pass %.3f s, text %.3f s (%.2f GB)\n", n,
@@ -1173,10 +1254,10 @@ int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, 
     uint64_t *d_len = reinterpret_cast<uint64_t *>(r.d_extra + o_len);
     b->d_scratch = r.d_extra + o_scratch;
     // (a stream that failed in the text pass -- a CRC -- keeps its chunks in the table: the kernels skip them by its status)
-    MK_HIP(hipMemcpyAsync(d_first, b->chunk_first.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, r.st));
+    MK_TRY(r.up(d_first, b->chunk_first.data(), ((size_t)n + 1) * 4));
     MK_TRY(launch_fasta_count(c, r.d_text, r.d_streams, n, d_first, b->n_chunks, b->d_scratch, d_len, r.st));
-    MK_HIP(hipMemcpyAsync(b->seq_len.data(), d_len, (size_t)n * 8, hipMemcpyDeviceToHost, r.st));
-    MK_HIP(hipStreamSynchronize(r.st));
+    MK_TRY(r.down(b->seq_len.data(), d_len, (size_t)n * 8));
+    MK_TRY(r.settle());
     if (getenv("MIEKKI_VERBOSE"))
         fprintf(stderr, "[gz] sequences measured in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
     *out = b.release();
@@ -1210,6 +1291,8 @@ void mk_gz_trim(mk_ctx *c)
     std::lock_guard<std::mutex> g(c->gz_m);
     for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
     c->gz_blocks.clear();
+    for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
+    c->gz_pins.clear();
 }
 
 }  // extern "C"

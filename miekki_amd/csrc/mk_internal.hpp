@@ -242,6 +242,7 @@ struct mk_ctx {
     // device blocks of finished mk_gz_unpack batches, kept for the next ones (allocating and freeing tens of gigabytes per
     // batch cost half a second each): (pointer, bytes); mk_gz_trim and mk_destroy free them
     std::vector<std::pair<void *, uint64_t>> gz_blocks;
+    std::vector<std::pair<void *, uint64_t>> gz_pins;   // page-locked staging of the inflater's small copies, kept likewise
     std::mutex gz_m;
 };
 
