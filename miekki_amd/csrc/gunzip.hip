@@ -35,7 +35,7 @@ namespace mk {
 
 namespace {
 
-constexpr uint32_t kLitRoot = 9, kDistRoot = 8, kLitSize = 1u << kLitRoot, kDistSize = 1u << kDistRoot;
+constexpr uint32_t kLitRoot = 6, kDistRoot = 7, kLitSize = 1u << kLitRoot, kDistSize = 1u << kDistRoot;
 constexpr uint32_t kTokMatch = 0x80000000u;    // | length << 16 | distance - 1
 constexpr uint32_t kTokMember = 0x40000000u;   // a member ends here: the next two words are its CRC-32 and ISIZE
 constexpr uint32_t kTokStored = 0x20000000u;   // | n (16 bits): n bytes of a stored block; the next word is where they lie in the stream
@@ -45,11 +45,14 @@ enum : uint32_t { ST_MEMBER = 0, ST_BLOCK = 1, ST_TOKENS = 2, ST_TRAILER = 4, ST
 
 // ---------------------------------------------------------------- phase 1: bits -> tokens
 // LDS of a wave (64 streams), every per-lane array interleaved [index][lane]:
-//   lit 512 x u16 (64 KiB), dist 256 x u16 (32 KiB): code length | kind | value, 0 = not in the table
+//   lit 64 x u16 (8 KiB), dist 128 x u16 (16 KiB): code length | kind | value, 0 = not in the table.  Six and seven bits of
+//   root: in gzip'd DNA 1.6 % of the literal / length symbols and 1.6 % of the distance symbols have longer codes (counted:
+//   literals 2-4 bits, lengths 4-7, distances 2-7) and take the bit-by-bit path -- and the whole structure is 78 KB, so TWO
+//   waves share a CU's LDS (with nine- and eight-bit roots it was 158 KB: one wave per CU, the kernel's bound)
 //   cnt_l / cnt_d 16 x u16: codes per length (the bit-by-bit path); nxt / ofs 16 x u16: scratch of the table build
 //   sym_d 32 x u8: distance symbols in code order; lens 352 x u8: the block's code lengths (the code length
 //   code's table borrows the lane's column of dist).  The literal / length symbols in code order live in global memory (aux: 288 x u16 per lane).
-constexpr uint32_t kInWords = 48, kInPitch = 52, kTokRing = 64, kTokPitch = 68;
+constexpr uint32_t kInWords = 32, kInPitch = 36, kTokRing = 48, kTokPitch = 52;
 struct TokLds {
     uint16_t lit[kLitSize][64];
     uint16_t dist[kDistSize][64];              // (its first 128 rows also serve as the code length code's table while a header is read:
@@ -179,26 +182,43 @@ __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, 
     return true;
 }
 
-// a symbol the root table does not hold: bit by bit against the counts (the canonical walk of RFC 1951 3.2.2); ~0u: no
-// such code
-__device__ uint32_t slow_symbol(TokLds &L, uint32_t lane, BitReader &br, bool dist_code, uint32_t *aux_sorted)
-{
-    uint16_t (*cnt)[64] = dist_code ? L.cnt_d : L.cnt_l;
-    const uint32_t bits = br.peek(15);
-    uint32_t code = 0, first = 0, index = 0;
-    for (uint32_t l = 1; l <= 15; ++l) {
-        code |= (bits >> (l - 1u)) & 1u;
-        const uint32_t c = cnt[l][lane];
-        if (code - first < c) {                                    // (code >= first always holds here)
-            br.drop(l);
-            const uint32_t at = index + (code - first);
-            // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
-            return dist_code ? (uint32_t)L.sym_d[at & 31u][lane] : __hip_atomic_load(&aux_sorted[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        index += c; first += c; first <<= 1; code <<= 1;
+// A symbol the root table does not hold is found bit by bit against the counts of the longer lengths (the canonical walk of
+// RFC 1951 3.2.2) -- from registers: a wave waits for its slowest lane, and with 64 lanes ONE of them meets a
+// code longer than the root table's index in most passes (1.6 % of the symbols each: 86 % of the passes with six- and seven-bit
+// roots) -- the walk above, fifteen dependent LDS reads, then cost every pass its time.  A lane keeps the counts of the
+// lengths beyond the root in registers (loaded when its block's tables are built) and where the walk stands after the root's
+// bits (first code and place in the sorted list); the loop is unrolled, nothing is indexed by a variable.
+template <uint32_t ROOT>
+struct LongCodes {
+    uint32_t cnt[15u - ROOT];       // codes of length ROOT + 1 + i
+    uint32_t first, index;          // the walk's state after ROOT lengths (before the shift that follows them)
+    __device__ __forceinline__ void load(const uint16_t (*c)[64], uint32_t lane)
+    {
+        uint32_t f = 0, ix = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= ROOT; ++l) { const uint32_t n = c[l][lane]; ix += n; f += n; f <<= 1; }
+        first = f; index = ix;
+#pragma unroll
+        for (uint32_t i = 0; i < 15u - ROOT; ++i) cnt[i] = c[ROOT + 1u + i][lane];
     }
-    return ~0u;
-}
+    // bits: the next fifteen bits of the stream (first bit lowest); returns the symbol's place in the sorted list and its
+    // length, or length 0: no such code
+    __device__ __forceinline__ uint32_t find(uint32_t bits, uint32_t &len) const
+    {
+        uint32_t code = (__brev(bits) >> (32u - ROOT)) << 1, f = first, ix = index, at = 0;
+        len = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 15u - ROOT; ++i) {
+            code |= (bits >> (ROOT + i)) & 1u;
+            const uint32_t n = cnt[i];
+            const bool hit = len == 0u && code - f < n;
+            at = hit ? ix + (code - f) : at;
+            len = hit ? ROOT + 1u + i : len;
+            ix += n; f += n; f <<= 1; code <<= 1;
+        }
+        return at;
+    }
+};
 
 // One lane per SEGMENT of a stream: from the stream's first byte, or from a block's first bit that the finder (below) has
 // vouched for, up to the next such bit that the decoding ARRIVES at between two blocks (or to the stream's end).  A segment
@@ -218,6 +238,11 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
     const bool live = s < n;
     mk_gz_seg job = live ? jobs[s] : mk_gz_seg{};
     uint32_t *const sorted = aux + (uint64_t)(live ? s : 0u) * 288u;
+    LongCodes<kLitRoot> long_l;                                   // (the lane's block: set with its tables)
+    LongCodes<kDistRoot> long_d;
+    long_l.first = long_l.index = long_d.first = long_d.index = 0;
+    for (uint32_t i = 0; i < 15u - kLitRoot; ++i) long_l.cnt[i] = 0;
+    for (uint32_t i = 0; i < 15u - kDistRoot; ++i) long_d.cnt[i] = 0;
     BitReader br;
     br.start(gz + job.in_off, live ? job.in_len : 0u, &L, lane);
     uint32_t state = live ? ST_MEMBER : ST_DONE, status = live ? MK_GZ_OK : MK_GZ_EMPTY;
@@ -296,8 +321,12 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 refill(act);
                 const uint32_t e = L.lit[(uint32_t)br.bb & (kLitSize - 1u)][col];
                 uint32_t kind = (e >> 4) & 7u, value = e >> 7, cl = e & 15u;
-                if (act && e == 0u) {                                  // a code of more than nine bits (one symbol in a thousand)
-                    const uint32_t sym = slow_symbol(L, lane, br, false, sorted);
+                if (act && e == 0u) {                                  // a code longer than the table's index
+                    uint32_t ll;
+                    const uint32_t at = long_l.find((uint32_t)br.bb & 0x7fffu, ll);
+                    // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
+                    const uint32_t sym = ll ? __hip_atomic_load(&sorted[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+                    br.bb >>= ll; br.bc -= ll;
                     cl = 0;
                     if (sym < 256u) { kind = 7; value = sym; }
                     else if (sym == 256u) { kind = 6; value = 0; }
@@ -316,10 +345,12 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 refill(is_len);
                 const uint32_t d = L.dist[(uint32_t)br.bb & (kDistSize - 1u)][col];
                 uint32_t dsym = d >> 4, dcl = d & 15u;
-                if (is_len && d == 0u) {                               // a distance code of more than eight bits
-                    dsym = slow_symbol(L, lane, br, true, sorted);
+                if (is_len && d == 0u) {                               // a distance code longer than the table's index
+                    uint32_t ll;
+                    const uint32_t at = long_d.find((uint32_t)br.bb & 0x7fffu, ll);
+                    dsym = ll ? (uint32_t)L.sym_d[at & 31u][lane] : ~0u;
+                    br.bb >>= ll; br.bc -= ll;
                     dcl = 0;
-                    pre = L.in[lane][min(br.wi - br.base, kInWords - 1u)];
                 }
                 if (is_len && dsym > 29u) { err = MK_GZ_BAD_CODE; dsym = 0; }
                 br.bb >>= (is_len ? dcl : 0u); br.bc -= (is_len ? dcl : 0u);
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 for (uint32_t i = 0; i < 32u; ++i) L.lens[288u + i][lane] = 5;
                 (void)build_code(L, lane, 0, 288, 0, sorted);
                 (void)build_code(L, lane, 288, 32, 1, sorted);      // (codes 30 and 31 decode to an error, as in zlib's fixed table)
+                long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane);
                 state = ST_TOKENS;
             } else if (type == 2u) {
                 const uint32_t hlit = br.get(5) + 257u, hdist = br.get(5) + 1u, hclen = br.get(4) + 4u;
@@ -409,7 +441,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 ok = ok && build_code(L, lane, 32, hlit, 0, sorted);
                 ok = ok && build_code(L, lane, 32u + hlit, hdist, 1, sorted);
                 if (!ok) fail(br.over ? MK_GZ_TRUNCATED : MK_GZ_BAD_LENGTHS);
-                else state = ST_TOKENS;
+                else { long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane); state = ST_TOKENS; }
             } else {
                 fail(MK_GZ_BAD_BLOCK);
             }
@@ -1103,7 +1135,7 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     uint64_t *d_cands = reinterpret_cast<uint64_t *>(r.blk_seg + o_cands);
     mk_gz_seg *d_segs = reinterpret_cast<mk_gz_seg *>(r.blk_seg + o_segs);
     uint32_t *d_aux = reinterpret_cast<uint32_t *>(r.blk_seg + o_aux);
-    static_assert(sizeof(TokLds) <= 160u << 10, "phase 1's tables and buffers fit one wave per CU");
+    static_assert(sizeof(TokLds) <= 80u << 10, "phase 1's tables and buffers: two waves per CU");
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
     if (!segs.empty()) {
         MK_TRY(r.up(d_cands, cands.data(), cands.size() * 8));
