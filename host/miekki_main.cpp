@@ -188,9 +188,13 @@ struct Driver {
     // one shard's share of index_file_of_file: files [f0, f1) of the list into ctx, in order.
     // `log` collects what the reference prints meanwhile (one '-' per genome kept, the
     // "Missed file" lines) so that several shards' output can be shown in list order.
-    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0, t_free = 0, t_recycle = 0, t_start = 0, t_total = 0; size_t gz_on_device = 0, gz_on_host = 0, from_readers = 0; };
+    vector<std::thread> trimmers;                  // (joined before the contexts go: ~Driver)
+    std::mutex trim_m;
+    ~Driver() { for (auto &t : trimmers) if (t.joinable()) t.join(); }
+    struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0, t_free = 0, t_recycle = 0, t_start = 0, t_total = 0, t_before = 0, t_after = 0; size_t gz_on_device = 0, gz_on_host = 0, from_readers = 0; };
     void build_shard(mk_ctx *ctx, const vector<string> &files, unsigned nthreads, bool live, ShardBuild &sb)
     {
+        const double t_enter = chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();
         // a doubling matrix would hold old and new copy at once: size it for the whole list up front
         if (!files.empty() && mk_reserve(ctx, (uint32_t)files.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return; }
         // readers parse into pinned buffers, three device batches ahead; the append of one
@@ -207,9 +211,13 @@ struct Driver {
         // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
         // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.
         static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return !e || atoi(e) != 0; }();
-        PinnedArena arena(ctx);                                    // (outlives the reader: declared first)
-        OrderedFastaReader reader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, &arena}, std::max<size_t>(3 * 64, (gz_in_flight + 2) * gz_batch + 64), true,
-                                  gz_batch != 0, gz_share ? gz_batch : 0, gz_in_flight);
+        // (the arena outlives the reader: declared first.  Both are handed to a thread of their own when the shard is built:
+        // giving gigabytes of page-locked memory back takes tenths of a second that nothing has to wait for)
+        std::shared_ptr<PinnedArena> arena_p = std::make_shared<PinnedArena>(ctx);
+        std::unique_ptr<OrderedFastaReader> reader_p(new OrderedFastaReader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, arena_p.get()},
+                                                                            std::max<size_t>(3 * 64, (gz_in_flight + 2) * gz_batch + 64), true, gz_batch != 0,
+                                                                            gz_share ? gz_batch : 0, gz_in_flight));
+        OrderedFastaReader &reader = *reader_p;
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         // What has been taken from the readers and waits for its turn, in list order: runs of up to 64 sequences the readers
@@ -341,6 +349,7 @@ struct Driver {
             return true;
         };
         const double t_loop = now();
+        sb.t_before = t_loop - t_enter;
         for (size_t i = 0; i < files.size(); ++i) {
             const string &fn = files[i];
             const double t0 = now();
@@ -363,8 +372,16 @@ struct Driver {
         close_run();
         if (!drain(true)) return;
         sb.t_total = now() - t_loop;
-        mk_gz_trim(ctx);                                           // (the inflater's blocks: the queries' buffers want the memory)
+        // the reader's pool, its page-locked arena and the inflater's blocks go back (the queries' buffers want the memory) on a
+        // thread of their own: nothing waits for that (mk_gz_trim touches the inflater's lists only)
+        {
+            const bool gz = sb.gz_on_device || sb.gz_on_host;
+            std::shared_ptr<OrderedFastaReader> r(reader_p.release());
+            std::lock_guard<std::mutex> g(trim_m);
+            trimmers.emplace_back([ctx, gz, r = std::move(r), a = std::move(arena_p)]() mutable { r.reset(); a.reset(); if (gz) mk_gz_trim(ctx); });
+        }
         if (mk_index_size(ctx) != sb.names.size()) sb.error = string("index build failed: ") + mk_last_error();   // settles the last batch
+        sb.t_after = now() - t_loop - sb.t_total;
     }
 
     // ---- Miekki.cpp:540-588.  `make_ctx(device ordinal)` creates one shard's context.
@@ -417,7 +434,7 @@ struct Driver {
         if (getenv("MIEKKI_VERBOSE"))
             for (size_t d = 0; d < D; ++d)
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
-                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s and for its batches' last kernels " << sb[d].t_free << "s (unmapping files " << sb[d].t_recycle << "s, starting batches " << sb[d].t_start << "s, the whole loop " << sb[d].t_total << "s); gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
+                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s and for its batches' last kernels " << sb[d].t_free << "s (unmapping files " << sb[d].t_recycle << "s, starting batches " << sb[d].t_start << "s, the whole loop " << sb[d].t_total << "s, before it " << sb[d].t_before << "s, after it " << sb[d].t_after << "s); gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
                      << ", refused by it and inflated here " << sb[d].gz_on_host << "; sequences that came from the readers " << sb[d].from_readers << endl;
         finish_index(true);
         compress_cold();
