@@ -324,29 +324,33 @@ OrderedFastaReader::~OrderedFastaReader()
     for (auto &b : pool_) pool_release(b.first);
 }
 
-char *OrderedFastaReader::pool_get(size_t need, size_t &cap)
+char *OrderedFastaReader::pool_get(size_t need, size_t &cap, bool plain)
 {
     {
         std::lock_guard<std::mutex> g(pool_m_);
+        // (page-locked and ordinary buffers share the pool but not their users: a packed sequence in ordinary memory would make
+        // its append's copy a staged one)
+        auto kind_ok = [&](char *p) { return !a_.alloc || (plain_.count(p) != 0) == plain; };
         size_t best = pool_.size();
         for (size_t i = 0; i < pool_.size(); ++i)
-            if (pool_[i].second >= need && (best == pool_.size() || pool_[i].second < pool_[best].second)) best = i;
+            if (pool_[i].second >= need && kind_ok(pool_[i].first) && (best == pool_.size() || pool_[i].second < pool_[best].second)) best = i;
         if (best != pool_.size()) {
             char *p = pool_[best].first;
             cap = pool_[best].second;
             pool_.erase(pool_.begin() + (long)best);
             return p;
         }
-        if (!pool_.empty()) {                                      // trade the smallest free buffer for a fitting one
-            size_t small = 0;
-            for (size_t i = 1; i < pool_.size(); ++i) if (pool_[i].second < pool_[small].second) small = i;
+        size_t small = pool_.size();                               // trade the smallest free buffer of the kind for a fitting one
+        for (size_t i = 0; i < pool_.size(); ++i)
+            if (kind_ok(pool_[i].first) && (small == pool_.size() || pool_[i].second < pool_[small].second)) small = i;
+        if (small != pool_.size()) {
             char *p = pool_[small].first;
             pool_.erase(pool_.begin() + (long)small);
             pool_release(p);
         }
     }
     cap = std::max<size_t>(need + need / 8, 1 << 16);
-    char *p = a_.alloc ? (char *)a_.alloc(a_.user, cap) : nullptr;
+    char *p = a_.alloc && !plain ? (char *)a_.alloc(a_.user, cap) : nullptr;
     if (!p) {                                                      // no allocator, or it is exhausted (page-lock limit):
         p = (char *)malloc(cap);                                   // ordinary memory is slower to copy from, never wrong
         if (!p) { cap = 0; return nullptr; }
@@ -418,14 +422,16 @@ void OrderedFastaReader::work()
             to_device = m == 1;
         }
         if (it.exists && to_device && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
-            // a gzip'd file as it is, for the device's inflater: read into a pooled buffer (page-locked while the allocator
-            // has room: the upload is then a plain DMA).  Not mapped: thousands of mappings made and taken down while
-            // sixteen threads fault pages in spent more time on the address space's lock than on the files.
+            // a gzip'd file as it is, for the device's inflater: read into a pooled buffer of ORDINARY memory (a gigabyte and
+            // more of these are alive at a time: page-locking that much -- 50 ms per 256 MB, every reader waiting behind the
+            // call -- cost more than the staged upload does on the batch's own thread).  Not mapped: thousands of mappings
+            // made and taken down while sixteen threads fault pages in spent more time on the address space's lock than
+            // on the files.
             const int fd = ::open(files_[i].c_str(), O_RDONLY);
             if (fd >= 0) {
                 unsigned char magic[2] = {0, 0};
                 if (pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-                    it.data = pool_get((size_t)st.st_size + 16, it.cap);
+                    it.data = pool_get((size_t)st.st_size + 16, it.cap, true);
                     size_t got = 0;
                     while (it.data && got < (size_t)st.st_size) {
                         const ssize_t r = pread(fd, it.data + got, (size_t)st.st_size - got, (off_t)got);

@@ -95,7 +95,7 @@ public:
     void recycle(Item &it);
 private:
     void work();
-    char *pool_get(size_t need, size_t &cap);
+    char *pool_get(size_t need, size_t &cap, bool plain = false);   // plain: ordinary memory even when there is an allocator
     void pool_release(char *p);                    // caller holds pool_m_ or is the destructor
     std::vector<std::string> files_;
     std::vector<Item> items_;

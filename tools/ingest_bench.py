@@ -15,7 +15,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 GZ = len(sys.argv) > 4 and sys.argv[4] == "gz"
 L = 5_000_000
-cli = os.path.join(ROOT, "miekki_amd", "miekki")
+cli = os.environ.get("MIEKKI_CLI") or os.path.join(ROOT, "miekki_amd", "miekki")
 with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     t0 = time.time()
     with open(os.path.join(d, "genomes.lst"), "w") as lst:
