@@ -248,8 +248,8 @@ struct Driver {
         // stripped and appended on the device, a few thousand at a time (a deflate stream is decoded by one lane, so it is
         // the number of streams in flight that makes the rate; MIEKKI_GZ_BATCH sets it, 0 = the readers inflate);
         // whatever the device refuses is inflated here
-        static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)128; }();
-        static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)6; }();
+        static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)512; }();
+        static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)3; }();
         // ... and the readers' own zlib takes what the device has no room for: the list goes in units of one device batch, a
         // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
         // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.

@@ -511,17 +511,29 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *__restrict__ p, uint6
     return v >> (bit & 7u);
 }
 
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x);
+
 __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict__ gz, const mk_gz_stream *__restrict__ streams, const uint64_t *__restrict__ word_first,
                                                       uint32_t n, uint64_t *__restrict__ hits, uint32_t *__restrict__ n_hits, uint32_t cap)
 {
-    // a thread: the 32 bit offsets of one 4-byte word of one stream.  The 32 + 17 + 57 bits they look at are words w .. w + 3
-    // of the stream (16-byte aligned, zero padding behind it): four aligned loads, every offset's bits by funnel shifts
-    // (the offsets that pass are collected in LDS and leave with ONE atomic per workgroup: an atomic each on one counter --
-    // twelve million of them for a thousand genomes -- took 130 ms by itself)
+    // a thread: the 32 bit offsets of one 4-byte word of one stream.  Two steps, because they differ a hundredfold in cost and
+    // in how many offsets take them: (1) every offset -- type bits, the two counts, room for a header: a handful of
+    // instructions, a fifth of the offsets pass; (2) the code length code's Kraft sum -- a loop over up to nineteen lengths --
+    // for those only, DENSELY: the wave's survivors are listed in LDS (a prefix sum over the lanes' counts) and walked 64 at a
+    // time with every lane busy, each from the four words its header can touch (words w .. w + 3 of the stream, kept in LDS
+    // by the lanes that own them).  (While each lane ran the loop for its own survivors the wave ran it for every offset --
+    // some lane always has one -- at a fifth of its lanes: 47 ms per 1,024 genomes.)
+    // The offsets that pass are collected in LDS and leave with ONE atomic per workgroup (an atomic each on one counter --
+    // twelve million of them for a thousand genomes -- took 130 ms by itself).
     __shared__ uint64_t s_hits[512];
     __shared__ uint32_t s_n, s_base;
+    __shared__ uint32_t s_w[4][64 + 4];                              // a wave's words: lane l's first, and three more behind the last lane's
+    __shared__ uint32_t s_lo[4][64];                                 // whose stream a lane's word is
+    __shared__ uint32_t s_wi[4][64];                                 // which word of its stream it is
+    __shared__ uint16_t s_list[4][64 * 32];                          // the wave's survivors of step 1: lane << 5 | offset
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool live = w < word_first[n];
     uint32_t lo = 0, hi = n;
@@ -531,34 +543,63 @@ __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict_
     const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(gz + st.in_off) + wi;
     const uint64_t bit0 = wi * 32u, nbits = live ? (uint64_t)st.in_len * 8u : 0u;
     const bool look = bit0 + 80u <= nbits;                           // (a block and a trailer need more than that)
-    const uint32_t w0 = look ? p[0] : 0u, w1 = look ? p[1] : 0u, w2 = look ? p[2] : 0u, w3 = look ? p[3] : 0u;   // (within the stream's padded room)
-#pragma unroll 4
-    for (uint32_t o = 0; look && o < 32u; ++o) {
+    const uint32_t w0 = live ? p[0] : 0u, w1 = live ? p[1] : 0u;     // (within the stream's padded room: sixteen bytes behind its end)
+    s_w[wave][lane] = w0;
+    if (lane == 63u) { s_w[wave][64] = w1; s_w[wave][65] = live ? p[2] : 0u; s_w[wave][66] = live ? p[3] : 0u; }
+    s_lo[wave][lane] = lo;
+    s_wi[wave][lane] = (uint32_t)wi;
+    // ---- step 1: which of the word's 32 offsets could start a dynamic block
+    uint32_t pass = 0;
+#pragma unroll 8
+    for (uint32_t o = 0; o < 32u; ++o) {
         const uint32_t a = o ? __builtin_amdgcn_alignbit(w1, w0, o) : w0;            // bits [o, o + 32)
-        if (((a >> 1) & 3u) != 2u) continue;                        // BTYPE: dynamic Huffman codes
-        if (((a >> 3) & 31u) > 29u || ((a >> 8) & 31u) > 29u) continue;   // HLIT, HDIST
-        if (bit0 + o + 80u > nbits) continue;
+        const bool ok = ((a >> 1) & 3u) == 2u && ((a >> 3) & 31u) <= 29u && ((a >> 8) & 31u) <= 29u;   // BTYPE: dynamic codes; HLIT, HDIST
+        pass |= ok ? 1u << o : 0u;
+    }
+    if (!look) pass = 0;
+    else if (bit0 + 31u + 80u > nbits) {                             // (the stream's last words: offset by offset)
+        for (uint32_t o = 0; o < 32u; ++o) if (bit0 + o + 80u > nbits) pass &= ~(1u << o);
+    }
+    // (a survivor's header lies in words w .. w + 3 of ITS stream: the lanes behind it hold them unless the stream ends within
+    // those words -- and then `look` has already failed for it)
+    const uint32_t mine = (uint32_t)__builtin_popcount(pass);
+    const uint32_t incl = wave_prefix_sum(mine);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    {
+        uint32_t at = incl - mine, m = pass;
+        while (m) {                                                  // (at most 32 passes; seven on average)
+            const uint32_t o = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            s_list[wave][at++] = (uint16_t)((lane << 5) | o);
+        }
+    }
+    __syncthreads();
+    // ---- step 2: the code length code's lengths, three bits each from bit 17 on: complete iff the sum of 2^(7 - length) is 2^7
+    for (uint32_t j = lane; j < total; j += 64u) {
+        const uint32_t e = s_list[wave][j], t = e >> 5, o = e & 31u;
+        const uint32_t x0 = s_w[wave][t], x1 = s_w[wave][t + 1u], x2 = s_w[wave][t + 2u], x3 = s_w[wave][t + 3u];
+        const uint32_t a = o ? __builtin_amdgcn_alignbit(x1, x0, o) : x0, bb = o ? __builtin_amdgcn_alignbit(x2, x1, o) : x1,
+                       c = o ? __builtin_amdgcn_alignbit(x3, x2, o) : x2;                      // bits [o, ..), [o + 32, ..), [o + 64, ..)
         const uint32_t hclen = ((a >> 13) & 15u) + 4u;
-        // the code length code's lengths, three bits each from bit 17 on: complete iff the sum of 2^(7 - length) is 2^7
-        const uint32_t b = o ? __builtin_amdgcn_alignbit(w2, w1, o) : w1, c = o ? __builtin_amdgcn_alignbit(w3, w2, o) : w2;   // bits [o + 32, ..), [o + 64, ..)
-        uint64_t x = (((uint64_t)b << 32) | a) >> 17;                 // 47 bits: fifteen lengths
+        uint64_t x = (((uint64_t)bb << 32) | a) >> 17;                // 47 bits: fifteen lengths
         uint32_t kraft = 0;
         for (uint32_t i = 0; i < hclen; ++i) {
-            if (i == 15u) x = (((uint64_t)c << 32) | b) >> 30;       // from bit 17 + 45 = 62 on
+            if (i == 15u) x = (((uint64_t)c << 32) | bb) >> 30;      // from bit 17 + 45 = 62 on
             const uint32_t l = (uint32_t)x & 7u;
             x >>= 3;
             kraft += l ? 128u >> l : 0u;
         }
         if (kraft != 128u) continue;
+        const uint64_t hit = ((uint64_t)s_lo[wave][t] << 40) | ((uint64_t)s_wi[wave][t] * 32u + o);
         const uint32_t at = atomicAdd(&s_n, 1u);
-        if (at < 512u) s_hits[at] = ((uint64_t)lo << 40) | (bit0 + o);
-        else { const uint32_t g = atomicAdd(n_hits, 1u); if (g < cap) hits[g] = ((uint64_t)lo << 40) | (bit0 + o); }
+        if (at < 512u) s_hits[at] = hit;
+        else { const uint32_t g = atomicAdd(n_hits, 1u); if (g < cap) hits[g] = hit; }
     }
     __syncthreads();
-    const uint32_t mine = min(s_n, 512u);
-    if (threadIdx.x == 0 && mine) s_base = atomicAdd(n_hits, mine);
+    const uint32_t got = min(s_n, 512u);
+    if (threadIdx.x == 0 && got) s_base = atomicAdd(n_hits, got);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < mine; i += 256u) if (s_base + i < cap) hits[s_base + i] = s_hits[i];
+    for (uint32_t i = threadIdx.x; i < got; i += 256u) if (s_base + i < cap) hits[s_base + i] = s_hits[i];
 }
 
 // the second part of the test, one thread per offset that passed the first; the offsets that pass this one too are appended
@@ -673,22 +714,28 @@ __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x)
 
 struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t byte_shift; };   // x^(512 (63 - lane)), x^(8 * 4096), x^8
 
-// Four streams per workgroup (a wave each, its own window; the CRC tables are shared).
-__global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
+// kResolveWaves streams per workgroup (a wave each, its own window; the CRC tables are shared).  Two, 76 KB: a workgroup then
+// shares a CU with another one or with a workgroup of the token kernel (78 KB); with four (148 KB) it took a CU for itself
+// -- and so did, seen from here, every single-wave workgroup of the token kernel: the two kernels of batches in flight
+// side by side kept each other off the CUs.
+constexpr uint32_t kResolveWaves = 2;
+__global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
                                                          const uint32_t *__restrict__ tokens, uint8_t *__restrict__ text, ResolveConsts K)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsmem[];
     uint32_t (*crc_tab)[256] = reinterpret_cast<uint32_t (*)[256]>(rsmem);           // slice-by-4 tables (reflected 0xEDB88320)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, s = blockIdx.x * 4u + wave;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, s = blockIdx.x * kResolveWaves + wave;
     uint8_t *const win = rsmem + 4096u + wave * kWin;
-    {
-        uint32_t c = threadIdx.x;
+    for (uint32_t e = threadIdx.x; e < 256u; e += 64u * kResolveWaves) {
+        uint32_t c = e;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
-        crc_tab[0][threadIdx.x] = c;
-        __syncthreads();
-        uint32_t v = c;
-        for (uint32_t t = 1; t < 4u; ++t) { v = crc_tab[0][v & 0xffu] ^ (v >> 8); crc_tab[t][threadIdx.x] = v; }
+        crc_tab[0][e] = c;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < 256u; e += 64u * kResolveWaves) {
+        uint32_t v = crc_tab[0][e];
+        for (uint32_t t = 1; t < 4u; ++t) { v = crc_tab[0][v & 0xffu] ^ (v >> 8); crc_tab[t][e] = v; }
     }
     __syncthreads();
     if (s >= n) return;
@@ -814,7 +861,7 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint8_t *__restri
         bool done = !act;
         if (act && !is_match) { win[dst % kWin] = (uint8_t)t; done = true; }
         unsigned long long todo = __ballot(!done);
-        uint8_t *const sink = rsmem + 4096u + 4u * kWin + wave * 64u + lane;     // where the bytes of a piece beyond a token's end go
+        uint8_t *const sink = rsmem + 4096u + kResolveWaves * kWin + wave * 64u + lane;     // where the bytes of a piece beyond a token's end go
         while (todo) {                                               // (each round finishes at least the lowest unfinished lane)
             const uint32_t low = (uint32_t)__ffsll((long long)todo) - 1u;
             const uint32_t frontier = (uint32_t)__builtin_amdgcn_readlane((int)dst, (int)low);
@@ -1228,9 +1275,9 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
     K.block_shift = x_pow_bytes(kFlush);
     K.byte_shift = x_pow_bytes(1);
-    const size_t lds2 = 4096u + 4u * kWin + 256u;                     // CRC tables, four windows, the lanes' sinks
+    const size_t lds2 = 4096u + kResolveWaves * kWin + 64u * kResolveWaves;   // CRC tables, the streams' windows, the lanes' sinks
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + 3u) / 4u), dim3(256), lds2, st, d_gz, r.d_streams, n, d_tok, r.d_text, K);
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + kResolveWaves - 1u) / kResolveWaves), dim3(64u * kResolveWaves), lds2, st, d_gz, r.d_streams, n, d_tok, r.d_text, K);
     MK_HIP(hipGetLastError());
     MK_TRY(r.down(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream)));
     MK_TRY(r.settle());
