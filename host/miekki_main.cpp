@@ -189,8 +189,7 @@ private:
     void fill()                                   // page-locks the next slab whenever the spare one has been taken
     {
         std::unique_lock<std::mutex> g(m_);
-        want_ = true;                             // (the first one at once)
-        for (;;) {
+        for (;;) {                                // (nothing until somebody asks: an arena that is hardly used locks one slab, on demand)
             cv_.wait(g, [&] { return stop_ || (want_ && !spare_ && !dry_); });
             if (stop_) return;
             want_ = false;
@@ -231,9 +230,11 @@ struct Driver {
     // one shard's share of index_file_of_file: files [f0, f1) of the list into ctx, in order.
     // `log` collects what the reference prints meanwhile (one '-' per genome kept, the
     // "Missed file" lines) so that several shards' output can be shown in list order.
-    vector<std::thread> trimmers;                  // (joined before the contexts go: ~Driver)
-    std::mutex trim_m;
-    ~Driver() { for (auto &t : trimmers) if (t.joinable()) t.join(); }
+    // what the shards' builds leave behind (see build_shard's end): readers first, then the arenas their buffers came from
+    vector<std::unique_ptr<OrderedFastaReader>> kept_readers;
+    vector<std::shared_ptr<PinnedArena>> kept_arenas;
+    std::mutex keep_m;
+    ~Driver() { kept_readers.clear(); kept_arenas.clear(); }
     struct ShardBuild { string log, error; vector<string> names; double t_append = 0, t_wait = 0, t_unpack_wait = 0, t_free = 0, t_recycle = 0, t_start = 0, t_total = 0, t_before = 0, t_after = 0, t_lock = 0; size_t slabs = 0; size_t gz_on_device = 0, gz_on_host = 0, from_readers = 0; };
     void build_shard(mk_ctx *ctx, const vector<string> &files, unsigned nthreads, bool live, ShardBuild &sb)
     {
@@ -416,13 +417,14 @@ struct Driver {
         if (!drain(true)) return;
         sb.t_total = now() - t_loop;
         sb.t_lock = arena_p->lock_s_; sb.slabs = arena_p->n_slabs_;
-        // the reader's pool, its page-locked arena and the inflater's blocks go back (the queries' buffers want the memory) on a
-        // thread of their own: nothing waits for that (mk_gz_trim touches the inflater's lists only)
+        // the reader's pool and its page-locked arena are kept until the process ends (~Driver), the inflater's blocks until
+        // their context goes: giving gigabytes back takes tenths of a second -- inside the index phase when done here, out of the
+        // queries' first batches when done beside them (freeing page-locked or device memory stalls the device) -- and a GPU
+        // with 288 GB does not miss them
         {
-            const bool gz = sb.gz_on_device || sb.gz_on_host;
-            std::shared_ptr<OrderedFastaReader> r(reader_p.release());
-            std::lock_guard<std::mutex> g(trim_m);
-            trimmers.emplace_back([ctx, gz, r = std::move(r), a = std::move(arena_p)]() mutable { r.reset(); a.reset(); if (gz) mk_gz_trim(ctx); });
+            std::lock_guard<std::mutex> g(keep_m);
+            kept_readers.emplace_back(reader_p.release());
+            kept_arenas.push_back(std::move(arena_p));
         }
         if (mk_index_size(ctx) != sb.names.size()) sb.error = string("index build failed: ") + mk_last_error();   // settles the last batch
         sb.t_after = now() - t_loop - sb.t_total;
