@@ -480,7 +480,7 @@ struct Driver {
         if (getenv("MIEKKI_VERBOSE"))
             for (size_t d = 0; d < D; ++d)
                 cout << "[ingest] shard " << d << ": " << sb[d].names.size() << " genomes, waited for the readers " << sb[d].t_wait
-                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s and for its batches' last kernels " << sb[d].t_free << "s (unmapping files " << sb[d].t_recycle << "s, starting batches " << sb[d].t_start << "s, the whole loop " << sb[d].t_total << "s, before it " << sb[d].t_before << "s, after it " << sb[d].t_after << "s; " << sb[d].slabs << " slabs of 256 MB page-locked in " << sb[d].t_lock << "s); gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
+                     << "s, in mk_index_append " << sb[d].t_append << "s, waited for the device's inflater " << sb[d].t_unpack_wait << "s and for its batches' last kernels " << sb[d].t_free << "s (giving the raw files' buffers back " << sb[d].t_recycle << "s, starting batches " << sb[d].t_start << "s, the whole loop " << sb[d].t_total << "s, before it " << sb[d].t_before << "s, after it " << sb[d].t_after << "s; " << sb[d].slabs << " slabs of 256 MB page-locked, readers waited for them " << sb[d].t_lock << "s); gzip'd files inflated on the device " << sb[d].gz_on_device - sb[d].gz_on_host
                      << ", refused by it and inflated here " << sb[d].gz_on_host << "; sequences that came from the readers " << sb[d].from_readers << endl;
         finish_index(true);
         compress_cold();
