@@ -202,8 +202,10 @@ struct LongCodes {
         for (uint32_t i = 0; i < 15u - ROOT; ++i) cnt[i] = c[ROOT + 1u + i][lane];
     }
     // bits: the next fifteen bits of the stream (first bit lowest); returns the symbol's place in the sorted list and its
-    // length, or length 0: no such code
-    __device__ __forceinline__ uint32_t find(uint32_t bits, uint32_t &len) const
+    // length, or length 0: no such code.  `wanted`: this lane is one of those that look (the others idle along); the walk
+    // ends when every lane that looks has its code -- the long codes of real streams are a bit or three longer than the
+    // root, and the nine steps to fifteen bits were a quarter of the kernel's instructions.
+    __device__ __forceinline__ uint32_t find(uint32_t bits, uint32_t &len, bool wanted) const
     {
         uint32_t code = (__brev(bits) >> (32u - ROOT)) << 1, f = first, ix = index, at = 0;
         len = 0;
@@ -215,6 +217,7 @@ struct LongCodes {
             at = hit ? ix + (code - f) : at;
             len = hit ? ROOT + 1u + i : len;
             ix += n; f += n; f <<= 1; code <<= 1;
+            if (!__any(wanted && len == 0u)) break;
         }
         return at;
     }
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 uint32_t kind = (e >> 4) & 7u, value = e >> 7, cl = e & 15u;
                 if (act && e == 0u) {                                  // a code longer than the table's index
                     uint32_t ll;
-                    const uint32_t at = long_l.find((uint32_t)br.bb & 0x7fffu, ll);
+                    const uint32_t at = long_l.find((uint32_t)br.bb & 0x7fffu, ll, true);
                     // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
                     const uint32_t sym = ll ? __hip_atomic_load(&sorted[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
                     br.bb >>= ll; br.bc -= ll;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 uint32_t dsym = d >> 4, dcl = d & 15u;
                 if (is_len && d == 0u) {                               // a distance code longer than the table's index
                     uint32_t ll;
-                    const uint32_t at = long_d.find((uint32_t)br.bb & 0x7fffu, ll);
+                    const uint32_t at = long_d.find((uint32_t)br.bb & 0x7fffu, ll, true);
                     dsym = ll ? (uint32_t)L.sym_d[at & 31u][lane] : ~0u;
                     br.bb >>= ll; br.bc -= ll;
                     dcl = 0;
