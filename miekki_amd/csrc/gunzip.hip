@@ -876,11 +876,15 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
             const bool wide = ready && dist >= 8u;
             while (__any(wide && j < len && d + 8u <= kWin && f + 8u <= kWin)) {
                 const bool go = wide && j < len && d + 8u <= kWin && f + 8u <= kWin;
-                uint8_t b8[8];
+                // (the eight source bytes as three aligned words and two byte shifts instead of eight byte reads: the copies' LDS
+                // operations are what this kernel's time is made of.  A word may reach four bytes past the window's end: the next
+                // window, or the sinks -- inside the allocation, and those bytes are shifted out)
+                const uint32_t fa = go ? f & ~3u : 0u, sh = f & 3u;
+                const uint32_t *__restrict__ w32 = reinterpret_cast<const uint32_t *>(win + fa);
+                const uint32_t a0 = w32[0], a1 = w32[1], a2 = w32[2];
+                const uint32_t lo8 = __builtin_amdgcn_alignbyte(a1, a0, sh), hi8 = __builtin_amdgcn_alignbyte(a2, a1, sh);
 #pragma unroll
-                for (uint32_t i = 0; i < 8u; ++i) b8[i] = win[go ? f + i : 0u];
-#pragma unroll
-                for (uint32_t i = 0; i < 8u; ++i) *(go && j + i < len ? win + d + i : sink) = b8[i];
+                for (uint32_t i = 0; i < 8u; ++i) *(go && j + i < len ? win + d + i : sink) = (uint8_t)((i < 4u ? lo8 : hi8) >> (8u * (i & 3u)));
                 if (go) {
                     const uint32_t adv = min(8u, len - j);
                     j += adv; d += adv; f += adv;
