@@ -520,7 +520,8 @@ def main(argv=None):
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             for e in pm["entries"]:
                 if (e["genomes_per_gpu"], e["queries"], e["h"], e["fp_bits"]) == (G, Q, args.h, args.fp_bits):
-                    traffic = e["traffic_bytes_per_launch"]
+                    # (per step in the file: a step's launches differ in size and the collective path cuts it its own way)
+                    traffic = e["traffic_bytes_per_step"] * args.steps / launches
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this config; " \
                                   "L2<->fabric bytes, Infinity-Cache hits included)"
         except Exception:

@@ -15,6 +15,7 @@ ap.add_argument("fetch"); ap.add_argument("write")
 ap.add_argument("--genomes", type=int, required=True); ap.add_argument("--queries", type=int, required=True)
 ap.add_argument("--h", type=int, required=True); ap.add_argument("--fp-bits", type=int, required=True)
 ap.add_argument("--source", default=""); ap.add_argument("--kernel", default="scan_slab_kernel")
+ap.add_argument("--steps-counted", type=int, default=2, help="steps the counter passes ran (--warmup 1 --steps 1: two)")
 a = ap.parse_args()
 
 
@@ -26,7 +27,8 @@ f, w = vals(a.fetch, "FETCH_SIZE"), vals(a.write, "WRITE_SIZE")
 assert f and w, "no launches of %s in the counter files" % a.kernel
 entry = {"genomes_per_gpu": a.genomes, "queries": a.queries, "h": a.h, "fp_bits": a.fp_bits, "kernel": a.kernel,
          "traffic_bytes_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024,
-         "fetch_size_kb_mean": sum(f) / len(f), "write_size_kb_mean": sum(w) / len(w), "launches_counted": len(f), "source": a.source}
+         "fetch_size_kb_mean": sum(f) / len(f), "write_size_kb_mean": sum(w) / len(w), "launches_counted": len(f), "launches_per_step": len(f) / a.steps_counted,
+         "traffic_bytes_per_step": (2 * sum(f) + sum(w)) * 1024 / a.steps_counted, "source": a.source}
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 pm = json.load(open(path))
 pm["entries"] = [e for e in pm["entries"] if (e["genomes_per_gpu"], e["queries"], e["h"], e["fp_bits"]) != (a.genomes, a.queries, a.h, a.fp_bits)] + [entry]
