@@ -201,7 +201,7 @@ typedef enum {
     MK_GZ_BAD_LENGTHS = 6,    /* a block's code lengths: over-subscribed, incomplete, bad repeat, no end-of-block code */
     MK_GZ_BAD_CODE = 7,       /* bits that are no code of the block's code */
     MK_GZ_BAD_DISTANCE = 8,   /* a match that reaches back beyond the member's first byte */
-    MK_GZ_TOKEN_ROOM = 9,     /* more symbols than the call provided for (about one per two bytes of text) */
+    MK_GZ_TOKEN_ROOM = 9,     /* (no longer reported: segments that outgrow their token slots are decoded again with exact rooms) */
     MK_GZ_OUTPUT_ROOM = 10,   /* more text than the room given */
     MK_GZ_TRAILING = 11,      /* bytes behind the last member that are not another member */
     MK_GZ_BAD_CRC = 12,
@@ -224,6 +224,16 @@ int mk_gz_inflate(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_byte
  * the one before). */
 typedef struct mk_gz_batch mk_gz_batch;
 int mk_gz_unpack(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out);
+/* mk_gz_unpack in steps, for a caller whose reader threads fetch the files themselves (zstr's read loop, zstr.hpp:186-190, is
+ * what they replace): mk_gz_open lays the batch out from the files' sizes; mk_gz_put hands over bytes [at, at + bytes) of file i
+ * -- staged != 0: `data` is a page-locked piece lent by mk_gz_stage (*cap bytes; NULL when none is to be had), the copy is a
+ * DMA nobody waits for and the piece is the library's again; staged == 0: any memory, copied before the call returns --;
+ * mk_gz_run, when every file has been put, inflates and measures the sequences (mk_gz_sequence, mk_index_append_gz).  mk_gz_stage
+ * and mk_gz_put may be called from any number of threads at once; a file never put reads as empty (MK_GZ_NOT_GZIP). */
+int mk_gz_open(mk_ctx *ctx, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out);
+void *mk_gz_stage(mk_gz_batch *batch, uint64_t *cap);
+int mk_gz_put(mk_gz_batch *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, int staged);
+int mk_gz_run(mk_gz_batch *batch);
 int mk_gz_sequence(const mk_gz_batch *batch, uint32_t i, uint64_t *len, int32_t *status);
 /* insert_sequences (Miekki.cpp:277-314) for files which[0 .. n) of the batch, in that order (each must have status MK_GZ_OK and
  * at least k characters); pipelined like mk_index_append. */

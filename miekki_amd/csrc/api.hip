@@ -549,6 +549,7 @@ void mk_destroy(mk_ctx *c)
     c->gz_blocks.clear();
     for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
     c->gz_pins.clear();
+    gz_release_staging(c);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     for (int b = 0; b < 2; ++b) {                                  // (d_counters, h_back, d_seq_off, d_seed_valid, d_ovf alias one of these)
         mk_ctx::BuildSide &sd = c->side[b];

@@ -226,69 +226,105 @@ struct LongCodes {
 // One lane per SEGMENT of a stream: from the stream's first byte, or from a block's first bit that the finder (below) has
 // vouched for, up to the next such bit that the decoding ARRIVES at between two blocks (or to the stream's end).  A segment
 // whose start was no block's start decodes noise until an error or until it falls into step with the real blocks: nobody
-// follows the chain through it.  write = 0: nothing is stored -- the pass that measures every segment (tokens, bytes, where
-// it ends), so that the pass that writes knows every segment's place.
-__global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict__ gz, mk_gz_seg *__restrict__ jobs, uint32_t n,
-                                                       const uint64_t *__restrict__ cands, uint32_t *__restrict__ tokens, uint32_t *__restrict__ aux)
+// follows the chain through it.
+// ONE pass: a segment's tokens go to slots that follow from where it starts -- one 4-byte slot per byte of the stream, the
+// segment that starts at bit b of stream s writes from slot (in_off(s) + b / 8) & ~3 on, up to the next candidate's slot:
+// gzip'd DNA spends 12-15 bits on a token, so a segment fills about half of its slots.  One that would need more (literals
+// only, a run of one-bit codes; or a candidate inside it that was no block's start) keeps COUNTING without writing; the chain
+// kernel sees n_tok > tok_cap, and those few segments are decoded again with exact rooms (`jobs`).
+// The workgroups are a fixed number (two per CU: the LDS each needs) and take groups of 64 segments from a counter until
+// there are none left -- the number of segments (streams + candidates that passed the check) lives on the device.
+struct TokArgs {
+    const uint8_t *gz;
+    const mk_gz_stream *streams;
+    uint32_t n;                      // streams: segment g < n is stream g from its first byte
+    const uint64_t *sorted;          // candidates (stream << 40 | bit), ascending: segment n + j starts at sorted[j]
+    const uint32_t *n_good;          // how many (on the device), at most good_cap
+    uint32_t good_cap;
+    mk_gz_seg *segs;                 // results, by segment
+    uint32_t *slots;                 // the token slots (one per byte of the input block)
+    uint32_t *aux;                   // 288 words per lane of the grid: a lane's literal / length symbols in code order
+    uint32_t *queue;                 // the counter groups are taken from (zero at launch)
+    const mk_gz_job *jobs;           // null, or the segments to decode (again), each with its room
+    uint32_t n_jobs;
+};
+constexpr uint64_t kBitMask = (1ull << 40) - 1ull;
+constexpr uint32_t kOutMax = 0xfff00000u;       // a stream's text and a segment's share of it stay below this
+
+__global__ __launch_bounds__(64) void gz_tokens_kernel(TokArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TokLds &L = *reinterpret_cast<TokLds *>(smem);
-    const uint32_t lane = threadIdx.x, s = blockIdx.x * 64u + lane;
+    const uint32_t lane = threadIdx.x;
     // a lane's column in the two-byte tables: lanes l and l + 32 share a word -- they are served in different halves of a wave's
     // access, so 32 lanes looking 32 different rows up meet on no bank (with columns in lane order neighbours always did: 64 % of
     // the LDS cycles were conflicts)
     const uint32_t col = ((lane & 31u) << 1) | (lane >> 5);
-    const bool live = s < n;
-    mk_gz_seg job = live ? jobs[s] : mk_gz_seg{};
-    uint32_t *const sorted = aux + (uint64_t)(live ? s : 0u) * 288u;
+    uint32_t *const sorted_syms = A.aux + ((uint64_t)blockIdx.x * 64u + lane) * 288u;
+    const uint32_t total = A.jobs ? A.n_jobs : A.n + min(*A.n_good, A.good_cap);
+    for (;;) {                                                       // (every wave leaves when the counter has passed the last group)
+    uint32_t grp = 0;
+    if (lane == 0) grp = atomicAdd(A.queue, 1u);
+    grp = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp);
+    if ((uint64_t)grp * 64u >= total) break;
+    const uint32_t idx = grp * 64u + lane;
+    bool live = idx < total;
+    const uint32_t g = live ? (A.jobs ? A.jobs[idx].seg : idx) : 0u;
+    const uint64_t key = !live || g < A.n ? 0ull : A.sorted[g - A.n];
+    const uint32_t sidx = !live ? 0u : g < A.n ? g : (uint32_t)(key >> 40);
+    const mk_gz_stream st = A.streams[min(sidx, A.n - 1u)];
+    if (live && (sidx >= A.n || st.status != MK_GZ_OK)) live = false;   // (a stream refused before anything ran has no segments)
+    const uint64_t start_bit = key & kBitMask;
+    const uint32_t cand_hi = st.cand_hi;
+    uint32_t ci = g < A.n ? st.cand_lo : g - A.n + 1u;               // the next candidate of the stream behind this segment's start
+    // the segment's slots
+    uint32_t *tok_base;
+    uint32_t cap;
+    if (A.jobs) {
+        tok_base = reinterpret_cast<uint32_t *>(live ? A.jobs[idx].tok_ptr : 0ull);
+        cap = live ? A.jobs[idx].tok_cap : 0u;
+    } else {
+        const uint64_t s0 = (st.in_off + (start_bit >> 3)) & ~3ull;
+        const uint64_t s1 = live && ci < cand_hi ? (st.in_off + ((A.sorted[ci] & kBitMask) >> 3)) & ~3ull
+                                                 : st.in_off + ((uint64_t)st.in_len + 31u) / 16u * 16u;     // (the next stream's first slot)
+        tok_base = A.slots + s0;
+        cap = live ? (uint32_t)(s1 - s0) : 0u;
+    }
     LongCodes<kLitRoot> long_l;                                   // (the lane's block: set with its tables)
     LongCodes<kDistRoot> long_d;
     long_l.first = long_l.index = long_d.first = long_d.index = 0;
     for (uint32_t i = 0; i < 15u - kLitRoot; ++i) long_l.cnt[i] = 0;
     for (uint32_t i = 0; i < 15u - kDistRoot; ++i) long_d.cnt[i] = 0;
     BitReader br;
-    br.start(gz + job.in_off, live ? job.in_len : 0u, &L, lane);
+    br.start(A.gz + st.in_off, live ? st.in_len : 0u, &L, lane);
     uint32_t state = live ? ST_MEMBER : ST_DONE, status = live ? MK_GZ_OK : MK_GZ_EMPTY;
-    uint32_t n_tok = 0, n_out = 0, out_len = 0, members = 0;        // n_out: tokens already in memory (the rest: the lane's ring)
-    uint32_t member_bytes = job.member_out0;                         // bytes of the member being decoded so far (what a match may reach back into)
-    uint32_t link = 0xffffffffu, ci = job.cand_next;                 // the candidate this segment stops at; the next one to look at
-    const uint64_t *__restrict__ my_cands = cands + job.cand_off;    // (ascending, ends with ~0)
-    const bool writing = job.write != 0u;
+    uint32_t n_tok = 0, n_out = 0, out_len = 0, members = 0;        // n_out: tokens that have left the ring (a multiple of four)
+    uint32_t link = 0xffffffffu;                                     // the segment this one stops at
     bool final_block = false;
-    if (live && job.start_bit == 0ull && job.in_len < 18u) { state = ST_DONE; status = MK_GZ_NOT_GZIP; }
-    if (live && job.start_bit != 0ull) {
-        br.seek_byte(job.start_bit >> 3);
-        br.drop((uint32_t)(job.start_bit & 7u));
+    if (live && start_bit == 0ull && st.in_len < 18u) { state = ST_DONE; status = MK_GZ_NOT_GZIP; }
+    if (live && start_bit != 0ull) {
+        br.seek_byte(start_bit >> 3);
+        br.drop((uint32_t)(start_bit & 7u));
         state = br.over ? ST_DONE : ST_BLOCK;
         if (br.over) status = MK_GZ_TRUNCATED;
     }
     auto fail = [&](uint32_t why) { status = why; state = ST_DONE; };
-    auto emit = [&](uint32_t t) {                                   // (the passes below emit at most three; round() keeps that much room)
-        if (n_tok < job.tok_cap) { L.tok[lane][n_tok - n_out] = t; ++n_tok; }
-        else fail(MK_GZ_TOKEN_ROOM);
-    };
-    // A lane's ring out to memory, four tokens per store (what is left over moves to the ring's start), and its row of
-    // input refilled from the word it reads next, four words per load.  Every lane its own stream: 64 cache lines per
-    // instruction, but only a few dozen instructions per round and a round every few dozen tokens.
-    const uint4 *__restrict__ in16 = reinterpret_cast<const uint4 *>(gz + job.in_off);
-    // (a segment's tokens start wherever the segment before it ended: the ring is written out in 16-byte pieces from the
-    // first multiple of four on -- n_out starts at the few tokens before it, which are stored one by one)
-    uint32_t *__restrict__ tok_base = tokens + job.tok_off;
-    const uint32_t lead = writing ? (uint32_t)((4u - (job.tok_off & 3u)) & 3u) : 0u;       // tokens before the first aligned one
+    auto emit = [&](uint32_t t) { L.tok[lane][n_tok - n_out] = t; ++n_tok; };   // (the passes below emit at most three; round() keeps that much room)
+    // A lane's ring out to memory, four tokens per store (what is left over moves to the ring's start) -- as far as the
+    // segment's slots go: the tokens beyond them are only counted --, and its row of input refilled from the word it reads
+    // next, four words per load.  Every lane its own stream: 64 cache lines per instruction, but only a few dozen
+    // instructions per round and a round every few dozen tokens.
+    const uint4 *__restrict__ in16 = reinterpret_cast<const uint4 *>(A.gz + st.in_off);
     auto round = [&]() {
-        uint32_t have = n_tok - n_out, done = 0;
-        // (the first tokens of a segment up to the 16-byte boundary of its place, one by one; then whole fours)
-        if (writing && n_out < lead) { done = min(lead - n_out, have); for (uint32_t i = 0; i < done; ++i) tok_base[n_out + i] = L.tok[lane][i]; }
-        const uint32_t whole = (have - done) & ~3u;
-        for (uint32_t i = 0; __any(writing && i < whole); i += 4u)
-            if (writing && i < whole) {
+        const uint32_t have = n_tok - n_out, whole = have & ~3u;
+        for (uint32_t i = 0; __any(i < whole); i += 4u)
+            if (i < whole && n_out + i + 4u <= cap) {
                 uint4 v;
-                v.x = L.tok[lane][done + i]; v.y = L.tok[lane][done + i + 1u]; v.z = L.tok[lane][done + i + 2u]; v.w = L.tok[lane][done + i + 3u];
-                *reinterpret_cast<uint4 *>(tok_base + n_out + done + i) = v;
+                v.x = L.tok[lane][i]; v.y = L.tok[lane][i + 1u]; v.z = L.tok[lane][i + 2u]; v.w = L.tok[lane][i + 3u];
+                *reinterpret_cast<uint4 *>(tok_base + n_out + i) = v;
             }
-        const uint32_t gone = writing ? done + whole : have & ~3u;
-        if (gone) for (uint32_t i = 0; i < have - gone; ++i) L.tok[lane][i] = L.tok[lane][gone + i];
-        n_out += gone;
+        if (whole) for (uint32_t i = 0; i < have - whole; ++i) L.tok[lane][i] = L.tok[lane][whole + i];
+        n_out += whole;
         br.base = br.wi & ~3u;
         uint4 v[kInWords / 4u];
 #pragma unroll
@@ -301,7 +337,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
         for (uint32_t i = 0; i < kInWords / 4u; ++i) *reinterpret_cast<uint4 *>(&L.in[lane][4u * i]) = v[i];
     };
     round();
-    // every pass of this loop consumes input bits, emits a token or ends a lane: bounded by the streams' bits and rooms
+    // every pass of this loop consumes input bits, emits a token or ends a lane: bounded by the streams' bits
     while (__any(state != ST_DONE)) {
         // a round when some ring may not take another pass's tokens, or some lane has used most of its buffered words
         if (__any(n_tok - n_out + 4u > kTokRing || (state != ST_DONE && br.wi - br.base + 4u > kInWords))) round();
@@ -328,7 +364,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                     uint32_t ll;
                     const uint32_t at = long_l.find((uint32_t)br.bb & 0x7fffu, ll, true);
                     // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
-                    const uint32_t sym = ll ? __hip_atomic_load(&sorted[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+                    const uint32_t sym = ll ? __hip_atomic_load(&sorted_syms[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
                     br.bb >>= ll; br.bc -= ll;
                     cl = 0;
                     if (sym < 256u) { kind = 7; value = sym; }
@@ -361,14 +397,13 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 const uint32_t dist = (dsym < 4u ? dsym + 1u : 1u + ((2u + (dsym & 1u)) << dex)) + ((uint32_t)br.bb & ((1u << dex) - 1u));
                 br.bb >>= dex; br.bc -= dex;
                 const uint32_t grow = is_len ? len : is_lit ? 1u : 0u;
-                if (is_len && dist > member_bytes) err = err ? err : MK_GZ_BAD_DISTANCE;
-                if (grow > job.out_cap - out_len) err = err ? err : MK_GZ_OUTPUT_ROOM;
-                if (grow && n_tok >= job.tok_cap) err = err ? err : MK_GZ_TOKEN_ROOM;
+                // (whether a distance reaches back beyond its member's first byte is the text kernel's to say: only there is it
+                // known how much of the member lies before this segment)
+                if (grow > kOutMax - out_len) err = err ? err : MK_GZ_OUTPUT_ROOM;
                 const bool put = grow != 0u && err == 0u;
                 L.tok[lane][put ? n_tok - n_out : kTokRing] = is_len ? kTokMatch | (len << 16) | (dist - 1u) : value;   // (column kTokRing: nobody reads it)
                 n_tok += put ? 1u : 0u;
                 out_len += put ? grow : 0u;
-                member_bytes += put ? grow : 0u;
                 if (err) { status = err; state = ST_DONE; }
                 else if (is_eob) state = final_block ? ST_TRAILER : ST_BLOCK;
                 // leave the loop for a block's end or an error somewhere, and for a round
@@ -381,11 +416,11 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
         } else if (state == ST_BLOCK && [&] {
                        // between two blocks: has the decoding arrived at a start that another segment decodes from?
                        const uint64_t here = br.consumed_bits();
-                       if (here == job.start_bit) return false;
-                       while (my_cands[ci] < here) ++ci;
-                       return my_cands[ci] == here;
+                       if (here == start_bit) return false;
+                       while (ci < cand_hi && (A.sorted[ci] & kBitMask) < here) ++ci;
+                       return ci < cand_hi && (A.sorted[ci] & kBitMask) == here;
                    }()) {
-            link = ci;
+            link = A.n + ci;
             state = ST_DONE;                                         // (status stays OK: the chain goes on in that segment)
         } else if (state == ST_BLOCK) {
             final_block = br.get(1) != 0;
@@ -395,17 +430,17 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 const uint32_t len = br.get(16), nlen = br.get(16);
                 const uint64_t at = br.consumed_bits() >> 3;        // (byte-aligned: the block's bytes lie here as they are)
                 if ((len ^ nlen) != 0xffffu) fail(MK_GZ_BAD_STORED);
-                else if (br.over || at + len > job.in_len) fail(MK_GZ_TRUNCATED);
-                else if (len > job.out_cap - out_len) fail(MK_GZ_OUTPUT_ROOM);
+                else if (br.over || at + len > st.in_len) fail(MK_GZ_TRUNCATED);
+                else if (len > kOutMax - out_len) fail(MK_GZ_OUTPUT_ROOM);
                 else {
-                    if (len) { emit(kTokStored | len); emit((uint32_t)at); out_len += len; member_bytes += len; }
-                    if (state != ST_DONE) { br.seek_byte(at + len); state = final_block ? ST_TRAILER : ST_BLOCK; }
+                    if (len) { emit(kTokStored | len); emit((uint32_t)at); out_len += len; }
+                    br.seek_byte(at + len); state = final_block ? ST_TRAILER : ST_BLOCK;
                 }
             } else if (type == 1u) {
                 for (uint32_t i = 0; i < 288u; ++i) L.lens[i][lane] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8);
                 for (uint32_t i = 0; i < 32u; ++i) L.lens[288u + i][lane] = 5;
-                (void)build_code(L, lane, 0, 288, 0, sorted);
-                (void)build_code(L, lane, 288, 32, 1, sorted);      // (codes 30 and 31 decode to an error, as in zlib's fixed table)
+                (void)build_code(L, lane, 0, 288, 0, sorted_syms);
+                (void)build_code(L, lane, 288, 32, 1, sorted_syms);      // (codes 30 and 31 decode to an error, as in zlib's fixed table)
                 long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane);
                 state = ST_TOKENS;
             } else if (type == 2u) {
@@ -418,11 +453,11 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                     const uint32_t which = i < 3u ? 16u + i : i == 3u ? 0u : (j & 1u) ? 7u - (j >> 1) : 8u + (j >> 1);
                     L.lens[which][lane] = (uint8_t)br.get(3);
                 }
-                ok = ok && build_code(L, lane, 0, 19, 2, sorted);
+                ok = ok && build_code(L, lane, 0, 19, 2, sorted_syms);
                 uint32_t i = 0, prev = 0;
-                const uint32_t total = hlit + hdist;
-                // the lengths of both alphabets, run-length coded (at most `total` passes: every pass writes a length)
-                while (ok && i < total) {
+                const uint32_t total_lens = hlit + hdist;
+                // the lengths of both alphabets, run-length coded (at most `total_lens` passes: every pass writes a length)
+                while (ok && i < total_lens) {
                     const uint32_t ce = L.dist[br.peek(7)][col];
                     if (!ce) { ok = false; break; }
                     br.drop(ce >> 5);
@@ -433,7 +468,7 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                         if (sym == 16u) { if (!i) { ok = false; break; } val = prev; rep = 3u + br.get(2); }
                         else if (sym == 17u) rep = 3u + br.get(3);
                         else rep = 11u + br.get(7);
-                        if (i + rep > total) { ok = false; break; }
+                        if (i + rep > total_lens) { ok = false; break; }
                         for (uint32_t r = 0; r < rep; ++r) L.lens[32u + i + r][lane] = (uint8_t)val;
                         i += rep; prev = val;
                     }
@@ -441,8 +476,8 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                 }
                 // (the lengths lie at lens[32 ...]: the code length code's own nineteen stay below them)
                 ok = ok && L.lens[32u + 256u][lane] != 0;             // no end-of-block code: inflate.c "missing end-of-block"
-                ok = ok && build_code(L, lane, 32, hlit, 0, sorted);
-                ok = ok && build_code(L, lane, 32u + hlit, hdist, 1, sorted);
+                ok = ok && build_code(L, lane, 32, hlit, 0, sorted_syms);
+                ok = ok && build_code(L, lane, 32u + hlit, hdist, 1, sorted_syms);
                 if (!ok) fail(br.over ? MK_GZ_TRUNCATED : MK_GZ_BAD_LENGTHS);
                 else { long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane); state = ST_TOKENS; }
             } else {
@@ -456,23 +491,21 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
             emit(crc);
             emit(isize);
             ++members;
-            member_bytes = 0;
             const uint64_t used = br.consumed_bits() >> 3;          // whole bytes: the reader is byte-aligned here
-            if (br.over || used > job.in_len) fail(MK_GZ_TRUNCATED);
-            else if (state != ST_DONE) {
-                if (used == job.in_len) state = ST_DONE;              // the stream ends with this member: status stays OK
-                else state = ST_MEMBER;                               // another member must follow (anything else: a status)
-            }
+            if (br.over || used > st.in_len) fail(MK_GZ_TRUNCATED);
+            else if (used == st.in_len) state = ST_DONE;              // the stream ends with this member: status stays OK
+            else state = ST_MEMBER;                                   // another member must follow (anything else: a status)
         } else if (state == ST_MEMBER) {
             // RFC 1952 2.3: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16]
-            const uint64_t left = (uint64_t)job.in_len - (br.consumed_bits() >> 3);
-            if (left < 18u) fail(members ? MK_GZ_TRAILING : MK_GZ_NOT_GZIP);
+            const uint64_t left = (uint64_t)st.in_len - (br.consumed_bits() >> 3);
+            const bool first = start_bit == 0ull && members == 0u && n_tok == 0u;
+            if (left < 18u) fail(first ? MK_GZ_NOT_GZIP : MK_GZ_TRAILING);
             else {
                 const uint32_t id = br.get(16), cm = br.get(8), flg = br.get(8);
                 (void)br.get(32); (void)br.get(16);
-                if (id != 0x8b1fu || cm != 8u || (flg & 0xe0u)) fail(members ? MK_GZ_TRAILING : MK_GZ_NOT_GZIP);
+                if (id != 0x8b1fu || cm != 8u || (flg & 0xe0u)) fail(first ? MK_GZ_NOT_GZIP : MK_GZ_TRAILING);
                 else {
-                    uint64_t budget = job.in_len;                     // bytes these loops may skip at most
+                    uint64_t budget = st.in_len;                      // bytes these loops may skip at most
                     if (flg & 4u) {
                         uint32_t xlen = br.get(16);
                         while (xlen && budget && !br.over) { (void)br.get(8); --xlen; --budget; }
@@ -480,21 +513,20 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(const uint8_t *__restrict
                     for (uint32_t f = 8u; f <= 16u; f <<= 1)          // name, comment: zero-terminated
                         if (flg & f) while (budget && !br.over && br.get(8) != 0u) --budget;
                     if (flg & 2u) (void)br.get(16);
-                    if (br.over || !budget || (br.consumed_bits() >> 3) + 8u > job.in_len) fail(MK_GZ_TRUNCATED);
+                    if (br.over || !budget || (br.consumed_bits() >> 3) + 8u > st.in_len) fail(MK_GZ_TRUNCATED);
                     else state = ST_BLOCK;
                 }
             }
         }
     }
     round();                                                         // what is left in the rings: whole fours, then the rest
-    if (writing) for (uint32_t i = 0; i < n_tok - n_out; ++i) tok_base[n_out + i] = L.tok[lane][i];
-    if (live) {
-        jobs[s].n_tok = n_tok;
-        jobs[s].out_len = out_len;
-        jobs[s].status = status;
-        jobs[s].members = members;
-        jobs[s].link = link;
-        jobs[s].member_tail = member_bytes;
+    for (uint32_t i = 0; i < n_tok - n_out; ++i) if (n_out + i < cap) tok_base[n_out + i] = L.tok[lane][i];
+    if (idx < total && g < A.n + A.good_cap) {
+        mk_gz_seg r;
+        r.tok_ptr = (uint64_t)tok_base; r.tok_cap = cap; r.n_tok = n_tok; r.out_len = out_len;
+        r.status = live ? status : (uint32_t)MK_GZ_EMPTY; r.members = members; r.link = link;
+        A.segs[g] = r;
+    }
     }
 }
 
@@ -612,8 +644,9 @@ __global__ __launch_bounds__(64) void gz_check_kernel(const uint8_t *__restrict_
                                                       uint32_t good_cap)
 {
     __shared__ uint8_t cl_tab[128][64];                              // the code length code's table, a column per lane: symbol | length << 5
-    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane, total = min(*n_hits, cap);
-    if (i >= total) return;
+    // (the number of hits lives on the device: a fixed grid walks them, every lane its own table column)
+    const uint32_t lane = threadIdx.x, total = min(*n_hits, cap);
+    for (uint32_t i = blockIdx.x * 64u + lane; i < total; i += gridDim.x * 64u) {
     const uint64_t h = hits[i];
     const uint32_t s = (uint32_t)(h >> 40);
     const uint64_t bit = h & ((1ull << 40) - 1ull);
@@ -685,6 +718,106 @@ __global__ __launch_bounds__(64) void gz_check_kernel(const uint8_t *__restrict_
         const uint32_t at = atomicAdd(n_good, 1u);
         if (at < good_cap) good[at] = h;
     }
+    }
+}
+
+// ---------------------------------------------------------------- the candidates in order, the chains
+// The starts that passed both tests arrive in no order (an atomic counter): they are counted per stream, every stream gets
+// its stretch of the list (a scan over the streams), they are dropped into it and ranked inside it -- a stream of 5 Mb has
+// sixty of them, so "how many of my stream's are smaller than me" is sixty reads.  All on the device: the host never
+// learns how many there are.
+__global__ __launch_bounds__(256) void gz_cand_count_kernel(const uint64_t *__restrict__ good, const uint32_t *__restrict__ n_good, uint32_t good_cap, uint32_t n,
+                                                            uint32_t *__restrict__ per_stream)
+{
+    const uint32_t total = min(*n_good, good_cap);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t s = (uint32_t)(good[i] >> 40);
+        if (s < n) atomicAdd(&per_stream[s], 1u);
+    }
+}
+
+// one workgroup: every stream's stretch [cand_lo, cand_hi) of the ordered list
+__global__ __launch_bounds__(1024) void gz_cand_scan_kernel(mk_gz_stream *__restrict__ streams, uint32_t n, const uint32_t *__restrict__ per_stream)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < n; s0 += 1024u) {
+        const uint32_t s = s0 + threadIdx.x, mine = s < n ? per_stream[s] : 0u;
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024u; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t hi = carry + part[threadIdx.x];
+        if (s < n) { streams[s].cand_lo = hi - mine; streams[s].cand_hi = hi; }
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = hi;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gz_cand_scatter_kernel(const uint64_t *__restrict__ good, const uint32_t *__restrict__ n_good, uint32_t good_cap, uint32_t n,
+                                                              const mk_gz_stream *__restrict__ streams, uint32_t *__restrict__ fill, uint64_t *__restrict__ tmp)
+{
+    const uint32_t total = min(*n_good, good_cap);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint64_t key = good[i];
+        const uint32_t s = (uint32_t)(key >> 40);
+        if (s < n) tmp[streams[s].cand_lo + atomicAdd(&fill[s], 1u)] = key;
+    }
+}
+
+// (tmp holds every stream's candidates in its stretch, unordered: a thread per entry finds its rank among its stream's)
+__global__ __launch_bounds__(256) void gz_cand_rank_kernel(const uint64_t *__restrict__ tmp, const uint32_t *__restrict__ n_good, uint32_t good_cap, uint32_t n,
+                                                           const mk_gz_stream *__restrict__ streams, uint64_t *__restrict__ sorted)
+{
+    const uint32_t total = min(*n_good, good_cap);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint64_t key = tmp[i];
+        const uint32_t s = (uint32_t)(key >> 40);
+        if (s >= n) continue;
+        const uint32_t lo = streams[s].cand_lo, hi = streams[s].cand_hi;
+        uint32_t rank = 0;
+        for (uint32_t j = lo; j < hi; ++j) { const uint64_t o = tmp[j]; rank += o < key || (o == key && j < i) ? 1u : 0u; }
+        sorted[lo + rank] = key;
+    }
+}
+
+// The chain of every stream: from its first byte from link to link to its end -- a thread per stream.  What it passes is the
+// stream's text: token count, length, members; a segment that failed, or that no link leads to, ends it with that status.
+__global__ __launch_bounds__(64) void gz_chain_kernel(mk_gz_stream *__restrict__ streams, uint32_t n, const mk_gz_seg *__restrict__ segs, uint32_t *__restrict__ chain,
+                                                      uint32_t *__restrict__ n_rewrite)
+{
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= n) return;
+    mk_gz_stream st = streams[s];
+    if (st.status != MK_GZ_OK) return;
+    const uint32_t room = st.cand_hi - st.cand_lo + 1u;               // segments of this stream
+    uint32_t *__restrict__ mine = chain + st.cand_lo + s;
+    uint64_t ntok = 0, nout = 0;
+    uint32_t members = 0, status = MK_GZ_OK, cur = s, steps = 0, rewrite = 0;
+    for (;;) {                                                       // (links only lead forward: at most `room` passes)
+        const mk_gz_seg sg = segs[cur];
+        if (sg.status != MK_GZ_OK) { status = sg.status; break; }
+        if (steps >= room) { status = MK_GZ_INTERNAL; break; }
+        mine[steps++] = cur;
+        rewrite |= sg.n_tok > sg.tok_cap ? 1u : 0u;
+        ntok += sg.n_tok; nout += sg.out_len; members += sg.members;
+        if (nout >= kOutMax || ntok >= kOutMax) { status = MK_GZ_OUTPUT_ROOM; break; }
+        if (sg.link == 0xffffffffu) break;                           // the stream's end
+        if (sg.link <= cur || sg.link < n + st.cand_lo || sg.link >= n + st.cand_hi) { status = MK_GZ_INTERNAL; break; }
+        cur = sg.link;
+    }
+    st.status = status; st.members = members; st.n_chain = status == MK_GZ_OK ? steps : 0u;
+    st.n_tok = (uint32_t)ntok; st.out_len = (uint32_t)nout;
+    st.rewrite = status == MK_GZ_OK ? rewrite : 0u;
+    streams[s] = st;
+    if (st.rewrite) atomicAdd(n_rewrite, 1u);
 }
 
 // ---------------------------------------------------------------- phase 2: tokens -> text
@@ -723,7 +856,8 @@ struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t b
 // side by side kept each other off the CUs.
 constexpr uint32_t kResolveWaves = 2;
 __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
-                                                         const uint32_t *__restrict__ tokens, uint8_t *__restrict__ text, ResolveConsts K)
+                                                         const mk_gz_seg *__restrict__ segs, const uint32_t *__restrict__ chain, uint8_t *__restrict__ text,
+                                                         ResolveConsts K)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsmem[];
     uint32_t (*crc_tab)[256] = reinterpret_cast<uint32_t (*)[256]>(rsmem);           // slice-by-4 tables (reflected 0xEDB88320)
@@ -744,10 +878,10 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
     if (s >= n) return;
     const mk_gz_stream job = jobs[s];
     if (job.status != MK_GZ_OK) return;
-    const uint32_t *__restrict__ tok = tokens + job.tok_off;
     uint8_t *__restrict__ out = text + job.out_off;
-    const uint32_t ntok = job.n_tok;
-    uint32_t t0 = 0, pos = 0, flushed = 0;          // pos: bytes produced so far; [0, flushed) are in `out` (flushed % kFlush == 0)
+    // the stream's tokens lie where its segments left them: the chain says in which order
+    const uint32_t *__restrict__ my_chain = chain + job.cand_lo + s;
+    uint32_t pos = 0, flushed = 0;                  // pos: bytes produced so far; [0, flushed) are in `out` (flushed % kFlush == 0)
     uint32_t crc_raw = 0;                             // remainder of the member's bytes [member_pos, crc_from) (start 0, no complement)
     uint32_t member_pos = 0, crc_from = 0;
     uint32_t status = MK_GZ_OK;
@@ -807,6 +941,12 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         const uint32_t whole = pos / kFlush * kFlush;
         if (whole > flushed) { crc_to(whole); flush_to(whole); }
     };
+    for (uint32_t ch = 0; ch < job.n_chain && status == MK_GZ_OK; ++ch) {
+    const mk_gz_seg sg = segs[my_chain[ch]];
+    const uint32_t *__restrict__ tok = reinterpret_cast<const uint32_t *>(sg.tok_ptr);
+    const uint32_t ntok = min(sg.n_tok, sg.tok_cap);                 // (more than its room: the host has had the segment decoded again)
+    if (sg.n_tok > sg.tok_cap) { status = MK_GZ_INTERNAL; break; }
+    uint32_t t0 = 0;
     uint32_t t_next = lane < ntok ? tok[lane] : kTokMember;          // the step's tokens, requested a step ahead
     uint32_t t_next_at = 0;
     while (t0 < ntok && status == MK_GZ_OK) {                        // (every pass takes at least one token)
@@ -857,7 +997,10 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         const bool act = lane < take;
         const uint32_t dst = pos + incl - len;
         const uint32_t dist = is_match ? (t & 0x7fffu) + 1u : 0u;
-        const uint32_t src = dst - dist;                             // (phase 1 checked dist <= bytes of this member so far)
+        const uint32_t src = dst - dist;
+        // a match may reach back as far as its member's first byte and no further (checked here: the token pass does not know
+        // how much of the member lies before a segment)
+        if (__any(act && is_match && dist > dst - member_pos)) { status = MK_GZ_BAD_DISTANCE; break; }
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(take - 1u));
         // rounds: a token is ready when its source bytes lie below the first unfinished token's place -- or when it IS that
         // token (its own bytes may overlap its source: such a copy runs byte by byte in order)
@@ -907,6 +1050,7 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         pos += total;
         t0 += take;
         leave();
+    }
     }
     if (status == MK_GZ_OK) {
         if (pos != job.out_len || member_pos != pos) status = MK_GZ_INTERNAL;      // (the last token is a member's end)
@@ -1005,23 +1149,35 @@ static void gz_pin_put(mk_ctx *c, void *p, uint64_t bytes)
     c->gz_pins.emplace_back(p, bytes);
 }
 
-// One batch of streams through the inflater: the files' bytes up, where their blocks start (gz_find / gz_check), every
-// segment measured (gz_tokens, write = 0), the chain of segments from each stream's first byte to its last followed on the
-// host -- which gives every stream's token count and text length exactly --, then the pass that writes the tokens and the
-// pass that turns them into text (gz_resolve).  The text stays on the device (blk_out) with the streams' results in
-// `streams`; a stream whose status is not MK_GZ_OK has no text.
+// One batch of streams through the inflater, three steps:
+//   gz_open    the layout (every stream's place follows from the files' sizes), the device blocks, the tables up;
+//   gz_put     a file's bytes (or a piece of them) to their place -- from a page-locked piece of the context's pool
+//              (mk_gz_stage) a DMA on one of four upload streams, from any other memory a staged copy; any thread;
+//   gz_finish  everything else, queued back to back on the run's stream: block starts (gz_find / gz_check), the candidates
+//              in order, every segment decoded into its slots (gz_tokens), the chains -- then the ONE point where the host
+//              must look (how long is every text: the out block is allocated from that) --, tokens to text (gz_resolve).
+// The text stays on the device (blk_out) with the streams' results in `streams`; a stream whose status is not MK_GZ_OK
+// has no text.
 struct GzRun {
     mk_ctx *c = nullptr;
     hipStream_t st = nullptr;
     uint32_t n = 0;
     std::vector<mk_gz_stream> streams;
-    uint8_t *blk_in = nullptr, *blk_seg = nullptr, *blk_out = nullptr;
-    uint64_t in_bytes = 0, seg_bytes = 0, out_bytes = 0;
-    uint8_t *d_text = nullptr;
+    uint8_t *blk_in = nullptr, *blk_tok = nullptr, *blk_out = nullptr;
+    uint64_t in_bytes = 0, tok_bytes = 0, out_bytes = 0;
+    uint8_t *d_gz = nullptr, *d_text = nullptr;
     mk_gz_stream *d_streams = nullptr;
+    uint64_t *d_wf = nullptr, *d_hits = nullptr, *d_good = nullptr, *d_tmp = nullptr, *d_sorted = nullptr;
+    uint32_t *d_per_stream = nullptr, *d_fill = nullptr, *d_cnt = nullptr;       // d_cnt: hits, good, the token kernel's queue, streams to rewrite
+    uint32_t *d_slots = nullptr, *d_chain = nullptr, *d_aux = nullptr;
+    mk_gz_seg *d_segs = nullptr;
     uint8_t *d_extra = nullptr;                                       // `extra` bytes of the out block for the caller (256-byte aligned)
-    uint32_t n_segs = 0, n_cands = 0;
-    double t_up = 0, t_find = 0, t_measure = 0, t_write = 0, t_text = 0;
+    uint64_t in_at = 0, total_words = 0;
+    uint32_t hit_cap = 0, good_cap = 0, tok_wgs = 0;
+    uint32_t n_segs = 0, n_rewritten = 0;
+    hipEvent_t ev_open = nullptr;                                     // the blocks are ready for the files' bytes
+    bool loose_puts = false;                                          // some file came from memory that is not the pool's: on the run's own stream
+    double t_open = 0, t_blocks = 0, t_text = 0;
     // page-locked staging: pieces in use, and the downloads that wait for the stream (staging -> the caller's memory)
     struct Pin { uint8_t *p; uint64_t size, used; };
     std::vector<Pin> pins;
@@ -1082,17 +1238,24 @@ struct GzRun {
     }
     ~GzRun()
     {
+        if (c) {
+            (void)hipSetDevice(c->p.device);
+            for (hipStream_t u : c->gz_up) if (u) (void)wait_stream(u);    // (copies into this run's blocks may still be queued there)
+        }
         if (st) { (void)wait_stream(st); (void)hipStreamDestroy(st); }
         if (ev) (void)hipEventDestroy(ev);
+        if (ev_open) (void)hipEventDestroy(ev_open);
         if (c) {
-            gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_seg, seg_bytes); gz_block_put(c, blk_out, out_bytes);
+            gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_tok, tok_bytes); gz_block_put(c, blk_out, out_bytes);
             for (Pin &p : pins) gz_pin_put(c, p.p, p.size);
         }
     }
 };
 
-static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, const uint64_t *out_room,
-                  const std::function<uint64_t(const std::vector<mk_gz_stream> &)> &extra_bytes)
+constexpr uint64_t kStagePiece = 4ull << 20;
+constexpr uint32_t kStagePieces = 96;                                 // at most 384 MB of page-locked pieces per context
+
+static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
 {
     r.c = c; r.n = n;
     r.streams.assign(n, mk_gz_stream{});
@@ -1102,7 +1265,7 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
     hipStream_t st = r.st;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    // ---- the input block: the files, the streams, the finder's lists
+    // ---- the input block: the files, the streams, the finder's lists, the candidates
     uint64_t in_at = 0;
     std::vector<uint64_t> word_first(n + 1, 0);
     for (uint32_t i = 0; i < n; ++i) {
@@ -1113,191 +1276,252 @@ static int gz_run(GzRun &r, mk_ctx *c, const uint8_t *const *gz, const uint64_t 
         in_at += ((uint64_t)j.in_len + 16u + 15u) / 16u * 16u;
         word_first[i + 1] = word_first[i] + ((uint64_t)j.in_len + 3u) / 4u;
     }
-    const uint64_t total_words = word_first[n];
-    const uint32_t hit_cap = (uint32_t)std::min<uint64_t>(total_words / 8u + 65536u, 1u << 30);       // (0.1 % of the bit offsets pass the first test: room for 0.4 %)
-    const uint32_t good_cap = (uint32_t)std::min<uint64_t>(in_at / 2048u + 64ull * n + 4096u, 1u << 28);   // (a block per 26 KB of gzip'd DNA)
+    r.in_at = in_at;
+    r.total_words = word_first[n];
+    r.hit_cap = (uint32_t)std::min<uint64_t>(r.total_words / 8u + 65536u, 1u << 30);       // (0.1 % of the bit offsets pass the first test: room for 0.4 %)
+    r.good_cap = (uint32_t)std::min<uint64_t>(in_at / 2048u + 64ull * n + 4096u, 1u << 28);   // (a block per 26 KB of gzip'd DNA)
+    int cus = 0;
+    MK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->p.device));
+    r.tok_wgs = 2u * (uint32_t)std::max(cus, 1);                      // (two workgroups of the token kernel share a CU's LDS)
     uint64_t at = 0;
     auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
     const uint64_t o_gz = carve(in_at + 16), o_streams = carve((uint64_t)n * sizeof(mk_gz_stream)), o_wf = carve(((uint64_t)n + 1) * 8),
-                   o_hits = carve((uint64_t)hit_cap * 8), o_good = carve((uint64_t)good_cap * 8), o_cnt = carve(64);
+                   o_hits = carve((uint64_t)r.hit_cap * 8), o_good = carve((uint64_t)r.good_cap * 8), o_tmp = carve((uint64_t)r.good_cap * 8),
+                   o_sorted = carve((uint64_t)r.good_cap * 8), o_per = carve((uint64_t)n * 4), o_fill = carve((uint64_t)n * 4), o_cnt = carve(64);
     r.blk_in = gz_block_get(c, at, &r.in_bytes);
     if (!r.blk_in) { set_error("no device memory for %u gzip'd files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
-    uint8_t *d_gz = r.blk_in + o_gz;
+    r.d_gz = r.blk_in + o_gz;
     r.d_streams = reinterpret_cast<mk_gz_stream *>(r.blk_in + o_streams);
-    uint64_t *d_wf = reinterpret_cast<uint64_t *>(r.blk_in + o_wf), *d_hits = reinterpret_cast<uint64_t *>(r.blk_in + o_hits),
-             *d_good = reinterpret_cast<uint64_t *>(r.blk_in + o_good);
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(r.blk_in + o_cnt);
-    for (uint32_t i = 0; i < n; ++i) {
-        const mk_gz_stream &j = r.streams[i];
-        if (j.in_len) MK_HIP(hipMemcpyAsync(d_gz + j.in_off, gz[i], j.in_len, hipMemcpyHostToDevice, st));
-        const uint64_t end = j.in_off + j.in_len, next = i + 1 < n ? r.streams[i + 1].in_off : in_at + 16;
-        MK_HIP(hipMemsetAsync(d_gz + end, 0, next - end, st));      // (the bit reader may look 16 bytes past a stream's end)
-    }
-    MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
-    MK_TRY(r.up(d_wf, word_first.data(), ((size_t)n + 1) * 8));
-    MK_HIP(hipMemsetAsync(d_cnt, 0, 64, st));
-    MK_TRY(r.settle());
-    r.t_up = now() - t0;
-    // ---- where blocks start
-    const double t1 = now();
-    uint32_t cnt[2] = {0, 0};
-    if (total_words) {
-        hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((total_words + 255u) / 256u)), dim3(256), 0, st, d_gz, r.d_streams, d_wf, n, d_hits, d_cnt, hit_cap);
-        MK_HIP(hipGetLastError());
-        MK_TRY(r.down(cnt, d_cnt, 4));
-        MK_TRY(r.settle());
-        const uint32_t nh = std::min(cnt[0], hit_cap);
-        if (nh) {
-            hipLaunchKernelGGL(gz_check_kernel, dim3((nh + 63u) / 64u), dim3(64), 0, st, d_gz, r.d_streams, d_hits, d_cnt, hit_cap, d_good, d_cnt + 1, good_cap);
-            MK_HIP(hipGetLastError());
-        }
-        MK_TRY(r.down(cnt, d_cnt, 8));
-        MK_TRY(r.settle());
-    }
-    const uint32_t ng = std::min(cnt[1], good_cap);
-    std::vector<uint64_t> good(ng);
-    if (ng) { MK_TRY(r.down(good.data(), d_good, (size_t)ng * 8)); MK_TRY(r.settle()); }
-    std::sort(good.begin(), good.end());                              // (stream << 40 | bit: by stream, then by place)
-    good.erase(std::unique(good.begin(), good.end()), good.end());
-    r.t_find = now() - t1;
-    // ---- the segments: every stream's first byte and every candidate start; a stream's candidates end with ~0
-    const double t2 = now();
-    std::vector<uint64_t> cands;
-    std::vector<mk_gz_seg> segs;
-    std::vector<uint32_t> seg_first(n + 1, 0);
-    cands.reserve(good.size() + n);
-    segs.reserve(good.size() + n);
-    size_t gi = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const mk_gz_stream &j = r.streams[i];
-        const uint64_t c_off = cands.size();
-        while (gi < good.size() && (uint32_t)(good[gi] >> 40) < i) ++gi;
-        size_t ge = gi;
-        while (ge < good.size() && (uint32_t)(good[ge] >> 40) == i) ++ge;
-        seg_first[i] = (uint32_t)segs.size();
-        if (j.status == MK_GZ_OK) {
-            mk_gz_seg sg;
-            memset(&sg, 0, sizeof sg);
-            sg.in_off = j.in_off; sg.in_len = j.in_len; sg.stream = i; sg.cand_off = c_off;
-            sg.tok_cap = sg.out_cap = 0xffffffffu; sg.member_out0 = 1u << 30;
-            sg.start_bit = 0; sg.cand_next = 0;
-            segs.push_back(sg);
-            for (size_t g = gi; g < ge; ++g) {
-                sg.start_bit = good[g] & ((1ull << 40) - 1ull);
-                sg.cand_next = (uint32_t)(g - gi) + 1u;
-                segs.push_back(sg);
-                cands.push_back(sg.start_bit);
-            }
-        }
-        cands.push_back(~0ull);
-        gi = ge;
-    }
-    seg_first[n] = (uint32_t)segs.size();
-    r.n_segs = (uint32_t)segs.size(); r.n_cands = (uint32_t)cands.size();
+    r.d_wf = reinterpret_cast<uint64_t *>(r.blk_in + o_wf); r.d_hits = reinterpret_cast<uint64_t *>(r.blk_in + o_hits);
+    r.d_good = reinterpret_cast<uint64_t *>(r.blk_in + o_good); r.d_tmp = reinterpret_cast<uint64_t *>(r.blk_in + o_tmp);
+    r.d_sorted = reinterpret_cast<uint64_t *>(r.blk_in + o_sorted);
+    r.d_per_stream = reinterpret_cast<uint32_t *>(r.blk_in + o_per); r.d_fill = reinterpret_cast<uint32_t *>(r.blk_in + o_fill);
+    r.d_cnt = reinterpret_cast<uint32_t *>(r.blk_in + o_cnt);
+    // ---- the token block: a slot per byte of the input block, the segments' results, the chains, the lanes' symbol lists
     at = 0;
-    const uint64_t o_cands = carve(cands.size() * 8), o_segs = carve(segs.size() * sizeof(mk_gz_seg)), o_aux = carve((uint64_t)segs.size() * 288u * 4u);
-    r.blk_seg = gz_block_get(c, at + 256, &r.seg_bytes);
-    if (!r.blk_seg) { set_error("no device memory for %zu segments", segs.size()); return MK_ERR_NOMEM; }
-    uint64_t *d_cands = reinterpret_cast<uint64_t *>(r.blk_seg + o_cands);
-    mk_gz_seg *d_segs = reinterpret_cast<mk_gz_seg *>(r.blk_seg + o_segs);
-    uint32_t *d_aux = reinterpret_cast<uint32_t *>(r.blk_seg + o_aux);
+    const uint64_t n_seg_room = (uint64_t)n + r.good_cap;
+    const uint64_t o_slots = carve((in_at + 16) * 4), o_segs = carve(n_seg_room * sizeof(mk_gz_seg)), o_chain = carve(n_seg_room * 4),
+                   o_aux = carve((uint64_t)r.tok_wgs * 64u * 288u * 4u);
+    r.blk_tok = gz_block_get(c, at, &r.tok_bytes);
+    if (!r.blk_tok) { set_error("no device memory for the tokens of %u gzip'd files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
+    r.d_slots = reinterpret_cast<uint32_t *>(r.blk_tok + o_slots);
+    r.d_segs = reinterpret_cast<mk_gz_seg *>(r.blk_tok + o_segs);
+    r.d_chain = reinterpret_cast<uint32_t *>(r.blk_tok + o_chain);
+    r.d_aux = reinterpret_cast<uint32_t *>(r.blk_tok + o_aux);
+    // (the bit reader may look 16 bytes past a stream's end, and a file that never arrives must read as nothing: zeros
+    // everywhere first -- one fill instead of one per file)
+    MK_HIP(hipMemsetAsync(r.d_gz, 0, in_at + 16, st));
+    MK_HIP(hipMemsetAsync(r.d_per_stream, 0, (o_cnt + 64) - o_per, st));     // the per-stream counts, the fill marks, the counters
+    MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
+    MK_TRY(r.up(r.d_wf, word_first.data(), ((size_t)n + 1) * 8));
+    MK_HIP(hipEventCreateWithFlags(&r.ev_open, hipEventDisableTiming));
+    MK_HIP(hipEventRecord(r.ev_open, st));
+    r.t_open = now() - t0;
+    return MK_OK;
+}
+
+// a page-locked piece of kStagePiece bytes to read (a piece of) a file into; null: none to be had (use any memory)
+static void *gz_stage_get(mk_ctx *c)
+{
+    (void)hipSetDevice(c->p.device);
+    mk_ctx::GzStage got{nullptr, nullptr};
+    bool wait = false;
+    {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        if (!c->gz_stage_free.empty()) { got = c->gz_stage_free.back(); c->gz_stage_free.pop_back(); }
+        else if (c->gz_stage_made < kStagePieces) ++c->gz_stage_made;
+        else if (!c->gz_stage_busy.empty()) { got = c->gz_stage_busy.front(); c->gz_stage_busy.pop_front(); wait = true; }
+        else return nullptr;                                          // (every piece is in some caller's hands)
+    }
+    if (!got.p) {
+        if (hipHostMalloc(&got.p, kStagePiece, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&got.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (got.p) (void)hipHostFree(got.p);
+            std::lock_guard<std::mutex> g(c->gz_m);
+            --c->gz_stage_made;
+            return nullptr;
+        }
+    } else if (wait) {
+        (void)hipEventSynchronize(got.ev);                            // the oldest queued copy: done soonest
+    }
+    std::lock_guard<std::mutex> g(c->gz_m);
+    c->gz_stage_held.push_back(got);
+    return got.p;
+}
+
+// bytes [at, at + bytes) of file i; staged: `data` is a piece from gz_stage_get, which takes it back when the copy is done
+static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
+{
+    mk_ctx *c = r.c;
+    if (i >= r.n || at + bytes > r.streams[i].in_len) { set_error("file %u: bytes beyond its size", i); return MK_ERR_ARG; }
+    MK_HIP(hipSetDevice(c->p.device));
+    uint8_t *dst = r.d_gz + r.streams[i].in_off + at;
+    if (!staged) {
+        if (bytes) MK_HIP(hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, r.st));
+        r.loose_puts = true;
+        return MK_OK;
+    }
+    mk_ctx::GzStage piece{nullptr, nullptr};
+    hipStream_t up = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        for (size_t k = 0; k < c->gz_stage_held.size(); ++k)
+            if (c->gz_stage_held[k].p == data) { piece = c->gz_stage_held[k]; c->gz_stage_held.erase(c->gz_stage_held.begin() + (long)k); break; }
+        const uint32_t k = c->gz_up_next++ % 4u;
+        if (piece.p && !c->gz_up[k] && hipStreamCreateWithFlags(&c->gz_up[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->gz_up[k] = nullptr; }
+        up = c->gz_up[k];
+    }
+    if (!piece.p) { set_error("not a piece of the context's staging pool"); return MK_ERR_ARG; }
+    int rc = MK_OK;
+    if (!up || bytes > kStagePiece) { set_error("cannot queue the copy of file %u", i); rc = MK_ERR_DEVICE; }
+    else if (hipStreamWaitEvent(up, r.ev_open, 0) != hipSuccess || (bytes && hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, up) != hipSuccess) ||
+             hipEventRecord(piece.ev, up) != hipSuccess) { set_error("copy of file %u: %s", i, hipGetErrorString(hipGetLastError())); rc = MK_ERR_DEVICE; }
+    std::lock_guard<std::mutex> g(c->gz_m);
+    if (rc == MK_OK) c->gz_stage_busy.push_back(piece); else c->gz_stage_free.push_back(piece);
+    return rc;
+}
+
+static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uint64_t(const std::vector<mk_gz_stream> &)> &extra_bytes)
+{
+    mk_ctx *c = r.c;
+    const uint32_t n = r.n;
+    if (!n) return MK_OK;
+    MK_HIP(hipSetDevice(c->p.device));
+    hipStream_t st = r.st;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t1 = now();
+    // the files' copies (queued by whoever put them, on the upload streams) before anything reads them
+    for (hipStream_t u : c->gz_up)
+        if (u) {
+            hipEvent_t e = nullptr;
+            MK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            hipError_t er = hipEventRecord(e, u);
+            if (er == hipSuccess) er = hipStreamWaitEvent(st, e, 0);
+            (void)hipEventDestroy(e);                                 // (released when the work queued on it is done)
+            MK_HIP(er);
+        }
+    // ---- where blocks start; the candidates in order; every segment's tokens; the chains
+    if (r.total_words) {
+        hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((r.total_words + 255u) / 256u)), dim3(256), 0, st, r.d_gz, r.d_streams, r.d_wf, n, r.d_hits, r.d_cnt, r.hit_cap);
+        MK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gz_check_kernel, dim3(std::min<uint32_t>((r.hit_cap + 63u) / 64u, 8192u)), dim3(64), 0, st, r.d_gz, r.d_streams, r.d_hits, r.d_cnt, r.hit_cap,
+                           r.d_good, r.d_cnt + 1, r.good_cap);
+        MK_HIP(hipGetLastError());
+        const uint32_t wide = std::min<uint32_t>((r.good_cap + 255u) / 256u, 512u);
+        hipLaunchKernelGGL(gz_cand_count_kernel, dim3(wide), dim3(256), 0, st, r.d_good, r.d_cnt + 1, r.good_cap, n, r.d_per_stream);
+        MK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gz_cand_scan_kernel, dim3(1), dim3(1024), 0, st, r.d_streams, n, r.d_per_stream);
+    MK_HIP(hipGetLastError());
+    if (r.total_words) {
+        const uint32_t wide = std::min<uint32_t>((r.good_cap + 255u) / 256u, 512u);
+        hipLaunchKernelGGL(gz_cand_scatter_kernel, dim3(wide), dim3(256), 0, st, r.d_good, r.d_cnt + 1, r.good_cap, n, r.d_streams, r.d_fill, r.d_tmp);
+        MK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gz_cand_rank_kernel, dim3(wide), dim3(256), 0, st, r.d_tmp, r.d_cnt + 1, r.good_cap, n, r.d_streams, r.d_sorted);
+        MK_HIP(hipGetLastError());
+    }
     static_assert(sizeof(TokLds) <= 80u << 10, "phase 1's tables and buffers: two waves per CU");
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
-    if (!segs.empty()) {
-        MK_TRY(r.up(d_cands, cands.data(), cands.size() * 8));
-        MK_TRY(r.up(d_segs, segs.data(), segs.size() * sizeof(mk_gz_seg)));
-        hipLaunchKernelGGL(gz_tokens_kernel, dim3((r.n_segs + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, r.n_segs, d_cands, (uint32_t *)nullptr, d_aux);
-        MK_HIP(hipGetLastError());
-        MK_TRY(r.down(segs.data(), d_segs, segs.size() * sizeof(mk_gz_seg)));
-        MK_TRY(r.settle());
-    }
-    // ---- the chain of every stream: from its first byte from link to link to its end
-    std::vector<mk_gz_seg> chain;                                     // the segments that are on a chain, with their places: the writing pass
-    uint64_t tok_at = 0, out_at = 0;
+    TokArgs A;
+    A.gz = r.d_gz; A.streams = r.d_streams; A.n = n; A.sorted = r.d_sorted; A.n_good = r.d_cnt + 1; A.good_cap = r.good_cap;
+    A.segs = r.d_segs; A.slots = r.d_slots; A.aux = r.d_aux; A.queue = r.d_cnt + 2; A.jobs = nullptr; A.n_jobs = 0;
+    hipLaunchKernelGGL(gz_tokens_kernel, dim3(r.tok_wgs), dim3(64), sizeof(TokLds), st, A);
+    MK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gz_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, r.d_streams, n, r.d_segs, r.d_chain, r.d_cnt + 3);
+    MK_HIP(hipGetLastError());
+    // ---- the one look: every stream's length and token count (and how many candidates there were)
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    MK_TRY(r.down(cnt, r.d_cnt, 16));
+    MK_TRY(r.down(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream)));
+    MK_TRY(r.settle());
+    const uint32_t ng = std::min(cnt[1], r.good_cap);
+    r.n_segs = n + ng;
+    uint64_t out_at = 0;
     for (uint32_t i = 0; i < n; ++i) {
         mk_gz_stream &j = r.streams[i];
-        if (j.status != MK_GZ_OK) continue;
-        const uint32_t s0 = seg_first[i], ns = seg_first[i + 1] - s0;
-        uint64_t ntok = 0, nout = 0;
-        uint32_t member_bytes = 0, members = 0, status = MK_GZ_OK, cur = 0, steps = 0;
-        const size_t chain0 = chain.size();
-        for (;;) {
-            const mk_gz_seg &sg = segs[s0 + cur];
-            if (sg.status != MK_GZ_OK) { status = sg.status; break; }
-            if (++steps > ns) { status = MK_GZ_INTERNAL; break; }   // (links only lead forward: cannot happen)
-            mk_gz_seg w = sg;
-            w.write = 1; w.tok_cap = sg.n_tok; w.out_cap = sg.out_len; w.member_out0 = member_bytes;
-            w.tok_off = ntok;                                          // (within the stream: its base is added below)
-            chain.push_back(w);
-            ntok += sg.n_tok; nout += sg.out_len;
-            members += sg.members;
-            member_bytes = sg.members ? sg.member_tail : member_bytes + sg.out_len;
-            if (nout >= 0xfffffff0ull || ntok >= 0xfffffff0ull) { status = MK_GZ_OUTPUT_ROOM; break; }
-            if (sg.link == 0xffffffffu) break;                        // the stream's end
-            cur = sg.link + 1u;                                        // candidate k is segment k + 1 of the stream
-            if (cur >= ns) { status = MK_GZ_INTERNAL; break; }
-        }
-        if (status == MK_GZ_OK && out_room && nout > out_room[i]) status = MK_GZ_OUTPUT_ROOM;
-        if (status == MK_GZ_OK && nout > (1ull << 30)) status = MK_GZ_OUTPUT_ROOM;          // (a larger text is the host's)
-        j.status = status; j.members = members;
-        if (status != MK_GZ_OK) { chain.resize(chain0); continue; }
-        j.n_tok = (uint32_t)ntok; j.out_len = (uint32_t)nout;
-        j.tok_off = tok_at; j.out_off = out_at;
-        // (a token's distance is checked against the bytes of its member so far, the first segment's member starts with it)
-        for (size_t k = chain0; k < chain.size(); ++k) chain[k].tok_off += tok_at;
-        tok_at += (ntok + 3u) / 4u * 4u;
-        out_at += (nout + 15u) / 16u * 16u;
+        if (j.status == MK_GZ_OK && out_room && j.out_len > out_room[i]) j.status = MK_GZ_OUTPUT_ROOM;
+        if (j.status != MK_GZ_OK) { j.n_chain = 0; j.rewrite = 0; j.out_len = 0; continue; }
+        j.out_off = out_at;
+        out_at += ((uint64_t)j.out_len + 15u) / 16u * 16u;
     }
-    r.t_measure = now() - t2;
-    // ---- the out block: tokens, text, whatever the caller wants behind them
+    // the few segments whose tokens did not fit their slots, once more with exact rooms (behind the text, in the out block)
+    std::vector<mk_gz_job> jobs;
+    uint64_t dense_words = 0;
+    if (cnt[3]) {
+        std::vector<mk_gz_seg> segs(r.n_segs);
+        std::vector<uint32_t> chain(r.n_segs);
+        MK_TRY(r.down(segs.data(), r.d_segs, segs.size() * sizeof(mk_gz_seg)));
+        MK_TRY(r.down(chain.data(), r.d_chain, chain.size() * 4));
+        MK_TRY(r.settle());
+        for (uint32_t i = 0; i < n; ++i) {
+            const mk_gz_stream &j = r.streams[i];
+            if (j.status != MK_GZ_OK || !j.rewrite) continue;
+            ++r.n_rewritten;
+            for (uint32_t k = 0; k < j.n_chain; ++k) {
+                const uint32_t g = chain[j.cand_lo + i + k];
+                if (g >= r.n_segs || segs[g].n_tok <= segs[g].tok_cap) continue;
+                mk_gz_job job;
+                job.seg = g; job.tok_cap = (segs[g].n_tok + 3u) & ~3u; job.tok_ptr = dense_words;   // (an offset for now)
+                dense_words += job.tok_cap;
+                jobs.push_back(job);
+            }
+        }
+    }
+    r.t_blocks = now() - t1;
+    // ---- the out block: text, whatever the caller wants behind it, the rewritten segments' tokens
     const double t3 = now();
     const uint64_t extra = extra_bytes ? extra_bytes(r.streams) : 0;
-    at = 0;
-    const uint64_t o_tok = carve((tok_at + 8) * 4), o_text = carve(out_at + 32), o_extra = carve(extra);
+    uint64_t at = 0;
+    auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
+    const uint64_t o_text = carve(out_at + 32), o_extra = carve(extra), o_dense = carve(dense_words * 4 + 16), o_jobs = carve(jobs.size() * sizeof(mk_gz_job) + 16);
     r.blk_out = gz_block_get(c, at + 256, &r.out_bytes);
     if (!r.blk_out) { set_error("no device memory for the text of %u files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
-    uint32_t *d_tok = reinterpret_cast<uint32_t *>(r.blk_out + o_tok);
     r.d_text = r.blk_out + o_text;
     r.d_extra = r.blk_out + o_extra;
     MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
-    if (!chain.empty()) {
-        const uint32_t nc = (uint32_t)chain.size();
-        MK_TRY(r.up(d_segs, chain.data(), chain.size() * sizeof(mk_gz_seg)));
-        hipLaunchKernelGGL(gz_tokens_kernel, dim3((nc + 63u) / 64u), dim3(64), sizeof(TokLds), st, d_gz, d_segs, nc, d_cands, d_tok, d_aux);
+    if (!jobs.empty()) {
+        for (mk_gz_job &job : jobs) job.tok_ptr = (uint64_t)(r.blk_out + o_dense) + job.tok_ptr * 4u;
+        mk_gz_job *d_jobs = reinterpret_cast<mk_gz_job *>(r.blk_out + o_jobs);
+        MK_TRY(r.up(d_jobs, jobs.data(), jobs.size() * sizeof(mk_gz_job)));
+        MK_HIP(hipMemsetAsync(r.d_cnt + 2, 0, 4, st));
+        A.jobs = d_jobs; A.n_jobs = (uint32_t)jobs.size();
+        hipLaunchKernelGGL(gz_tokens_kernel, dim3(std::min<uint32_t>(r.tok_wgs, (A.n_jobs + 63u) / 64u)), dim3(64), sizeof(TokLds), st, A);
         MK_HIP(hipGetLastError());
-        MK_TRY(r.down(chain.data(), d_segs, chain.size() * sizeof(mk_gz_seg)));
-        MK_TRY(r.settle());
-        // the writing pass must have seen what the measuring pass saw
-        for (const mk_gz_seg &w : chain)
-            if (w.status != MK_GZ_OK || w.n_tok != w.tok_cap || w.out_len != w.out_cap) {
-                mk_gz_stream &j = r.streams[w.stream];
-                if (j.status == MK_GZ_OK) j.status = w.status != MK_GZ_OK ? w.status : MK_GZ_INTERNAL;
-            }
-        MK_TRY(r.up(r.d_streams, r.streams.data(), (size_t)n * sizeof(mk_gz_stream)));
     }
-    r.t_write = now() - t3;
     // ---- tokens -> text
-    const double t4 = now();
     ResolveConsts K;
     for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
     K.block_shift = x_pow_bytes(kFlush);
     K.byte_shift = x_pow_bytes(1);
     const size_t lds2 = 4096u + kResolveWaves * kWin + 64u * kResolveWaves;   // CRC tables, the streams' windows, the lanes' sinks
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + kResolveWaves - 1u) / kResolveWaves), dim3(64u * kResolveWaves), lds2, st, d_gz, r.d_streams, n, d_tok, r.d_text, K);
+    hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + kResolveWaves - 1u) / kResolveWaves), dim3(64u * kResolveWaves), lds2, st, r.d_gz, r.d_streams, n, r.d_segs, r.d_chain,
+                       r.d_text, K);
     MK_HIP(hipGetLastError());
     MK_TRY(r.down(r.streams.data(), r.d_streams, (size_t)n * sizeof(mk_gz_stream)));
-    MK_TRY(r.settle());
-    r.t_text = now() - t4;
+    r.t_text = now() - t3;                                           // (queued: the caller settles, with whatever it queues behind)
     if (getenv("MIEKKI_VERBOSE"))
-        fprintf(stderr, "[gz] %u files, %.2f GB: %u segments; upload %.3f s, block starts %.3f s, measuring pass %.3f s, writing pass %.3f s, text %.3f s (%.2f GB)\n", n,
-                in_at / 1e9, r.n_segs, r.t_up, r.t_find, r.t_measure, r.t_write, r.t_text, out_at / 1e9);
+        fprintf(stderr, "[gz] %u files, %.2f GB: %u segments, %u streams decoded again with exact rooms (%zu segments); blocks made ready %.3f s, block starts + tokens + chains %.3f s, "
+                        "text queued after %.3f s (%.2f GB)\n", n, r.in_at / 1e9, r.n_segs, r.n_rewritten, jobs.size(), r.t_open, r.t_blocks, r.t_text, out_at / 1e9);
     return MK_OK;
 }
 
 }  // namespace mk
 
 using namespace mk;
+
+// A batch of genome FILES (gzip members holding FASTA text): inflated, their sequences as index_file_of_file would read
+// them (Miekki.cpp:559-567) measured (fasta.hip) -- the text stays on the device until mk_gz_free; mk_index_append_gz strips
+// it straight into the build's sequence buffer, sixty-four genomes a call.
+struct mk_gz_batch {
+    GzRun run;
+    std::vector<uint32_t> chunk_first;
+    std::vector<uint64_t> seq_len;
+    uint32_t n_chunks = 0;
+    void *d_scratch = nullptr;
+    bool ran = false;
+};
 
 extern "C" {
 
@@ -1309,7 +1533,10 @@ int mk_gz_inflate(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes,
     if (!c || (n && (!gz || !gz_bytes || !out || !out_room || !out_bytes || !status))) { set_error("null argument"); return MK_ERR_ARG; }
     if (!n) return MK_OK;
     GzRun r;
-    MK_TRY(gz_run(r, c, gz, gz_bytes, n, out_room, nullptr));
+    MK_TRY(gz_open(r, c, gz_bytes, n));
+    for (uint32_t i = 0; i < n; ++i) if (r.streams[i].in_len) MK_TRY(gz_put(r, i, 0, gz[i], r.streams[i].in_len, false));
+    MK_TRY(gz_finish(r, out_room, nullptr));
+    MK_TRY(r.settle());
     for (uint32_t i = 0; i < n; ++i) {
         const mk_gz_stream &j = r.streams[i];
         status[i] = (int32_t)j.status;
@@ -1320,23 +1547,44 @@ int mk_gz_inflate(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes,
     return MK_OK;
 }
 
-// A batch of genome FILES (gzip members holding FASTA text): inflated, their sequences as index_file_of_file would read
-// them (Miekki.cpp:559-567) measured (fasta.hip) -- the text stays on the device until mk_gz_free; mk_index_append_gz strips
-// it straight into the build's sequence buffer, sixty-four genomes a call.
-struct mk_gz_batch {
-    GzRun run;
-    std::vector<uint32_t> chunk_first;
-    std::vector<uint64_t> seq_len;
-    uint32_t n_chunks = 0;
-    void *d_scratch = nullptr;
-};
-
-int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out)
+// The batch in three steps, for callers that read their files themselves (host/fasta_reader.cpp: sixteen readers put the
+// files of a batch side by side): mk_gz_open fixes the layout from the files' sizes, mk_gz_put moves bytes -- from a piece
+// mk_gz_stage lent (page-locked: a DMA the caller does not wait for; the piece is the library's again) or from any other
+// memory --, mk_gz_run does the rest and returns when the sequences' lengths are known.
+int mk_gz_open(mk_ctx *c, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out)
 {
-    if (!c || !out || (n && (!gz || !gz_bytes))) { set_error("null argument"); return MK_ERR_ARG; }
+    if (!c || !out || (n && !gz_bytes)) { set_error("null argument"); return MK_ERR_ARG; }
     *out = nullptr;
     std::unique_ptr<mk_gz_batch> b(new mk_gz_batch());
     b->chunk_first.assign(n + 1, 0); b->seq_len.assign(n, 0);
+    MK_TRY(gz_open(b->run, c, gz_bytes, n));
+    *out = b.release();
+    return MK_OK;
+}
+
+void *mk_gz_stage(mk_gz_batch *b, uint64_t *cap)
+{
+    if (!b || !b->run.c) return nullptr;
+    void *p = gz_stage_get(b->run.c);
+    if (p && cap) *cap = kStagePiece;
+    return p;
+}
+
+int mk_gz_put(mk_gz_batch *b, uint32_t i, uint64_t at, const void *data, uint64_t bytes, int staged)
+{
+    if (!b || (!data && bytes)) { set_error("null argument"); return MK_ERR_ARG; }
+    if (b->ran) { set_error("the batch has run"); return MK_ERR_ARG; }
+    return gz_put(b->run, i, at, data, bytes, staged != 0);
+}
+
+int mk_gz_run(mk_gz_batch *b)
+{
+    if (!b) { set_error("null argument"); return MK_ERR_ARG; }
+    if (b->ran) { set_error("the batch has run"); return MK_ERR_ARG; }
+    b->ran = true;
+    GzRun &r = b->run;
+    const uint32_t n = r.n;
+    if (!n) return MK_OK;
     uint64_t o_first = 0, o_len = 0, o_scratch = 0;
     auto extra = [&](const std::vector<mk_gz_stream> &streams) {      // behind the text: the chunks' table, the lengths, the scan's scratch
         for (uint32_t i = 0; i < n; ++i) b->chunk_first[i + 1] = b->chunk_first[i] + (streams[i].status == MK_GZ_OK ? (streams[i].out_len + 4095u) / 4096u : 0u);
@@ -1344,20 +1592,27 @@ int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, 
         o_first = 0; o_len = (((uint64_t)n + 1) * 4 + 255u) / 256u * 256u; o_scratch = o_len + ((uint64_t)n * 8 + 255u) / 256u * 256u;
         return o_scratch + fasta_scratch_bytes(b->n_chunks);
     };
-    MK_TRY(gz_run(b->run, c, gz, gz_bytes, n, nullptr, extra));
-    if (!n) { *out = b.release(); return MK_OK; }
-    GzRun &r = b->run;
-    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    MK_TRY(gz_finish(r, nullptr, extra));
     uint32_t *d_first = reinterpret_cast<uint32_t *>(r.d_extra + o_first);
     uint64_t *d_len = reinterpret_cast<uint64_t *>(r.d_extra + o_len);
     b->d_scratch = r.d_extra + o_scratch;
     // (a stream that failed in the text pass -- a CRC -- keeps its chunks in the table: the kernels skip them by its status)
     MK_TRY(r.up(d_first, b->chunk_first.data(), ((size_t)n + 1) * 4));
-    MK_TRY(launch_fasta_count(c, r.d_text, r.d_streams, n, d_first, b->n_chunks, b->d_scratch, d_len, r.st));
+    MK_TRY(launch_fasta_count(r.c, r.d_text, r.d_streams, n, d_first, b->n_chunks, b->d_scratch, d_len, r.st));
     MK_TRY(r.down(b->seq_len.data(), d_len, (size_t)n * 8));
     MK_TRY(r.settle());
-    if (getenv("MIEKKI_VERBOSE"))
-        fprintf(stderr, "[gz] sequences measured in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+    return MK_OK;
+}
+
+int mk_gz_unpack(mk_ctx *c, const uint8_t *const *gz, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out)
+{
+    if (!c || !out || (n && (!gz || !gz_bytes))) { set_error("null argument"); return MK_ERR_ARG; }
+    *out = nullptr;
+    mk_gz_batch *raw = nullptr;
+    MK_TRY(mk_gz_open(c, gz_bytes, n, &raw));
+    std::unique_ptr<mk_gz_batch> b(raw);
+    for (uint32_t i = 0; i < n; ++i) if (b->run.streams[i].in_len) MK_TRY(gz_put(b->run, i, 0, gz[i], b->run.streams[i].in_len, false));
+    MK_TRY(mk_gz_run(b.get()));
     *out = b.release();
     return MK_OK;
 }
@@ -1386,23 +1641,37 @@ void mk_gz_trim(mk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
-    std::lock_guard<std::mutex> g(c->gz_m);
-    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
-    c->gz_blocks.clear();
-    for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
-    c->gz_pins.clear();
+    {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
+        c->gz_blocks.clear();
+        for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
+        c->gz_pins.clear();
+    }
+    gz_release_staging(c);
 }
 
 }  // extern "C"
 
-// the batch's text for the strip kernels of mk_index_append_gz (api.hip)
 namespace mk {
+// the pieces files are read into and the streams their copies run on (pieces a caller still holds stay its own)
+void gz_release_staging(mk_ctx *c)
+{
+    std::lock_guard<std::mutex> g(c->gz_m);
+    for (hipStream_t &u : c->gz_up) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); u = nullptr; }
+    for (auto &pc : c->gz_stage_busy) c->gz_stage_free.push_back(pc);
+    c->gz_stage_busy.clear();
+    for (auto &pc : c->gz_stage_free) { (void)hipHostFree(pc.p); (void)hipEventDestroy(pc.ev); --c->gz_stage_made; }
+    c->gz_stage_free.clear();
+}
+
+// the batch's text for the strip kernels of mk_index_append_gz (api.hip)
 int gz_batch_strip(mk_ctx *c, const mk_gz_batch *b, const uint32_t *which, uint32_t m, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st)
 {
     return launch_fasta_strip(c, b->run.d_text, b->run.d_streams, which, m, b->chunk_first.data(), b->n_chunks, b->d_scratch, d_dst, dst_off, st);
 }
 uint32_t gz_batch_size(const mk_gz_batch *b) { return b->run.n; }
-bool gz_batch_ok(const mk_gz_batch *b, uint32_t i) { return b->run.streams[i].status == MK_GZ_OK; }
+bool gz_batch_ok(const mk_gz_batch *b, uint32_t i) { return b->ran && b->run.streams[i].status == MK_GZ_OK; }
 uint64_t gz_batch_len(const mk_gz_batch *b, uint32_t i) { return b->seq_len[i]; }
 const mk_ctx *gz_batch_owner(const mk_gz_batch *b) { return b->run.c; }
 }  // namespace mk

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -244,6 +245,15 @@ struct mk_ctx {
     std::vector<std::pair<void *, uint64_t>> gz_blocks;
     std::vector<std::pair<void *, uint64_t>> gz_pins;   // page-locked staging of the inflater's small copies, kept likewise
     std::mutex gz_m;
+    // page-locked pieces the callers read their files into (mk_gz_stage): free ones, and those whose copy to the device is
+    // still queued (each with the event that says when it is done), oldest first; the streams those copies take turns on
+    struct GzStage { void *p; hipEvent_t ev; };
+    std::vector<GzStage> gz_stage_free;
+    std::deque<GzStage> gz_stage_busy;
+    std::vector<GzStage> gz_stage_held;  // ... and those a caller is reading a file into
+    uint32_t gz_stage_made = 0;
+    hipStream_t gz_up[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t gz_up_next = 0;
 };
 
 namespace mk { struct DenseLut; struct mk_gz_stream; struct mk_gz_seg; }
@@ -417,26 +427,26 @@ inline MatRef mat_ref(const mk_ctx *c);
 // ---- gunzip.hip: gzip streams inflated on the device
 struct mk_gz_stream {              // a stream (a file) of a batch
     uint64_t in_off;               // its bytes at gz + in_off (16-byte aligned, >= 16 zero bytes behind them)
-    uint64_t tok_off;              // its tokens at tokens + tok_off (32-bit words; a multiple of four)
     uint64_t out_off;              // its text at text + out_off (16-byte aligned)
-    uint32_t in_len, n_tok, out_len, status, members, pad;      // status: mk_gz_status
+    uint32_t in_len, n_tok, out_len, status, members;      // status: mk_gz_status
+    uint32_t cand_lo, cand_hi;     // its candidate block starts: sorted[cand_lo, cand_hi) (ascending bit offsets)
+    uint32_t n_chain;              // segments on its chain: chain[cand_lo + its index ...] (a stream has one more segment than candidates)
+    uint32_t rewrite;              // a segment on its chain had more tokens than its slots: those segments are decoded once more, with exact rooms
+    uint32_t pad[3];
 };
-struct mk_gz_seg {                 // a lane's work in gz_tokens_kernel: a stretch of a stream from a block's first bit on
-    uint64_t in_off;               // the stream's bytes
-    uint64_t start_bit;            // 0: the stream's first byte (a member's header comes first)
-    uint64_t cand_off;             // the stream's candidate starts at cands + cand_off (ascending bit offsets, then ~0)
-    uint64_t tok_off;              // (write) where this segment's tokens go
-    uint32_t in_len, stream, cand_next, write;     // cand_next: the first candidate behind start_bit
-    uint32_t tok_cap, out_cap, member_out0, pad;   // rooms (all ones while measuring); bytes of the open member before this segment
-    uint32_t n_tok, out_len, status, members;      // results ...
-    uint32_t link, member_tail;                    // ... the candidate it arrived at (all ones: the stream's end), bytes of the member open at its end
-    uint64_t pad2;
+struct mk_gz_seg {                 // what a lane of gz_tokens_kernel found: a stretch of a stream from a block's first bit on
+    uint64_t tok_ptr;              // where its tokens lie (a device address, 16-byte aligned)
+    uint32_t tok_cap;              // room there (a multiple of four); n_tok > tok_cap: the tokens beyond were counted, not kept
+    uint32_t n_tok, out_len, status, members;
+    uint32_t link;                 // the segment it arrived at between two blocks (all ones: the stream's end)
 };
+struct mk_gz_job { uint64_t tok_ptr; uint32_t seg, tok_cap; };   // a segment to decode again, with its exact room
 int launch_fasta_count(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, uint32_t n, const uint32_t *d_chunk_first, uint32_t n_chunks,
                        void *d_scratch, uint64_t *d_seq_len, hipStream_t st);
 int launch_fasta_strip(mk_ctx *c, const uint8_t *d_text, const mk_gz_stream *d_jobs, const uint32_t *which, uint32_t m, const uint32_t *h_chunk_first,
                        uint32_t n_chunks, const void *d_scratch, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st);
 uint64_t fasta_scratch_bytes(uint32_t n_chunks);
+void gz_release_staging(mk_ctx *c);     // the inflater's page-locked pieces, upload streams and symbol lists (mk_destroy, mk_gz_trim)
 }  // namespace mk
 struct mk_gz_batch;
 namespace mk {

@@ -5,7 +5,7 @@ The list names n_genomes files; only `distinct` different ones are written, the 
 symlinks to them (the page cache is warm either way; the device work per genome is the same).
 gz: the files are gzip members (level 6, what NCBI ships and what the reference's zstr reader inflates on the fly,
 zstr.hpp:78-82): every reader thread then spends its time in zlib's inflate."""
-import gzip, os, re, subprocess, sys, tempfile, time
+import gzip, os, re, shlex, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
@@ -16,6 +16,8 @@ D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 GZ = len(sys.argv) > 4 and sys.argv[4] == "gz"
 L = 5_000_000
 cli = os.environ.get("MIEKKI_CLI") or os.path.join(ROOT, "miekki_amd", "miekki")
+# MIEKKI_PREFIX: words put before the binary ("rocprofv3 --kernel-trace -d DIR{rep} -o t --": {rep} = the run's number)
+prefix = os.environ.get("MIEKKI_PREFIX", "")
 with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     t0 = time.time()
     with open(os.path.join(d, "genomes.lst"), "w") as lst:
@@ -34,7 +36,7 @@ with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     print(f"generated {D} distinct {'gzipped ' if GZ else ''}genomes ({G} listed) in {time.time() - t0:.1f}s", flush=True)
     for rep in range(2):
         t0 = time.time()
-        out = subprocess.run([cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1"),
+        out = subprocess.run(shlex.split(prefix.replace("{rep}", str(rep))) + [cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1"),
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
         el = re.findall(r"elapsed time: ([0-9.e+-]+)s", out)
         wall = time.time() - t0
