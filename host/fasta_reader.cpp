@@ -303,10 +303,13 @@ FileText::~FileText()
 }
 
 OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed,
-                                       bool raw_gz, size_t raw_unit, size_t raw_units_ahead)
+                                       bool raw_gz, size_t raw_unit, size_t raw_units_ahead, RawSink sink, bool share)
     : files_(std::move(files)), items_(files_.size()), ready_(files_.size()), a_(a), pack_(packed), raw_gz_(raw_gz),
-      raw_unit_(raw_gz ? raw_unit : 0), raw_limit_((long)(raw_unit * raw_units_ahead)), umode_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0)
+      raw_unit_(raw_gz ? raw_unit : 0), raw_limit_((long)(raw_unit * raw_units_ahead)), umode_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0),
+      ubatch_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0, nullptr), udone_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0), sink_(sink), share_(share)
 {
+    for (auto &d : udone_) d.store(0);
+    if (!raw_unit_ || !sink_.open || !sink_.put) sink_ = RawSink();     // (a sink works on units)
     for (auto &u : umode_) u.store(0);
     if (raw_gz_) ahead_limit_ = 16ull << 30;                        // (a device batch is thousands of files: their bytes wait here)
     for (auto &r : ready_) r.store(0);
@@ -392,6 +395,42 @@ OrderedFastaReader::Item OrderedFastaReader::take(size_t i)
     return it;
 }
 
+// file i of a device unit, piece by piece through the sink's buffers: true when all of it went (the item is raw then, and
+// holds no bytes); false: not a gzip member, changed since the unit was opened, unreadable -- the ordinary path takes it
+// (what has been put of it is noise in a slot nobody will ask about)
+bool OrderedFastaReader::put_raw(size_t i, const stat_view &sv, Item &it)
+{
+    if (!sv.regular || sv.size < 18 || sv.size >= (1ll << 31)) return false;
+    const int fd = ::open(files_[i].c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    std::vector<char> own;                                          // (only when the sink has no buffer to lend)
+    uint64_t at = 0;
+    const uint64_t size = (uint64_t)sv.size;
+    bool ok = true;
+    while (ok && at < size) {
+        uint64_t cap = 0;
+        char *buf = sink_.stage ? (char *)sink_.stage(sink_.user, it.unit_batch, &cap) : nullptr;
+        const bool staged = buf != nullptr;
+        if (!buf) { own.resize(4u << 20); buf = own.data(); cap = own.size(); }
+        const uint64_t want = std::min<uint64_t>(cap, size - at);
+        uint64_t got = 0;
+        while (got < want) {
+            const ssize_t r = pread(fd, buf + got, (size_t)(want - got), (off_t)(at + got));
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        if (at == 0 && (got < 2 || (unsigned char)buf[0] != 0x1f || (unsigned char)buf[1] != 0x8b)) ok = false;      // not a gzip member
+        if (got != want) ok = false;
+        // (a piece that was lent goes back through put even when the file is given up: zero bytes of it)
+        if (!sink_.put(sink_.user, it.unit_batch, it.unit_index, at, buf, ok ? got : 0, staged)) ok = false;
+        at += got;
+    }
+    close(fd);
+    if (!ok) return false;
+    it.raw = true; it.len = (size_t)size; it.data = nullptr; it.cap = 0;
+    return true;
+}
+
 void OrderedFastaReader::work()
 {
     std::vector<char> text, scratch;                               // per thread, reused from file to file
@@ -410,18 +449,58 @@ void OrderedFastaReader::work()
         bool raw_done = false;
         // whose unit is this file's: the device's while it has room for one more (the first reader to touch a unit says)
         bool to_device = raw_gz_;
+        const size_t unit = raw_unit_ ? i / raw_unit_ : 0;
         if (raw_unit_) {
-            std::atomic<int> &mode = umode_[i / raw_unit_];
+            std::atomic<int> &mode = umode_[unit];
             int m = mode.load();
             if (!m) {
-                const size_t u0 = i / raw_unit_ * raw_unit_;
+                const size_t u0 = unit * raw_unit_;
                 const long in_unit = (long)(std::min(files_.size(), u0 + raw_unit_) - u0);
-                const int want = raw_out_.load() < raw_limit_ ? 1 : 2;
-                if (mode.compare_exchange_strong(m, want)) { m = want; if (want == 1) raw_out_.fetch_add(in_unit); }
+                int want = !share_ || raw_out_.load() < raw_limit_ ? 1 : 2;
+                if (sink_.open) {
+                    // with a sink the unit has to be OPENED (its files' sizes fix the batch's layout): by the first reader here,
+                    // the others wait for it
+                    if (mode.compare_exchange_strong(m, 3)) {
+                        void *batch = nullptr;
+                        if (want == 1) {
+                            std::vector<uint64_t> sizes((size_t)in_unit, 0);
+                            bool gz_first = false;
+                            for (long j = 0; j < in_unit; ++j) {
+                                struct stat sj;
+                                if (stat(files_[u0 + (size_t)j].c_str(), &sj) == 0 && S_ISREG(sj.st_mode) && sj.st_size >= 18 && sj.st_size < (1ll << 31))
+                                    sizes[(size_t)j] = (uint64_t)sj.st_size;
+                            }
+                            // (a unit whose first readable file is no gzip member is a list of plain files: the readers' own)
+                            for (long j = 0; j < in_unit && !gz_first; ++j)
+                                if (sizes[(size_t)j]) {
+                                    const int fd = ::open(files_[u0 + (size_t)j].c_str(), O_RDONLY);
+                                    unsigned char magic[2] = {0, 0};
+                                    if (fd >= 0) { gz_first = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b; close(fd); }
+                                    break;
+                                }
+                            if (gz_first) batch = sink_.open(sink_.user, sizes.data(), (uint32_t)in_unit);
+                        }
+                        m = batch ? 1 : 2;
+                        if (batch) raw_out_.fetch_add(in_unit);
+                        { std::lock_guard<std::mutex> g(m_); ubatch_[unit] = batch; mode.store(m); }
+                        cv_.notify_all();
+                    }
+                } else if (mode.compare_exchange_strong(m, want)) { m = want; if (want == 1) raw_out_.fetch_add(in_unit); }
+            }
+            if (m == 3) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || mode.load() != 3; });
+                if (stop_) return;
+                m = mode.load();
             }
             to_device = m == 1;
         }
-        if (it.exists && to_device && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
+        if (sink_.open && to_device) {
+            it.unit_batch = ubatch_[unit];
+            it.unit_index = (uint32_t)(i - unit * raw_unit_);
+            it.unit_last = i + 1 == files_.size() || (i + 1) % raw_unit_ == 0;
+            if (it.exists) raw_done = put_raw(i, stat_view{S_ISREG(st.st_mode) != 0, (long long)st.st_size}, it);
+        } else if (it.exists && to_device && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
             // a gzip'd file as it is, for the device's inflater: read into a pooled buffer of ORDINARY memory (a gigabyte and
             // more of these are alive at a time: page-locking that much -- 50 ms per 256 MB, every reader waiting behind the
             // call -- cost more than the staged upload does on the batch's own thread).  Not mapped: thousands of mappings
@@ -472,7 +551,13 @@ void OrderedFastaReader::work()
                 else it.failed = true;
             }
         }
-        if (raw_unit_ && to_device && !raw_done) raw_out_.fetch_sub(1);     // (a file of a device unit that does not go there)
+        if (raw_unit_ && to_device && !raw_done && !sink_.open) raw_out_.fetch_sub(1);     // (a file of a device unit that does not go there; with a sink the
+                                                                                            // consumer counts every file of the unit back)
+        if (it.unit_batch && sink_.complete) {
+            const size_t u0 = unit * raw_unit_;
+            const uint32_t in_unit = (uint32_t)(std::min(files_.size(), u0 + raw_unit_) - u0);
+            if (udone_[unit].fetch_add(1) + 1 == in_unit) sink_.complete(sink_.user, it.unit_batch);
+        }
         { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
         cv_.notify_all();
     }

@@ -21,6 +21,8 @@
 
 namespace mkhost {
 
+struct stat_view { bool regular; long long size; };
+
 // CPUs this process may use: the affinity mask, capped by the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota) --
 // std::thread::hardware_concurrency() knows neither (a 256-thread host that grants a job 16 CPUs reports 256)
 unsigned usable_cpus();
@@ -63,6 +65,24 @@ private:
     size_t maplen_ = 0;
 };
 
+// Where the gzip'd files of a device unit go when the caller's device takes them piece by piece (the driver binds these to
+// mk_gz_open / mk_gz_stage / mk_gz_put): the readers then read every file straight into a page-locked piece the sink lends
+// and hand it over -- the files' bytes never wait in host memory, and their way to the device is a DMA per piece that
+// nobody waits for.  Without a sink (all null) raw items carry the file's bytes, as before.
+struct RawSink {
+    void *user = nullptr;
+    // a unit of m files of these sizes (0: that file does not go to the device): a batch, or null -- the unit is the readers' then
+    void *(*open)(void *user, const uint64_t *sizes, uint32_t m) = nullptr;
+    // a buffer of *cap bytes to read into; null: none to be had (the reader uses its own, and says staged = false)
+    void *(*stage)(void *user, void *batch, uint64_t *cap) = nullptr;
+    // bytes [at, at + bytes) of file i of the batch; staged: `data` came from stage() and is the sink's again
+    bool (*put)(void *user, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged) = nullptr;
+    // every file of the unit has been dealt with (put, or found to be none of the device's): the batch may run -- called by
+    // the reader that finished the unit's last file, BEFORE that file's item can be taken, so that the device works on a
+    // unit while the consumer is still busy with the units before it
+    void (*complete)(void *user, void *batch) = nullptr;
+};
+
 class OrderedFastaReader {
 public:
     struct Item {
@@ -75,6 +95,13 @@ public:
         // raw items (a reader made with raw_gz): `data` is the FILE as it is -- gzip members, for the device to inflate
         // (mk_gz_unpack) -- len bytes in a pooled buffer like any other item's
         bool raw = false;
+        // with a RawSink: every file of a device unit says whose it is -- unit_batch (what the sink's open returned), its place
+        // unit_index in it, unit_last on the unit's last file: when that one has been taken, every file of the unit has been
+        // put.  A raw item then has no `data` (its bytes are on the device); a file of the unit that did not go there (not
+        // gzip after all, unreadable, missing) comes as the ordinary item it would have been.
+        void *unit_batch = nullptr;
+        uint32_t unit_index = 0;
+        bool unit_last = false;
         uint64_t *codes = nullptr, *except = nullptr;
         char head[32] = {0};
     };
@@ -85,8 +112,10 @@ public:
     // the list is cut into units of raw_unit files; a unit goes to the device (its files come raw) while fewer than
     // raw_units_ahead units' worth of raw files are waiting for the consumer's raw_consumed(), and is inflated here
     // otherwise.  raw_unit 0: every gzip'd file raw.
+    // sink + share: with a sink the list is always cut into units of raw_unit files; share = false: every unit whose first
+    // file is gzip'd goes to the device (the read-ahead window is what bounds the units in flight)
     OrderedFastaReader(std::vector<std::string> files, unsigned threads, HostAllocator a, size_t window, bool packed = false,
-                       bool raw_gz = false, size_t raw_unit = 0, size_t raw_units_ahead = 0);
+                       bool raw_gz = false, size_t raw_unit = 0, size_t raw_units_ahead = 0, RawSink sink = RawSink(), bool share = true);
     // the consumer is done with n raw items (appended or given up)
     void raw_consumed(size_t n) { raw_out_.fetch_sub((long)n); }
     ~OrderedFastaReader();
@@ -111,7 +140,12 @@ private:
     bool pack_ = false, raw_gz_ = false;
     size_t raw_unit_ = 0;
     long raw_limit_ = 0;
-    std::vector<std::atomic<int>> umode_;          // per unit: 0 undecided, 1 to the device, 2 inflated here
+    std::vector<std::atomic<int>> umode_;          // per unit: 0 undecided, 1 to the device, 2 inflated here, 3 being opened
+    std::vector<void *> ubatch_;                   // per unit: the sink's batch (mode 1 with a sink)
+    std::vector<std::atomic<uint32_t>> udone_;     // per unit: files dealt with
+    RawSink sink_;
+    bool share_ = true;
+    bool put_raw(size_t i, const struct stat_view &sv, Item &it);
     std::atomic<long> raw_out_{0};                 // files of device units handed out or still to come, not yet consumed
     std::mutex pool_m_;
     std::vector<std::pair<char *, size_t>> pool_;   // free buffers (pointer, capacity)

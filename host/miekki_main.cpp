@@ -255,69 +255,119 @@ struct Driver {
         // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
         // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.
         static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return !e || atoi(e) != 0; }();
+        // A unit's files go to the device as the readers read them (RawSink -> mk_gz_open / mk_gz_stage / mk_gz_put): straight
+        // from the page cache into page-locked pieces the library lends, a DMA each, into a batch whose layout the files'
+        // sizes fixed -- nothing of a gzip'd file waits in host memory.  A unit the device has no memory for is the readers'.
+        // A unit RUNS (mk_gz_run, on a thread of its own) as soon as its last file has been put -- the reader that put it says
+        // so -- not when this thread gets round to it: the device inflates the units ahead while the ones before them are
+        // being appended.
+        struct UnitRun { std::future<int> ran; string error; };
+        struct Sink {
+            mk_ctx *ctx;
+            std::mutex m;
+            std::unordered_map<void *, std::shared_ptr<UnitRun>> runs;
+            static void *open(void *u, const uint64_t *sizes, uint32_t m)
+            {
+                mk_gz_batch *b = nullptr;
+                return mk_gz_open(((Sink *)u)->ctx, sizes, m, &b) == MK_OK ? b : nullptr;
+            }
+            static void *stage(void *, void *batch, uint64_t *cap) { return mk_gz_stage((mk_gz_batch *)batch, cap); }
+            static bool put(void *, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
+            {
+                return mk_gz_put((mk_gz_batch *)batch, i, at, data, bytes, staged ? 1 : 0) == MK_OK;
+            }
+            static void complete(void *u, void *batch)
+            {
+                std::shared_ptr<UnitRun> r = std::make_shared<UnitRun>();
+                UnitRun *rp = r.get();
+                r->ran = std::async(std::launch::async, [rp, batch]() -> int {
+                    const int rc = mk_gz_run((mk_gz_batch *)batch);
+                    if (rc != MK_OK) rp->error = mk_last_error();
+                    return rc;
+                });
+                std::lock_guard<std::mutex> g(((Sink *)u)->m);
+                ((Sink *)u)->runs[batch] = std::move(r);
+            }
+            std::shared_ptr<UnitRun> take(void *batch)
+            {
+                std::lock_guard<std::mutex> g(m);
+                auto it = runs.find(batch);
+                if (it == runs.end()) return nullptr;
+                std::shared_ptr<UnitRun> r = std::move(it->second);
+                runs.erase(it);
+                return r;
+            }
+            ~Sink() { for (auto &kv : runs) if (kv.second && kv.second->ran.valid()) (void)kv.second->ran.get(); }
+        } sink_user;
+        sink_user.ctx = ctx;
+        mkhost::RawSink sink;
+        sink.user = &sink_user; sink.open = Sink::open; sink.stage = Sink::stage; sink.put = Sink::put; sink.complete = Sink::complete;
         // (the arena outlives the reader: declared first.  Both are handed to a thread of their own when the shard is built:
         // giving gigabytes of page-locked memory back takes tenths of a second that nothing has to wait for)
         std::shared_ptr<PinnedArena> arena_p = std::make_shared<PinnedArena>(ctx);
         std::unique_ptr<OrderedFastaReader> reader_p(new OrderedFastaReader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, arena_p.get()},
                                                                             std::max<size_t>(3 * 64, (gz_in_flight + 2) * gz_batch + 64), true, gz_batch != 0,
-                                                                            gz_share ? gz_batch : 0, gz_in_flight));
+                                                                            gz_batch, gz_in_flight, gz_batch ? sink : mkhost::RawSink(), gz_share));
         OrderedFastaReader &reader = *reader_p;
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
         auto show = [&]() { if (live) { cout << sb.log << flush_stream(); sb.log.clear(); } };
         // What has been taken from the readers and waits for its turn, in list order: runs of up to 64 sequences the readers
-        // made (packed), and batches of raw gzip'd files the device is unpacking -- by a thread of its own each (mk_gz_unpack
-        // works on a stream of its own; a deflate stream is decoded by few lanes, so it is batches side by side that fill
-        // the device).  Everything is appended in list order, sixty-four at a time.
+        // made (packed), and whole UNITS that went to the device -- each run by a thread of its own (mk_gz_run works on a
+        // stream of its own; a deflate stream is decoded by few lanes, so it is batches side by side that fill the device).
+        // Everything is appended in list order, sixty-four at a time.
         struct Pending {
             vector<OrderedFastaReader::Item> items;
             vector<string> names;
-            bool raw = false;
-            std::future<mk_gz_batch *> unpacked;
-            string error;
+            mk_gz_batch *batch = nullptr;                           // a device unit: its files' bytes are there already
+            std::shared_ptr<UnitRun> run;                           // ... and it runs, or has run (the readers started it)
         };
         std::deque<std::unique_ptr<Pending>> pending;
         size_t raw_in_flight = 0, host_waiting = 0;
         std::unique_ptr<Pending> cur;                               // the run being collected
         uint64_t cur_bytes = 0;
+        // (whatever way this function is left: no thread of a batch still runs, no batch keeps its blocks)
+        struct Cleanup {
+            std::deque<std::unique_ptr<Pending>> &pending; std::unique_ptr<Pending> &cur;
+            ~Cleanup()
+            {
+                auto drop = [](Pending *p) { if (!p) return; if (p->run && p->run->ran.valid()) (void)p->run->ran.get(); if (p->batch && p->run) mk_gz_free(p->batch); p->batch = nullptr; };
+                for (auto &p : pending) drop(p.get());
+                drop(cur.get());
+            }
+        } cleanup{pending, cur};
         auto close_run = [&]() {
             if (!cur) return;
-            if (cur->raw) {
-                const double ts = now();
-                Pending *r = cur.get();
-                r->unpacked = std::async(std::launch::async, [r, ctx]() -> mk_gz_batch * {
-                    vector<const uint8_t *> gp;
-                    vector<uint64_t> gl;
-                    for (auto &it : r->items) { gp.push_back((const uint8_t *)it.data); gl.push_back(it.len); }
-                    mk_gz_batch *gzb = nullptr;
-                    if (mk_gz_unpack(ctx, gp.data(), gl.data(), (uint32_t)gp.size(), &gzb) != MK_OK) { r->error = mk_last_error(); return nullptr; }
-                    return gzb;
-                });
+            if (cur->batch) {
+                cur->run = sink_user.take(cur->batch);                // (started when the unit's last file had been put: before its item could be taken)
                 ++raw_in_flight;
-                sb.t_start += now() - ts;
             } else {
                 host_waiting += cur->items.size();
             }
             pending.push_back(std::move(cur));
             cur_bytes = 0;
         };
-        auto append_host_run = [&](Pending &run) {
+        auto append_items = [&](const OrderedFastaReader::Item *items, size_t n) {      // sequences the readers made, one call
             const double t0 = now();
             int rc;
-            if (run.items[0].packed) {
-                vector<mk_packed_seq> p(run.items.size());
-                for (size_t i = 0; i < run.items.size(); ++i) {
-                    p[i].codes = run.items[i].codes; p[i].except = run.items[i].dirty ? run.items[i].except : nullptr; p[i].len = run.items[i].len;
-                    memcpy(p[i].head, run.items[i].head, 32);
+            if (items[0].packed) {
+                vector<mk_packed_seq> p(n);
+                for (size_t i = 0; i < n; ++i) {
+                    p[i].codes = items[i].codes; p[i].except = items[i].dirty ? items[i].except : nullptr; p[i].len = items[i].len;
+                    memcpy(p[i].head, items[i].head, 32);
                 }
-                rc = mk_index_append_packed(ctx, p.data(), (uint32_t)p.size());
+                rc = mk_index_append_packed(ctx, p.data(), (uint32_t)n);
             } else {
                 vector<const char *> p;
                 vector<uint64_t> l;
-                for (auto &s : run.items) { p.push_back(s.data); l.push_back(s.len); }
-                rc = mk_index_append(ctx, p.data(), l.data(), (uint32_t)run.items.size());
+                for (size_t i = 0; i < n; ++i) { p.push_back(items[i].data); l.push_back(items[i].len); }
+                rc = mk_index_append(ctx, p.data(), l.data(), (uint32_t)n);
             }
             if (rc != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
             sb.t_append += now() - t0;
+            return true;
+        };
+        auto append_host_run = [&](Pending &run) {
+            if (!append_items(run.items.data(), run.items.size())) return false;
             sb.names.insert(sb.names.end(), run.names.begin(), run.names.end());
             sb.log.append(run.items.size(), '-');
             host_waiting -= run.items.size();
@@ -325,51 +375,65 @@ struct Driver {
             for (auto &s : run.items) reader.recycle(s);
             return true;
         };
-        auto append_raw_batch = [&](Pending &rb) {
+        // a file the device did not take (or a whole unit it failed on): read and inflated here, appended in its place
+        auto append_from_disk = [&](const string &fn) {
+            vector<char> text, scratch, seq;
+            if (!mkhost::read_file(fn, text, scratch)) { sb.error = "cannot read " + fn; return false; }
+            seq.resize(text.size() + 1);
+            seq.resize(mkhost::strip_fasta(text.data(), text.size(), seq.data()));
+            ++sb.gz_on_host;
+            if (seq.size() < k) return true;
+            const char *p = seq.data();
+            const uint64_t l = seq.size();
+            if (mk_index_append(ctx, &p, &l, 1) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
+            sb.names.push_back(fn); sb.log += '-';
+            return true;
+        };
+        auto append_unit = [&](Pending &rb) {
             const double t0 = now();
-            mk_gz_batch *gzb = rb.unpacked.get();
+            const int ran = rb.run ? rb.run->ran.get() : MK_ERR_STATE;
             sb.t_unpack_wait += now() - t0;
             --raw_in_flight;
-            if (!gzb) { sb.error = "index build failed: " + rb.error; reader.raw_consumed(rb.items.size()); return false; }
+            // (a batch the device could not run -- no memory for its text, say -- is read again and inflated here, file by
+            // file: slower, never wrong; its blocks go back first)
+            if (ran != MK_OK) { mk_gz_free(rb.batch); rb.batch = nullptr; }
             vector<uint32_t> which;                                // files of the batch waiting to be appended together
             vector<string> kept;
             bool ok = true;
             auto append = [&]() {
                 if (which.empty()) return true;
                 const double ta = now();
-                if (mk_index_append_gz(ctx, gzb, which.data(), (uint32_t)which.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
+                if (mk_index_append_gz(ctx, rb.batch, which.data(), (uint32_t)which.size()) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); return false; }
                 sb.t_append += now() - ta;
                 sb.names.insert(sb.names.end(), kept.begin(), kept.end());
                 which.clear(); kept.clear();
                 return true;
             };
             for (size_t i = 0; i < rb.items.size() && ok; ++i) {
-                uint64_t len = 0;
-                int32_t st = 0;
-                mk_gz_sequence(gzb, (uint32_t)i, &len, &st);
-                if (st != MK_GZ_OK) {
-                    // the device refused the file: inflated here, appended in its place
-                    vector<char> seq;
-                    if (!mkhost::inflate_fasta(rb.items[i].data, rb.items[i].len, seq)) { sb.error = "cannot read " + rb.names[i]; ok = false; break; }
-                    ++sb.gz_on_host;
-                    if (seq.size() >= k) {
-                        ok = append();
-                        const char *p = seq.data();
-                        const uint64_t l = seq.size();
-                        if (ok && mk_index_append(ctx, &p, &l, 1) != MK_OK) { sb.error = string("index build failed: ") + mk_last_error(); ok = false; }
-                        if (ok) { sb.names.push_back(rb.names[i]); sb.log += '-'; }
+                OrderedFastaReader::Item &it = rb.items[i];
+                if (!it.exists) { ok = append(); sb.log += "Missed file: " + rb.names[i] + "\n"; show(); continue; }
+                if (it.failed) { ok = append(); if (ok) { sb.error = "cannot read " + rb.names[i]; ok = false; } break; }
+                if (!it.raw) {                                     // a file of the unit that came the ordinary way (not gzip'd after all)
+                    if (it.len >= k) {
+                        ok = append() && append_items(&it, 1);
+                        if (ok) { sb.names.push_back(rb.names[i]); sb.log += '-'; ++sb.from_readers; }
                     }
                     continue;
                 }
+                uint64_t len = 0;
+                int32_t st = MK_GZ_INTERNAL;
+                if (rb.batch) mk_gz_sequence(rb.batch, it.unit_index, &len, &st);
+                if (st != MK_GZ_OK) { ok = append() && append_from_disk(rb.names[i]); continue; }
                 if (len >= k) {
-                    which.push_back((uint32_t)i); kept.push_back(rb.names[i]);
+                    which.push_back(it.unit_index); kept.push_back(rb.names[i]);
                     sb.log += '-';
                     if (which.size() >= 64) { ok = append(); show(); }
                 }
             }
             ok = ok && append();
             const double tf = now();
-            mk_gz_free(gzb);                                           // (waits for the strip kernels that read the batch's text)
+            if (rb.batch) mk_gz_free(rb.batch);                        // (waits for the strip kernels that read the batch's text)
+            rb.batch = nullptr;
             sb.t_free += now() - tf;
             sb.gz_on_device += rb.items.size();
             const double tr = now();
@@ -383,9 +447,9 @@ struct Driver {
         auto drain = [&](bool all) {
             while (!pending.empty()) {
                 Pending &f = *pending.front();
-                if (f.raw && !all && raw_in_flight <= gz_in_flight && host_waiting < 4096 &&
-                    f.unpacked.wait_for(chrono::seconds(0)) != std::future_status::ready) break;
-                const bool ok = f.raw ? append_raw_batch(f) : append_host_run(f);
+                if (f.batch && !all && raw_in_flight <= gz_in_flight && host_waiting < 4096 &&
+                    f.run && f.run->ran.wait_for(chrono::seconds(0)) != std::future_status::ready) break;
+                const bool ok = f.batch ? append_unit(f) : append_host_run(f);
                 pending.pop_front();
                 show();
                 if (!ok) return false;
@@ -399,18 +463,24 @@ struct Driver {
             const double t0 = now();
             OrderedFastaReader::Item item = reader.take(i);
             sb.t_wait += now() - t0;
+            if (item.unit_batch) {
+                // a file of a device unit, whatever became of it: the unit stays together, in list order, and runs when its
+                // last file has been taken (every file has been put then)
+                if (cur && cur->batch != (mk_gz_batch *)item.unit_batch) close_run();
+                if (!cur) { cur.reset(new Pending()); cur->batch = (mk_gz_batch *)item.unit_batch; }
+                cur->items.push_back(item); cur->names.push_back(fn);
+                if (item.unit_last) close_run();
+                if (!drain(false)) return;
+                continue;
+            }
             if (!item.exists) { close_run(); if (!drain(true)) return; sb.log += "Missed file: " + fn + "\n"; show(); reader.recycle(item); continue; }
             if (item.failed) { close_run(); (void)drain(true); if (sb.error.empty()) sb.error = "cannot read " + fn; return; }
-            if (!item.raw && item.len < k) { reader.recycle(item); continue; }
-            if (cur && cur->raw != item.raw) close_run();
-            if (!cur) { cur.reset(new Pending()); cur->raw = item.raw; }
+            if (item.len < k) { reader.recycle(item); continue; }
+            if (cur && cur->batch) close_run();
+            if (!cur) cur.reset(new Pending());
             cur->items.push_back(item); cur->names.push_back(fn);
-            if (item.raw) {
-                if (cur->items.size() >= gz_batch) close_run();
-            } else {
-                cur_bytes += item.len;
-                if (cur->items.size() >= 64 || cur_bytes > (1ull << 30)) close_run();
-            }
+            cur_bytes += item.len;
+            if (cur->items.size() >= 64 || cur_bytes > (1ull << 30)) close_run();
             if (!drain(false)) return;
         }
         close_run();

@@ -64,24 +64,38 @@ __device__ __forceinline__ Sum summarise(const Piece &p)
     return s;
 }
 
-// inclusive scan of the 256 pieces' summaries through LDS; returns the thread's EXCLUSIVE value (identity for thread 0)
-__device__ Sum block_scan(Sum mine, Sum (*buf)[256], Sum *total)
+// A summary in one word (a chunk is 4 KiB: both counts fit thirteen bits): bit 0 has, bit 1 st, head from bit 2, body from
+// bit 15 -- so that a scan step is ONE lane shuffle.  (Through LDS, sixteen bytes a thread and two barriers a step, the two
+// kernels ran at 0.3 TB/s: 8.4 ms to count a batch of 512 genomes, 1.3 ms to strip 64.)
+__device__ __forceinline__ uint32_t pack_sum(const Sum &s) { return s.has | (s.st << 1) | (s.head << 2) | (s.body << 15); }
+__device__ __forceinline__ Sum unpack_sum(uint32_t w) { return Sum{w & 1u, (w >> 1) & 1u, (w >> 2) & 0x1fffu, (w >> 15) & 0x1fffu}; }
+__device__ __forceinline__ uint32_t combine_packed(uint32_t a, uint32_t b) { return pack_sum(combine(unpack_sum(a), unpack_sum(b))); }
+
+// scan of the 256 pieces' summaries: inside a wave by lane shuffles, the four waves' totals through LDS; returns the thread's
+// EXCLUSIVE value (identity for thread 0)
+__device__ Sum block_scan(Sum mine, uint32_t *wave_tot, Sum *total)
 {
-    const uint32_t t = threadIdx.x;
-    buf[0][t] = mine;
-    __syncthreads();
-    uint32_t cur = 0;
-    for (uint32_t o = 1; o < 256u; o <<= 1) {
-        Sum v = buf[cur][t];
-        if (t >= o) v = combine(buf[cur][t - o], v);
-        buf[cur ^ 1u][t] = v;
-        cur ^= 1u;
-        __syncthreads();
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t v = pack_sum(mine);
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v = combine_packed(up, v);
     }
-    *total = buf[cur][255];
-    const Sum ex = t ? buf[cur][t - 1] : Sum{0, 0, 0, 0};
+    if (lane == 63u) wave_tot[wave] = v;
     __syncthreads();
-    return ex;
+    uint32_t before = 0, all = 0;                                    // (the identity packs to zero)
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        const uint32_t tw = wave_tot[w];
+        if (w < wave) before = combine_packed(before, tw);
+        all = combine_packed(all, tw);
+    }
+    *total = unpack_sum(all);
+    uint32_t ex = (uint32_t)__shfl_up((int)v, 1u);
+    ex = lane ? combine_packed(before, ex) : before;
+    __syncthreads();                                                 // (wave_tot may be written again by the caller's next use)
+    return unpack_sum(ex);
 }
 
 struct ChunkSum { uint32_t has, st, head, body; };
@@ -90,7 +104,7 @@ struct ChunkPlace { uint32_t seq_off, in_header; };
 __global__ __launch_bounds__(256) void fasta_count_kernel(const uint8_t *__restrict__ text, const mk_gz_stream *__restrict__ jobs,
                                                           const uint32_t *__restrict__ chunk_first, uint32_t n, ChunkSum *__restrict__ sums)
 {
-    __shared__ Sum buf[2][256];
+    __shared__ uint32_t buf[4];
     // which stream this chunk belongs to: the last one whose first chunk is not beyond it
     uint32_t lo = 0, hi = n;
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (chunk_first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
@@ -131,7 +145,7 @@ struct StripCall {
 __global__ __launch_bounds__(256) void fasta_strip_kernel(const uint8_t *__restrict__ text, const mk_gz_stream *__restrict__ jobs, StripCall call,
                                                           const ChunkPlace *__restrict__ places, uint8_t *__restrict__ dst)
 {
-    __shared__ Sum buf[2][256];
+    __shared__ uint32_t buf[4];
     uint32_t lo = 0, hi = call.n;
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (call.first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
     const mk_gz_stream job = jobs[call.stream[lo]];

@@ -59,7 +59,11 @@ struct TokLds {
                                                // the lane's own column -- done with before the distance table is built)
     uint16_t cnt_l[16][64], cnt_d[16][64], nxt[16][64], ofs[16][64];
     uint8_t sym_d[32][64];
-    uint8_t lens[352][64];                     // [0, 19): the code length code's own; [32, 32 + 316): the two alphabets' (fixed code: [0, 320))
+    // a block's code lengths while its tables are built, one byte each -- [0, 19): the code length code's own; [32, 32 + 316):
+    // the two alphabets' (fixed code: [0, 320)) -- and, once they are built, the literal / length symbols whose codes are
+    // longer than the root table's index, in code order (long_sym[j]: the j-th of them): a lane's bytes are the same in
+    // both views (byte i of a lane = half i & 1 of its word i >> 1), so a lane that reads a header disturbs nobody's list
+    uint16_t lens16[176][64];
     // The bit loop touches no global memory: a lane reads its stream from its row of `in` (the next kInWords words of it)
     // and leaves its tokens in its row of `tok`; every few dozen steps each lane refills its row with 16-byte loads and
     // writes its ring out with 16-byte stores (round(), below).  With a load or a store per lane and token in the loop --
@@ -68,6 +72,9 @@ struct TokLds {
     uint32_t in[64][kInPitch];
     uint32_t tok[64][kTokPitch];
 };
+
+__device__ __forceinline__ uint8_t &lens_at(TokLds &L, uint32_t i, uint32_t lane) { return reinterpret_cast<uint8_t *>(&L.lens16[i >> 1][lane])[i & 1u]; }
+constexpr uint32_t kLongSyms = 176;            // literal / length symbols with long codes a lane keeps in LDS (the rest: its list in memory)
 
 struct BitReader {
     const uint32_t *in32;          // the stream's words (16-byte aligned, zero padding behind the last byte)
@@ -114,7 +121,7 @@ struct BitReader {
     }
 };
 
-// canonical code of `n` symbols (lengths in L.lens[base ...]) into a root table and the counts of the bit-by-bit path.
+// canonical code of `n` symbols (lengths in the block's list from `base` on) into a root table and the counts of the bit-by-bit path.
 // kind: 0 literal / length alphabet, 1 distance alphabet, 2 the code length code (complete codes only).
 // Returns false for what zlib's inflate_table refuses: an over-subscribed set, an incomplete one unless it is a single
 // code of one bit (or, for the two data alphabets, no code at all).
@@ -125,7 +132,7 @@ __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, 
     for (uint32_t l = 0; l < 16; ++l) cnt[l][lane] = 0;
     uint32_t maxlen = 0;
     for (uint32_t s = 0; s < n; ++s) {
-        const uint32_t l = L.lens[base + s][lane];
+        const uint32_t l = lens_at(L, base + s, lane);
         if (l) { cnt[l][lane] = (uint16_t)(cnt[l][lane] + 1u); maxlen = max(maxlen, l); }
     }
     int left = 1;
@@ -146,7 +153,7 @@ __device__ bool build_code(TokLds &L, uint32_t lane, uint32_t base, uint32_t n, 
     else if (kind == 1) for (uint32_t i = 0; i < size; ++i) L.dist[i][col] = 0;
     else for (uint32_t i = 0; i < size; ++i) L.dist[i][col] = 0;
     for (uint32_t s = 0; s < n; ++s) {
-        const uint32_t l = L.lens[base + s][lane];
+        const uint32_t l = lens_at(L, base + s, lane);
         if (!l) continue;
         const uint32_t c = L.nxt[l][lane];
         L.nxt[l][lane] = (uint16_t)(c + 1u);
@@ -310,6 +317,19 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(TokArgs A)
     }
     auto fail = [&](uint32_t why) { status = why; state = ST_DONE; };
     auto emit = [&](uint32_t t) { L.tok[lane][n_tok - n_out] = t; ++n_tok; };   // (the passes below emit at most three; round() keeps that much room)
+    // The symbols with codes longer than the root's index, from the lane's list in memory (build_code has just written it)
+    // into LDS, where the block's lengths lay: a wave meets such a code in two passes of three (some lane of its 64), and a
+    // load from memory there -- a microsecond -- was a third of the kernel's time.
+    uint32_t n_short = 0;                                           // codes no longer than the root's index: they come first in the list
+    auto keep_long = [&]() {
+        n_short = long_l.index;
+        uint32_t n_long = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 15u - kLitRoot; ++i) n_long += long_l.cnt[i];
+        const uint32_t m = min(n_long, kLongSyms);
+        for (uint32_t j = 0; j < m; ++j)
+            L.lens16[j][lane] = (uint16_t)__hip_atomic_load(&sorted_syms[n_short + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // A lane's ring out to memory, four tokens per store (what is left over moves to the ring's start) -- as far as the
     // segment's slots go: the tokens beyond them are only counted --, and its row of input refilled from the word it reads
     // next, four words per load.  Every lane its own stream: 64 cache lines per instruction, but only a few dozen
@@ -364,7 +384,9 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(TokArgs A)
                     uint32_t ll;
                     const uint32_t at = long_l.find((uint32_t)br.bb & 0x7fffu, ll, true);
                     // (the list was written by this lane through the L2; an L1 line of it from an earlier block would be stale)
-                    const uint32_t sym = ll ? __hip_atomic_load(&sorted_syms[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+                    const uint32_t j = at - n_short;                   // (a long code's place in the list is behind the short ones)
+                    const uint32_t sym = !ll ? ~0u : j < kLongSyms ? (uint32_t)L.lens16[min(j, kLongSyms - 1u)][lane]
+                                                                   : __hip_atomic_load(&sorted_syms[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     br.bb >>= ll; br.bc -= ll;
                     cl = 0;
                     if (sym < 256u) { kind = 7; value = sym; }
@@ -437,21 +459,22 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(TokArgs A)
                     br.seek_byte(at + len); state = final_block ? ST_TRAILER : ST_BLOCK;
                 }
             } else if (type == 1u) {
-                for (uint32_t i = 0; i < 288u; ++i) L.lens[i][lane] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8);
-                for (uint32_t i = 0; i < 32u; ++i) L.lens[288u + i][lane] = 5;
+                for (uint32_t i = 0; i < 288u; ++i) lens_at(L, i, lane) = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8);
+                for (uint32_t i = 0; i < 32u; ++i) lens_at(L, 288u + i, lane) = 5;
                 (void)build_code(L, lane, 0, 288, 0, sorted_syms);
                 (void)build_code(L, lane, 288, 32, 1, sorted_syms);      // (codes 30 and 31 decode to an error, as in zlib's fixed table)
                 long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane);
+                keep_long();
                 state = ST_TOKENS;
             } else if (type == 2u) {
                 const uint32_t hlit = br.get(5) + 257u, hdist = br.get(5) + 1u, hclen = br.get(4) + 4u;
                 bool ok = hlit <= 286u && hdist <= 30u;
-                for (uint32_t i = 0; i < 19u; ++i) L.lens[i][lane] = 0;
+                for (uint32_t i = 0; i < 19u; ++i) lens_at(L, i, lane) = 0;
                 for (uint32_t i = 0; i < hclen; ++i) {
                     // whose length comes i-th (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                     const uint32_t j = i - 4u;
                     const uint32_t which = i < 3u ? 16u + i : i == 3u ? 0u : (j & 1u) ? 7u - (j >> 1) : 8u + (j >> 1);
-                    L.lens[which][lane] = (uint8_t)br.get(3);
+                    lens_at(L, which, lane) = (uint8_t)br.get(3);
                 }
                 ok = ok && build_code(L, lane, 0, 19, 2, sorted_syms);
                 uint32_t i = 0, prev = 0;
@@ -462,24 +485,24 @@ __global__ __launch_bounds__(64) void gz_tokens_kernel(TokArgs A)
                     if (!ce) { ok = false; break; }
                     br.drop(ce >> 5);
                     const uint32_t sym = ce & 31u;
-                    if (sym < 16u) { L.lens[32u + i][lane] = (uint8_t)sym; prev = sym; ++i; }
+                    if (sym < 16u) { lens_at(L, 32u + i, lane) = (uint8_t)sym; prev = sym; ++i; }
                     else {
                         uint32_t rep, val = 0;
                         if (sym == 16u) { if (!i) { ok = false; break; } val = prev; rep = 3u + br.get(2); }
                         else if (sym == 17u) rep = 3u + br.get(3);
                         else rep = 11u + br.get(7);
                         if (i + rep > total_lens) { ok = false; break; }
-                        for (uint32_t r = 0; r < rep; ++r) L.lens[32u + i + r][lane] = (uint8_t)val;
+                        for (uint32_t r = 0; r < rep; ++r) lens_at(L, 32u + i + r, lane) = (uint8_t)val;
                         i += rep; prev = val;
                     }
                     if (br.over) ok = false;
                 }
                 // (the lengths lie at lens[32 ...]: the code length code's own nineteen stay below them)
-                ok = ok && L.lens[32u + 256u][lane] != 0;             // no end-of-block code: inflate.c "missing end-of-block"
+                ok = ok && lens_at(L, 32u + 256u, lane) != 0;             // no end-of-block code: inflate.c "missing end-of-block"
                 ok = ok && build_code(L, lane, 32, hlit, 0, sorted_syms);
                 ok = ok && build_code(L, lane, 32u + hlit, hdist, 1, sorted_syms);
                 if (!ok) fail(br.over ? MK_GZ_TRUNCATED : MK_GZ_BAD_LENGTHS);
-                else { long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane); state = ST_TOKENS; }
+                else { long_l.load(L.cnt_l, lane); long_d.load(L.cnt_d, lane); keep_long(); state = ST_TOKENS; }
             } else {
                 fail(MK_GZ_BAD_BLOCK);
             }
@@ -547,6 +570,7 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *__restrict__ p, uint6
 }
 
 __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x);
+constexpr uint32_t kFindTiles = 16;
 
 __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict__ gz, const mk_gz_stream *__restrict__ streams, const uint64_t *__restrict__ word_first,
                                                       uint32_t n, uint64_t *__restrict__ hits, uint32_t *__restrict__ n_hits, uint32_t cap)
@@ -569,10 +593,23 @@ __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict_
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    // (kFindTiles tiles of 256 words per workgroup: the hits of all of them leave with one atomic on the one counter -- at a
+    // tile per workgroup that counter took 1.5 million atomics for a thousand genomes, 12 ns each: the kernel's whole time)
+    for (uint32_t tile = 0; tile < kFindTiles; ++tile) {
+    const uint64_t w = ((uint64_t)blockIdx.x * kFindTiles + tile) * 256u + threadIdx.x;
+    if (((uint64_t)blockIdx.x * kFindTiles + tile) * 256u >= word_first[n]) break;                 // (the same for every thread)
     const bool live = w < word_first[n];
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (word_first[mid] <= w) lo = mid; else hi = mid; }
+    // whose word: the last stream that starts at or before it.  Searched ONCE per wave, for the wave's first word, on scalar
+    // registers (ten dependent loads from the scalar cache instead of ten dependent vector loads per lane -- the kernel's
+    // time was that chain); a lane whose word lies in a later stream steps forward from there
+    uint32_t lo = 0;
+    {
+        const uint64_t w_wave = ((uint64_t)blockIdx.x * kFindTiles + tile) * 256u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+        uint32_t a = 0, b = n;
+        while (b - a > 1u) { const uint32_t mid = (a + b) / 2u; if (word_first[mid] <= w_wave) a = mid; else b = mid; }
+        lo = a;
+    }
+    while (lo + 1u < n && word_first[lo + 1u] <= w) ++lo;
     const mk_gz_stream st = streams[lo];
     const uint64_t wi = live ? w - word_first[lo] : 0u;
     const uint32_t *__restrict__ p = reinterpret_cast<const uint32_t *>(gz + st.in_off) + wi;
@@ -583,13 +620,15 @@ __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict_
     if (lane == 63u) { s_w[wave][64] = w1; s_w[wave][65] = live ? p[2] : 0u; s_w[wave][66] = live ? p[3] : 0u; }
     s_lo[wave][lane] = lo;
     s_wi[wave][lane] = (uint32_t)wi;
-    // ---- step 1: which of the word's 32 offsets could start a dynamic block
-    uint32_t pass = 0;
-#pragma unroll 8
-    for (uint32_t o = 0; o < 32u; ++o) {
-        const uint32_t a = o ? __builtin_amdgcn_alignbit(w1, w0, o) : w0;            // bits [o, o + 32)
-        const bool ok = ((a >> 1) & 3u) == 2u && ((a >> 3) & 31u) <= 29u && ((a >> 8) & 31u) <= 29u;   // BTYPE: dynamic codes; HLIT, HDIST
-        pass |= ok ? 1u << o : 0u;
+    // ---- step 1: which of the word's 32 offsets could start a dynamic block -- all 32 at once: bit o of (w1:w0) >> k is bit
+    // o + k of the stream, so "BTYPE = 2" (bit o + 1 clear, bit o + 2 set), "HLIT <= 29" (not all of bits o + 4 .. o + 7 set)
+    // and "HDIST <= 29" (not all of o + 9 .. o + 12) are a dozen word operations instead of a dozen per offset
+    uint32_t pass;
+    {
+        auto sh = [&](uint32_t k) { return __builtin_amdgcn_alignbit(w1, w0, k); };
+        const uint32_t dyn = ~sh(1) & sh(2);
+        const uint32_t hlit30 = sh(4) & sh(5) & sh(6) & sh(7), hdist30 = sh(9) & sh(10) & sh(11) & sh(12);
+        pass = dyn & ~hlit30 & ~hdist30;
     }
     if (!look) pass = 0;
     else if (bit0 + 31u + 80u > nbits) {                             // (the stream's last words: offset by offset)
@@ -616,19 +655,22 @@ __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict_
         const uint32_t a = o ? __builtin_amdgcn_alignbit(x1, x0, o) : x0, bb = o ? __builtin_amdgcn_alignbit(x2, x1, o) : x1,
                        c = o ? __builtin_amdgcn_alignbit(x3, x2, o) : x2;                      // bits [o, ..), [o + 32, ..), [o + 64, ..)
         const uint32_t hclen = ((a >> 13) & 15u) + 4u;
-        uint64_t x = (((uint64_t)bb << 32) | a) >> 17;                // 47 bits: fifteen lengths
-        uint32_t kraft = 0;
-        for (uint32_t i = 0; i < hclen; ++i) {
-            if (i == 15u) x = (((uint64_t)c << 32) | bb) >> 30;      // from bit 17 + 45 = 62 on
-            const uint32_t l = (uint32_t)x & 7u;
-            x >>= 3;
-            kraft += l ? 128u >> l : 0u;
-        }
+        // the (up to nineteen) three-bit lengths as one 57-bit number, cut off behind the last one; its three bit planes say
+        // which fields hold which length, a population count each how many: no loop over the lengths
+        uint64_t x = ((((uint64_t)bb << 32) | a) >> 17) | ((uint64_t)c << 47);
+        x &= (1ull << (3u * hclen)) - 1ull;
+        constexpr uint64_t kEvery3rd = 0x1249249249249249ull;
+        const uint64_t p0 = x & kEvery3rd, p1 = (x >> 1) & kEvery3rd, p2 = (x >> 2) & kEvery3rd;
+        const uint64_t hi = p1 & p2, mid2 = p1 & ~p2, mid4 = ~p1 & p2, lo = ~p1 & ~p2;     // lengths 6-7, 2-3, 4-5, 0-1
+        const uint32_t kraft = (uint32_t)__popcll(hi & p0) + 2u * (uint32_t)__popcll(hi & ~p0) + 4u * (uint32_t)__popcll(mid4 & p0) + 8u * (uint32_t)__popcll(mid4 & ~p0) +
+                               16u * (uint32_t)__popcll(mid2 & p0) + 32u * (uint32_t)__popcll(mid2 & ~p0) + 64u * (uint32_t)__popcll(lo & p0);
         if (kraft != 128u) continue;
         const uint64_t hit = ((uint64_t)s_lo[wave][t] << 40) | ((uint64_t)s_wi[wave][t] * 32u + o);
         const uint32_t at = atomicAdd(&s_n, 1u);
         if (at < 512u) s_hits[at] = hit;
         else { const uint32_t g = atomicAdd(n_hits, 1u); if (g < cap) hits[g] = hit; }
+    }
+    __syncthreads();                                                 // (the next tile writes the words and the list again)
     }
     __syncthreads();
     const uint32_t got = min(s_n, 512u);
@@ -916,7 +958,9 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
     auto crc_to = [&](uint32_t upto) {
         while (crc_from < upto) {
             const uint32_t end = min(upto, (crc_from / kFlush + 1u) * kFlush);
+#if !defined(GZ_EXP) || GZ_EXP != 1
             crc_span(crc_from, end);
+#endif
             crc_from = end;
         }
     };
@@ -947,13 +991,15 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
     const uint32_t ntok = min(sg.n_tok, sg.tok_cap);                 // (more than its room: the host has had the segment decoded again)
     if (sg.n_tok > sg.tok_cap) { status = MK_GZ_INTERNAL; break; }
     uint32_t t0 = 0;
-    uint32_t t_next = lane < ntok ? tok[lane] : kTokMember;          // the step's tokens, requested a step ahead
-    uint32_t t_next_at = 0;
+    // the tokens of this step and of the two after it are in registers, those of the third are requested now: a load from
+    // memory takes a microsecond and a step a third of that (requested one step ahead, the wait for it was a quarter of the
+    // kernel's time).  The usual step takes all 64; any other starts the queue again.
+    auto fetch = [&](uint32_t from) { return from + lane < ntok ? tok[from + lane] : kTokMember; };
+    uint32_t q0 = fetch(0), q1 = fetch(64u), q2 = fetch(128u), q_at = 0;
     while (t0 < ntok && status == MK_GZ_OK) {                        // (every pass takes at least one token)
-        const uint32_t idx = t0 + lane;
-        uint32_t t = t_next_at == t0 ? t_next : (idx < ntok ? tok[idx] : kTokMember);
-        t_next_at = t0 + 64u;                                        // (the usual step takes all 64)
-        t_next = t_next_at + lane < ntok ? tok[t_next_at + lane] : kTokMember;
+        if (q_at != t0) { q0 = fetch(t0); q1 = fetch(t0 + 64u); q2 = fetch(t0 + 128u); q_at = t0; }
+        const uint32_t t = q0;
+        const uint32_t q3 = fetch(t0 + 192u);
         // a stored block or a member's end among these tokens: the tokens before it first, then the special itself
         const unsigned long long special = __ballot((t & (kTokMember | kTokStored)) && !(t & kTokMatch));
         const uint32_t upto_lane = special ? (uint32_t)__ffsll((long long)special) - 1u : 64u;
@@ -1007,6 +1053,13 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         bool done = !act;
         if (act && !is_match) { win[dst % kWin] = (uint8_t)t; done = true; }
         unsigned long long todo = __ballot(!done);
+#if defined(GZ_EXP) && GZ_EXP == 2
+        todo = 0;                                                    // (experiment: no copies at all)
+#endif
+#if defined(GZ_EXP) && GZ_EXP == 3
+        done = done || dist < 512u;                                  // (experiment: nothing that could depend on this step)
+        todo = __ballot(!done);
+#endif
         uint8_t *const sink = rsmem + 4096u + kResolveWaves * kWin + wave * 64u + lane;     // where the bytes of a piece beyond a token's end go
         while (todo) {                                               // (each round finishes at least the lowest unfinished lane)
             const uint32_t low = (uint32_t)__ffsll((long long)todo) - 1u;
@@ -1049,6 +1102,7 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         }
         pos += total;
         t0 += take;
+        if (take == 64u) { q0 = q1; q1 = q2; q2 = q3; q_at = t0; }
         leave();
     }
     }
@@ -1350,36 +1404,49 @@ static void *gz_stage_get(mk_ctx *c)
     return got.p;
 }
 
-// bytes [at, at + bytes) of file i; staged: `data` is a piece from gz_stage_get, which takes it back when the copy is done
+// bytes [at, at + bytes) of file i; staged: `data` is a piece from gz_stage_get, which takes it back -- when the copy is
+// done, or at once when there is nothing to copy or the call fails
 static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
 {
     mk_ctx *c = r.c;
-    if (i >= r.n || at + bytes > r.streams[i].in_len) { set_error("file %u: bytes beyond its size", i); return MK_ERR_ARG; }
-    MK_HIP(hipSetDevice(c->p.device));
+    mk_ctx::GzStage piece{nullptr, nullptr};
+    hipStream_t up = nullptr;
+    if (staged) {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        for (size_t k = 0; k < c->gz_stage_held.size(); ++k)
+            if (c->gz_stage_held[k].p == data) { piece = c->gz_stage_held[k]; c->gz_stage_held.erase(c->gz_stage_held.begin() + (long)k); break; }
+        if (!piece.p) { set_error("not a piece of the context's staging pool"); return MK_ERR_ARG; }
+        const uint32_t k = c->gz_up_next++ % 4u;
+        if (!c->gz_up[k] && (hipSetDevice(c->p.device) != hipSuccess || hipStreamCreateWithFlags(&c->gz_up[k], hipStreamNonBlocking) != hipSuccess)) {
+            (void)hipGetLastError();
+            c->gz_up[k] = nullptr;
+        }
+        up = c->gz_up[k];
+    }
+    auto give_back = [&](bool queued) {
+        if (!piece.p) return;
+        std::lock_guard<std::mutex> g(c->gz_m);
+        if (queued) c->gz_stage_busy.push_back(piece); else c->gz_stage_free.push_back(piece);
+    };
+    if (i >= r.n || at + bytes > r.streams[i].in_len) { give_back(false); set_error("file %u: bytes beyond its size", i); return MK_ERR_ARG; }
+    if (hipSetDevice(c->p.device) != hipSuccess) { give_back(false); set_error("cannot use the device"); return MK_ERR_DEVICE; }
     uint8_t *dst = r.d_gz + r.streams[i].in_off + at;
     if (!staged) {
         if (bytes) MK_HIP(hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, r.st));
         r.loose_puts = true;
         return MK_OK;
     }
-    mk_ctx::GzStage piece{nullptr, nullptr};
-    hipStream_t up = nullptr;
-    {
-        std::lock_guard<std::mutex> g(c->gz_m);
-        for (size_t k = 0; k < c->gz_stage_held.size(); ++k)
-            if (c->gz_stage_held[k].p == data) { piece = c->gz_stage_held[k]; c->gz_stage_held.erase(c->gz_stage_held.begin() + (long)k); break; }
-        const uint32_t k = c->gz_up_next++ % 4u;
-        if (piece.p && !c->gz_up[k] && hipStreamCreateWithFlags(&c->gz_up[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->gz_up[k] = nullptr; }
-        up = c->gz_up[k];
+    if (!bytes) { give_back(false); return MK_OK; }
+    if (!up || bytes > kStagePiece || hipStreamWaitEvent(up, r.ev_open, 0) != hipSuccess || hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, up) != hipSuccess ||
+        hipEventRecord(piece.ev, up) != hipSuccess) {
+        (void)hipGetLastError();
+        if (up) (void)hipStreamSynchronize(up);                       // (whatever of it was queued is done before the piece is lent again)
+        give_back(false);
+        set_error("cannot queue the copy of file %u", i);
+        return MK_ERR_DEVICE;
     }
-    if (!piece.p) { set_error("not a piece of the context's staging pool"); return MK_ERR_ARG; }
-    int rc = MK_OK;
-    if (!up || bytes > kStagePiece) { set_error("cannot queue the copy of file %u", i); rc = MK_ERR_DEVICE; }
-    else if (hipStreamWaitEvent(up, r.ev_open, 0) != hipSuccess || (bytes && hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, up) != hipSuccess) ||
-             hipEventRecord(piece.ev, up) != hipSuccess) { set_error("copy of file %u: %s", i, hipGetErrorString(hipGetLastError())); rc = MK_ERR_DEVICE; }
-    std::lock_guard<std::mutex> g(c->gz_m);
-    if (rc == MK_OK) c->gz_stage_busy.push_back(piece); else c->gz_stage_free.push_back(piece);
-    return rc;
+    give_back(true);
+    return MK_OK;
 }
 
 static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uint64_t(const std::vector<mk_gz_stream> &)> &extra_bytes)
@@ -1403,9 +1470,9 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
         }
     // ---- where blocks start; the candidates in order; every segment's tokens; the chains
     if (r.total_words) {
-        hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((r.total_words + 255u) / 256u)), dim3(256), 0, st, r.d_gz, r.d_streams, r.d_wf, n, r.d_hits, r.d_cnt, r.hit_cap);
+        hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((r.total_words + 256u * kFindTiles - 1u) / (256u * kFindTiles))), dim3(256), 0, st, r.d_gz, r.d_streams, r.d_wf, n, r.d_hits, r.d_cnt, r.hit_cap);
         MK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(gz_check_kernel, dim3(std::min<uint32_t>((r.hit_cap + 63u) / 64u, 8192u)), dim3(64), 0, st, r.d_gz, r.d_streams, r.d_hits, r.d_cnt, r.hit_cap,
+        hipLaunchKernelGGL(gz_check_kernel, dim3(std::min<uint32_t>((r.hit_cap + 63u) / 64u, 1u << 20)), dim3(64), 0, st, r.d_gz, r.d_streams, r.d_hits, r.d_cnt, r.hit_cap,
                            r.d_good, r.d_cnt + 1, r.good_cap);
         MK_HIP(hipGetLastError());
         const uint32_t wide = std::min<uint32_t>((r.good_cap + 255u) / 256u, 512u);

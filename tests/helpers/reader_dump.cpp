@@ -6,6 +6,10 @@
 // With "share:<unit>:<ahead>" instead of "packed" the reader packs AND shares gzip'd files with the device in units of <unit>
 // files (fasta_reader.hpp): a raw item's line is "raw <length> <fnv1a64 of the file's bytes>"; raw items are given back
 // (raw_consumed) only when <unit> of them have been seen, as a device batch would.
+// With "sink:<unit>:<ahead>" the same through a RawSink (what the driver binds to mk_gz_open / mk_gz_stage / mk_gz_put): the
+// files of a device unit are put piece by piece (lent pieces of 3,000 bytes, every fifth request refused) into a batch this
+// helper keeps in memory; a raw item has no bytes of its own, its line is made from the batch's when the unit's last file
+// has been taken (the lines still come in list order).
 // With a budget the reader gets an allocator that hands out at most that many bytes and then
 // fails (the page-lock limit of pinned memory); with "take only N" the reader is destroyed
 // while workers are still parked on the read-ahead bound (must not hang).
@@ -13,7 +17,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +35,48 @@ static void *budget_alloc(void *, size_t bytes)
 }
 static void budget_free(void *, void *p) { --g_live; free(p); }
 
+// a stand-in for the device: a unit's files assembled in memory
+struct FakeBatch { std::vector<std::vector<unsigned char>> files; };
+static std::mutex g_sink_m;
+static std::vector<void *> g_lent;
+static std::atomic<long> g_stage_calls{0};
+static void *fake_open(void *, const uint64_t *sizes, uint32_t m)
+{
+    FakeBatch *b = new FakeBatch();
+    for (uint32_t i = 0; i < m; ++i) b->files.emplace_back((size_t)sizes[i], (unsigned char)0);
+    return b;
+}
+static void *fake_stage(void *, void *, uint64_t *cap)
+{
+    if (g_stage_calls.fetch_add(1) % 5 == 4) return nullptr;           // (none to be had: the reader uses its own memory)
+    void *p = malloc(3000);
+    std::lock_guard<std::mutex> g(g_sink_m);
+    g_lent.push_back(p);
+    *cap = 3000;
+    return p;
+}
+static bool fake_put(void *, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
+{
+    FakeBatch *b = (FakeBatch *)batch;
+    bool ok = i < b->files.size() && at + bytes <= b->files[i].size();
+    if (ok && bytes) memcpy(b->files[i].data() + at, data, (size_t)bytes);
+    if (staged) {
+        std::lock_guard<std::mutex> g(g_sink_m);
+        bool found = false;
+        for (size_t k = 0; k < g_lent.size(); ++k) if (g_lent[k] == data) { g_lent.erase(g_lent.begin() + (long)k); found = true; break; }
+        if (!found) ok = false;
+        else free(const_cast<void *>(data));
+    }
+    return ok;
+}
+
+static uint64_t fnv(const unsigned char *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t j = 0; j < n; ++j) { h ^= p[j]; h *= 1099511628211ull; }
+    return h;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) return 2;
@@ -43,21 +91,28 @@ int main(int argc, char **argv)
         if (budget > 0) a = mkhost::HostAllocator{budget_alloc, budget_free, nullptr};
         const std::string mode = argc > 6 ? argv[6] : "";
         size_t unit = 0, ahead = 0;
-        const bool share = sscanf(mode.c_str(), "share:%zu:%zu", &unit, &ahead) == 2;
+        const bool with_sink = sscanf(mode.c_str(), "sink:%zu:%zu", &unit, &ahead) == 2;
+        const bool share = with_sink || sscanf(mode.c_str(), "share:%zu:%zu", &unit, &ahead) == 2;
         const bool packed = share || mode == "packed";
+        mkhost::RawSink sink;
+        if (with_sink) { sink.open = fake_open; sink.stage = fake_stage; sink.put = fake_put; }
         mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), a, argc > 3 ? (size_t)atoi(argv[3]) : 4,
-                                          packed, share, unit, ahead);
+                                          packed, share, unit, ahead, sink);
         size_t raw_held = 0;
-        for (size_t i = 0; i < files.size() && i < only; ++i) {
-            mkhost::OrderedFastaReader::Item it = reader.take(i);
-            uint64_t h = 1469598103934665603ull;
+        std::vector<mkhost::OrderedFastaReader::Item> held;             // a device unit's items until its last file has come
+        auto line = [&](mkhost::OrderedFastaReader::Item &it) {
+            if (it.raw && it.unit_batch) {                              // (its bytes are in the sink's batch)
+                const auto &bytes = ((FakeBatch *)it.unit_batch)->files[it.unit_index];
+                printf("raw %zu %016llx\n", bytes.size(), (unsigned long long)fnv(bytes.data(), bytes.size()));
+                return;
+            }
             if (it.raw) {
-                for (size_t j = 0; j < it.len; ++j) { h ^= (unsigned char)it.data[j]; h *= 1099511628211ull; }
-                printf("raw %zu %016llx\n", it.len, (unsigned long long)h);
+                printf("raw %zu %016llx\n", it.len, (unsigned long long)fnv((const unsigned char *)it.data, it.len));
                 reader.recycle(it);
                 if (++raw_held >= unit) { reader.raw_consumed(raw_held); raw_held = 0; }
-                continue;
+                return;
             }
+            uint64_t h = 1469598103934665603ull;
             if (packed && it.exists && !it.failed) {
                 for (size_t j = 0; j < it.len; ++j) {
                     const bool bad = (it.except[j / 64] >> (j % 64)) & 1u;
@@ -68,13 +123,25 @@ int main(int argc, char **argv)
                 for (size_t j = 0; j < 32 && j < it.len; ++j) printf("%02x", (unsigned char)it.head[j]);
                 printf("\n");
                 reader.recycle(it);
+                return;
+            }
+            printf("%d %zu %016llx %d\n", it.exists ? 1 : 0, it.len, (unsigned long long)fnv((const unsigned char *)it.data, it.len), it.failed ? 1 : 0);
+            reader.recycle(it);
+        };
+        for (size_t i = 0; i < files.size() && i < only; ++i) {
+            mkhost::OrderedFastaReader::Item it = reader.take(i);
+            if (it.unit_batch) {
+                held.push_back(it);
+                if (!it.unit_last) continue;
+                for (auto &u : held) line(u);
+                delete (FakeBatch *)it.unit_batch;
+                reader.raw_consumed(held.size());
+                held.clear();
                 continue;
             }
-            for (size_t j = 0; j < it.len; ++j) { h ^= (unsigned char)it.data[j]; h *= 1099511628211ull; }
-            printf("%d %zu %016llx %d\n", it.exists ? 1 : 0, it.len, (unsigned long long)h, it.failed ? 1 : 0);
-            reader.recycle(it);
+            line(it);
         }
     }                                                  // destructor: joins the workers, releases the pool
-    printf("done live=%ld\n", (long)g_live.load());
+    printf("done live=%ld lent=%zu\n", (long)g_live.load(), g_lent.size());
     return 0;
 }
