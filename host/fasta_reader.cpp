@@ -309,6 +309,11 @@ OrderedFastaReader::OrderedFastaReader(std::vector<std::string> files, unsigned 
       ubatch_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0, nullptr), udone_(raw_unit_ ? files_.size() / raw_unit_ + 1 : 0), sink_(sink), share_(share)
 {
     for (auto &d : udone_) d.store(0);
+    usize_.resize(udone_.size()); uoff_.resize(udone_.size());
+    // a reader takes runs of eight files where there are plenty (a run of a device unit is read into ONE page-locked piece and
+    // goes up as one copy: at a copy per file the copies' fixed cost -- a fifth of a millisecond each, whatever the runtime
+    // does with them -- was what the upload ran at: 8 GB/s); a run never straddles two units
+    if (sink_.open && sink_.put_span && raw_unit_ % 8 == 0 && files_.size() >= (size_t)64 * std::max(1u, threads)) run_ = 8;
     if (!raw_unit_ || !sink_.open || !sink_.put) sink_ = RawSink();     // (a sink works on units)
     for (auto &u : umode_) u.store(0);
     if (raw_gz_) ahead_limit_ = 16ull << 30;                        // (a device batch is thousands of files: their bytes wait here)
@@ -401,6 +406,8 @@ OrderedFastaReader::Item OrderedFastaReader::take(size_t i)
 bool OrderedFastaReader::put_raw(size_t i, const stat_view &sv, Item &it)
 {
     if (!sv.regular || sv.size < 18 || sv.size >= (1ll << 31)) return false;
+    const size_t unit = i / raw_unit_;
+    if (!usize_[unit].empty() && usize_[unit][it.unit_index] != (uint64_t)sv.size) return false;    // (changed since the unit was opened)
     const int fd = ::open(files_[i].c_str(), O_RDONLY);
     if (fd < 0) return false;
     std::vector<char> own;                                          // (only when the sink has no buffer to lend)
@@ -431,18 +438,102 @@ bool OrderedFastaReader::put_raw(size_t i, const stat_view &sv, Item &it)
     return true;
 }
 
+// A reader's span: files of one unit that follow each other in the list, read into ONE lent piece at the places they have in
+// the batch's input (zeros between them), put with one call.  Their items are published when the span has been put, and only
+// then do they count as dealt with -- the unit must not run before their bytes are on their way.
+struct OrderedFastaReader::RunStage {
+    char *buf = nullptr;
+    uint64_t cap = 0, used = 0;            // bytes of the piece, bytes laid out so far
+    void *batch = nullptr;
+    size_t unit = 0;
+    uint32_t first = 0, count = 0;         // files [first, first + count) of the unit
+    bool last_held = false;                // the file stage_raw took last lies in the span (not put piecewise)
+    std::vector<std::pair<size_t, Item>> held;   // (list index, item): published when the span has been put
+};
+
+void OrderedFastaReader::publish(size_t i, const Item &it)
+{
+    { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
+    cv_.notify_all();
+}
+
+// k files of the unit have been dealt with: the one that makes the unit whole says so to the sink (before its item is published)
+void OrderedFastaReader::unit_file_done(size_t unit, void *batch, uint32_t k)
+{
+    if (!batch || !sink_.complete || !k) return;
+    const size_t u0 = unit * raw_unit_;
+    const uint32_t in_unit = (uint32_t)(std::min(files_.size(), u0 + raw_unit_) - u0);
+    if (udone_[unit].fetch_add(k) + k == in_unit) sink_.complete(sink_.user, batch);
+}
+
+void OrderedFastaReader::flush_stage(RunStage &rs)
+{
+    if (!rs.buf) return;
+    const bool ok = sink_.put_span(sink_.user, rs.batch, rs.first, rs.count, rs.buf, rs.used, true);
+    rs.buf = nullptr;
+    (void)ok;                                                        // (a copy that could not be queued leaves the files empty on the device, which says
+                                                                     //  so per file: the consumer then reads them itself)
+    unit_file_done(rs.unit, rs.batch, (uint32_t)rs.held.size());
+    for (auto &h : rs.held) publish(h.first, h.second);
+    rs.held.clear(); rs.count = 0; rs.used = 0;
+}
+
+// file i of a device unit into the reader's span (a new one when it does not follow the span's last file or does not fit);
+// true: the item is raw and HELD in rs (published by flush_stage).  A file larger than a piece goes the piecewise way.
+bool OrderedFastaReader::stage_raw(size_t i, size_t unit, const stat_view &sv, Item &it, RunStage &rs)
+{
+    rs.last_held = false;
+    if (!sv.regular || sv.size < 18 || sv.size >= (1ll << 31)) return false;
+    const std::vector<uint64_t> &off = uoff_[unit];
+    const uint32_t j = it.unit_index;
+    if (usize_[unit][j] != (uint64_t)sv.size) return false;         // (changed since the unit was opened)
+    const uint64_t size = (uint64_t)sv.size, room = off[j + 1] - off[j];
+    if (rs.buf && (rs.batch != it.unit_batch || rs.first + rs.count != j || off[j + 1] - off[rs.first] > rs.cap)) flush_stage(rs);
+    if (!rs.buf) {
+        uint64_t cap = 0;
+        char *buf = sink_.stage ? (char *)sink_.stage(sink_.user, it.unit_batch, &cap) : nullptr;
+        if (!buf) return put_raw(i, sv, it);                        // (none to be had)
+        if (room > cap) { (void)sink_.put(sink_.user, it.unit_batch, j, 0, buf, 0, true); return put_raw(i, sv, it); }   // (a file larger than a piece)
+        rs.buf = buf; rs.cap = cap; rs.used = 0; rs.batch = it.unit_batch; rs.unit = unit; rs.first = j; rs.count = 0;
+    }
+    char *dst = rs.buf + (off[j] - off[rs.first]);
+    bool ok = false;
+    const int fd = ::open(files_[i].c_str(), O_RDONLY);
+    if (fd >= 0) {
+        uint64_t got = 0;
+        while (got < size) {
+            const ssize_t r = pread(fd, dst + got, (size_t)(size - got), (off_t)got);
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        close(fd);
+        ok = got == size && (unsigned char)dst[0] == 0x1f && (unsigned char)dst[1] == 0x8b;
+    }
+    // (a file that is given up leaves zeros at its place: the device sees nothing there, and the item goes the ordinary way)
+    if (!ok) memset(dst, 0, (size_t)room); else memset(dst + size, 0, (size_t)(room - size));
+    rs.count = j + 1 - rs.first;
+    rs.used = off[j + 1] - off[rs.first];
+    if (!ok) return false;
+    it.raw = true; it.len = (size_t)size; it.data = nullptr; it.cap = 0;
+    rs.last_held = true;
+    return true;
+}
+
 void OrderedFastaReader::work()
 {
     std::vector<char> text, scratch;                               // per thread, reused from file to file
+    RunStage rs;
     for (;;) {
-        const size_t i = next_.fetch_add(1);
-        if (i >= files_.size()) return;
+        const size_t base = next_.fetch_add(run_);
+        if (base >= files_.size()) return;
+        for (size_t i = base; i < std::min(files_.size(), base + run_); ++i) {
         {
             std::unique_lock<std::mutex> lk(m_);
             // bounded read-ahead, in files and in bytes (the file the consumer waits for always goes)
             cv_.wait(lk, [&] { return stop_ || (i < consumed_ + window_ && (ahead_bytes_ < ahead_limit_ || i == consumed_)); });
-            if (stop_) return;                                          // destroyed before every item was taken
+            if (stop_) { lk.unlock(); flush_stage(rs); return; }        // destroyed before every item was taken
         }
+        bool staged_now = false;
         Item it;
         struct stat st;
         it.exists = stat(files_[i].c_str(), &st) == 0;
@@ -478,7 +569,9 @@ void OrderedFastaReader::work()
                                     if (fd >= 0) { gz_first = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b; close(fd); }
                                     break;
                                 }
-                            if (gz_first) batch = sink_.open(sink_.user, sizes.data(), (uint32_t)in_unit);
+                            std::vector<uint64_t> offs((size_t)in_unit + 1, 0);
+                            if (gz_first) batch = sink_.open(sink_.user, sizes.data(), (uint32_t)in_unit, offs.data());
+                            if (batch) { usize_[unit] = sizes; uoff_[unit] = offs; }
                         }
                         m = batch ? 1 : 2;
                         if (batch) raw_out_.fetch_add(in_unit);
@@ -499,7 +592,11 @@ void OrderedFastaReader::work()
             it.unit_batch = ubatch_[unit];
             it.unit_index = (uint32_t)(i - unit * raw_unit_);
             it.unit_last = i + 1 == files_.size() || (i + 1) % raw_unit_ == 0;
-            if (it.exists) raw_done = put_raw(i, stat_view{S_ISREG(st.st_mode) != 0, (long long)st.st_size}, it);
+            if (it.exists) {
+                const stat_view sv{S_ISREG(st.st_mode) != 0, (long long)st.st_size};
+                raw_done = run_ > 1 ? stage_raw(i, unit, sv, it, rs) : put_raw(i, sv, it);
+                staged_now = raw_done && run_ > 1 && rs.last_held;
+            }
         } else if (it.exists && to_device && S_ISREG(st.st_mode) && st.st_size >= 18 && st.st_size < (1ll << 31)) {
             // a gzip'd file as it is, for the device's inflater: read into a pooled buffer of ORDINARY memory (a gigabyte and
             // more of these are alive at a time: page-locking that much -- 50 ms per 256 MB, every reader waiting behind the
@@ -553,13 +650,11 @@ void OrderedFastaReader::work()
         }
         if (raw_unit_ && to_device && !raw_done && !sink_.open) raw_out_.fetch_sub(1);     // (a file of a device unit that does not go there; with a sink the
                                                                                             // consumer counts every file of the unit back)
-        if (it.unit_batch && sink_.complete) {
-            const size_t u0 = unit * raw_unit_;
-            const uint32_t in_unit = (uint32_t)(std::min(files_.size(), u0 + raw_unit_) - u0);
-            if (udone_[unit].fetch_add(1) + 1 == in_unit) sink_.complete(sink_.user, it.unit_batch);
+        if (staged_now) { rs.held.emplace_back(i, it); continue; }      // (published, and counted, when its span has been put)
+        unit_file_done(unit, it.unit_batch, it.unit_batch ? 1u : 0u);
+        publish(i, it);
         }
-        { std::lock_guard<std::mutex> g(m_); items_[i] = it; ahead_bytes_ += it.cap; ready_[i].store(1); }
-        cv_.notify_all();
+        flush_stage(rs);
     }
 }
 

@@ -71,12 +71,17 @@ private:
 // nobody waits for.  Without a sink (all null) raw items carry the file's bytes, as before.
 struct RawSink {
     void *user = nullptr;
-    // a unit of m files of these sizes (0: that file does not go to the device): a batch, or null -- the unit is the readers' then
-    void *(*open)(void *user, const uint64_t *sizes, uint32_t m) = nullptr;
+    // a unit of m files of these sizes (0: that file does not go to the device): a batch, or null -- the unit is the readers'
+    // then.  offsets[0 .. m]: where each file's bytes lie in the batch's input (file i at offsets[i], room up to offsets[i + 1],
+    // what lies between a file's end and the next file is zero): files that follow each other can be put as ONE span
+    void *(*open)(void *user, const uint64_t *sizes, uint32_t m, uint64_t *offsets) = nullptr;
     // a buffer of *cap bytes to read into; null: none to be had (the reader uses its own, and says staged = false)
     void *(*stage)(void *user, void *batch, uint64_t *cap) = nullptr;
     // bytes [at, at + bytes) of file i of the batch; staged: `data` came from stage() and is the sink's again
     bool (*put)(void *user, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged) = nullptr;
+    // files [first, first + count) at once: `data` holds offsets[first + count] - offsets[first] bytes or fewer, laid out as
+    // the batch's input is (null: the reader puts file by file)
+    bool (*put_span)(void *user, void *batch, uint32_t first, uint32_t count, const void *data, uint64_t bytes, bool staged) = nullptr;
     // every file of the unit has been dealt with (put, or found to be none of the device's): the batch may run -- called by
     // the reader that finished the unit's last file, BEFORE that file's item can be taken, so that the device works on a
     // unit while the consumer is still busy with the units before it
@@ -143,6 +148,13 @@ private:
     std::vector<std::atomic<int>> umode_;          // per unit: 0 undecided, 1 to the device, 2 inflated here, 3 being opened
     std::vector<void *> ubatch_;                   // per unit: the sink's batch (mode 1 with a sink)
     std::vector<std::atomic<uint32_t>> udone_;     // per unit: files dealt with
+    std::vector<std::vector<uint64_t>> usize_, uoff_;   // per unit (mode 1 with a sink): the files' sizes as the batch knows them, their places
+    size_t run_ = 1;                               // files a reader takes at a time (a run of a device unit goes up as one span)
+    struct RunStage;                               // a reader's span being filled
+    bool stage_raw(size_t i, size_t unit, const stat_view &sv, Item &it, RunStage &rs);
+    void flush_stage(RunStage &rs);
+    void publish(size_t i, const Item &it);
+    void unit_file_done(size_t unit, void *batch, uint32_t k);
     RawSink sink_;
     bool share_ = true;
     bool put_raw(size_t i, const struct stat_view &sv, Item &it);

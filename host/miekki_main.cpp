@@ -254,7 +254,7 @@ struct Driver {
         // ... and the readers' own zlib takes what the device has no room for: the list goes in units of one device batch, a
         // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
         // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.
-        static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return !e || atoi(e) != 0; }();
+        static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return e && atoi(e) != 0; }();
         // A unit's files go to the device as the readers read them (RawSink -> mk_gz_open / mk_gz_stage / mk_gz_put): straight
         // from the page cache into page-locked pieces the library lends, a DMA each, into a batch whose layout the files'
         // sizes fixed -- nothing of a gzip'd file waits in host memory.  A unit the device has no memory for is the readers'.
@@ -266,10 +266,16 @@ struct Driver {
             mk_ctx *ctx;
             std::mutex m;
             std::unordered_map<void *, std::shared_ptr<UnitRun>> runs;
-            static void *open(void *u, const uint64_t *sizes, uint32_t m)
+            static void *open(void *u, const uint64_t *sizes, uint32_t m, uint64_t *offsets)
             {
                 mk_gz_batch *b = nullptr;
-                return mk_gz_open(((Sink *)u)->ctx, sizes, m, &b) == MK_OK ? b : nullptr;
+                if (mk_gz_open(((Sink *)u)->ctx, sizes, m, &b) != MK_OK) return nullptr;
+                if (mk_gz_layout(b, offsets) != MK_OK) { mk_gz_free(b); return nullptr; }
+                return b;
+            }
+            static bool put_span(void *, void *batch, uint32_t first, uint32_t count, const void *data, uint64_t bytes, bool staged)
+            {
+                return mk_gz_put_span((mk_gz_batch *)batch, first, count, data, bytes, staged ? 1 : 0) == MK_OK;
             }
             static void *stage(void *, void *batch, uint64_t *cap) { return mk_gz_stage((mk_gz_batch *)batch, cap); }
             static bool put(void *, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
@@ -301,12 +307,12 @@ struct Driver {
         } sink_user;
         sink_user.ctx = ctx;
         mkhost::RawSink sink;
-        sink.user = &sink_user; sink.open = Sink::open; sink.stage = Sink::stage; sink.put = Sink::put; sink.complete = Sink::complete;
+        sink.user = &sink_user; sink.open = Sink::open; sink.stage = Sink::stage; sink.put = Sink::put; sink.put_span = Sink::put_span; sink.complete = Sink::complete;
         // (the arena outlives the reader: declared first.  Both are handed to a thread of their own when the shard is built:
         // giving gigabytes of page-locked memory back takes tenths of a second that nothing has to wait for)
         std::shared_ptr<PinnedArena> arena_p = std::make_shared<PinnedArena>(ctx);
         std::unique_ptr<OrderedFastaReader> reader_p(new OrderedFastaReader(files, nthreads, mkhost::HostAllocator{pinned_alloc, pinned_free, arena_p.get()},
-                                                                            std::max<size_t>(3 * 64, (gz_in_flight + 2) * gz_batch + 64), true, gz_batch != 0,
+                                                                            std::max<size_t>(3 * 64, gz_in_flight * gz_batch + 64), true, gz_batch != 0,
                                                                             gz_batch, gz_in_flight, gz_batch ? sink : mkhost::RawSink(), gz_share));
         OrderedFastaReader &reader = *reader_p;
         auto now = [] { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -389,6 +395,8 @@ struct Driver {
             sb.names.push_back(fn); sb.log += '-';
             return true;
         };
+        mk_gz_batch *retired = nullptr;                              // the unit appended last: its text may still be read
+        struct Retire { mk_gz_batch *&b; ~Retire() { if (b) mk_gz_free(b); b = nullptr; } } retire{retired};
         auto append_unit = [&](Pending &rb) {
             const double t0 = now();
             const int ran = rb.run ? rb.run->ran.get() : MK_ERR_STATE;
@@ -431,8 +439,11 @@ struct Driver {
                 }
             }
             ok = ok && append();
+            // the batch goes when the NEXT unit has been appended (mk_gz_free waits for the strip kernels that read its text:
+            // by then they are long done, and this thread has queued the next appends instead of standing here)
             const double tf = now();
-            if (rb.batch) mk_gz_free(rb.batch);                        // (waits for the strip kernels that read the batch's text)
+            if (retired) mk_gz_free(retired);
+            retired = rb.batch;
             rb.batch = nullptr;
             sb.t_free += now() - tf;
             sb.gz_on_device += rb.items.size();
@@ -1029,6 +1040,10 @@ struct Driver {
 int main(int argc, char **argv)
 {
     if (argc < 2) { help(); return 0; }
+    // (the HIP runtime folds its streams onto four hardware queues unless told otherwise; the ingest has a dozen streams with
+    // work at a time -- a batch's own, the upload streams, the build's -- and a copy that shares a queue with a long kernel of
+    // another stream waits behind it: eight queues, unless the user has said something)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     string index_file, list_file, query_lines, query_list, output_file("out.txt"), index_dump;
     uint64_t H = 17, core_number = 8, kmer_size = 31, bloom_size = 33, fingerprint_size = 3;   // main.cpp:131
     double threshold = 200;

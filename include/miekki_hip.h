@@ -233,6 +233,10 @@ int mk_gz_unpack(mk_ctx *ctx, const uint8_t *const *gz, const uint64_t *gz_bytes
 int mk_gz_open(mk_ctx *ctx, const uint64_t *gz_bytes, uint32_t n, mk_gz_batch **out);
 void *mk_gz_stage(mk_gz_batch *batch, uint64_t *cap);
 int mk_gz_put(mk_gz_batch *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, int staged);
+/* the files' places in the batch's input: offsets[0 .. n] (file i's bytes at offsets[i], zeros from its end to offsets[i + 1]);
+ * files that follow each other, laid out like that in one piece, go with one call (and one copy): mk_gz_put_span */
+int mk_gz_layout(const mk_gz_batch *batch, uint64_t *offsets);
+int mk_gz_put_span(mk_gz_batch *batch, uint32_t first, uint32_t count, const void *data, uint64_t bytes, int staged);
 int mk_gz_run(mk_gz_batch *batch);
 int mk_gz_sequence(const mk_gz_batch *batch, uint32_t i, uint64_t *len, int32_t *status);
 /* insert_sequences (Miekki.cpp:277-314) for files which[0 .. n) of the batch, in that order (each must have status MK_GZ_OK and

@@ -545,11 +545,11 @@ void mk_destroy(mk_ctx *c)
     dev_free(c->d_cold_stage);
     for (int i = 0; i < 5; ++i) if (c->ev_cold[i]) (void)hipEventDestroy(c->ev_cold[i]);
     dev_free(c->d_hits); dev_free(c->d_nhits);
-    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);        // (the inflater's blocks and staging: gunzip.hip)
+    gz_release_staging(c);                                         // (the inflater's staging first: block makers at work finish, gunzip.hip)
+    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
     c->gz_blocks.clear();
     for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
     c->gz_pins.clear();
-    gz_release_staging(c);
     for (int i = 0; i < 10; ++i) if (c->exact_buf[i]) (void)hipFree(c->exact_buf[i]);
     for (int b = 0; b < 2; ++b) {                                  // (d_counters, h_back, d_seq_off, d_seed_valid, d_ovf alias one of these)
         mk_ctx::BuildSide &sd = c->side[b];
@@ -705,6 +705,7 @@ int mk_index_append_gz(mk_ctx *c, const mk_gz_batch *batch, const uint32_t *whic
         const int buf = c->seq_cur ^ 1;
         MK_TRY(ensure_build_scratch(c, off[nb], buf));
         MK_TRY(gz_batch_strip(c, batch, which + g0, nb, reinterpret_cast<uint8_t *>(c->d_seq[buf]), off, c->copy_stream));
+        MK_TRY(gz_batch_used(batch, c->copy_stream));                // (the strip kernel is the batch's only reader: mk_gz_free waits for the last one)
         MK_HIP(hipEventRecord(c->ev_copy, c->copy_stream));
         MK_TRY(enqueue_front(c, off, nb, buf, kChars, c->ev_copy));
         MK_TRY(enqueue_back(c));

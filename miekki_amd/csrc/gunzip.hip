@@ -22,11 +22,14 @@
 // a status and nothing else: the caller (host/fasta_reader.cpp) hands such a file to the host's own inflater, which
 // then says what the file is worth.  Behind it, fasta.hip strips header lines and line ends and packs the sequences.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "mk_internal.hpp"
@@ -994,12 +997,14 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
     // the tokens of this step and of the two after it are in registers, those of the third are requested now: a load from
     // memory takes a microsecond and a step a third of that (requested one step ahead, the wait for it was a quarter of the
     // kernel's time).  The usual step takes all 64; any other starts the queue again.
-    auto fetch = [&](uint32_t from) { return from + lane < ntok ? tok[from + lane] : kTokMember; };
-    uint32_t q0 = fetch(0), q1 = fetch(64u), q2 = fetch(128u), q_at = 0;
+    // (a load is not looked at before its step: from a clamped place without a condition -- a select right behind the load
+    // would wait for it there and then -- and "beyond the segment's end" is decided where the token is used)
+    auto fetch = [&](uint32_t from) { return tok[min(from + lane, ntok - 1u)]; };
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q_at = ~0u;
     while (t0 < ntok && status == MK_GZ_OK) {                        // (every pass takes at least one token)
         if (q_at != t0) { q0 = fetch(t0); q1 = fetch(t0 + 64u); q2 = fetch(t0 + 128u); q_at = t0; }
-        const uint32_t t = q0;
         const uint32_t q3 = fetch(t0 + 192u);
+        const uint32_t t = t0 + lane < ntok ? q0 : kTokMember;
         // a stored block or a member's end among these tokens: the tokens before it first, then the special itself
         const unsigned long long special = __ballot((t & (kTokMember | kTokStored)) && !(t & kTokMatch));
         const uint32_t upto_lane = special ? (uint32_t)__ffsll((long long)special) - 1u : 64u;
@@ -1135,13 +1140,19 @@ static uint32_t x_pow_bytes(uint64_t nbytes)                          // x^(8 n)
 
 // ---- device memory of the inflater: blocks kept by the context between batches (allocating and freeing tens of gigabytes
 // per batch cost a second each)
-static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got)
+// (what MIEKKI_VERBOSE shows of the pool: device allocations made and their time, time readers stood waiting for a piece)
+static std::atomic<uint64_t> g_malloc_n{0}, g_malloc_us{0}, g_stage_wait_us{0}, g_stage_waits{0}, g_put_us{0};
+
+// (a block is taken only for the role it was made for -- a batch's input + tokens, or its text: with one list for all, a text
+// block would take the place of a token block and the next batch allocate a new one, in the middle of the run: an
+// allocation of gigabytes while the device is busy took up to a second and a half)
+static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got, int role)
 {
     {
         std::lock_guard<std::mutex> g(c->gz_m);
         size_t best = c->gz_blocks.size();
         for (size_t i = 0; i < c->gz_blocks.size(); ++i)
-            if (c->gz_blocks[i].second >= need && c->gz_blocks[i].second <= 2 * need + (64ull << 20) &&
+            if (c->gz_blocks[i].role == role && c->gz_blocks[i].second >= need &&
                 (best == c->gz_blocks.size() || c->gz_blocks[i].second < c->gz_blocks[best].second)) best = i;
         if (best != c->gz_blocks.size()) {
             uint8_t *p = (uint8_t *)c->gz_blocks[best].first;
@@ -1152,6 +1163,8 @@ static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got)
     }
     void *p = nullptr;
     const uint64_t want = need + need / 8 + 4096;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Count { std::chrono::steady_clock::time_point t0; ~Count() { ++g_malloc_n; g_malloc_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } } count{t0};
     if (hipMalloc(&p, want) != hipSuccess) {
         (void)hipGetLastError();
         {                                                            // what is kept and does not fit makes room
@@ -1165,11 +1178,11 @@ static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got)
     return (uint8_t *)p;
 }
 
-static void gz_block_put(mk_ctx *c, uint8_t *p, uint64_t bytes)
+static void gz_block_put(mk_ctx *c, uint8_t *p, uint64_t bytes, int role)
 {
     if (!p) return;
     std::lock_guard<std::mutex> g(c->gz_m);
-    c->gz_blocks.emplace_back(p, bytes);
+    c->gz_blocks.push_back(mk_ctx::GzBlock{p, bytes, role});
 }
 
 // Page-locked staging for the run's small copies (stream tables, block starts, segments): a copy to or from ordinary memory
@@ -1227,9 +1240,11 @@ struct GzRun {
     mk_gz_seg *d_segs = nullptr;
     uint8_t *d_extra = nullptr;                                       // `extra` bytes of the out block for the caller (256-byte aligned)
     uint64_t in_at = 0, total_words = 0;
-    uint32_t hit_cap = 0, good_cap = 0, tok_wgs = 0;
+    uint32_t hit_cap = 0, good_cap = 0, tok_wgs = 0, lds_tok = 0, lds_text = 0;
     uint32_t n_segs = 0, n_rewritten = 0;
     hipEvent_t ev_open = nullptr;                                     // the blocks are ready for the files' bytes
+    std::atomic<uint32_t> up_waited{0};                               // upload streams that wait for ev_open already
+    bool uploads_joined = false;                                      // the run's stream waits for every copy queued for it
     bool loose_puts = false;                                          // some file came from memory that is not the pool's: on the run's own stream
     double t_open = 0, t_blocks = 0, t_text = 0;
     // page-locked staging: pieces in use, and the downloads that wait for the stream (staging -> the caller's memory)
@@ -1294,20 +1309,22 @@ struct GzRun {
     {
         if (c) {
             (void)hipSetDevice(c->p.device);
-            for (hipStream_t u : c->gz_up) if (u) (void)wait_stream(u);    // (copies into this run's blocks may still be queued there)
+            // (copies into this run's blocks may still be queued on the upload streams -- unless gz_finish has made the run's own
+            // stream wait for them: then the wait for that stream below covers them)
+            if (!uploads_joined) for (hipStream_t u : c->gz_up) if (u) (void)wait_stream(u);
         }
         if (st) { (void)wait_stream(st); (void)hipStreamDestroy(st); }
         if (ev) (void)hipEventDestroy(ev);
         if (ev_open) (void)hipEventDestroy(ev_open);
         if (c) {
-            gz_block_put(c, blk_in, in_bytes); gz_block_put(c, blk_tok, tok_bytes); gz_block_put(c, blk_out, out_bytes);
+            gz_block_put(c, blk_in, in_bytes, 0); gz_block_put(c, blk_out, out_bytes, 1);
             for (Pin &p : pins) gz_pin_put(c, p.p, p.size);
         }
     }
 };
 
-constexpr uint64_t kStagePiece = 4ull << 20;
-constexpr uint32_t kStagePieces = 96;                                 // at most 384 MB of page-locked pieces per context
+constexpr uint64_t kStagePiece = 16ull << 20;                         // (room for a run of eight 5 Mb genomes gzip'd: a copy per run)
+constexpr uint32_t kStagePieces = 24;                                 // at most 384 MB of page-locked pieces per context
 
 static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
 {
@@ -1336,14 +1353,52 @@ static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
     r.good_cap = (uint32_t)std::min<uint64_t>(in_at / 2048u + 64ull * n + 4096u, 1u << 28);   // (a block per 26 KB of gzip'd DNA)
     int cus = 0;
     MK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->p.device));
-    r.tok_wgs = 2u * (uint32_t)std::max(cus, 1);                      // (two workgroups of the token kernel share a CU's LDS)
+    // LDS asked for by the two long-running kernels (token, text): what they need, or more -- so that fewer of their
+    // workgroups share a CU and the build's kernels find room beside them (experiments: MIEKKI_GZ_LDS_KB)
+    static const uint32_t lds_floor = [] { const char *e = getenv("MIEKKI_GZ_LDS_KB"); return e ? (uint32_t)atoi(e) << 10 : 0u; }();
+    r.lds_tok = std::max<uint32_t>((uint32_t)sizeof(TokLds), lds_floor);
+    r.lds_text = std::max<uint32_t>(4096u + kResolveWaves * kWin + 64u * kResolveWaves, lds_floor);
+    r.tok_wgs = (r.lds_tok <= (80u << 10) ? 2u : 1u) * (uint32_t)std::max(cus, 1);   // (workgroups of the token kernel that share a CU's LDS)
     uint64_t at = 0;
     auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
     const uint64_t o_gz = carve(in_at + 16), o_streams = carve((uint64_t)n * sizeof(mk_gz_stream)), o_wf = carve(((uint64_t)n + 1) * 8),
                    o_hits = carve((uint64_t)r.hit_cap * 8), o_good = carve((uint64_t)r.good_cap * 8), o_tmp = carve((uint64_t)r.good_cap * 8),
                    o_sorted = carve((uint64_t)r.good_cap * 8), o_per = carve((uint64_t)n * 4), o_fill = carve((uint64_t)n * 4), o_cnt = carve(64);
-    r.blk_in = gz_block_get(c, at, &r.in_bytes);
-    if (!r.blk_in) { set_error("no device memory for %u gzip'd files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
+    // ---- ... and behind them: a slot per byte of the files, the segments' results, the chains, the lanes' symbol lists
+    const uint64_t n_seg_room = (uint64_t)n + r.good_cap;
+    const uint64_t o_slots = carve((in_at + 16) * 4), o_segs = carve(n_seg_room * sizeof(mk_gz_seg)), o_chain = carve(n_seg_room * 4),
+                   o_aux = carve((uint64_t)r.tok_wgs * 64u * 288u * 4u);
+    r.blk_in = gz_block_get(c, at, &r.in_bytes, 0);
+    if (!r.blk_in) { set_error("no device memory for %u gzip'd files and their tokens (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
+    r.blk_tok = r.blk_in;
+    // (an allocation of gigabytes now and then takes a second -- the driver's doing, seen in one run of two: the blocks of the
+    // NEXT batch are made on a thread of their own while this one is being filled, so that only a context's first batch can
+    // stand waiting for one.  Text blocks are made for four times the files' bytes -- gzip'd DNA: 3.3; a batch that needs
+    // more makes its own)
+    {
+        const uint64_t need0 = at, need1 = in_at * 4u + (64ull << 20);
+        bool start = false;
+        { std::lock_guard<std::mutex> g(c->gz_m); start = !c->gz_closing; if (start) ++c->gz_making; }
+        if (start) std::thread([c, need0, need1] {
+            if (hipSetDevice(c->p.device) == hipSuccess) {
+                for (int role = 0; role < 2; ++role) {
+                    const uint64_t need = role == 0 ? need0 : need1;
+                    bool have = false;
+                    {
+                        std::lock_guard<std::mutex> g(c->gz_m);
+                        for (auto &blk : c->gz_blocks) have = have || (blk.role == role && blk.second >= need);
+                    }
+                    if (have || c->gz_closing) continue;
+                    uint64_t got = 0;
+                    uint8_t *p = gz_block_get(c, need, &got, -1 - role);  // (a role nobody holds: always a new block)
+                    if (p) gz_block_put(c, p, got, role);
+                }
+            } else (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(c->gz_m);
+            --c->gz_making;
+            c->gz_cv.notify_all();
+        }).detach();
+    }
     r.d_gz = r.blk_in + o_gz;
     r.d_streams = reinterpret_cast<mk_gz_stream *>(r.blk_in + o_streams);
     r.d_wf = reinterpret_cast<uint64_t *>(r.blk_in + o_wf); r.d_hits = reinterpret_cast<uint64_t *>(r.blk_in + o_hits);
@@ -1351,13 +1406,6 @@ static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
     r.d_sorted = reinterpret_cast<uint64_t *>(r.blk_in + o_sorted);
     r.d_per_stream = reinterpret_cast<uint32_t *>(r.blk_in + o_per); r.d_fill = reinterpret_cast<uint32_t *>(r.blk_in + o_fill);
     r.d_cnt = reinterpret_cast<uint32_t *>(r.blk_in + o_cnt);
-    // ---- the token block: a slot per byte of the input block, the segments' results, the chains, the lanes' symbol lists
-    at = 0;
-    const uint64_t n_seg_room = (uint64_t)n + r.good_cap;
-    const uint64_t o_slots = carve((in_at + 16) * 4), o_segs = carve(n_seg_room * sizeof(mk_gz_seg)), o_chain = carve(n_seg_room * 4),
-                   o_aux = carve((uint64_t)r.tok_wgs * 64u * 288u * 4u);
-    r.blk_tok = gz_block_get(c, at, &r.tok_bytes);
-    if (!r.blk_tok) { set_error("no device memory for the tokens of %u gzip'd files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
     r.d_slots = reinterpret_cast<uint32_t *>(r.blk_tok + o_slots);
     r.d_segs = reinterpret_cast<mk_gz_seg *>(r.blk_tok + o_segs);
     r.d_chain = reinterpret_cast<uint32_t *>(r.blk_tok + o_chain);
@@ -1375,9 +1423,20 @@ static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
 }
 
 // a page-locked piece of kStagePiece bytes to read (a piece of) a file into; null: none to be had (use any memory)
+// (a reader thread selects the device once, not with every call: every runtime call takes the runtime's lock, and sixteen
+// readers at five calls a file stood in line for it)
+static inline bool gz_use_device(const mk_ctx *c)
+{
+    static thread_local int current = -1;
+    if (current == c->p.device) return true;
+    if (hipSetDevice(c->p.device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    current = c->p.device;
+    return true;
+}
+
 static void *gz_stage_get(mk_ctx *c)
 {
-    (void)hipSetDevice(c->p.device);
+    (void)gz_use_device(c);
     mk_ctx::GzStage got{nullptr, nullptr};
     bool wait = false;
     {
@@ -1397,7 +1456,11 @@ static void *gz_stage_get(mk_ctx *c)
             return nullptr;
         }
     } else if (wait) {
-        (void)hipEventSynchronize(got.ev);                            // the oldest queued copy: done soonest
+        const auto t0 = std::chrono::steady_clock::now();
+        // the oldest queued copy: done soonest -- usually long done (a blocking wait costs a sleep even then: ask first)
+        if (hipEventQuery(got.ev) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(got.ev); }
+        ++g_stage_waits;
+        g_stage_wait_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     }
     std::lock_guard<std::mutex> g(c->gz_m);
     c->gz_stage_held.push_back(got);
@@ -1406,18 +1469,22 @@ static void *gz_stage_get(mk_ctx *c)
 
 // bytes [at, at + bytes) of file i; staged: `data` is a piece from gz_stage_get, which takes it back -- when the copy is
 // done, or at once when there is nothing to copy or the call fails
-static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
+static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged, uint32_t span = 1)
 {
     mk_ctx *c = r.c;
     mk_ctx::GzStage piece{nullptr, nullptr};
     hipStream_t up = nullptr;
+    uint32_t k_up = 0;
+    const auto t_in = std::chrono::steady_clock::now();
+    struct Count { std::chrono::steady_clock::time_point t0; ~Count() { g_put_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); } } count{t_in};
     if (staged) {
         std::lock_guard<std::mutex> g(c->gz_m);
         for (size_t k = 0; k < c->gz_stage_held.size(); ++k)
             if (c->gz_stage_held[k].p == data) { piece = c->gz_stage_held[k]; c->gz_stage_held.erase(c->gz_stage_held.begin() + (long)k); break; }
         if (!piece.p) { set_error("not a piece of the context's staging pool"); return MK_ERR_ARG; }
-        const uint32_t k = c->gz_up_next++ % 4u;
-        if (!c->gz_up[k] && (hipSetDevice(c->p.device) != hipSuccess || hipStreamCreateWithFlags(&c->gz_up[k], hipStreamNonBlocking) != hipSuccess)) {
+        k_up = c->gz_up_next++ % 4u;
+        const uint32_t k = k_up;
+        if (!c->gz_up[k] && (!gz_use_device(c) || hipStreamCreateWithFlags(&c->gz_up[k], hipStreamNonBlocking) != hipSuccess)) {
             (void)hipGetLastError();
             c->gz_up[k] = nullptr;
         }
@@ -1428,8 +1495,12 @@ static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t 
         std::lock_guard<std::mutex> g(c->gz_m);
         if (queued) c->gz_stage_busy.push_back(piece); else c->gz_stage_free.push_back(piece);
     };
-    if (i >= r.n || at + bytes > r.streams[i].in_len) { give_back(false); set_error("file %u: bytes beyond its size", i); return MK_ERR_ARG; }
-    if (hipSetDevice(c->p.device) != hipSuccess) { give_back(false); set_error("cannot use the device"); return MK_ERR_DEVICE; }
+    // (a span of files: laid out by the caller as the input block is -- each file at its place, zeros up to the next)
+    const bool fits = i < r.n && span >= 1u && (uint64_t)i + span <= r.n &&
+                      (span == 1u ? at + bytes <= r.streams[i].in_len
+                                  : at == 0 && bytes <= (i + span < r.n ? r.streams[i + span].in_off : r.in_at) - r.streams[i].in_off);
+    if (!fits) { give_back(false); set_error("file %u: bytes beyond its size", i); return MK_ERR_ARG; }
+    if (!gz_use_device(c)) { give_back(false); set_error("cannot use the device"); return MK_ERR_DEVICE; }
     uint8_t *dst = r.d_gz + r.streams[i].in_off + at;
     if (!staged) {
         if (bytes) MK_HIP(hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, r.st));
@@ -1437,7 +1508,9 @@ static int gz_put(GzRun &r, uint32_t i, uint64_t at, const void *data, uint64_t 
         return MK_OK;
     }
     if (!bytes) { give_back(false); return MK_OK; }
-    if (!up || bytes > kStagePiece || hipStreamWaitEvent(up, r.ev_open, 0) != hipSuccess || hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, up) != hipSuccess ||
+    // (an upload stream waits for the run's blocks once, not with every piece)
+    const bool first_on_stream = !(r.up_waited.fetch_or(1u << k_up) & (1u << k_up));
+    if (!up || bytes > kStagePiece || (first_on_stream && hipStreamWaitEvent(up, r.ev_open, 0) != hipSuccess) || hipMemcpyAsync(dst, data, bytes, hipMemcpyHostToDevice, up) != hipSuccess ||
         hipEventRecord(piece.ev, up) != hipSuccess) {
         (void)hipGetLastError();
         if (up) (void)hipStreamSynchronize(up);                       // (whatever of it was queued is done before the piece is lent again)
@@ -1468,6 +1541,7 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
             (void)hipEventDestroy(e);                                 // (released when the work queued on it is done)
             MK_HIP(er);
         }
+    r.uploads_joined = true;
     // ---- where blocks start; the candidates in order; every segment's tokens; the chains
     if (r.total_words) {
         hipLaunchKernelGGL(gz_find_kernel, dim3((uint32_t)((r.total_words + 256u * kFindTiles - 1u) / (256u * kFindTiles))), dim3(256), 0, st, r.d_gz, r.d_streams, r.d_wf, n, r.d_hits, r.d_cnt, r.hit_cap);
@@ -1489,11 +1563,11 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
         MK_HIP(hipGetLastError());
     }
     static_assert(sizeof(TokLds) <= 80u << 10, "phase 1's tables and buffers: two waves per CU");
-    MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TokLds)));
+    MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_tokens_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.lds_tok));
     TokArgs A;
     A.gz = r.d_gz; A.streams = r.d_streams; A.n = n; A.sorted = r.d_sorted; A.n_good = r.d_cnt + 1; A.good_cap = r.good_cap;
     A.segs = r.d_segs; A.slots = r.d_slots; A.aux = r.d_aux; A.queue = r.d_cnt + 2; A.jobs = nullptr; A.n_jobs = 0;
-    hipLaunchKernelGGL(gz_tokens_kernel, dim3(r.tok_wgs), dim3(64), sizeof(TokLds), st, A);
+    hipLaunchKernelGGL(gz_tokens_kernel, dim3(r.tok_wgs), dim3(64), r.lds_tok, st, A);
     MK_HIP(hipGetLastError());
     hipLaunchKernelGGL(gz_chain_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, r.d_streams, n, r.d_segs, r.d_chain, r.d_cnt + 3);
     MK_HIP(hipGetLastError());
@@ -1542,7 +1616,7 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
     uint64_t at = 0;
     auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
     const uint64_t o_text = carve(out_at + 32), o_extra = carve(extra), o_dense = carve(dense_words * 4 + 16), o_jobs = carve(jobs.size() * sizeof(mk_gz_job) + 16);
-    r.blk_out = gz_block_get(c, at + 256, &r.out_bytes);
+    r.blk_out = gz_block_get(c, at + 256, &r.out_bytes, 1);
     if (!r.blk_out) { set_error("no device memory for the text of %u files (%.1f GB)", n, at / 1e9); return MK_ERR_NOMEM; }
     r.d_text = r.blk_out + o_text;
     r.d_extra = r.blk_out + o_extra;
@@ -1553,7 +1627,7 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
         MK_TRY(r.up(d_jobs, jobs.data(), jobs.size() * sizeof(mk_gz_job)));
         MK_HIP(hipMemsetAsync(r.d_cnt + 2, 0, 4, st));
         A.jobs = d_jobs; A.n_jobs = (uint32_t)jobs.size();
-        hipLaunchKernelGGL(gz_tokens_kernel, dim3(std::min<uint32_t>(r.tok_wgs, (A.n_jobs + 63u) / 64u)), dim3(64), sizeof(TokLds), st, A);
+        hipLaunchKernelGGL(gz_tokens_kernel, dim3(std::min<uint32_t>(r.tok_wgs, (A.n_jobs + 63u) / 64u)), dim3(64), r.lds_tok, st, A);
         MK_HIP(hipGetLastError());
     }
     // ---- tokens -> text
@@ -1561,7 +1635,7 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
     for (uint32_t l = 0; l < 64; ++l) K.lane_shift[l] = x_pow_bytes(64u * (63u - l));
     K.block_shift = x_pow_bytes(kFlush);
     K.byte_shift = x_pow_bytes(1);
-    const size_t lds2 = 4096u + kResolveWaves * kWin + 64u * kResolveWaves;   // CRC tables, the streams' windows, the lanes' sinks
+    const size_t lds2 = r.lds_text;                                   // CRC tables, the streams' windows, the lanes' sinks (or more: gz_open)
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gz_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     hipLaunchKernelGGL(gz_resolve_kernel, dim3((n + kResolveWaves - 1u) / kResolveWaves), dim3(64u * kResolveWaves), lds2, st, r.d_gz, r.d_streams, n, r.d_segs, r.d_chain,
                        r.d_text, K);
@@ -1570,7 +1644,10 @@ static int gz_finish(GzRun &r, const uint64_t *out_room, const std::function<uin
     r.t_text = now() - t3;                                           // (queued: the caller settles, with whatever it queues behind)
     if (getenv("MIEKKI_VERBOSE"))
         fprintf(stderr, "[gz] %u files, %.2f GB: %u segments, %u streams decoded again with exact rooms (%zu segments); blocks made ready %.3f s, block starts + tokens + chains %.3f s, "
-                        "text queued after %.3f s (%.2f GB)\n", n, r.in_at / 1e9, r.n_segs, r.n_rewritten, jobs.size(), r.t_open, r.t_blocks, r.t_text, out_at / 1e9);
+                        "text queued after %.3f s (%.2f GB); so far %llu device allocations in %.3f s, %llu waits for a page-locked piece in %.3f s\n", n, r.in_at / 1e9, r.n_segs,
+                r.n_rewritten, jobs.size(), r.t_open, r.t_blocks, r.t_text, out_at / 1e9, (unsigned long long)g_malloc_n.load(), g_malloc_us.load() / 1e6,
+                (unsigned long long)g_stage_waits.load(), g_stage_wait_us.load() / 1e6);
+    if (getenv("MIEKKI_VERBOSE")) fprintf(stderr, "[gz] in mk_gz_put so far %.3f s\n", g_put_us.load() / 1e6);
     return MK_OK;
 }
 
@@ -1588,6 +1665,7 @@ struct mk_gz_batch {
     uint32_t n_chunks = 0;
     void *d_scratch = nullptr;
     bool ran = false;
+    mutable hipEvent_t last_use = nullptr;                          // behind the last strip kernel queued on the batch's text
 };
 
 extern "C" {
@@ -1644,6 +1722,21 @@ int mk_gz_put(mk_gz_batch *b, uint32_t i, uint64_t at, const void *data, uint64_
     return gz_put(b->run, i, at, data, bytes, staged != 0);
 }
 
+int mk_gz_layout(const mk_gz_batch *b, uint64_t *offsets)
+{
+    if (!b || !offsets) { set_error("null argument"); return MK_ERR_ARG; }
+    for (uint32_t i = 0; i < b->run.n; ++i) offsets[i] = b->run.streams[i].in_off;
+    offsets[b->run.n] = b->run.in_at;
+    return MK_OK;
+}
+
+int mk_gz_put_span(mk_gz_batch *b, uint32_t first, uint32_t count, const void *data, uint64_t bytes, int staged)
+{
+    if (!b || (!data && bytes)) { set_error("null argument"); return MK_ERR_ARG; }
+    if (b->ran) { set_error("the batch has run"); return MK_ERR_ARG; }
+    return gz_put(b->run, first, 0, data, bytes, staged != 0, std::max(count, 1u));
+}
+
 int mk_gz_run(mk_gz_batch *b)
 {
     if (!b) { set_error("null argument"); return MK_ERR_ARG; }
@@ -1695,10 +1788,10 @@ int mk_gz_sequence(const mk_gz_batch *b, uint32_t i, uint64_t *len, int32_t *sta
 void mk_gz_free(mk_gz_batch *b)
 {
     if (!b) return;
-    if (b->run.c) {
-        (void)hipSetDevice(b->run.c->p.device);
-        (void)b->run.wait_stream(b->run.c->front_stream);             // (the appends' strip kernels read the batch's text)
-        (void)b->run.wait_stream(b->run.c->copy_stream);
+    if (b->run.c) (void)hipSetDevice(b->run.c->p.device);
+    if (b->last_use) {                                               // (the appends' strip kernels read the batch's text: the last of them)
+        (void)hipEventSynchronize(b->last_use);
+        (void)hipEventDestroy(b->last_use);
     }
     delete b;                                                        // (the blocks go back to the context's list)
 }
@@ -1708,14 +1801,12 @@ void mk_gz_trim(mk_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
-    {
-        std::lock_guard<std::mutex> g(c->gz_m);
-        for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
-        c->gz_blocks.clear();
-        for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
-        c->gz_pins.clear();
-    }
-    gz_release_staging(c);
+    gz_release_staging(c);                                           // (block makers at work finish first)
+    std::lock_guard<std::mutex> g(c->gz_m);
+    for (auto &blk : c->gz_blocks) (void)hipFree(blk.first);
+    c->gz_blocks.clear();
+    for (auto &pin : c->gz_pins) (void)hipHostFree(pin.first);
+    c->gz_pins.clear();
 }
 
 }  // extern "C"
@@ -1724,7 +1815,10 @@ namespace mk {
 // the pieces files are read into and the streams their copies run on (pieces a caller still holds stay its own)
 void gz_release_staging(mk_ctx *c)
 {
-    std::lock_guard<std::mutex> g(c->gz_m);
+    std::unique_lock<std::mutex> g(c->gz_m);
+    c->gz_closing = true;                                            // (no new block maker starts; those at work finish first)
+    c->gz_cv.wait(g, [&] { return c->gz_making == 0; });
+    c->gz_closing = false;
     for (hipStream_t &u : c->gz_up) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); u = nullptr; }
     for (auto &pc : c->gz_stage_busy) c->gz_stage_free.push_back(pc);
     c->gz_stage_busy.clear();
@@ -1736,6 +1830,12 @@ void gz_release_staging(mk_ctx *c)
 int gz_batch_strip(mk_ctx *c, const mk_gz_batch *b, const uint32_t *which, uint32_t m, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st)
 {
     return launch_fasta_strip(c, b->run.d_text, b->run.d_streams, which, m, b->chunk_first.data(), b->n_chunks, b->d_scratch, d_dst, dst_off, st);
+}
+int gz_batch_used(const mk_gz_batch *b, hipStream_t st)
+{
+    if (!b->last_use) MK_HIP(hipEventCreateWithFlags(&b->last_use, hipEventBlockingSync | hipEventDisableTiming));
+    MK_HIP(hipEventRecord(b->last_use, st));
+    return MK_OK;
 }
 uint32_t gz_batch_size(const mk_gz_batch *b) { return b->run.n; }
 bool gz_batch_ok(const mk_gz_batch *b, uint32_t i) { return b->ran && b->run.streams[i].status == MK_GZ_OK; }

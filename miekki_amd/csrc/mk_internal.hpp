@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <deque>
 #include <functional>
 #include <mutex>
@@ -242,7 +243,11 @@ struct mk_ctx {
     std::vector<mk::Timer> free_timers;
     // device blocks of finished mk_gz_unpack batches, kept for the next ones (allocating and freeing tens of gigabytes per
     // batch cost half a second each): (pointer, bytes); mk_gz_trim and mk_destroy free them
-    std::vector<std::pair<void *, uint64_t>> gz_blocks;
+    struct GzBlock { void *first; uint64_t second; int role; };   // role: 0 a batch's input + token block, 1 its text block
+    std::vector<GzBlock> gz_blocks;
+    uint32_t gz_making = 0;              // block makers at work (threads of their own: gunzip.hip, gz_open)
+    bool gz_closing = false;
+    std::condition_variable gz_cv;
     std::vector<std::pair<void *, uint64_t>> gz_pins;   // page-locked staging of the inflater's small copies, kept likewise
     std::mutex gz_m;
     // page-locked pieces the callers read their files into (mk_gz_stage): free ones, and those whose copy to the device is
@@ -451,6 +456,7 @@ void gz_release_staging(mk_ctx *c);     // the inflater's page-locked pieces, up
 struct mk_gz_batch;
 namespace mk {
 int gz_batch_strip(mk_ctx *c, const mk_gz_batch *b, const uint32_t *which, uint32_t m, uint8_t *d_dst, const uint64_t *dst_off, hipStream_t st);
+int gz_batch_used(const mk_gz_batch *b, hipStream_t st);       // a kernel that reads the batch's text has been queued on st
 uint32_t gz_batch_size(const mk_gz_batch *b);
 bool gz_batch_ok(const mk_gz_batch *b, uint32_t i);
 uint64_t gz_batch_len(const mk_gz_batch *b, uint32_t i);

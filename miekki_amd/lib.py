@@ -121,6 +121,8 @@ SIGNATURES = {
     "mk_gz_open": (i32, [vp, vp, u32, PP(vp)]),
     "mk_gz_stage": (vp, [vp, PP(u64)]),
     "mk_gz_put": (i32, [vp, u32, u64, vp, u64, C.c_int]),
+    "mk_gz_layout": (i32, [vp, vp]),
+    "mk_gz_put_span": (i32, [vp, u32, u32, vp, u64, C.c_int]),
     "mk_gz_run": (i32, [vp]),
     "mk_gz_sequence": (i32, [vp, u32, PP(u64), PP(C.c_int32)]),
     "mk_index_append_gz": (i32, [vp, vp, vp, u32]),

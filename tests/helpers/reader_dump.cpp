@@ -36,23 +36,51 @@ static void *budget_alloc(void *, size_t bytes)
 static void budget_free(void *, void *p) { --g_live; free(p); }
 
 // a stand-in for the device: a unit's files assembled in memory
-struct FakeBatch { std::vector<std::vector<unsigned char>> files; };
+struct FakeBatch { std::vector<std::vector<unsigned char>> files; std::vector<uint64_t> offsets; };
 static std::mutex g_sink_m;
 static std::vector<void *> g_lent;
 static std::atomic<long> g_stage_calls{0};
-static void *fake_open(void *, const uint64_t *sizes, uint32_t m)
+static size_t g_piece = 3000;
+static std::atomic<long> g_spans{0}, g_span_files{0};
+static void *fake_open(void *, const uint64_t *sizes, uint32_t m, uint64_t *offsets)
 {
     FakeBatch *b = new FakeBatch();
-    for (uint32_t i = 0; i < m; ++i) b->files.emplace_back((size_t)sizes[i], (unsigned char)0);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < m; ++i) {
+        b->files.emplace_back((size_t)sizes[i], (unsigned char)0);
+        offsets[i] = at;
+        at += (sizes[i] + 16 + 15) / 16 * 16;                            // (the device's layout: sixteen zeros at least behind every file)
+    }
+    offsets[m] = at;
+    b->offsets.assign(offsets, offsets + m + 1);
     return b;
+}
+static bool fake_put(void *, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged);
+// files [first, first + count) laid out as the batch's input is: taken apart again (what lies between two files must be zero)
+static bool fake_put_span(void *u, void *batch, uint32_t first, uint32_t count, const void *data, uint64_t bytes, bool staged)
+{
+    FakeBatch *b = (FakeBatch *)batch;
+    ++g_spans; g_span_files += count;
+    bool ok = first + count <= b->files.size() && bytes <= b->offsets[first + count] - b->offsets[first];
+    const unsigned char *p = (const unsigned char *)data;
+    for (uint32_t k = 0; ok && k < count; ++k) {
+        const uint64_t o = b->offsets[first + k] - b->offsets[first], n = b->files[first + k].size(), room = b->offsets[first + k + 1] - b->offsets[first + k];
+        if (o + room > bytes) { ok = false; break; }
+        // (a file that was given up is all zeros at its place; one that went is its bytes, then zeros)
+        bool all_zero = true;
+        for (uint64_t x = 0; x < n; ++x) all_zero = all_zero && p[o + x] == 0;
+        if (!all_zero) memcpy(b->files[first + k].data(), p + o, (size_t)n);
+        for (uint64_t x = n; x < room; ++x) ok = ok && p[o + x] == 0;
+    }
+    return fake_put(u, batch, first, 0, data, 0, staged) && ok;          // (gives the piece back)
 }
 static void *fake_stage(void *, void *, uint64_t *cap)
 {
     if (g_stage_calls.fetch_add(1) % 5 == 4) return nullptr;           // (none to be had: the reader uses its own memory)
-    void *p = malloc(3000);
+    void *p = malloc(g_piece);
     std::lock_guard<std::mutex> g(g_sink_m);
     g_lent.push_back(p);
-    *cap = 3000;
+    *cap = g_piece;
     return p;
 }
 static bool fake_put(void *, void *batch, uint32_t i, uint64_t at, const void *data, uint64_t bytes, bool staged)
@@ -95,7 +123,8 @@ int main(int argc, char **argv)
         const bool share = with_sink || sscanf(mode.c_str(), "share:%zu:%zu", &unit, &ahead) == 2;
         const bool packed = share || mode == "packed";
         mkhost::RawSink sink;
-        if (with_sink) { sink.open = fake_open; sink.stage = fake_stage; sink.put = fake_put; }
+        if (mode.find(":span") != std::string::npos) g_piece = 20000;        // (room for a few of the test's files: spans form)
+        if (with_sink) { sink.open = fake_open; sink.stage = fake_stage; sink.put = fake_put; if (mode.find(":span") != std::string::npos) sink.put_span = fake_put_span; }
         mkhost::OrderedFastaReader reader(files, (unsigned)atoi(argv[2]), a, argc > 3 ? (size_t)atoi(argv[3]) : 4,
                                           packed, share, unit, ahead, sink);
         size_t raw_held = 0;
@@ -142,6 +171,6 @@ int main(int argc, char **argv)
             line(it);
         }
     }                                                  // destructor: joins the workers, releases the pool
-    printf("done live=%ld lent=%zu\n", (long)g_live.load(), g_lent.size());
+    printf("done live=%ld spans=%ld of %ld files lent=%zu\n", (long)g_live.load(), (long)g_spans.load(), (long)g_span_files.load(), g_lent.size());
     return 0;
 }

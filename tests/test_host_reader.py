@@ -6,6 +6,7 @@ plain, gzip, multi-member gzip, CRLF, unterminated, empty and missing files, for
 thread counts and read-ahead windows (order must be list order for every -t).
 """
 import gzip
+import re
 import os
 import subprocess
 
@@ -178,3 +179,42 @@ def test_gzipd_files_are_shared_between_the_device_and_the_readers_in_whole_unit
         else:
             # (the helper gives raw items back a unit at a time, so the device's room comes back: raw units keep coming)
             assert "raw" in kinds[len(kinds) // 2:], (threads, ahead, kinds)
+
+
+def test_runs_of_a_device_unit_go_up_as_one_span(dumper, tmp_path):
+    """With plenty of files a reader takes runs of eight: the files of a run that belong to one device unit are read into
+    one lent piece, laid out as the batch's input is (zeros between them), and put with one call -- their items appear when
+    the span has been put, still in list order; a plain file, a missing one and a file larger than a piece inside a run do
+    not disturb their neighbours."""
+    rng = np.random.default_rng(23)
+    texts, names = [], []
+    for i in range(400):
+        n = int(rng.integers(100, 3000)) if i != 77 else 60_000                  # (one file larger than a lent piece)
+        body = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) if i != 77 else bytes(rng.integers(65, 90, n, dtype=np.uint8))
+        t = b">g%d\n" % i + b"\n".join(body[j:j + 70] for j in range(0, len(body), 70)) + b"\n"
+        plain = i in (9, 130, 131, 399)
+        fn = tmp_path / ("g%d.fa" % i if plain else "g%d.fa.gz" % i)
+        if i != 200:                                                              # (listed, not there)
+            fn.write_bytes(t if plain else gzip.compress(t, 6))
+        texts.append(t); names.append(str(fn))
+    (tmp_path / "l.txt").write_text("\n".join(names) + "\n")
+    for threads, unit in ((2, 16), (5, 32), (1, 8)):
+        out = subprocess.run([dumper, str(tmp_path / "l.txt"), str(threads), "64", "0", str(len(names)), f"sink:{unit}:1000:span"],
+                             check=True, stdout=subprocess.PIPE, timeout=120).stdout.decode().splitlines()
+        assert out[-1].startswith("done") and out[-1].endswith("lent=0"), out[-1]
+        assert len(out) == len(names) + 1
+        raw = 0
+        for i, line in enumerate(out[:-1]):
+            f = line.split()
+            if i == 200:
+                assert f[0] == "0"
+            elif f[0] == "raw":
+                blob = open(names[i], "rb").read()
+                assert (int(f[1]), int(f[2], 16)) == (len(blob), fnv1a(blob)), (threads, unit, i)
+                raw += 1
+            else:
+                seq = reference_sequence(texts[i])
+                assert int(f[1]) == len(seq) and int(f[2], 16) == fnv1a(seq), (threads, unit, i)
+        assert raw == 400 - 5, raw
+        spans, span_files = (int(x) for x in re.search(r"spans=(\d+) of (\d+) files", out[-1]).groups())
+        assert spans > 0 and span_files >= 2 * spans, out[-1]                     # (runs of several files did go as spans)

@@ -34,14 +34,22 @@ with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     with open(os.path.join(d, "q.fa"), "wb") as f:
         f.write(b">q0\n" + synth.genome_bases(3, 1000, 1000) + b"\n")
     print(f"generated {D} distinct {'gzipped ' if GZ else ''}genomes ({G} listed) in {time.time() - t0:.1f}s", flush=True)
-    for rep in range(2):
+    # MIEKKI_VARIANTS="name:K=V,K=V;other:K=V": the same files under several environments, one after the other (A/B on one box)
+    variants = [("", {})]
+    if os.environ.get("MIEKKI_VARIANTS"):
+        variants = [(v.split(":", 1)[0], dict(kv.split("=", 1) for kv in v.split(":", 1)[1].split(",") if kv)) for v in os.environ["MIEKKI_VARIANTS"].split(";")]
+    for vname, venv, rep in [(a, b, r) for a, b in variants for r in range(2)]:
+        if vname and rep == 0:
+            print(f"# variant {vname}: {venv}", flush=True)
+        time.sleep(float(os.environ.get("MIEKKI_PAUSE", "0")))      # (between runs: lets the driver finish with the process before)
         t0 = time.time()
-        out = subprocess.run(shlex.split(prefix.replace("{rep}", str(rep))) + [cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1"),
+        out = subprocess.run(shlex.split(prefix.replace("{rep}", str(rep))) + [cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1", **venv),
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
         el = re.findall(r"elapsed time: ([0-9.e+-]+)s", out)
         wall = time.time() - t0
         idx = float(el[0]) if el else float("nan")
         print(f"run {rep}: wall {wall:.2f}s; index phase {idx:.2f}s = {G / idx:.0f} genomes/s, {G * L / idx / 1e9:.2f} GB/s of sequence", flush=True)
         for line in out.splitlines():
-            if line.startswith("[ingest]") or line.startswith("[gz]"):
-                print("   ", line)
+            for tag in ("[ingest]", "[gz]"):          # (the [gz] lines come on stderr, in the middle of the progress marks)
+                if tag in line:
+                    print("   ", line[line.index(tag):])
