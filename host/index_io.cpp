@@ -150,16 +150,21 @@ int dump_index(const std::vector<mk_ctx *> &ctxs, const std::string &path, std::
 // ---- -d with one process per GPU
 namespace {
 
-// every rank's `bytes` bytes -> all ranks (host to host through the communicator's device buffers)
+// every rank's `bytes` bytes -> all ranks (host to host through the communicator's device buffers).  A rank whose own part
+// fails (its upload, say) still ENTERS the collective -- with whatever its buffer holds -- and reports afterwards: the other
+// ranks must not be left waiting in it.  Only the buffer itself (a few kilobytes) has to exist before.
 bool allgather_host(mk_ctx *ctx, mk_comm *comm, const void *mine, uint64_t bytes, std::vector<uint8_t> &all, std::string &err)
 {
     const int W = mk_comm_world(comm);
     all.assign((size_t)bytes * W, 0);
     void *d = nullptr;
     if (mk_dev_alloc(ctx, bytes * (W + 1), &d) != MK_OK) { err = mk_last_error(); return false; }
-    bool ok = mk_dev_upload(ctx, (uint8_t *)d + bytes * W, mine, bytes) == MK_OK && mk_comm_allgather(comm, (uint8_t *)d + bytes * W, bytes, d) == MK_OK &&
-              mk_dev_download(ctx, all.data(), d, bytes * W) == MK_OK;
+    std::string local;
+    if (mk_dev_upload(ctx, (uint8_t *)d + bytes * W, mine, bytes) != MK_OK) local = mk_last_error();
+    bool ok = mk_comm_allgather(comm, (uint8_t *)d + bytes * W, bytes, d) == MK_OK;
     if (!ok) err = mk_last_error();
+    if (ok && mk_dev_download(ctx, all.data(), d, bytes * W) != MK_OK) { ok = false; err = mk_last_error(); }
+    if (ok && !local.empty()) { ok = false; err = local; }
     mk_dev_free(ctx, d);
     return ok;
 }
@@ -208,7 +213,7 @@ int dump_index_ranked(mk_ctx *ctx, mk_comm *comm, const std::string &path, std::
     {
         char msg[256] = {0};
         snprintf(msg, sizeof msg, "%s", my_err.c_str());
-        if (!allgather_host(ctx, comm, msg, sizeof msg, all, err)) return -1;
+        if (!allgather_host(ctx, comm, msg, sizeof msg, all, err)) { mk_dev_free(ctx, d_send); mk_dev_free(ctx, d_recv); return -1; }
         for (int r = 0; r < world && first.empty(); ++r) first = std::string((const char *)all.data() + 256 * r, strnlen((const char *)all.data() + 256 * r, 255));
     }
     for (uint32_t pb = 0; first.empty() && coll_ok && pb < P; pb += rows) {

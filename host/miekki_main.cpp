@@ -249,12 +249,17 @@ struct Driver {
         // stripped and appended on the device, a few thousand at a time (a deflate stream is decoded by one lane, so it is
         // the number of streams in flight that makes the rate; MIEKKI_GZ_BATCH sets it, 0 = the readers inflate);
         // whatever the device refuses is inflated here
+        // the list goes to the device in units of 512 files, three of them ahead of this thread (fixed: what was measured is in
+        // profiles/r6_ingest_gz.txt; a -DMK_TUNE_BUILD binary reads MIEKKI_GZ_BATCH -- 0: the readers inflate everything --,
+        // MIEKKI_GZ_IN_FLIGHT, and MIEKKI_GZ_SHARE=1: the readers' own zlib takes a unit whenever three are waiting at the device)
+#ifdef MK_TUNE_BUILD
         static const size_t gz_batch = [] { const char *e = getenv("MIEKKI_GZ_BATCH"); return e ? (size_t)std::max(0L, atol(e)) : (size_t)512; }();
         static const size_t gz_in_flight = [] { const char *e = getenv("MIEKKI_GZ_IN_FLIGHT"); return e ? (size_t)std::max(1L, atol(e)) : (size_t)3; }();
-        // ... and the readers' own zlib takes what the device has no room for: the list goes in units of one device batch, a
-        // unit to the device while fewer than gz_in_flight are waiting there, to the readers otherwise (fasta_reader.hpp) --
-        // whichever side is faster takes more.  MIEKKI_GZ_SHARE=0: every gzip'd file to the device.
         static const bool gz_share = [] { const char *e = getenv("MIEKKI_GZ_SHARE"); return e && atoi(e) != 0; }();
+#else
+        constexpr size_t gz_batch = 512, gz_in_flight = 3;
+        constexpr bool gz_share = false;
+#endif
         // A unit's files go to the device as the readers read them (RawSink -> mk_gz_open / mk_gz_stage / mk_gz_put): straight
         // from the page cache into page-locked pieces the library lends, a DMA each, into a batch whose layout the files'
         // sizes fixed -- nothing of a gzip'd file waits in host memory.  A unit the device has no memory for is the readers'.

@@ -131,7 +131,8 @@ bool rendezvous_fetch(const Rendezvous &r, void *payload, size_t n, long timeout
                     const bool mine = std::string((const char *)b.data() + 16, (size_t)nl) == r.nonce;
                     const bool alive = !pid_check || (start_time_of((long)pid) == start && start != 0);
                     if (!mine) why = "another run's file (nonce)";
-                    else if (!alive) why = "left behind by a run whose rank 0 is gone";
+                    else if (!alive) why = "left behind by a run whose rank 0 is gone (ranks in separate pid namespaces, or a /proc that hides other users' "
+                                           "processes, cannot see rank 0: set MIEKKI_COMM_NO_PID_CHECK=1)";
                     else if (pn != n || 16 + nl + 24 + pn + 8 != b.size()) why = "payload of another size";
                     else { memcpy(payload, p + 24, n); return true; }
                 } else why = "malformed";

@@ -9,7 +9,9 @@
 //   * the content is: magic, nonce, the writer's pid and start time, the payload, a checksum.  A reader opens with
 //     O_NOFOLLOW, wants a regular file of its own user, the magic, ITS nonce, a checksum that holds -- and a writer that
 //     is still alive (pid and start time in /proc): a file a crashed run left behind under a fixed MIEKKI_COMM_FILE has a
-//     dead writer, is ignored, and the reader goes on waiting for this run's;
+//     dead writer, is ignored, and the reader goes on waiting for this run's.  (Ranks that cannot see each other's /proc
+//     entries -- a container per rank, hidepid -- would take every writer for dead: MIEKKI_COMM_NO_PID_CHECK=1 leaves that
+//     one test out; nonce, owner and checksum still hold);
 //   * rank 0 removes the file once every rank has joined the communicator, and at exit whatever happens.
 #pragma once
 #include <cstddef>

@@ -105,7 +105,9 @@ static int ensure_capacity(mk_ctx *c, uint32_t need)
         cap = ld / c->W;
         P_hot = hot_rows_for(c, ld, c->hbm_matrix_budget);
     }
-    if (hipMalloc((void **)&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)) != hipSuccess) {
+    if (hipMalloc((void **)&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)) != hipSuccess && !(gz_release_idle_blocks() &&
+        hipMalloc((void **)&nM, std::max<uint64_t>((uint64_t)P_hot * ld, 16)) == hipSuccess)) {
+        // (the inflater's idle blocks have been given back and it still does not fit)
         // the doubled matrix does not fit beside the old one: take exactly what is needed, and if
         // even that does not fit the free memory, keep the rows that do and put the rest in host memory
         (void)hipGetLastError();

@@ -82,7 +82,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         uint64_t n8 = 0;
         for (uint32_t q = 0; q < nq; ++q) {
             const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
-            n8 += nk > kShortMax && nk >= c->P / 8 ? 1 : 0;
+            n8 += beyond_short_len(c->p.k, lens[q]) && nk >= c->P / 8 ? 1 : 0;
         }
         if (n8 >= 16 && n8 * c->P * c->W * 3 <= (8ull << 30)) dense_div = 8;       // (vector: P W bytes per query; tables: 2 P W per query)
     }
@@ -90,10 +90,10 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
         const uint64_t nk = lens[q] > c->p.k ? lens[q] - c->p.k : 0;
         if (lens[q] >= (1ull << 40)) { set_error("query too long"); return MK_ERR_ARG; }
         qs->h_off[q + 1] = qs->h_off[q] + lens[q];
-        const bool dense = nk > kShortMax && nk >= c->P / dense_div;
+        const bool dense = beyond_short_len(c->p.k, lens[q]) && nk >= c->P / dense_div;
         qs->h_ent_off[q + 1] = qs->h_ent_off[q] + (dense ? 0 : std::min<uint64_t>(nk, c->P));
         if (dense) qs->dense_q.push_back(q);
-        else if (nk > kShortMax) qs->long_q.push_back(q);
+        else if (beyond_short_len(c->p.k, lens[q])) qs->long_q.push_back(q);
         else qs->short_max_nk = std::max<uint32_t>(qs->short_max_nk, (uint32_t)nk);
     }
     qs->total_len = qs->h_off[nq];
@@ -324,6 +324,8 @@ static uint64_t chunk_budget(uint64_t want, uint64_t have)
 {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
+    // (what an ingest of gzip'd genomes left with the inflater counts as free: given back when the chunk would shrink for it)
+    if (free_b / 3 < want && want > have && gz_release_idle_blocks() && hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
     return std::max<uint64_t>(std::min<uint64_t>(want, std::max<uint64_t>(have, free_b / 3)), 64ull << 20);
 }
 
@@ -556,6 +558,7 @@ static int qset_select(mk_ctx *c, uint32_t n, const uint32_t *d_scores, const ui
 
 using namespace mk;
 
+
 // transient: the set lives for one mk_query call -- borrowed arena, and no wait for the copy
 // (the caller's buffers have been copied into the pinned image; the call's own final wait covers it)
 static int qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t nq, mk_qset **out, bool transient)
@@ -613,7 +616,7 @@ int mk_qset_upload(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uin
     // a set that mixes short queries with longer ones: a shell over two sets (mk_internal.hpp), so that the short ones keep
     // the slab schedule inside ONE mk_qset_run
     std::vector<uint32_t> idx[2];
-    for (uint32_t q = 0; q < nq; ++q) idx[lens[q] > (uint64_t)c->p.k + kShortMax ? 1 : 0].push_back(q);
+    for (uint32_t q = 0; q < nq; ++q) idx[beyond_short_len(c->p.k, lens[q]) ? 1 : 0].push_back(q);
     if (idx[0].empty() || idx[1].empty()) return qset_upload(c, seqs, lens, nq, out, false);
     std::unique_ptr<mk_qset, void (*)(mk_qset *)> shell(new mk_qset(), qset_release);
     mk_qset *qs = shell.get();
@@ -854,7 +857,7 @@ int mk_query(mk_ctx *c, const char *const *seqs, const uint64_t *lens, uint32_t 
     {
         std::vector<uint32_t> idx_short, idx_long;
         for (uint32_t q = 0; q < nq; ++q)
-            (lens[q] > (uint64_t)c->p.k + kShortMax ? idx_long : idx_short).push_back(q);
+            (beyond_short_len(c->p.k, lens[q]) ? idx_long : idx_short).push_back(q);
         if (!idx_short.empty() && !idx_long.empty() && nresults > 0) {
             for (const std::vector<uint32_t> *part : {&idx_short, &idx_long}) {
                 const uint32_t n = (uint32_t)part->size();

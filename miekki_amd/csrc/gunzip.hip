@@ -961,9 +961,7 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
     auto crc_to = [&](uint32_t upto) {
         while (crc_from < upto) {
             const uint32_t end = min(upto, (crc_from / kFlush + 1u) * kFlush);
-#if !defined(GZ_EXP) || GZ_EXP != 1
             crc_span(crc_from, end);
-#endif
             crc_from = end;
         }
     };
@@ -1058,13 +1056,6 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
         bool done = !act;
         if (act && !is_match) { win[dst % kWin] = (uint8_t)t; done = true; }
         unsigned long long todo = __ballot(!done);
-#if defined(GZ_EXP) && GZ_EXP == 2
-        todo = 0;                                                    // (experiment: no copies at all)
-#endif
-#if defined(GZ_EXP) && GZ_EXP == 3
-        done = done || dist < 512u;                                  // (experiment: nothing that could depend on this step)
-        todo = __ballot(!done);
-#endif
         uint8_t *const sink = rsmem + 4096u + kResolveWaves * kWin + wave * 64u + lane;     // where the bytes of a piece beyond a token's end go
         while (todo) {                                               // (each round finishes at least the lowest unfinished lane)
             const uint32_t low = (uint32_t)__ffsll((long long)todo) - 1u;
@@ -1178,11 +1169,43 @@ static uint8_t *gz_block_get(mk_ctx *c, uint64_t need, uint64_t *got, int role)
     return (uint8_t *)p;
 }
 
+// contexts that keep blocks (for gz_release_idle_blocks)
+static std::mutex g_keepers_m;
+static std::vector<mk_ctx *> g_keepers;
+
 static void gz_block_put(mk_ctx *c, uint8_t *p, uint64_t bytes, int role)
 {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_keepers_m);
+        if (std::find(g_keepers.begin(), g_keepers.end(), c) == g_keepers.end()) g_keepers.push_back(c);
+    }
     std::lock_guard<std::mutex> g(c->gz_m);
     c->gz_blocks.push_back(mk_ctx::GzBlock{p, bytes, role});
+}
+
+// every context's idle blocks back to the device; returns the bytes given back
+uint64_t gz_release_idle_blocks()
+{
+    uint64_t freed = 0;
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+    std::lock_guard<std::mutex> gk(g_keepers_m);
+    for (mk_ctx *c : g_keepers) {
+        std::lock_guard<std::mutex> g(c->gz_m);
+        if (c->gz_blocks.empty()) continue;
+        (void)hipSetDevice(c->p.device);
+        for (auto &blk : c->gz_blocks) { (void)hipFree(blk.first); freed += blk.second; }
+        c->gz_blocks.clear();
+    }
+    if (have_dev) (void)hipSetDevice(dev);
+    return freed;
+}
+
+static void gz_forget_keeper(mk_ctx *c)
+{
+    std::lock_guard<std::mutex> g(g_keepers_m);
+    g_keepers.erase(std::remove(g_keepers.begin(), g_keepers.end(), c), g_keepers.end());
 }
 
 // Page-locked staging for the run's small copies (stream tables, block starts, segments): a copy to or from ordinary memory
@@ -1353,11 +1376,10 @@ static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
     r.good_cap = (uint32_t)std::min<uint64_t>(in_at / 2048u + 64ull * n + 4096u, 1u << 28);   // (a block per 26 KB of gzip'd DNA)
     int cus = 0;
     MK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->p.device));
-    // LDS asked for by the two long-running kernels (token, text): what they need, or more -- so that fewer of their
-    // workgroups share a CU and the build's kernels find room beside them (experiments: MIEKKI_GZ_LDS_KB)
-    static const uint32_t lds_floor = [] { const char *e = getenv("MIEKKI_GZ_LDS_KB"); return e ? (uint32_t)atoi(e) << 10 : 0u; }();
-    r.lds_tok = std::max<uint32_t>((uint32_t)sizeof(TokLds), lds_floor);
-    r.lds_text = std::max<uint32_t>(4096u + kResolveWaves * kWin + 64u * kResolveWaves, lds_floor);
+    // (asking for more LDS than they need, so that one workgroup of the two long-running kernels has a CU to itself and the
+    // build's kernels find room beside it, was measured and left: 3.6k against 3.8k genomes/s, profiles/r6_ingest_gz.txt)
+    r.lds_tok = (uint32_t)sizeof(TokLds);
+    r.lds_text = 4096u + kResolveWaves * kWin + 64u * kResolveWaves;
     r.tok_wgs = (r.lds_tok <= (80u << 10) ? 2u : 1u) * (uint32_t)std::max(cus, 1);   // (workgroups of the token kernel that share a CU's LDS)
     uint64_t at = 0;
     auto carve = [&at](uint64_t bytes) { const uint64_t o = at; at += (bytes + 255u) / 256u * 256u; return o; };
@@ -1815,6 +1837,7 @@ namespace mk {
 // the pieces files are read into and the streams their copies run on (pieces a caller still holds stay its own)
 void gz_release_staging(mk_ctx *c)
 {
+    gz_forget_keeper(c);                                             // (called when the context goes, or gives everything back: it registers again with its next block)
     std::unique_lock<std::mutex> g(c->gz_m);
     c->gz_closing = true;                                            // (no new block maker starts; those at work finish first)
     c->gz_cv.wait(g, [&] { return c->gz_making == 0; });

@@ -32,6 +32,12 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 constexpr uint32_t kShortMax = 4096;     // k-mers a query may have for the in-LDS sketch
+}  // namespace mk
+// ONE definition of "more k-mers than the short path takes" (len - k of them are sketched: Miekki.cpp:162 skips the last), used
+// by a query set's own classes and by the callers that split a mixed set
+struct mk_ctx;
+namespace mk {
+inline bool beyond_short_len(uint32_t k, uint64_t len) { return len > (uint64_t)k + kShortMax; }
 constexpr uint32_t kBuildBatch = 64;     // most genomes sketched per build batch
 constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans (64 lanes x 16 B)
 constexpr uint64_t kEmptyKey = ~0ULL;
@@ -340,11 +346,18 @@ struct ScopedTimer {
 };
 
 // ---- api.hip, for its sister files (api_query.hip, api_multi.hip)
+// gunzip.hip: the inflater keeps its batches' device blocks for the next batches (tens of gigabytes after an ingest of gzip'd
+// genomes); whoever finds device memory short gives the idle ones back -- every context's -- and tries again
+uint64_t gz_release_idle_blocks();
 template <typename T>
 inline int dev_alloc(T **p, uint64_t count)
 {
     *p = nullptr;
     if (!count) return MK_OK;
+    if (hipMalloc((void **)p, count * sizeof(T)) == hipSuccess) return MK_OK;
+    (void)hipGetLastError();
+    *p = nullptr;
+    if (gz_release_idle_blocks() == 0) { set_error("HIP error: out of memory (%llu bytes)", (unsigned long long)(count * sizeof(T))); return MK_ERR_DEVICE; }
     MK_HIP(hipMalloc((void **)p, count * sizeof(T)));
     return MK_OK;
 }

@@ -378,3 +378,69 @@ def test_bloom_positions_when_the_low_word_carries(hip, b):
             fresh.close()
     finally:
         ix.close()
+
+
+def test_first_batch_on_fresh_contexts_sharing_a_gpu_keeps_its_exceptions(hip):
+    """The race fixed in round 5 (build.hip: a build side's counters were cleared on the back stream and could land after the
+    front stage had set a batch's exception flags): the FIRST batch of a context whose Bloom arrays have just been allocated
+    (-b 33: a gigabyte's fill still queued), genomes with N runs, lower case and junk -- on four contexts that share device 0
+    and build at the same time, once from characters (mk_index_append) and once from gzip'd files (mk_gz_unpack +
+    mk_index_append_gz).  Every context must hold what the oracle holds."""
+    import threading
+    import zlib
+    from oracle import oracle as orc
+    k, h = 31, 12
+    rng = np.random.default_rng(99)
+    genomes = []
+    for g in range(24):
+        s = bytearray(synth.genome_bases(500 + g, 0, 150_000 + 1000 * g))
+        for _ in range(30):                                          # N runs, lower case, junk: exception bits in most workgroups
+            a = int(rng.integers(0, len(s) - 400))
+            n = int(rng.integers(1, 300))
+            kind = int(rng.integers(0, 3))
+            s[a:a + n] = b"N" * n if kind == 0 else bytes(s[a:a + n]).lower() if kind == 1 else bytes(rng.integers(63, 90, n, dtype=np.uint8))   # (no '>': at a line's start it would make the line a header)
+        genomes.append(bytes(s))
+    want = orc.OracleMiekki(k, h, 8, 33, 10)
+    want.insert_sequences(genomes)
+    # what is compared: header, columns, genome sizes and the filter's first 64 MiB -- every byte a 62-bit k-mer can reach
+    # at -b 33 -- (not the gigabyte of zeros behind them), and the sketch sizes
+    head_bytes = 39 + (1 << h) * len(genomes) + 8 * len(genomes) + (64 << 20)
+    want_head = bytearray(want.serialize()[:head_bytes].tobytes()); want_head[32] = 0
+
+    def head_of(ix):
+        out = bytearray()
+        for piece in ix.serialize():
+            out += piece
+            if len(out) >= head_bytes:
+                break
+        out[32] = 0
+        return bytes(out[:head_bytes])
+    blobs = []
+    for g, s in enumerate(genomes):
+        text = b">g%d\n" % g + b"\n".join(s[i:i + 80] for i in range(0, len(s), 80)) + b"\n"
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        blobs.append(c.compress(text) + c.flush())
+    for how in ("chars", "gz"):
+        ctxs = [hip.Miekki(k, h, 8, 33, 10) for _ in range(4)]       # fresh: nothing has run on them yet
+        errs = []
+
+        def build(ix):
+            try:
+                if how == "chars":
+                    ix.insert_sequences(genomes)
+                else:
+                    assert ix.insert_gz_files(blobs, fallback=False) == [0] * len(blobs)
+            except Exception as e:                                   # noqa: BLE001
+                errs.append(e)
+
+        try:
+            th = [threading.Thread(target=build, args=(ix,)) for ix in ctxs]
+            for t in th: t.start()
+            for t in th: t.join()
+            assert not errs, errs
+            for ix in ctxs:
+                np.testing.assert_array_equal(ix.sketch_size, want.sketch_size)
+                np.testing.assert_array_equal(ix.genome_size, want.genome_size)
+                assert head_of(ix) == bytes(want_head), how
+        finally:
+            for ix in ctxs: ix.close()
