@@ -1,26 +1,37 @@
 // gzip'd FASTA on the GPU (the reference's normal input: index_file_of_file reads every genome
 // through zstr::ifstream, Miekki.cpp:559-567, zstr.hpp:78 inflateInit2(15 + 32)).
 //
-// A deflate stream is serial -- a symbol's first bit is known only when the symbol before it has been decoded -- but a
-// collection is thousands of streams, and decoding splits into a serial part that needs no history and a copying part
-// that needs no bit reading:
-//   gz_tokens_kernel   ONE LANE PER STREAM walks the bits: gzip member headers, stored / fixed / dynamic blocks, Huffman
-//                      codes through per-lane lookup tables in LDS (9 bits for literals and lengths, 8 for distances:
-//                      99.9 % / 99.2 % of the codes of gzip'd DNA; longer ones bit by bit from the codes' counts), and
-//                      writes TOKENS -- a literal, or (length, distance), 4 bytes each.  No window: a token does not
-//                      depend on earlier output.  Streams written by one compressor change tables at the same token
-//                      counts (zlib: every 16,383 symbols), so the lanes of a wave stay in step.
-//   gz_resolve_kernel  ONE WAVE PER STREAM executes the tokens, 64 at a time, in a 36 KiB window in LDS (32 KiB of
-//                      history + 4 KiB being written): places from a prefix sum of the lengths, copies byte by byte
-//                      inside LDS -- a token whose source lies among the bytes the same step writes waits for a later
-//                      round of the step -- finished 4 KiB blocks leave for the text buffer in 16-byte stores, and
-//                      their CRC-32 (each lane a 64-byte slice by table, the slices joined by multiplication with
-//                      powers of x modulo the CRC polynomial) is held against every member's trailer, as is ISIZE.
-// Every loop is bounded by the stream's input length, its token room or its output room, and whatever is not a sequence
-// of well-formed gzip members from the first byte to the last -- truncated input, an over-subscribed or incomplete code,
-// a distance beyond the output so far, a stored block whose length check fails, trailing bytes -- ends that stream with
-// a status and nothing else: the caller (host/fasta_reader.cpp) hands such a file to the host's own inflater, which
-// then says what the file is worth.  Behind it, fasta.hip strips header lines and line ends and packs the sequences.
+// A deflate stream is serial twice over -- a symbol's first bit is known only when the symbol before it has been decoded, and
+// a match copies bytes that must have been produced -- but a collection is thousands of streams, a stream is dozens of
+// blocks whose first bits can be FOUND, and decoding splits into a part that needs no history and a part that reads no bits:
+//   gz_find_kernel     every bit offset of every file tested for the beginning of a dynamic block's header (type bits, counts,
+//   gz_check_kernel    a complete code length code: bit-sliced over a word's 32 offsets, the Kraft sum by population counts);
+//                      the few survivors validated in full (both codes by zlib's inflate_table rules).  What is left are the
+//                      blocks' real starts (one per 26 KB of gzip'd DNA) and next to no impostors.
+//   gz_cand_*          the starts ordered per stream ON THE DEVICE (count, scan over the streams, scatter, rank): the host
+//                      never learns how many there are.
+//   gz_tokens_kernel   ONE LANE PER SEGMENT -- from a stream's first byte, or from a found start, to the next start the decoding
+//                      arrives at between two blocks: member headers, stored / fixed / dynamic blocks, Huffman codes through
+//                      per-lane tables in LDS (six- and seven-bit roots, the longer codes' symbols beside them) into 4-byte
+//                      TOKENS (a literal, length + distance, a stored run, a member's end).  One pass: a segment's tokens go
+//                      to slots that follow from where it starts (a slot per byte of input); workgroups take groups of 64
+//                      segments from a counter until none are left.
+//   gz_chain_kernel    a thread per stream follows its segments from link to link: token count, text length, members -- the
+//                      one thing the host must look at (the text block is sized from it).  A segment that outgrew its slots
+//                      (literals only, say) is decoded once more with an exact room.
+//   gz_resolve_kernel  ONE WAVE PER STREAM executes the tokens, 64 at a time, in a 36 KiB window in LDS (32 KiB of history +
+//                      4 KiB being written): places from a prefix sum of the lengths, copies inside LDS -- a token whose
+//                      source lies among the bytes the same step writes waits for a later round of the step --, distances
+//                      checked against the member's first byte, finished 4 KiB blocks out in 16-byte stores, their CRC-32
+//                      (each lane a 64-byte slice by table, the slices joined by multiplication with powers of x modulo the
+//                      CRC polynomial) held against every member's trailer, as is ISIZE.
+// The host's part (gz_open / gz_put / gz_finish below): the files' bytes come in as their readers read them -- page-locked
+// pieces lent by the context, a DMA per run of files --, then the whole chain is queued back to back on the batch's own
+// stream with ONE host look in the middle.  Every loop is bounded by the stream's input length or its rooms, and whatever
+// is not a sequence of well-formed gzip members from the first byte to the last -- truncated input, an over-subscribed or
+// incomplete code, a distance beyond the member's first byte, a stored block whose length check fails, trailing bytes --
+// ends that stream with a status and nothing else: the caller (host/miekki_main.cpp) reads such a file itself, with the
+// host's inflater, which then says what the file is worth.  Behind it, fasta.hip strips header lines and line ends.
 #include <algorithm>
 #include <atomic>
 #include <chrono>

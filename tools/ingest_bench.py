@@ -41,7 +41,7 @@ with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     for vname, venv, rep in [(a, b, r) for a, b in variants for r in range(2)]:
         if vname and rep == 0:
             print(f"# variant {vname}: {venv}", flush=True)
-        time.sleep(float(os.environ.get("MIEKKI_PAUSE", "0")))      # (between runs: lets the driver finish with the process before)
+        time.sleep(float(os.environ.get("MIEKKI_PAUSE", "6")))      # (between runs: the driver is still taking back the tens of gigabytes of the process before -- device allocations of the next one then take seconds, profiles/r6_ingest_gz.txt)
         t0 = time.time()
         out = subprocess.run(shlex.split(prefix.replace("{rep}", str(rep))) + [cli, "-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-h", "20", "-t", str(T)], cwd=d, env=dict(os.environ, MIEKKI_VERBOSE="1", **venv),
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
