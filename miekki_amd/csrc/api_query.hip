@@ -112,7 +112,7 @@ static int qset_alloc(mk_ctx *c, const uint64_t *lens, uint32_t nq, mk_qset **ou
                    o_ent_off = carve(((uint64_t)nq + 1) * 8), o_entries = carve((qs->h_ent_off[nq] + 1) * 8),
                    o_nent = carve(((uint64_t)nq + 1) * 4), o_scan_n = carve(((uint64_t)nq + 1) * 4),
                    o_dense = carve(dense_bytes), o_dense_q = carve(qs->dense_q.size() * 4),
-                   o_lut = carve((uint64_t)((qs->dense_q.size() / 4 + 1) / 2) * c->P * 16 * c->W),
+                   o_lut = carve((uint64_t)((qs->dense_q.size() / 4 + 1) / 2) * c->P * 32),     // (32 bytes of tables per octet of queries and row, either width)
                    o_split = carve(qs->split_room ? (uint64_t)nq * (qs->split_room + 1) * 4 : 0);
     if (transient && !c->qarena_busy) {
         if (at > c->qarena_cap) {

@@ -68,18 +68,31 @@ int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
     // (the table kernel walks rows in groups of sixteen: every window and chunk of rows is a multiple of that for P >= 16;
     // sketches of fewer partitions take the compare kernel below)
     if (a.lut && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
-        const uint32_t no = a.noctets >= 2 ? 2 : 1;
-        const uint64_t work = (uint64_t)((a.noctets + no - 1) / no) * a.ntiles * a.nchunks;
-        if (work == 0) return MK_OK;
-        if (work >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }
-        const uint32_t blocks = (uint32_t)((work + 3) / 4);
+        static const int force_no = [] { const char *e = getenv("MIEKKI_DENSE_NO"); return e ? atoi(e) : 0; }();
+        const uint32_t no = force_no == 1 ? 1u : a.noctets >= 2 ? 2 : 1;
+        // the sets of sixteen (eight) queries share a tile's rows through LDS, two or four waves of a workgroup (scan_kernel.hpp)
+        const uint32_t nsets = (a.noctets + no - 1) / no, gs = nsets >= 3 ? 4 : nsets == 2 ? 2 : 1;
+        const uint64_t groups = (uint64_t)((nsets + gs - 1) / gs) * a.ntiles * a.nchunks;
+        if (groups == 0) return MK_OK;
+        if (groups >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }
+        const uint32_t per_wg = 4 / gs, blocks = (uint32_t)((groups + per_wg - 1) / per_wg);
+#define MK_DENSE_LUT(W_, NO_, GS_) hipLaunchKernelGGL((scan_dense_lut_kernel<W_, NO_, GS_>), dim3(blocks), dim3(256), 0, c->stream, a)
         if (c->W == 1) {
-            if (no == 2) hipLaunchKernelGGL((scan_dense_lut_kernel<1, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
-            else         hipLaunchKernelGGL((scan_dense_lut_kernel<1, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+            if (no == 1 && gs == 1) MK_DENSE_LUT(1, 1, 1);
+            else if (no == 1 && gs == 2) MK_DENSE_LUT(1, 1, 2);
+            else if (no == 1) MK_DENSE_LUT(1, 1, 4);
+            else if (gs == 1) MK_DENSE_LUT(1, 2, 1);
+            else if (gs == 2) MK_DENSE_LUT(1, 2, 2);
+            else MK_DENSE_LUT(1, 2, 4);
         } else {
-            if (no == 2) hipLaunchKernelGGL((scan_dense_lut_kernel<2, 2>), dim3(blocks), dim3(256), 0, c->stream, a);
-            else         hipLaunchKernelGGL((scan_dense_lut_kernel<2, 1>), dim3(blocks), dim3(256), 0, c->stream, a);
+            if (no == 1 && gs == 1) MK_DENSE_LUT(2, 1, 1);
+            else if (no == 1 && gs == 2) MK_DENSE_LUT(2, 1, 2);
+            else if (no == 1) MK_DENSE_LUT(2, 1, 4);
+            else if (gs == 1) MK_DENSE_LUT(2, 2, 1);
+            else if (gs == 2) MK_DENSE_LUT(2, 2, 2);
+            else MK_DENSE_LUT(2, 2, 4);
         }
+#undef MK_DENSE_LUT
         MK_HIP(hipGetLastError());
         return MK_OK;
     }

@@ -463,9 +463,9 @@ __global__ __launch_bounds__(256) void dense_lut_kernel(const uint8_t *__restric
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x, octet = blockIdx.y;
     if (p >= P) return;
-    DenseLut t[W];
+    DenseLut t[2];                                                    // (one byte: the three fields' tables; two bytes: the low byte's, the high byte's)
 #pragma unroll
-    for (uint32_t x = 0; x < (uint32_t)W; ++x) t[x].t[0] = t[x].t[1] = t[x].t[2] = t[x].t[3] = 0;
+    for (uint32_t x = 0; x < 2u; ++x) t[x].t[0] = t[x].t[1] = t[x].t[2] = t[x].t[3] = 0;
 #pragma unroll
     for (uint32_t half = 0; half < 2; ++half) {
         const uint32_t group = octet * 2 + half;
@@ -478,14 +478,22 @@ __global__ __launch_bounds__(256) void dense_lut_kernel(const uint8_t *__restric
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t v = W == 1 ? (f4[0] >> (8 * j)) & 0xffu : (f4[j / 2] >> (16 * (j & 1u))) & 0xffffu, bit = 1u << (half * 4 + j);
             if (v == empty) continue;
+            if (W == 1) {
+                // fields of three, three and two bits: two eight-entry byte tables (a pair of words each) and a four-entry one
+                const uint32_t f0 = v & 7u, f1 = (v >> 3) & 7u, f2 = v >> 6;
+                t[0].t[f0 >> 2] |= bit << (8 * (f0 & 3u));
+                t[0].t[2 + (f1 >> 2)] |= bit << (8 * (f1 & 3u));
+                t[1].t[0] |= bit << (8 * f2);
+            } else {
 #pragma unroll
-            for (uint32_t x = 0; x < (uint32_t)W; ++x)
+                for (uint32_t x = 0; x < 2u; ++x)
 #pragma unroll
-                for (uint32_t f = 0; f < 4; ++f) t[x].t[f] |= bit << (8 * ((v >> (8 * x + 2 * f)) & 3u));
+                    for (uint32_t f = 0; f < 4; ++f) t[x].t[f] |= bit << (8 * ((v >> (8 * x + 2 * f)) & 3u));
+            }
         }
     }
 #pragma unroll
-    for (uint32_t x = 0; x < (uint32_t)W; ++x) lut[((uint64_t)octet * P + p) * W + x] = t[x];
+    for (uint32_t x = 0; x < 2u; ++x) lut[((uint64_t)octet * P + p) * 2 + x] = t[x];
 }
 
 // sum and carry of three one-bit inputs per bit position
@@ -495,20 +503,34 @@ __device__ __forceinline__ void csa(uint32_t &carry, uint32_t &sum, uint32_t a, 
     sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);              // parity: one more
 }
 
-template <int W, int NO>
+// GS: the sets (of NO octets) whose waves SHARE the rows of one (tile, chunk of rows): 1 -- a wave loads its rows itself --, or
+// 2 or 4 waves of the workgroup: each loads a share of a batch of eight rows, leaves it in LDS, and all of them work from
+// there.  (Round 4 let the sets of a tile walk the same rows as neighbouring waves and trusted the caches: the counters saw
+// every row come through the fabric 1.8 times at two sets, and a wave that carries sixteen queries has one neighbour on its
+// SIMD to hide a load's latency behind -- vector issue stood at 0.66.)
+// (a row's tables are the wave's -- every lane the same address -- and the compiler loads them with VECTOR loads: it cannot know
+// that the score rows' atomics do not touch them.  Forced through the constant address space they become scalar loads, and the
+// kernel twice as slow at 64 queries (162 against 80 ms: 268 MB of tables stream through a 16 KiB scalar cache): left as it is.)
+__device__ __forceinline__ uint4 load_tables16(const DenseLut *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+template <int W, int NO, int GS>
 __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
 {
     constexpr uint32_t kPlanes = 13;                                 // counts up to 8,191: the host cuts chunks of at most 8,176 rows
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t work = blockIdx.x * 4u + wave;
     const uint32_t nsets = (a.noctets + NO - 1) / NO;
-    if (work >= nsets * a.ntiles * a.nchunks) return;
-    // the sets of one (tile, chunk of rows) are neighbours in the grid -- waves of one workgroup: they walk the same rows at the
-    // same time, and all but the first find them in a cache (the Infinity Cache mostly: profiles/r4_pmc_dense.txt) instead of
-    // waiting for HBM again
-    const uint32_t set = work % nsets, ct = work / nsets, chunk = ct % a.nchunks, tile = ct / a.nchunks;
-    if ((uint64_t)tile * kTileBytes + lane * 16u >= (uint64_t)a.G * W) return;
+    // a sharing group: GS waves, one (tile, chunk) and GS sets; a workgroup holds 4 / GS of them.  A wave without work of its own
+    // (a set beyond the last, a group beyond the grid's end, no query of this pass) still loads its share and keeps the barriers
+    const uint32_t nsg = (nsets + GS - 1) / GS, ngroups_all = nsg * a.ntiles * a.nchunks;
+    const uint32_t grp_in_wg = wave / GS, w_in_grp = wave % GS;
+    const uint32_t group_id = blockIdx.x * (4u / GS) + grp_in_wg;
+    const bool group_live = group_id < ngroups_all;
+    if (GS == 1 && !group_live) return;
+    const uint32_t gid = min(group_id, ngroups_all - 1u);
+    const uint32_t set = (gid % nsg) * GS + w_in_grp, ct = gid / nsg, chunk = ct % a.nchunks, tile = ct / a.nchunks;
+    const bool lane_live = (uint64_t)tile * kTileBytes + lane * 16u < (uint64_t)a.G * W;
+    // (a lane beyond the tile's last genome stays: it carries its share of the rows' tables, below; its rows lie in the tile's padding)
     uint32_t qidx[NO][8];
     bool any = false;
 #pragma unroll
@@ -516,18 +538,19 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
             const uint32_t slot = (set * NO + o) * 8 + j;
-            const uint32_t qi = slot < a.ngroups * 4 ? a.dense_q[slot] : 0xffffffffu;
+            const uint32_t qi = group_live && set < nsets && slot < a.ngroups * 4 ? a.dense_q[slot] : 0xffffffffu;
             qidx[o][j] = qi;
             any |= qi >= a.q0 && qi < a.q1;
         }
-    if (!any) return;
+    if (GS == 1 && !any) return;
+    const bool working = any && lane_live;                              // (wave-uniform but for the tile's last lanes)
     const uint32_t row0 = a.row_lo + chunk * a.rows_per_item, row1 = min(a.row_hi, row0 + a.rows_per_item);
     const uint8_t *__restrict__ base = a.M + (uint64_t)tile * kTileBytes;
     const uint8_t *__restrict__ cbase = (a.Mc ? a.Mc : a.M) + (uint64_t)tile * kTileBytes;
     const uint32_t voff = lane * 16u;
     const DenseLut *__restrict__ lut[NO];
 #pragma unroll
-    for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P * W;
+    for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P * 2;
     // plane[o][w][k]: bit k of the counters of mask word w (bit 8 b + j = query j of octet o against genome byte b of the word)
     // With sixteen queries the second octet's upper planes -- touched once per sixteen rows -- live in LDS (9 KiB per wave, lane-
     // major: no bank conflicts): both octets' counters in registers are 104 of them and left one wave per SIMD (282 registers;
@@ -546,20 +569,63 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                 else s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = 0;
             }
     constexpr uint32_t RB = 8;                                           // rows per batch of loads
-    uint4 tbn[2][NO][W];                                                 // the tables of the pair of rows that comes next
+    // shared rows: two batches of eight rows (1 KiB each) per sharing group -- one being worked from, one being filled
+    constexpr uint32_t kMine = RB / GS;                                  // rows of a batch this wave loads
+    __shared__ uint4 s_rows[GS == 1 ? 1 : 4 / GS][GS == 1 ? 1 : 2][GS == 1 ? 1 : RB][GS == 1 ? 1 : 64];
+    // (every group of a workgroup makes the same number of passes -- a chunk's rows, clamped at its end -- so that the barriers match)
+    const uint32_t row_span = a.rows_per_item;
+    auto load_mine = [&](uint32_t rb, uint4 (&v)[kMine]) {               // this wave's share of the batch whose first row is rb
 #pragma unroll
-    for (uint32_t v = 0; v < 2; ++v)
+        for (uint32_t u = 0; u < kMine; ++u) {
+            const uint32_t rr = min(rb + u * GS + w_in_grp, row1 - 1u);
+            v[u] = load_row16<false>(row_base(base, cbase, a.P_hot, rr, a.ld) + voff);
+        }
+    };
+    auto store_mine = [&](uint32_t buf, const uint4 (&v)[kMine]) {
 #pragma unroll
-        for (uint32_t o = 0; o < (uint32_t)NO; ++o)
-#pragma unroll
-            for (uint32_t x = 0; x < (uint32_t)W; ++x) tbn[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)(row0 + v) * W + x);
-    for (uint32_t r = row0; r < row1; r += 16) {
+        for (uint32_t u = 0; u < kMine; ++u) s_rows[grp_in_wg][buf][u * GS + w_in_grp][lane] = v[u];
+    };
+    uint32_t nbuf = 0;
+    if (GS > 1) {
+        uint4 v0[kMine];
+        load_mine(row0, v0);
+        store_mine(0, v0);
+        __syncthreads();
+    }
+    // The tables of sixteen rows -- 32 bytes per row and octet, 512 bytes per octet: contiguous -- come with ONE load of the wave
+    // (a lane: 16 bytes; lanes 0-31 the first octet's, 32-63 the second's, with one octet lanes 32-63 idle along), a block of
+    // sixteen rows ahead, and wait in LDS, where a pair of rows' tables are read as broadcasts.  (Before: 68 vector loads of 64
+    // equal addresses per sixteen rows and wave -- a third of a wave's cycles were waits for them, profiles/r6_pmc_dense.txt.)
+    __shared__ uint4 s_tab[4][2][64];
+    auto load_tab = [&](uint32_t rb) {                                   // this lane's piece of the tables of rows [rb, rb + 16)
+        const uint32_t o = NO == 2 ? lane >> 5 : 0u, piece = lane & 31u;
+        const uint32_t rr = min(rb + (piece >> 1), row1 - 1u);
+        return load_tables16(lut[NO == 2 ? o : 0] + (uint64_t)rr * 2 + (piece & 1u));
+    };
+    uint32_t tbuf = 0;
+    uint4 tab_next = load_tab(row0);
+    for (uint32_t r = row0; r < (GS == 1 ? row1 : row0 + row_span); r += 16) {
         uint32_t twosP[NO][4], foursP[NO][4], eightsP[NO][4];            // carries waiting for their partner
+        s_tab[wave][tbuf][lane] = tab_next;                              // (this block's tables: in LDS before its first pair asks)
+        tab_next = load_tab(r + 16);
 #pragma unroll
         for (uint32_t bt = 0; bt < 16 / RB; ++bt) {                       // a batch: its loads first (all in flight), then the work
             uint4 d[RB];
+            uint4 vnext[kMine];
+            if (GS == 1) {
 #pragma unroll
-            for (uint32_t u = 0; u < RB; ++u) d[u] = load_row16<false>(row_base(base, cbase, a.P_hot, r + bt * RB + u, a.ld) + voff);
+                for (uint32_t u = 0; u < RB; ++u) d[u] = load_row16<false>(row_base(base, cbase, a.P_hot, r + bt * RB + u, a.ld) + voff);
+            } else {
+                // the NEXT batch's share from memory (in flight under this batch's work), this batch's rows from LDS
+                load_mine(r + bt * RB + RB, vnext);
+#pragma unroll
+                for (uint32_t u = 0; u < RB; ++u) d[u] = s_rows[grp_in_wg][nbuf][u][lane];
+            }
+#if defined(DENSE_EXP) && DENSE_EXP == 3
+            if (row0 == 0xffffffffu) {                                   // (experiment: rows and barriers only)
+#else
+            if (GS == 1 || (working && r < row1)) {
+#endif
             // Two rows at a time (their tables: four scalar words per row and octet, asked for when their turn comes -- all
             // rows' tables at once do not fit the scalar registers and end up as vector copies): masks of the pair's four words,
             // into the ones; a carry waits for its partner of the same weight.  The fences keep the compiler from pooling the pairs.
@@ -567,25 +633,14 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
             for (uint32_t pp = 0; pp < RB / 2; ++pp) {
                 const uint32_t pr = bt * (RB / 2) + pp;                   // pair 0 .. 7 of the sixteen rows
                 __builtin_amdgcn_sched_barrier(0);
-                // this pair's tables were asked for a pair ago (scalar loads: a row is the wave's); the next pair's are asked for now,
-                // so that their latency passes under this pair's work (a wave that carries sixteen queries has one neighbour on its SIMD)
-                uint4 tb[2][NO][W];
+                // this pair's tables: four (eight) broadcast reads
+                uint4 tb[2][NO][2];
 #pragma unroll
                 for (uint32_t v = 0; v < 2; ++v)
 #pragma unroll
                     for (uint32_t o = 0; o < (uint32_t)NO; ++o)
 #pragma unroll
-                        for (uint32_t x = 0; x < (uint32_t)W; ++x) tb[v][o][x] = tbn[v][o][x];
-                {
-                    const uint32_t nr = min(r + pr * 2 + 2, row1 - 2);       // (the pair after the chunk's last: the last once more, unused)
-#pragma unroll
-                    for (uint32_t v = 0; v < 2; ++v)
-#pragma unroll
-                        for (uint32_t o = 0; o < (uint32_t)NO; ++o)
-#pragma unroll
-                            for (uint32_t x = 0; x < (uint32_t)W; ++x)
-                                tbn[v][o][x] = *reinterpret_cast<const uint4 *>(lut[o] + (uint64_t)(nr + v) * W + x);
-                }
+                        for (uint32_t x = 0; x < 2u; ++x) tb[v][o][x] = s_tab[wave][tbuf][o * 32u + (pr * 2u + v) * 2u + x];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (uint32_t w = 0; w < 4; ++w) {
@@ -594,7 +649,8 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                     for (uint32_t v = 0; v < 2; ++v) {
                         const uint4 &dd = d[pp * 2 + v];
                         const uint32_t dw = w == 0 ? dd.x : w == 1 ? dd.y : w == 2 ? dd.z : dd.w;
-                        sel[v][0] = dw & 0x03030303u; sel[v][1] = (dw >> 2) & 0x03030303u; sel[v][2] = (dw >> 4) & 0x03030303u; sel[v][3] = (dw >> 6) & 0x03030303u;
+                        if (W == 1) { sel[v][0] = dw & 0x07070707u; sel[v][1] = (dw >> 3) & 0x07070707u; sel[v][2] = (dw >> 6) & 0x03030303u; sel[v][3] = 0; }
+                        else { sel[v][0] = dw & 0x03030303u; sel[v][1] = (dw >> 2) & 0x03030303u; sel[v][2] = (dw >> 4) & 0x03030303u; sel[v][3] = (dw >> 6) & 0x03030303u; }
                         // two-byte fingerprints: a word's high bytes (1 and 3) look their fields up in the high byte's tables -- the
                         // upper half of an eight-entry table whose lower half is the low byte's
                         if (W == 2) { sel[v][0] |= 0x04000400u; sel[v][1] |= 0x04000400u; sel[v][2] |= 0x04000400u; sel[v][3] |= 0x04000400u; }
@@ -604,12 +660,28 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                         uint32_t m[2];
 #pragma unroll
                         for (uint32_t v = 0; v < 2; ++v) {
-                            const uint4 lo = tb[v][o][0], hi = tb[v][o][W - 1];
-                            const uint32_t both = __builtin_amdgcn_perm(W == 2 ? hi.x : 0u, lo.x, sel[v][0]) & __builtin_amdgcn_perm(W == 2 ? hi.y : 0u, lo.y, sel[v][1]) &
-                                                  __builtin_amdgcn_perm(W == 2 ? hi.z : 0u, lo.z, sel[v][2]) & __builtin_amdgcn_perm(W == 2 ? hi.w : 0u, lo.w, sel[v][3]);
-                            // (two bytes: a fingerprint matches where its low byte's set and its high byte's meet; the result sits in the low byte's place)
-                            m[v] = W == 1 ? both : both & (both >> 8) & 0x00ff00ffu;
+                            const uint4 lo = tb[v][o][0], hi = tb[v][o][1];
+                            if (W == 1) {
+                                // three lookups -- two in eight-entry tables (a pair of words: v_perm_b32's two sources, of which the
+                                // compiler copies one into a vector register per row: a quarter of an instruction per word) and one in
+                                // a four-entry table -- and ONE three-input AND
+                                m[v] = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_perm(lo.y, lo.x, sel[v][0]), __builtin_amdgcn_perm(lo.w, lo.z, sel[v][1]),
+                                                                   __builtin_amdgcn_perm(0u, hi.x, sel[v][2]), 0x80);
+                            } else {
+                                const uint32_t both = __builtin_amdgcn_perm(hi.x, lo.x, sel[v][0]) & __builtin_amdgcn_perm(hi.y, lo.y, sel[v][1]) &
+                                                      __builtin_amdgcn_perm(hi.z, lo.z, sel[v][2]) & __builtin_amdgcn_perm(hi.w, lo.w, sel[v][3]);
+                                // (two bytes: a fingerprint matches where its low byte's set and its high byte's meet; the result sits in the low byte's place)
+                                m[v] = both & (both >> 8) & 0x00ff00ffu;
+                            }
                         }
+#if defined(DENSE_EXP) && DENSE_EXP == 4
+                        plane[o][w][0] ^= tb[0][o][0].x ^ tb[1][o][0].y ^ tb[0][o][1].x ^ tb[1][o][1].x;   // (experiment: tables loaded, nothing looked up or counted)
+                        continue;
+#endif
+#if defined(DENSE_EXP) && DENSE_EXP == 5
+                        plane[o][w][0] ^= m[0] ^ m[1];                    // (experiment: lookups, no counting)
+                        continue;
+#endif
                         uint32_t twos;
                         csa(twos, plane[o][w][0], plane[o][w][0], m[0], m[1]);
                         if (!(pr & 1u)) { twosP[o][w] = twos; continue; }
@@ -637,9 +709,20 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                     }
                 }
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if (GS > 1) {                                                 // the next batch into the other half; everybody has read this one after the barrier
+                store_mine(nbuf ^ 1u, vnext);
+                nbuf ^= 1u;
+                __syncthreads();
+            }
         }
+        tbuf ^= 1u;
     }
+    if (!working) return;
+#if defined(DENSE_EXP) && DENSE_EXP == 2
+    if (row0 != 0xffffffffu) return;                                     // (experiment: no conversion, no atomics)
+#endif
     // the counters' planes -> numbers, query by query: four genomes of a word at a time (low eight planes into byte counters,
     // the upper planes into a second set), added to the score rows with integer atomics
 #pragma unroll
