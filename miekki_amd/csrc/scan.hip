@@ -68,8 +68,9 @@ int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
     // (the table kernel walks rows in groups of sixteen: every window and chunk of rows is a multiple of that for P >= 16;
     // sketches of fewer partitions take the compare kernel below)
     if (a.lut && a.rows_per_item % 16 == 0 && (a.row_hi - a.row_lo) % 16 == 0) {
-        static const int force_no = [] { const char *e = getenv("MIEKKI_DENSE_NO"); return e ? atoi(e) : 0; }();
-        const uint32_t no = force_no == 1 ? 1u : a.noctets >= 2 ? 2 : 1;
+        // (sixteen queries per wave: eight -- a third more instructions per query for a third wave per SIMD -- measured 97 against
+        // 79 ms at 64 queries, profiles/r6_pmc_dense.txt)
+        const uint32_t no = a.noctets >= 2 ? 2 : 1;
         // the sets of sixteen (eight) queries share a tile's rows through LDS, two or four waves of a workgroup (scan_kernel.hpp)
         const uint32_t nsets = (a.noctets + no - 1) / no, gs = nsets >= 3 ? 4 : nsets == 2 ? 2 : 1;
         const uint64_t groups = (uint64_t)((nsets + gs - 1) / gs) * a.ntiles * a.nchunks;

@@ -621,11 +621,7 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
 #pragma unroll
                 for (uint32_t u = 0; u < RB; ++u) d[u] = s_rows[grp_in_wg][nbuf][u][lane];
             }
-#if defined(DENSE_EXP) && DENSE_EXP == 3
-            if (row0 == 0xffffffffu) {                                   // (experiment: rows and barriers only)
-#else
             if (GS == 1 || (working && r < row1)) {
-#endif
             // Two rows at a time (their tables: four scalar words per row and octet, asked for when their turn comes -- all
             // rows' tables at once do not fit the scalar registers and end up as vector copies): masks of the pair's four words,
             // into the ones; a carry waits for its partner of the same weight.  The fences keep the compiler from pooling the pairs.
@@ -674,14 +670,6 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                                 m[v] = both & (both >> 8) & 0x00ff00ffu;
                             }
                         }
-#if defined(DENSE_EXP) && DENSE_EXP == 4
-                        plane[o][w][0] ^= tb[0][o][0].x ^ tb[1][o][0].y ^ tb[0][o][1].x ^ tb[1][o][1].x;   // (experiment: tables loaded, nothing looked up or counted)
-                        continue;
-#endif
-#if defined(DENSE_EXP) && DENSE_EXP == 5
-                        plane[o][w][0] ^= m[0] ^ m[1];                    // (experiment: lookups, no counting)
-                        continue;
-#endif
                         uint32_t twos;
                         csa(twos, plane[o][w][0], plane[o][w][0], m[0], m[1]);
                         if (!(pr & 1u)) { twosP[o][w] = twos; continue; }
@@ -720,9 +708,6 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
         tbuf ^= 1u;
     }
     if (!working) return;
-#if defined(DENSE_EXP) && DENSE_EXP == 2
-    if (row0 != 0xffffffffu) return;                                     // (experiment: no conversion, no atomics)
-#endif
     // the counters' planes -> numbers, query by query: four genomes of a word at a time (low eight planes into byte counters,
     // the upper planes into a second set), added to the score rows with integer atomics
 #pragma unroll
