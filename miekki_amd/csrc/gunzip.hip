@@ -911,6 +911,10 @@ struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t b
 // -- and so did, seen from here, every single-wave workgroup of the token kernel: the two kernels of batches in flight
 // side by side kept each other off the CUs.
 constexpr uint32_t kResolveWaves = 2;
+#ifndef GZ_WIDE_PIECES
+#define GZ_WIDE_PIECES 2
+#endif
+constexpr uint32_t kWidePieces = GZ_WIDE_PIECES;     // eight-byte pieces a lane copies of its own match before the whole wave takes the rest
 __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const uint8_t *__restrict__ gz, mk_gz_stream *__restrict__ jobs, uint32_t n,
                                                          const mk_gz_seg *__restrict__ segs, const uint32_t *__restrict__ chain, uint8_t *__restrict__ text,
                                                          ResolveConsts K)
@@ -1077,7 +1081,8 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
             // run crosses the window's end: the reads of a piece are independent of each other, and a write beyond the
             // token's end goes to the lane's sink instead of under a branch (most matches of gzip'd DNA are one piece)
             const bool wide = ready && dist >= 8u;
-            while (__any(wide && j < len && d + 8u <= kWin && f + 8u <= kWin)) {
+            // (two pieces at most -- sixteen bytes: 97 % of the matches of gzip'd DNA; what is left of a longer one goes below)
+            for (uint32_t piece = 0; piece < kWidePieces && __any(wide && j < len && d + 8u <= kWin && f + 8u <= kWin); ++piece) {
                 const bool go = wide && j < len && d + 8u <= kWin && f + 8u <= kWin;
                 // (the eight source bytes as three aligned words and two byte shifts instead of eight byte reads: the copies' LDS
                 // operations are what this kernel's time is made of.  A word may reach four bytes past the window's end: the next
@@ -1095,13 +1100,25 @@ __global__ __launch_bounds__(64 * kResolveWaves) void gz_resolve_kernel(const ui
                     f = f == kWin ? 0u : f;
                 }
             }
-            // ... the rest (short distances, runs across the window's end) byte by byte
-            while (__any(ready && j < len)) {
-                if (ready && j < len) {
-                    win[d] = win[f];
-                    ++j;
-                    d = d + 1u == kWin ? 0u : d + 1u;
-                    f = f + 1u == kWin ? 0u : f + 1u;
+            // ... the rest -- long matches, short distances, runs across the window's end -- one token at a time by the WHOLE
+            // wave, 64 bytes a pass: byte k of a token is byte k of its source when the source lies 64 or more back (an earlier
+            // pass, or earlier text), and byte k mod distance of it otherwise -- the `distance` bytes before the token, which
+            // are final: a run of one byte or a short period repeats them.  (Left to the token's own lane -- eight bytes a
+            // pass, a byte a pass below distance 8 -- a text of long repeats ran at 50 MB/s and a run of N at a byte per 200
+            // cycles: tests/test_gpu_gunzip.py's 1.1 GiB text took 23 s of this kernel.)
+            unsigned long long rest = __ballot(ready && j < len);
+            while (rest) {                                               // (wave-uniform: every pass takes one token off)
+                const int l = __ffsll((long long)rest) - 1;
+                rest &= rest - 1ull;
+                const uint32_t t_dst = (uint32_t)__builtin_amdgcn_readlane((int)dst, l), t_len = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+                const uint32_t t_dist = (uint32_t)__builtin_amdgcn_readlane((int)dist, l), t_j = (uint32_t)__builtin_amdgcn_readlane((int)j, l);
+                const uint32_t t_src = t_dst - t_dist;
+                for (uint32_t k0 = t_j; k0 < t_len; k0 += 64u) {
+                    const uint32_t k = k0 + lane;
+                    if (k < t_len) {
+                        const uint32_t sk = t_dist >= 64u ? k : k % t_dist;
+                        win[(t_dst + k) % kWin] = win[(t_src + sk) % kWin];
+                    }
                 }
             }
             if (ready) done = true;

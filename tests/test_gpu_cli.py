@@ -85,9 +85,9 @@ def test_exact_mode_like_the_reference(workdirs, golden_dir, name):
     assert got == want
 
 
+# (rnd4 and rnd5 also ran here until round 6: the GPU suite's time -- their shapes are covered by rnd1 / rnd2, three and four shards)
 @pytest.mark.parametrize("name,devices", [("messy", "0,0,0"), ("h20", "0,0"), ("w16", "0,0,0"), ("c2mini", "0,0"),
-                                          ("h16z", "0,0,0,0,0"), ("rnd1", "0,0,0"), ("rnd2", "0,0,0,0"), ("rnd4", "0,0,0"),
-                                          ("rnd5", "0,0")])
+                                          ("h16z", "0,0,0,0,0"), ("rnd1", "0,0,0"), ("rnd2", "0,0,0,0")])
 def test_several_gpus_in_one_process_like_the_reference(workdirs, golden_dir, name, devices):
     """The `miekki` binary over several contexts (MIEKKI_DEVICES repeats GPU 0: genome shards in list
     order, Bloom first-writer fold, 8-byte entrant rows copied GPU-to-GPU, device merge): every file and
@@ -128,7 +128,8 @@ def run_ranked(args, cwd, extra_env=None):
     return r.stdout                                              # (RCCL's version banner goes to stderr: mk_comm_create)
 
 
-@pytest.mark.parametrize("name", ["messy", "h20", "w16", "rnd1", "rnd4"])
+# (rnd1 and rnd4 too until round 6: 11 s each, mostly RCCL starting up eight times; the multi-rank driver tests below keep both)
+@pytest.mark.parametrize("name", ["messy", "h20", "w16"])
 def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name):
     """`miekki` with a communicator (RCCL called from the C++ host through the C ABI): -l with -a, -A, -e and -A -e must
     give the reference's files and banners."""
