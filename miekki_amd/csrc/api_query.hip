@@ -426,9 +426,9 @@ static int qset_scan(mk_ctx *c, mk_qset *qs, uint32_t q0, uint32_t q1, uint32_t 
         DenseArgs d;
         d.M = M; d.Mc = Mc; d.P_hot = P_hot; d.ld = c->ld; d.G = c->G; d.ntiles = nt; d.P = c->P;
         d.row_lo = row_lo; d.row_hi = row_hi;
-        d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, 8176);          // (below 2^13: the table kernel counts in 13 bit planes)
-        d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
         d.ngroups = (uint32_t)(qs->dense_q.size() / 4);
+        d.rows_per_item = std::min<uint32_t>(row_hi - row_lo, dense_chunk_rows((d.ngroups + 1) / 2));   // (the table kernel counts in 14 or 13 bit planes)
+        d.nchunks = (row_hi - row_lo + d.rows_per_item - 1) / d.rows_per_item;
         d.dense = qs->d_dense; d.dense_q = qs->d_dense_q; d.q0 = q0; d.q1 = q1; d.scores = d_scores;
         d.lut = qs->d_dense_lut; d.noctets = (d.ngroups + 1) / 2;
         d.score_tile_stride = lay.tile_stride; d.score_q_stride = lay.q_stride; d.empty = c->empty;

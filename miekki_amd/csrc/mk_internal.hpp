@@ -549,6 +549,10 @@ struct DenseArgs {
 };
 int launch_scan_dense(mk_ctx *c, const DenseArgs &a);
 int launch_dense_lut(mk_ctx *c, const uint8_t *d_dense, uint32_t ngroups, DenseLut *d_lut);
+// how the table kernel shares rows between its sets of queries (scan.hip, scan_kernel.hpp): sets of sixteen (eight) queries,
+// sharing groups of 1, 2 or 4 sets -- and the rows a chunk may hold for the counters' bit planes
+inline uint32_t dense_share(uint32_t noctets) { const uint32_t no = noctets >= 2 ? 2 : 1, nsets = (noctets + no - 1) / no; return nsets >= 3 ? 4u : nsets == 2 ? 2u : 1u; }
+inline uint32_t dense_chunk_rows(uint32_t noctets) { (void)noctets; return 16368u; }
 int probe_stream_read(mk_ctx *c, uint32_t rounds, double *gbps, uint64_t *bytes);
 
 // ---- select.hip

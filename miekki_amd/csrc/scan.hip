@@ -72,11 +72,11 @@ int launch_scan_dense(mk_ctx *c, const DenseArgs &a)
         // 79 ms at 64 queries, profiles/r6_pmc_dense.txt)
         const uint32_t no = a.noctets >= 2 ? 2 : 1;
         // the sets of sixteen (eight) queries share a tile's rows through LDS, two or four waves of a workgroup (scan_kernel.hpp)
-        const uint32_t nsets = (a.noctets + no - 1) / no, gs = nsets >= 3 ? 4 : nsets == 2 ? 2 : 1;
+        const uint32_t nsets = (a.noctets + no - 1) / no, gs = dense_share(a.noctets);
         const uint64_t groups = (uint64_t)((nsets + gs - 1) / gs) * a.ntiles * a.nchunks;
         if (groups == 0) return MK_OK;
         if (groups >= (1ull << 31)) { set_error("dense scan launch too large"); return MK_ERR_ARG; }
-        const uint32_t per_wg = 4 / gs, blocks = (uint32_t)((groups + per_wg - 1) / per_wg);
+        const uint32_t per_wg = 4 / gs, blocks = ((uint32_t)((groups + per_wg - 1) / per_wg) + 7u) / 8u * 8u;   // (a multiple of eight: the kernel deals them to the XCDs)
 #define MK_DENSE_LUT(W_, NO_, GS_) hipLaunchKernelGGL((scan_dense_lut_kernel<W_, NO_, GS_>), dim3(blocks), dim3(256), 0, c->stream, a)
         if (c->W == 1) {
             if (no == 1 && gs == 1) MK_DENSE_LUT(1, 1, 1);

@@ -516,7 +516,8 @@ __device__ __forceinline__ uint4 load_tables16(const DenseLut *p) { return *rein
 template <int W, int NO, int GS>
 __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
 {
-    constexpr uint32_t kPlanes = 13;                                 // counts up to 8,191: the host cuts chunks of at most 8,176 rows
+    // counts up to 16,383: the host cuts chunks of at most 16,368 rows (dense_chunk_rows)
+    constexpr uint32_t kPlanes = 14;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nsets = (a.noctets + NO - 1) / NO;
@@ -524,11 +525,17 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     // (a set beyond the last, a group beyond the grid's end, no query of this pass) still loads its share and keeps the barriers
     const uint32_t nsg = (nsets + GS - 1) / GS, ngroups_all = nsg * a.ntiles * a.nchunks;
     const uint32_t grp_in_wg = wave / GS, w_in_grp = wave % GS;
-    const uint32_t group_id = blockIdx.x * (4u / GS) + grp_in_wg;
+    // Workgroups are dealt to the eight XCDs round robin: XCD x walks the groups x * n / 8 ... in order, and a group's number has
+    // the TILE running fastest -- so the workgroups in flight on one XCD walk the same chunk of rows of neighbouring tiles and
+    // find that chunk's tables (32 bytes per row and octet, the same for every tile) in their L2 instead of fetching them
+    // once per tile (98 x 268 MB at 64 queries: a quarter on top of the matrix at the fabric, profiles/r6_pmc_dense.txt).
+    // (The grid is a multiple of eight workgroups: launch_scan_dense.)
+    const uint32_t per_xcd = gridDim.x / 8u, wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t group_id = wg * (4u / GS) + grp_in_wg;
     const bool group_live = group_id < ngroups_all;
     if (GS == 1 && !group_live) return;
     const uint32_t gid = min(group_id, ngroups_all - 1u);
-    const uint32_t set = (gid % nsg) * GS + w_in_grp, ct = gid / nsg, chunk = ct % a.nchunks, tile = ct / a.nchunks;
+    const uint32_t tile = gid % a.ntiles, cs = gid / a.ntiles, set = (cs % nsg) * GS + w_in_grp, chunk = cs / nsg;
     const bool lane_live = (uint64_t)tile * kTileBytes + lane * 16u < (uint64_t)a.G * W;
     // (a lane beyond the tile's last genome stays: it carries its share of the rows' tables, below; its rows lie in the tile's padding)
     uint32_t qidx[NO][8];
@@ -551,24 +558,41 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
     const DenseLut *__restrict__ lut[NO];
 #pragma unroll
     for (uint32_t o = 0; o < (uint32_t)NO; ++o) lut[o] = a.lut + (uint64_t)min(set * NO + o, a.noctets - 1) * a.P * 2;
-    // plane[o][w][k]: bit k of the counters of mask word w (bit 8 b + j = query j of octet o against genome byte b of the word)
-    // With sixteen queries the second octet's upper planes -- touched once per sixteen rows -- live in LDS (9 KiB per wave, lane-
-    // major: no bank conflicts): both octets' counters in registers are 104 of them and left one wave per SIMD (282 registers;
-    // 188 and two waves this way.  Variants measured side by side on one box, 32 queries x 100,000 genomes: this one 55.3 ms;
-    // batches of four rows 57.4; all upper planes in LDS 55-58; three waves per SIMD forced, with 23 spilled words: 66.1).
-    constexpr uint32_t kRegOctets = NO == 2 ? 1 : NO;
-    __shared__ uint32_t s_up[NO == 2 ? 4 : 1][NO == 2 ? (kPlanes - 4) * 4 : 1][64];
-    uint32_t plane[NO][4][kPlanes];
+    // plane[o][w][k]: bit k of the counters of mask word w (bit 8 b + j = query j of octet o against genome byte b of the word).
+    // The low EIGHT planes live in registers; a carry out of them -- a counter passes a multiple of 256: at most once per counter in
+    // 256 rows -- is OR-ed into a pending word and rippled through the five upper planes, which live in LDS (10 KiB per wave,
+    // lane-major: no bank conflicts), once per 256 rows.  (Round 4 rippled every carry of weight sixteen through all nine upper
+    // planes, one octet's in registers, the other's in LDS: eighteen instructions per sixteen rows, word and octet; nine now.)
+    constexpr uint32_t kRegPlanes = 8, kUp = kPlanes - kRegPlanes;
+    __shared__ uint32_t s_up[4][NO * kUp * 4][64];
+    uint32_t plane[NO][4][kRegPlanes], pend[NO][4];
 #pragma unroll
     for (uint32_t o = 0; o < (uint32_t)NO; ++o)
 #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w)
+        for (uint32_t w = 0; w < 4; ++w) {
+            pend[o][w] = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kPlanes; ++k) {
-                if (o < kRegOctets || k < 4) plane[o][w][k] = 0;
-                else s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = 0;
+                if (k < kRegPlanes) plane[o][w][k] = 0;
+                else s_up[wave][(o * kUp + (k - kRegPlanes)) * 4 + w][lane] = 0;
             }
-    constexpr uint32_t RB = 8;                                           // rows per batch of loads
+        }
+    auto flush_pending = [&]() {                                         // the pending carries of weight 256 into the upper planes
+#pragma unroll
+        for (uint32_t o = 0; o < (uint32_t)NO; ++o)
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                uint32_t c = pend[o][w];
+                pend[o][w] = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kUp; ++k) {
+                    const uint32_t t = s_up[wave][(o * kUp + k) * 4 + w][lane];
+                    s_up[wave][(o * kUp + k) * 4 + w][lane] = t ^ c;
+                    c &= t;
+                }
+            }
+    };
+    constexpr uint32_t RB = GS == 2 ? 4 : 8;                             // rows per batch of loads (two sharing groups in a workgroup: half, for their row buffers' LDS)
     // shared rows: two batches of eight rows (1 KiB each) per sharing group -- one being worked from, one being filled
     constexpr uint32_t kMine = RB / GS;                                  // rows of a batch this wave loads
     __shared__ uint4 s_rows[GS == 1 ? 1 : 4 / GS][GS == 1 ? 1 : 2][GS == 1 ? 1 : RB][GS == 1 ? 1 : 64];
@@ -681,19 +705,14 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                         if (!(pr & 4u)) { eightsP[o][w] = eights; continue; }
                         uint32_t carry;
                         csa(carry, plane[o][w][3], plane[o][w][3], eightsP[o][w], eights);
-                        // one bit of weight sixteen per position: rippled through the upper planes
+                        // one bit of weight sixteen per position: through planes 4-7, what falls out of them waits in `pend`
 #pragma unroll
-                        for (uint32_t k = 4; k < kPlanes; ++k) {
-                            if (o < kRegOctets) {
-                                const uint32_t t = plane[o][w][k];
-                                plane[o][w][k] = t ^ carry;
-                                carry &= t;
-                            } else {
-                                const uint32_t t = s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
-                                s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane] = t ^ carry;
-                                carry &= t;
-                            }
+                        for (uint32_t k = 4; k < kRegPlanes; ++k) {
+                            const uint32_t t = plane[o][w][k];
+                            plane[o][w][k] = t ^ carry;
+                            carry &= t;
                         }
+                        pend[o][w] |= carry;
                     }
                 }
             }
@@ -706,8 +725,10 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
             }
         }
         tbuf ^= 1u;
+        if ((((r - row0) >> 4) & 15u) == 15u) flush_pending();            // (256 rows since the last time: wave-uniform)
     }
     if (!working) return;
+    flush_pending();
     // the counters' planes -> numbers, query by query: four genomes of a word at a time (low eight planes into byte counters,
     // the upper planes into a second set), added to the score rows with integer atomics
 #pragma unroll
@@ -724,12 +745,12 @@ __global__ __launch_bounds__(256) void scan_dense_lut_kernel(const DenseArgs a)
                 uint32_t lo = 0, hi = 0;
 #pragma unroll
                 for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t pl = (o < kRegOctets || k < 4) ? plane[o][w][k] : s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
+                    const uint32_t pl = plane[o][w][k];
                     lo += ((pl >> j) & 0x01010101u) << k;
                 }
 #pragma unroll
-                for (uint32_t k = 8; k < kPlanes; ++k) {
-                    const uint32_t pl = o < kRegOctets ? plane[o][w][k] : s_up[wave][((o - kRegOctets) * (kPlanes - 4) + (k - 4)) * 4 + w][lane];
+                for (uint32_t k = 8; k < kPlanes; ++k) {                   // (at most six planes: the upper count stays below 64)
+                    const uint32_t pl = s_up[wave][(o * kUp + (k - kRegPlanes)) * 4 + w][lane];
                     hi += ((pl >> j) & 0x01010101u) << (k - 8);
                 }
 #pragma unroll
