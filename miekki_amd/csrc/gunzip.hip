@@ -749,12 +749,15 @@ __global__ __launch_bounds__(64) void gz_check_kernel(const uint8_t *__restrict_
     const uint32_t total_syms = hlit + hdist;
     uint32_t k = 0, prev = 0, kraft_l = 0, kraft_d = 0, max_l = 0, max_d = 0, eob = 0;
     bool ok = true;
-    auto take = [&](uint32_t len, uint32_t rep) {                    // `rep` symbols of length `len` from symbol k on
-        for (uint32_t r = 0; r < rep; ++r, ++k) {
-            if (!len) continue;
-            if (k < hlit) { kraft_l += 32768u >> len; max_l = max(max_l, len); if (k == 256u) eob = 1; }
-            else { kraft_d += 32768u >> len; max_d = max(max_d, len); }
+    auto take = [&](uint32_t len, uint32_t rep) {                    // `rep` symbols of length `len` from symbol k on (no loop over them)
+        if (len) {
+            const uint32_t n_l = k < hlit ? min(rep, hlit - k) : 0u, n_d = rep - n_l, w = 32768u >> len;
+            kraft_l += n_l * w; kraft_d += n_d * w;
+            if (n_l) max_l = max(max_l, len);
+            if (n_d) max_d = max(max_d, len);
+            if (k <= 256u && 256u < k + n_l) eob = 1;
         }
+        k += rep;
     };
     while (ok && k < total_syms) {                                   // (every pass takes at least one symbol's length)
         if (q + 64u > nbits + 64u) { ok = false; break; }
@@ -767,6 +770,9 @@ __global__ __launch_bounds__(64) void gz_check_kernel(const uint8_t *__restrict_
         else if (sym == 17u) { const uint32_t rep = 3u + ((uint32_t)v & 7u); q += 3u; if (k + rep > total_syms) { ok = false; break; } take(0, rep); prev = 0; }
         else { const uint32_t rep = 11u + ((uint32_t)v & 127u); q += 7u; if (k + rep > total_syms) { ok = false; break; } take(0, rep); prev = 0; }
         if (q > nbits) ok = false;
+        // (an over-subscribed alphabet stays one: noise is over the limit after a dozen lengths, and a wave of 64 offsets of which
+        // none is a block's start -- two in three -- leaves here instead of reading three hundred lengths of each)
+        if (kraft_l > 32768u || kraft_d > 32768u) ok = false;
     }
     // what inflate_table takes: not over-subscribed; incomplete only as a single one-bit code (or, the distances, none at all)
     ok = ok && eob && kraft_l <= 32768u && (kraft_l == 32768u || max_l <= 1u) && kraft_d <= 32768u && (kraft_d == 32768u || max_d <= 1u);
