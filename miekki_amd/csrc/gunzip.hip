@@ -1479,14 +1479,13 @@ static int gz_open(GzRun &r, mk_ctx *c, const uint64_t *gz_bytes, uint32_t n)
 }
 
 // a page-locked piece of kStagePiece bytes to read (a piece of) a file into; null: none to be had (use any memory)
-// (a reader thread selects the device once, not with every call: every runtime call takes the runtime's lock, and sixteen
-// readers at five calls a file stood in line for it)
+// (a reader thread selects the device when it is not the thread's current one, not with every call: sixteen readers at five
+// runtime calls a file stood in line for the runtime's lock)
 static inline bool gz_use_device(const mk_ctx *c)
 {
-    static thread_local int current = -1;
-    if (current == c->p.device) return true;
+    int current = -1;                                               // (asked, not remembered: other calls of this thread may have chosen another)
+    if (hipGetDevice(&current) == hipSuccess && current == c->p.device) return true;
     if (hipSetDevice(c->p.device) != hipSuccess) { (void)hipGetLastError(); return false; }
-    current = c->p.device;
     return true;
 }
 

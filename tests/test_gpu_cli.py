@@ -378,3 +378,53 @@ def test_index_columns_inflated_on_the_gpu(workdirs, golden_dir, name):
         r = subprocess.run([CLI, "-i", "idx_bad.gz", "-a", "queries.fa", "-o", "out_bad.txt", "-t", "2"], cwd=d, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, timeout=600, env=env)
         assert r.returncode != 0 or b"orrupt" in r.stdout or b"truncated" in r.stdout, r.stdout.decode(errors="replace")
+
+
+def test_a_long_list_of_gzipd_files_goes_up_in_spans_and_builds_the_oracle_s_index(tmp_path):
+    """`-l` over 1,100 gzip'd genome files with two reader threads: plenty of files per reader, so the readers take runs of
+    eight and a run goes to the device as ONE span (host/fasta_reader.cpp, mk_gz_put_span), three units of 512 files run beside
+    each other, the units' appends follow in list order.  Inside the list: a plain FASTA file, a file that is missing, an empty
+    gzip member, a file of two members, a member with every optional header field, a sequence shorter than k.  The index must be the one the oracle builds from the same sequences in list order; stdout
+    names the missing file where the reference would."""
+    import zlib
+    from oracle import oracle as orc
+    k, h = 21, 10
+    rng = np.random.default_rng(2026)
+    seqs, lines, names = [], [], []
+    for i in range(1100):
+        s = synth.genome_bases(9000 + i, 0, int(rng.integers(2000, 30000)))
+        text = b">g%d\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n"
+        fn = tmp_path / ("g%d.fa.gz" % i)
+        c = zlib.compressobj(int(rng.choice([1, 6, 9])), zlib.DEFLATED, 31)
+        blob = c.compress(text) + c.flush()
+        if i == 13:                                     # plain FASTA inside a device unit
+            fn = tmp_path / "g13.fa"; blob = text
+        elif i == 200:                                  # listed, not there
+            names.append(str(fn)); continue
+        elif i == 333:                                  # an empty member: no sequence
+            blob = gzip.compress(b"", 6); s = b""
+        elif i == 600:                                  # two members
+            c1 = zlib.compressobj(6, zlib.DEFLATED, 31); c2 = zlib.compressobj(1, zlib.DEFLATED, 31)
+            blob = c1.compress(text[:len(text) // 2]) + c1.flush() + c2.compress(text[len(text) // 2:]) + c2.flush()
+        elif i == 777:                                  # every optional header field (FEXTRA, FNAME, FCOMMENT, FHCRC) before the data
+            import struct
+            hdr = struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4 | 8 | 16 | 2, 0, 0, 3, 5) + b"extra" + b"g777.fa\0" + b"a comment\0"
+            hdr += struct.pack("<H", zlib.crc32(hdr) & 0xffff)
+            body = zlib.compressobj(6, zlib.DEFLATED, -15)
+            blob = hdr + body.compress(text) + body.flush() + struct.pack("<II", zlib.crc32(text), len(text))
+        elif i == 900:                                  # shorter than k: skipped
+            s = b"ACGTACGT"; blob = gzip.compress(b">tiny\n" + s + b"\n", 6)
+        fn.write_bytes(blob)
+        names.append(str(fn))
+        if len(s) >= k:
+            seqs.append(s)
+    (tmp_path / "genomes.lst").write_text("\n".join(names) + "\n")
+    (tmp_path / "q.fa").write_bytes(b">q\n" + seqs[5][:1000] + b"\n")
+    out = run(["-l", "genomes.lst", "-a", "q.fa", "-o", "out.txt", "-d", "idx.gz", "-k", str(k), "-h", str(h), "-b", "32", "-s", "5", "-t", "2"], tmp_path)
+    assert b"Missed file: " + names[200].encode() in out
+    assert ("Reference indexed: %d" % len(seqs)).encode() in out
+    want = orc.OracleMiekki(k, h, 8, 32, 5)
+    want.insert_sequences(seqs)
+    raw = bytearray(gzip.decompress((tmp_path / "idx.gz").read_bytes())); raw[32] = 0; raw[38] = 0
+    ref = bytearray(want.serialize().tobytes()); ref[32] = 0; ref[38] = 0
+    assert hashlib.sha256(bytes(raw)).hexdigest() == hashlib.sha256(bytes(ref)).hexdigest()
