@@ -148,7 +148,8 @@ def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name)
         assert (d / "exactA_r.txt").read_bytes() == open(exa, "rb").read()
     # -d and -i per rank (main.cpp:189-206, Miekki.cpp:649-719): the dump is the single process's stream (masked SHA of the
     # reference's), the load keeps this rank's slice of the columns and answers like the reference
-    if name not in ("messy", "w16"):                             # (every run starts RCCL: two cases, both widths, keep the suite short)
+    # (every run starts RCCL: one case here keeps the suite short; the 16-bit slices are test_an_index_loads_in_slices_as_the_ranks_take_it[w16-2])
+    if name != "messy":
         return
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     so_d = run_ranked(["-l", "genomes.lst", "-a", "queries.fa", "-o", "out_rd.txt", "-d", "idx_r.gz", *base], d)
