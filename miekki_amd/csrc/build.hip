@@ -194,6 +194,17 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
     return mantis_halves(ahi & ((1u << (32u - h)) - 1u), alo, h, f, empty);
 }
 
+// LDS by ADDRESS (a 32-bit integer) instead of by pointer: the scatter kernel's block is dynamic, so its base is a symbol the
+// compiler adds to every pointer it derives from it, one v_add_u32 per access; an address carried in a register -- in the
+// items' keys, in the counters' starts -- is added to once.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ __forceinline__ uint32_t lds_address(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)p;
+}
+__device__ __forceinline__ lds_u32 *lds_word(uint32_t a) { return (lds_u32 *)(uintptr_t)a; }
+
 // The hash loop of one thread: sixteen consecutive k-mers rolled out of three words of packed digits (w0, w1, w2:
 // the thread's 48 positions; x*: their exception bits), each one's item and, from an LDS counter, its rank in its bin.
 // KBIG: k >= 17 -- the entering reverse digit then always lands in the state's high word and the forward state's low
@@ -201,7 +212,7 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
 // the whole workgroup; they only take instructions out of a loop that is bound by instruction issue.
 template <int W, bool KBIG, bool FULL>
 __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bool has_x, uint32_t x01, uint32_t x2, uint32_t i0,
-                                       uint32_t cnt, uint32_t *bins, const uint32_t *sum32, typename ItemOf<W>::type (&it)[kPer],
+                                       uint32_t cnt, uint32_t ctr_a, uint32_t sum_a, typename ItemOf<W>::type (&it)[kPer],
                                        uint32_t (&key)[kPer], const SketchParams &sp, const BuildShape &bs)
 {
     // digit j of the thread's 48 positions at bits 2j: forward digits F, reverse-strand digits R
@@ -225,46 +236,63 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     const uint32_t topshift = 2 * sp.k - 2;                       // even: the entering reverse digit lies within ONE half
     const bool top_hi = KBIG || topshift >= 32;
     const uint32_t tsh = top_hi ? topshift - 32 : topshift;
+    // KBIG: no state is carried from k-mer to k-mer -- k-mer u is a 64-bit window of a 96-bit word that holds the seed and all
+    // sixteen entering digits, two funnel shifts by a constant and one mask each way (update_kmer / update_kmer_RC,
+    // Miekki.cpp:51-62, sixteen times over): forward {S0 | entering digits, first on top, below it}, read 2 (u + 1) bits further down per
+    // k-mer; reverse {entering digits << 2k | RC0}, read 2 (u + 1) bits further up.
+    const uint32_t S0lo = Slo, S0hi = Shi;
+    const uint32_t FR = (uint32_t)(reverse_digits((uint64_t)fnew) >> 32);
+    const uint32_t Vlo = Rlo;
+    const uint32_t Vmid = KBIG ? Rhi | (rnew << (2 * sp.k - 32)) : 0u, Vtop = KBIG ? rnew >> (64 - 2 * sp.k) : 0u;   // (k >= 17: 2 <= 64 - 2k <= 30)
     const uint32_t bshift = 32u - sp.h;                           // bucket = anc >> (64 - h)  (Miekki.cpp:169)
     const uint32_t sumshift = bs.sum_words ? sp.bloom_log2 - 32u + 3u + 11u : 31u;   // canon's high word -> group of 2048 cells
+    const uint32_t wordshift = min(sumshift + 5u, 31u);           // ... -> the summary word of the group (canon < 2^62: >> 31 leaves 0)
+    const uint32_t binshift = bshift + bs.low_bits;                // the bin: the partition's bits above the low 12
+    // (three loop constants pinned in vector registers: v_bfe_u32 takes one scalar operand, not two, and the compiler would
+    // rather make a constant again with a v_mov_b32 per k-mer than keep it)
+    uint32_t binbits = sp.h - bs.low_bits, partbits = bs.low_bits, four = 4u;
+    asm volatile("" : "+v"(binbits), "+v"(partbits), "+v"(four));
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
-        const uint32_t fd = (fnew >> (2 * u)) & 3u, rd = (rnew >> (2 * u)) & 3u;
         if (KBIG) {
-            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;                  // update_kmer, Miekki.cpp:51-55
-            Slo = (Slo << 2) | fd;
-            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);                         // update_kmer_RC, Miekki.cpp:59-62
-            Rhi = (Rhi >> 2) | (rd << tsh);
+            Slo = __builtin_amdgcn_alignbit(S0lo, FR, 30 - 2 * u);
+            Shi = __builtin_amdgcn_alignbit(S0hi, S0lo, 30 - 2 * u) & mhi;
+            Rlo = u == kPer - 1 ? Vmid : __builtin_amdgcn_alignbit(Vmid, Vlo, 2 * u + 2);
+            Rhi = (u == kPer - 1 ? Vtop : __builtin_amdgcn_alignbit(Vtop, Vmid, 2 * u + 2)) & mhi;
         } else {
-            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;
+            const uint32_t fd = (fnew >> (2 * u)) & 3u, rd = (rnew >> (2 * u)) & 3u;
+            Shi = __builtin_amdgcn_alignbit(Shi, Slo, 30) & mhi;                  // update_kmer, Miekki.cpp:51-55
             Slo = ((Slo << 2) | fd) & mlo;
-            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);
+            Rlo = __builtin_amdgcn_alignbit(Rhi, Rlo, 2);                         // update_kmer_RC, Miekki.cpp:59-62
             Rhi >>= 2;
             if (top_hi) Rhi |= rd << tsh; else Rlo |= rd << tsh;
         }
         const uint64_t S = ((uint64_t)Shi << 32) | Slo, RC = ((uint64_t)Rhi << 32) | Rlo;
         const uint64_t canon = S < RC ? S : RC;
         // Would inserting this k-mer into the Bloom filter still change anything (Miekki.cpp:121-131)?  Its five positions
-        // are (canon + t_i) >> b with t_i < 1024 and b >= 32 (universal_hash, utils.cpp:197-199): ONE cell unless the low
-        // word can carry, and the summary says whether every cell of that cell's group of 2048 is taken already.  Cells are
-        // never emptied, so a summary older than the filter only flags more.
+        // are (canon + t_i) >> b with t_i < 1024 and b >= 32 (universal_hash, utils.cpp:197-199): ONE cell, or, when the low
+        // word carries, that cell and the next; the summary bit of a group of 2048 cells says that all of them AND the first
+        // cell of the next group are taken (bloom_summary_kernel, sketch.hip) -- no test of the low word here.  Cells are never
+        // emptied, so a summary older than the filter only flags more.
         // (asked before the hash so that the LDS read is under way while the hash is computed)
-        // (no branch here: without a summary the shift leaves group 0 and the one word there says "nothing is settled", or,
+        // (no branch here: without a summary the shifts leave group 0 and the one word there says "nothing is settled", or,
         // for an index without a filter, "everything is")
-        const uint32_t s3 = (uint32_t)(canon >> 32) >> sumshift;                  // cell >> 11
-        const uint32_t sword = (uint32_t)canon <= 0xFFFFFC00u ? sum32[s3 >> 5] : 0u;
+        const uint32_t chi = (uint32_t)(canon >> 32);
+        const uint32_t s3 = chi >> sumshift;                                      // cell >> 11
+        const uint32_t sword = *lds_word(sum_a + ((chi >> wordshift) << 2));
         const uint32_t settled = __builtin_amdgcn_ubfe(sword, s3, 1u);            // bit s3 & 31 of the word (v_bfe_u32 takes the offset's low five bits)
         const uint64_t anc = revhash64(canon);                                    // Miekki.cpp:167-168
         const uint32_t ahi = (uint32_t)(anc >> 32);
         const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
         if (fp == sp.empty || (!FULL && i0 + u >= cnt)) continue;    // (past the segment's end only in a sequence's last workgroup)
-        const uint32_t bucket = ahi >> bshift;
-        const uint32_t part = bucket & ((1u << bs.low_bits) - 1u);
-        const uint32_t binoff = (((bucket >> bs.low_bits) << 1) | settled) << 2;   // byte offset of the bin's counter: flagged, settled
-        const uint32_t rank = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(bins) + binoff), 1u);
+        const uint32_t part = __builtin_amdgcn_ubfe(ahi, bshift, partbits);
+        // the address of the bin's counter: flagged, settled (a field of no bits is 0: -h 12 and below have one bin).  The
+        // counters count BYTES of items (4 per item): what comes back is the item's place in its run as the stage wants it
+        const uint32_t caddr = (ctr_a + (__builtin_amdgcn_ubfe(ahi, binshift, binbits) << 3)) | (settled << 2);
+        const uint32_t rank4 = __hip_atomic_fetch_add(lds_word(caddr), four, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // (W == 2: the low eight position bits are (i0 + u) & 255, known to whoever stores the item: they are not kept here)
         it[u] = W == 1 ? (fp << 24) | (part << kBin) | (i0 + u) : (fp << 16) | (part << 4) | ((i0 + u) >> 8);
-        key[u] = (binoff << 12) | rank;                              // rank < 4096 (among the bin's flagged / settled items)
+        key[u] = (caddr << 14) | rank4;                              // rank < 4096 (among the bin's flagged / settled items); addresses < 2^18
     }
 }
 
@@ -283,22 +311,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     using item_t = typename ItemOf<W>::type;
     constexpr uint32_t kIPV = 4;                                      // items per 16-byte store of the main array
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *stage = reinterpret_cast<uint32_t *>(smem);             // kSeg + kIPV: the workgroup's items (main words), sorted by bin
-    uint8_t *stage_low = smem + (kSeg + kIPV) * 4;                    // W == 2: their low position bytes, kSeg + 16
+    // (everything in the one dynamic block: with no static arrays before it the block starts at LDS address 0 and the offsets
+    // below are the instructions' own offset fields)
+    constexpr uint32_t kLead = (2 * (kSeg / 16 + 4) + 4) * 4;         // cw, xw, wave_sum: 2,096 bytes
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + kLead);     // kSeg + kIPV: the workgroup's items (main words), sorted by bin
+    uint8_t *stage_low = smem + kLead + (kSeg + kIPV) * 4;            // W == 2: their low position bytes, kSeg + 16
     constexpr uint32_t kStageBytes = (kSeg + kIPV) * 4 + (W == 2 ? kSeg + 16 : 0);
-    // 2 * nbins + 1 counters (per bin: flagged items, then settled ones), later the places where their runs start
-    uint32_t *bins = reinterpret_cast<uint32_t *>(smem + kStageBytes);
+    // 2 * nbins counters (per bin: flagged items, then settled ones; padded with zeros to a multiple of eight), later the
+    // places where their runs start -- as LDS addresses in the stage -- and behind them one word that no k-mer counts in (the "dump
+    // slot": where the items that do not exist go, below).
+    const uint32_t nctr = 2 * bs.nbins, pad8 = (nctr + 7u) & ~7u;
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(smem + kLead + kStageBytes);   // (16-byte aligned)
     // the Bloom summary (one bit per 2048 cells: all taken), when there is one: 4 KiB at -b 33 -- as a snapshot of whatever
     // the array holds right now (the summary kernel of the batch before may be writing it: bits only ever get set)
-    uint32_t *sum32 = bins + ((2 * bs.nbins + 1 + 3) & ~3u);          // (at least one word)
-    __shared__ uint32_t cw[kSeg / 16 + 4];                            // the workgroup's positions, 16 per word
-    __shared__ uint32_t xw[kSeg / 16 + 4];                            // their exception bits (low 16)
-    __shared__ uint32_t wave_sum[4];
+    uint32_t *sum32 = ctr + pad8 + 4;                                 // (at least one word)
+    uint32_t *cw = reinterpret_cast<uint32_t *>(smem);                // [kSeg / 16 + 4] the workgroup's positions, 16 per word
+    uint32_t *xw = cw + kSeg / 16 + 4;                                // [kSeg / 16 + 4] their exception bits (low 16)
+    uint32_t *wave_sum = xw + kSeg / 16 + 4;                          // [4]
     const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
     const uint64_t len = off[g + 1] - off[g];
     const uint64_t nk = len > sp.k ? len - sp.k : 0;                  // Miekki.cpp:162: the last k-mer is skipped
     const uint64_t seg0 = (uint64_t)wg * kSeg;
-    for (uint32_t b = tid; b <= 2 * bs.nbins; b += 256) bins[b] = 0;
+    for (uint32_t b = tid; b < pad8; b += 256) ctr[b] = 0;
+    if (tid == 0) ctr[pad8] = lds_address(stage) + kSeg * 4u;         // (the stage's slack behind its last item)
     // (the summary: at most 8 KiB = two 16-byte pieces per thread, both requested before the first is stored -- the workgroup
     // lives ~12 us, a chain of dependent loads at its start would be a third of that)
     const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(summary);
@@ -325,53 +360,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     const uint32_t i0 = tid * kPer;
     item_t it[kPer];
-    uint32_t key[kPer];                                               // byte offset of the bin's counter << 12 | rank in bin; ~0: no item
+    // LDS address of the bin's counter << 14 | 4 x rank in bin.  no_item: the dump slot's address, rank 0 -- it goes where that
+    // slot says, behind the stage's last item (no test per item below; there is one such k-mer in 2^(24 - f), and a sequence's tail)
+    uint32_t key[kPer];
+    const uint32_t ctr_a = lds_address(ctr), sum32_a = lds_address(sum32), stage_a = lds_address(stage);
+    const uint32_t no_item = (ctr_a + pad8 * 4u) << 14;
 #pragma unroll
-    for (uint32_t u = 0; u < kPer; ++u) key[u] = ~0u;
+    for (uint32_t u = 0; u < kPer; ++u) key[u] = no_item;
     if (i0 < cnt) {
         const uint32_t w0 = cw[tid], w1 = cw[tid + 1], w2 = cw[tid + 2];
         const uint32_t x01 = has_x ? xw[tid] | (xw[tid + 1] << 16) : 0u, x2 = has_x ? xw[tid + 2] : 0u;
-        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, sum32, it, key, sp, bs);
-        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, bins, sum32, it, key, sp, bs);
+        if (cnt == kSeg) hash16<W, KBIG, true>(w0, w1, w2, has_x, x01, x2, i0, cnt, ctr_a, sum32_a, it, key, sp, bs);
+        else             hash16<W, KBIG, false>(w0, w1, w2, has_x, x01, x2, i0, cnt, ctr_a, sum32_a, it, key, sp, bs);
     }
     __syncthreads();
-    // ---- where each run starts among the workgroup's sorted items: exclusive prefix of the counts (a thread: four bins)
+    // ---- where each run starts among the workgroup's sorted items: exclusive prefix of the counts.  A thread: eight
+    // counters = four bins, two 16-byte reads; only the waves that have counters take part (-h 20: 512 counters, one wave
+    // of the four -- the scan's six steps are then paid once per workgroup); the prefix within a wave by DPP moves.
     uint32_t c8[8], start4[4];
-    {
-        uint32_t sum = 0;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const bool scanning = wave * 512u < nctr;                         // (wave-uniform)
+    uint32_t sum = 0, incl = 0;
 #pragma unroll
-        for (uint32_t e = 0; e < 8; ++e) {
-            const uint32_t b = tid * 8 + e;
-            c8[e] = b < 2 * bs.nbins ? bins[b] : 0u;
-            sum += c8[e];
+    for (uint32_t e = 0; e < 8; ++e) c8[e] = 0;
+    if (scanning) {
+        if (tid * 8 < pad8) {
+            const uint4 a = reinterpret_cast<const uint4 *>(ctr)[2 * tid], b = reinterpret_cast<const uint4 *>(ctr)[2 * tid + 1];
+            c8[0] = a.x; c8[1] = a.y; c8[2] = a.z; c8[3] = a.w; c8[4] = b.x; c8[5] = b.y; c8[6] = b.z; c8[7] = b.w;
         }
-        uint32_t incl = sum;
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-        for (uint32_t o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();                                              // (every count has been read: the starts may overwrite them)
-        uint32_t base = incl - sum;
+        sum = ((c8[0] + c8[1]) + (c8[2] + c8[3])) + ((c8[4] + c8[5]) + (c8[6] + c8[7]));
+        incl = wave_prefix_sum(sum);
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();                                                  // (every count has been read: the starts may overwrite them)
+    if (scanning) {
+        uint32_t base = stage_a + incl - sum;
         for (uint32_t w = 0; w < wave; ++w) base += wave_sum[w];
+        uint32_t s8[8];
 #pragma unroll
         for (uint32_t e = 0; e < 8; ++e) {
-            const uint32_t b = tid * 8 + e;
+            s8[e] = base;
             if (!(e & 1u)) start4[e >> 1] = base;
-            if (b < 2 * bs.nbins) bins[b] = base;
             base += c8[e];
         }
+        if (tid * 8 < pad8) {
+            reinterpret_cast<uint4 *>(ctr)[2 * tid] = make_uint4(s8[0], s8[1], s8[2], s8[3]);
+            reinterpret_cast<uint4 *>(ctr)[2 * tid + 1] = make_uint4(s8[4], s8[5], s8[6], s8[7]);
+        }
     }
     __syncthreads();
-    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    const uint32_t total = (wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3]) >> 2;
+    // (all sixteen starts asked for before the first item is stored: a read behind a write would wait for it)
 #pragma unroll
-    for (uint32_t u = 0; u < kPer; ++u)
-        if (key[u] != ~0u) {
-            const uint32_t at = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(bins) + (key[u] >> 12)) + (key[u] & 4095u);
-            stage[at] = it[u];
-            if (W == 2) stage_low[at] = (uint8_t)(i0 + u);
-        }
+    for (uint32_t u = 0; u < kPer; ++u) key[u] = *lds_word(key[u] >> 14) + (key[u] & 0x3FFCu);
+    const uint32_t low_bias = lds_address(stage_low) - (stage_a >> 2);    // (W == 2: item at stage_a + 4 i <-> byte at stage_low + i)
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        *lds_word(key[u]) = it[u];
+        if (W == 2) *(lds_u8 *)(uintptr_t)((key[u] >> 2) + low_bias) = (uint8_t)(i0 + u);
+    }
     __syncthreads();
     // ---- out: the sorted items as they lie, 16 bytes per lane (a pure stream), and one word per bin
     const uint64_t seg = (uint64_t)g * bs.nwg + wg;
@@ -383,11 +430,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const uint4 *__restrict__ sl = reinterpret_cast<const uint4 *>(stage_low);
         for (uint32_t i = tid; i * 16 < total; i += 256) dl[i] = sl[i];
     }
-    uint32_t *__restrict__ m = meta + seg * bs.nbins;
+    if (tid * 4 < bs.nbins) {                                         // (a thread's eight counters are four bins)
+        uint32_t *__restrict__ m = meta + seg * bs.nbins + tid * 4;
+        uint32_t w4[4];
 #pragma unroll
-    for (uint32_t e = 0; e < 4; ++e) {
-        const uint32_t b = tid * 4 + e, flagged = c8[2 * e], length = flagged + c8[2 * e + 1];      // length <= 4096
-        if (b < bs.nbins) m[b] = ((start4[e] & (kSeg - 1u)) << 20) | (length << 7) | min(flagged, kAllFlagged);
+        for (uint32_t e = 0; e < 4; ++e)                              // run start << 20 | run length << 7 | flagged, from byte counts; length <= 4096
+            w4[e] = (((start4[e] - stage_a) & (4u * kSeg - 4u)) << 18) | ((c8[2 * e] + c8[2 * e + 1]) << 5) | min(c8[2 * e] >> 2, kAllFlagged);
+        if (bs.nbins >= 4) *reinterpret_cast<uint4 *>(m) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        else {
+            m[0] = w4[0];
+            if (bs.nbins > 1) m[1] = w4[1];
+        }
     }
 }
 
@@ -874,7 +927,8 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     const SketchParams sp = make_sp(c);
     MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
     const size_t stage_bytes = (kSeg + 4) * 4 + (c->W == 2 ? kSeg + 16 : 0);
-    size_t lds = stage_bytes + (((size_t)2 * bs.nbins + 1 + 3) & ~(size_t)3) * 4 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
+    // positions and wave sums, stage, counters, dump slot, summary
+    size_t lds = (2 * (kSeg / 16 + 4) + 4) * 4 + stage_bytes + (((size_t)2 * bs.nbins + 7) & ~(size_t)7) * 4 + 16 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, st ? st : c->front_stream, d_codes,     \
                        d_except,                                                                                                \

@@ -583,7 +583,6 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *__restrict__ p, uint6
     return v >> (bit & 7u);
 }
 
-__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x);
 constexpr uint32_t kFindTiles = 16;
 
 __global__ __launch_bounds__(256) void gz_find_kernel(const uint8_t *__restrict__ gz, const mk_gz_stream *__restrict__ streams, const uint64_t *__restrict__ word_first,
@@ -895,19 +894,6 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
         b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
     }
     return p;
-}
-
-// inclusive prefix sum over the wave's 64 lanes by data-parallel-primitive moves (no LDS round trips: __shfl_up is one each)
-__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x)
-{
-    uint32_t v = x;
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1 (rows of 16 lanes)
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
-    return v;
 }
 
 struct ResolveConsts { uint32_t lane_shift[64]; uint32_t block_shift; uint32_t byte_shift; };   // x^(512 (63 - lane)), x^(8 * 4096), x^8

@@ -171,4 +171,19 @@ MK_HD uint64_t strain_word(uint64_t g, uint64_t word, uint32_t strains, uint32_t
     return w;
 }
 
+#if defined(__HIPCC__)
+// inclusive prefix sum over the wave's 64 lanes by data-parallel-primitive moves (no LDS round trips: __shfl_up is one each)
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x)
+{
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1 (rows of 16 lanes)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+#endif
+
 }  // namespace mk

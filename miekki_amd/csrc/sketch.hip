@@ -494,9 +494,15 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
         if (w < nwords) full[w] = bits;
         both = both && bits == 0xffffffffu;
     }
-    // coarse level: one bit per EIGHT summary words = "all 2048 cells taken" -- 4 KiB for the 64 MiB of reachable cells at
+    // coarse level: one bit per EIGHT summary words = "all 2048 cells taken, and the cell after them" -- 4 KiB for the 64 MiB of reachable cells at
     // -b 33, small enough to ride in the LDS of the build's scatter kernel (build.hip), which asks it for every k-mer.
     // Four neighbouring threads hold those eight words; a wave writes its 16 bits.
+    // (... and the first cell of the NEXT 2048: a k-mer whose Bloom positions straddle a carry of the low word lands in its
+    // cell or the one after it, and the scatter kernel does not look which)
+    if ((t & 3u) == 3u) {
+        const uint64_t next = (t + 1) * 512;
+        both = both && next < bloom_dev_bytes && bloom[next] != 0;
+    }
     unsigned long long m = __ballot(both);
     m &= m >> 1; m &= m >> 2;                                                 // bit 4i: threads 4i .. 4i+3 all full
     uint32_t packed = 0;
