@@ -173,6 +173,12 @@ int ensure_build_counters(mk_ctx *c)
     return MK_OK;
 }
 
+uint64_t bloom_regions(const mk_ctx *c)
+{
+    // (+ 2: the region of the last cell, and the one the summary's last thread may name behind it)
+    return ((c->bloom_dev_bytes >> kBloomRegionLog2) + 2 + 15) / 16 * 16;
+}
+
 // bytes of the coarse summary level: one bit per 2048 cells, written 16 bits per wave of bloom_summary_kernel
 uint64_t bloom_summary_bytes(const mk_ctx *c)
 {
@@ -235,9 +241,9 @@ int ensure_build_scratch(mk_ctx *c, uint64_t seq_bytes, int buf, bool for_append
     if (for_append && c->d_bloom && !c->d_bloom_order) {
         MK_TRY(dev_alloc(&c->d_bloom_order, c->bloom_dev_bytes));
         MK_HIP(hipMemsetAsync(c->d_bloom_order, 0xFF, c->bloom_dev_bytes * 4, c->stream));
-        const uint64_t regions = (c->bloom_dev_bytes >> kBloomRegionLog2) + 1;
-        MK_TRY(dev_alloc(&c->d_bloom_touched, regions));
-        MK_HIP(hipMemsetAsync(c->d_bloom_touched, 0, regions, c->stream));
+        const uint64_t regions = bloom_regions(c);
+        MK_TRY(dev_alloc(&c->d_bloom_touched, 2 * regions));          // "a key was posted", "swept since the last summary"
+        MK_HIP(hipMemsetAsync(c->d_bloom_touched, 0, 2 * regions, c->stream));
     }
     if (!c->h_sizes) MK_HIP(hipHostMalloc((void **)&c->h_sizes, 2 * sizeof *c->h_sizes, hipHostMallocDefault));
     if (!c->h_img) MK_HIP(hipHostMalloc((void **)&c->h_img, sizeof *c->h_img, hipHostMallocDefault));

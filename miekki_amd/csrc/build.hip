@@ -193,6 +193,10 @@ __device__ __forceinline__ uint32_t fingerprint_of(uint32_t ahi, uint32_t alo, u
     if (__builtin_expect(fingerprint_top32_ok(v, f), 1)) return fingerprint_from_top32(v, f);
     return mantis_halves(ahi & ((1u << (32u - h)) - 1u), alo, h, f, empty);
 }
+// The scatter kernel converts with rounding TOWARD ZERO: the conversion then drops the low bits itself and the mask that made
+// it exact (fingerprint_from_top32) is not needed.  MODE register (hardware register 1), bits 1:0 = rounding of
+// single-precision results, 3 = toward zero; until the wave ends.
+__device__ __forceinline__ void round_toward_zero() { __builtin_amdgcn_s_setreg(1 | (0 << 6) | ((2 - 1) << 11), 3); }
 
 // LDS by ADDRESS (a 32-bit integer) instead of by pointer: the scatter kernel's block is dynamic, so its base is a symbol the
 // compiler adds to every pointer it derives from it, one v_add_u32 per access; an address carried in a register -- in the
@@ -248,10 +252,10 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     const uint32_t sumshift = bs.sum_words ? sp.bloom_log2 - 32u + 3u + 11u : 31u;   // canon's high word -> group of 2048 cells
     const uint32_t wordshift = min(sumshift + 5u, 31u);           // ... -> the summary word of the group (canon < 2^62: >> 31 leaves 0)
     const uint32_t binshift = bshift + bs.low_bits;                // the bin: the partition's bits above the low 12
-    // (three loop constants pinned in vector registers: v_bfe_u32 takes one scalar operand, not two, and the compiler would
+    // (four loop constants pinned in vector registers: v_bfe_u32 takes one scalar operand, not two, and the compiler would
     // rather make a constant again with a v_mov_b32 per k-mer than keep it)
-    uint32_t binbits = sp.h - bs.low_bits, partbits = bs.low_bits, four = 4u;
-    asm volatile("" : "+v"(binbits), "+v"(partbits), "+v"(four));
+    uint32_t binbits = sp.h - bs.low_bits, partbits = bs.low_bits, four = 4u, fp_bias = 0x08000000u;
+    asm volatile("" : "+v"(binbits), "+v"(partbits), "+v"(four), "+v"(fp_bias));
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         if (KBIG) {
@@ -283,15 +287,28 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
         const uint32_t settled = __builtin_amdgcn_ubfe(sword, s3, 1u);            // bit s3 & 31 of the word (v_bfe_u32 takes the offset's low five bits)
         const uint64_t anc = revhash64(canon);                                    // Miekki.cpp:167-168
         const uint32_t ahi = (uint32_t)(anc >> 32);
-        const uint32_t fp = fingerprint_of(ahi, (uint32_t)anc, sp.h, sp.f, sp.empty);
-        if (fp == sp.empty || (!FULL && i0 + u >= cnt)) continue;    // (past the segment's end only in a sequence's last workgroup)
+        // The fingerprint where the item wants it, on top (kFpShift = 24 or 16), straight from the float's bits: fp =
+        // (bits >> (23 - f)) - (127 << f) (mk_device.hpp) and f = 3 or 11 with the width, so fp << kFpShift is bits << 4 minus
+        // 127 << 27, i.e. plus 1 << 27 mod 2^32, with mantissa bits that do not belong to it below kFpShift (the v_bfi_b32
+        // below drops them).  The empty fingerprint is all ones.
+        constexpr uint32_t kFpShift = W == 1 ? 24 : 16, kFpMask = ~0u << kFpShift;
+        const uint32_t v = __builtin_amdgcn_alignbit(ahi, (uint32_t)anc, 32u - sp.h);
+        uint32_t fptop;
+        if (__builtin_expect(fingerprint_top32_ok(v, sp.f), 1)) fptop = (__float_as_uint((float)v) << 4) + fp_bias;   // (rounding toward zero: see the kernel)
+        else fptop = mantis_halves(ahi & ((1u << (32u - sp.h)) - 1u), (uint32_t)anc, sp.h, sp.f, sp.empty) << kFpShift;
+        if (fptop >= kFpMask || (!FULL && i0 + u >= cnt)) continue;  // (past the segment's end only in a sequence's last workgroup)
         const uint32_t part = __builtin_amdgcn_ubfe(ahi, bshift, partbits);
         // the address of the bin's counter: flagged, settled (a field of no bits is 0: -h 12 and below have one bin).  The
         // counters count BYTES of items (4 per item): what comes back is the item's place in its run as the stage wants it
         const uint32_t caddr = (ctr_a + (__builtin_amdgcn_ubfe(ahi, binshift, binbits) << 3)) | (settled << 2);
         const uint32_t rank4 = __hip_atomic_fetch_add(lds_word(caddr), four, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // (W == 2: the low eight position bits are (i0 + u) & 255, known to whoever stores the item: they are not kept here)
-        it[u] = W == 1 ? (fp << 24) | (part << kBin) | (i0 + u) : (fp << 16) | (part << 4) | ((i0 + u) >> 8);
+        const uint32_t below = W == 1 ? (part << kBin) | (i0 + u) : (part << 4) | ((i0 + u) >> 8);
+        {
+            uint32_t word;                                           // (fptop & kFpMask) | (below & ~kFpMask), which the compiler would make of three
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(word) : "s"(kFpMask), "v"(fptop), "v"(below));
+            it[u] = word;
+        }
         key[u] = (caddr << 14) | rank4;                              // rank < 4096 (among the bin's flagged / settled items); addresses < 2^18
     }
 }
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t *__restrict__ meta, const uint32_t *summary, SketchParams sp, BuildShape bs)
 {
     using item_t = typename ItemOf<W>::type;
+    round_toward_zero();                                              // (the one conversion of this kernel: the fingerprint in hash16)
     constexpr uint32_t kIPV = 4;                                      // items per 16-byte store of the main array
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (everything in the one dynamic block: with no static arrays before it the block starts at LDS address 0 and the offsets

@@ -43,7 +43,7 @@ constexpr uint32_t kTileBytes = 1024;    // bytes of one matrix row a wave scans
 constexpr uint64_t kEmptyKey = ~0ULL;
 constexpr int kPosBits = 40;                      // a minimum key in a table: fingerprint << 40 | position
 constexpr int kCopyStreams = 2;                   // copy streams of a packed append (see mk_ctx::copy_extra; three: 30.9k sketches/s, four: 37.8k, two: 39.0k)
-constexpr uint32_t kBloomRegionLog2 = 16;          // cells per region of the Bloom sweep (bloom_sweep_kernel)
+constexpr uint32_t kBloomRegionLog2 = 12;          // cells per region of the Bloom sweep (bloom_sweep_kernel): one pass of a workgroup
 
 // packed query-sketch entry: partition in the low word, fingerprint in the high word
 __host__ __device__ inline uint64_t make_entry(uint32_t p, uint32_t fp) { return (uint64_t)p | ((uint64_t)fp << 32); }
@@ -240,7 +240,8 @@ struct mk_ctx {
     uint64_t res_cap;
     uint64_t *d_long_table;        // P keys, long-query path
     uint8_t *d_fpT;                // build: fingerprints of the batch, genome-major [build_batch][P] (fused build kernel)
-    uint8_t *d_bloom_touched;      // build: per region of 2^kBloomRegionLog2 cells "a first-writer key was posted here" (allocated with d_bloom_order)
+    uint8_t *d_bloom_touched;      // build: per region of 2^kBloomRegionLog2 cells "a first-writer key was posted here" (allocated with d_bloom_order),
+                                   // and behind those flags (bloom_regions(c) of them) "swept since the last summary": what bloom_summary_kernel redoes
     uint64_t *d_ovf;               // (genome << 32 | bucket, item) pairs that missed their slot
     uint32_t *d_ovf_count;
     // stats
@@ -381,7 +382,8 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort);
-int launch_bloom_summary(mk_ctx *c);
+int launch_bloom_summary(mk_ctx *c, bool after_sweep = false);   // after_sweep: only the regions the sweep has just changed, when the rest is current
+uint64_t bloom_regions(const mk_ctx *c);                          // flags per array of d_bloom_touched
 int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0);     // matrix rows, Bloom pass B, summary (after a fused reduce kernel)
 // ---- build.hip: the index build from packed sequences (2-bit codes + exception bits)
 // (these four run on c->front_stream, on side b's arrays; launch_unpack on c->stream)

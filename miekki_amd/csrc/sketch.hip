@@ -277,7 +277,7 @@ int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0)
                            mat_ref(c), c->ld, c->d_ovf_count, sp);
     if (c->d_bloom) {
         MK_TRY(launch_bloom_sweep(c));                               // the cells that took a key get their byte
-        MK_TRY(launch_bloom_summary(c));
+        MK_TRY(launch_bloom_summary(c, true));
     }
     MK_HIP(hipGetLastError());
     return MK_OK;
@@ -416,16 +416,21 @@ __global__ __launch_bounds__(256) void bloom_post_kernel(const uint64_t *__restr
     }
 }
 
-// One workgroup per region of 2^kBloomRegionLog2 cells; regions nobody posted to cost one byte read.
+// One workgroup per region of 2^kBloomRegionLog2 cells; a region nobody posted to costs one byte read, one that took a key
+// is ONE pass of its workgroup, sixteen cells per thread in four independent steps.  (Round 5 had regions of 2^16 cells: once
+// the filter has filled up the regions that still take keys -- the top twentieth of the range, where canonical k-mers are
+// rare -- were 64 dependent steps of one workgroup each, 40 us per batch on fifty CUs with the rest idle.)
+// A swept region is noted for the summary (`swept`), which then redoes those regions only.
 __global__ __launch_bounds__(256) void bloom_sweep_kernel(const uint32_t *__restrict__ order, uint8_t *__restrict__ bloom,
-                                                          uint8_t *__restrict__ touched, uint64_t bloom_dev_bytes)
+                                                          uint8_t *__restrict__ touched, uint8_t *__restrict__ swept, uint64_t bloom_dev_bytes)
 {
     const uint32_t r = blockIdx.x;
     if (!touched[r]) return;                                // (uniform over the workgroup)
     __syncthreads();
-    if (threadIdx.x == 0) touched[r] = 0;
+    if (threadIdx.x == 0) { touched[r] = 0; swept[r] = 1; }
     const uint64_t base = (uint64_t)r << kBloomRegionLog2;
     constexpr uint32_t kCells = 1u << kBloomRegionLog2;
+#pragma unroll
     for (uint32_t i = threadIdx.x * 4u; i < kCells; i += 256u * 4u) {
         const uint64_t cell = base + i;
         if (cell + 4 <= bloom_dev_bytes) {
@@ -447,21 +452,26 @@ __global__ __launch_bounds__(256) void bloom_sweep_kernel(const uint32_t *__rest
 static int launch_bloom_sweep(mk_ctx *c)
 {
     if (!c->d_bloom || !c->d_bloom_order) return MK_OK;
-    const uint32_t regions = (uint32_t)((c->bloom_dev_bytes >> kBloomRegionLog2) + 1);
-    hipLaunchKernelGGL(bloom_sweep_kernel, dim3(regions), dim3(256), 0, c->stream, c->d_bloom_order, c->d_bloom, c->d_bloom_touched,
-                       c->bloom_dev_bytes);
+    const uint64_t regions = bloom_regions(c);
+    hipLaunchKernelGGL(bloom_sweep_kernel, dim3((uint32_t)((c->bloom_dev_bytes >> kBloomRegionLog2) + 1)), dim3(256), 0, c->stream, c->d_bloom_order,
+                       c->d_bloom, c->d_bloom_touched, c->d_bloom_touched + regions, c->bloom_dev_bytes);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
 
 // full[grp] = all eight cells of group grp are non-zero.  Cells never go back to zero, so a
 // summary taken before a batch stays true during it; it is refreshed after every pass B.
+// `swept` (or null: everything): the regions of 2^kBloomRegionLog2 cells that changed since the summary was last made
+// (bloom_sweep_kernel); a thread whose cells lie in another region keeps its two words as they are.
 __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
                                                             uint32_t *__restrict__ full, uint64_t nwords,
-                                                            uint16_t *__restrict__ full2, uint64_t n16)
+                                                            uint16_t *__restrict__ full2, uint64_t n16, uint8_t *__restrict__ swept)
 {
     // a thread makes TWO summary words (each = 32 groups = 256 cells): words 2t and 2t + 1
+    static_assert(kBloomRegionLog2 >= 11, "the four threads of a coarse bit share a region");
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t region = (t * 512) >> kBloomRegionLog2;
+    const bool redo = !swept || (2 * t < nwords && swept[region] != 0);
     bool both = true;
     for (uint32_t half = 0; half < 2; ++half) {
         const uint64_t w = 2 * t + half;
@@ -469,6 +479,8 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
         const uint64_t base = w * 256;
         if (w >= nwords) {
             bits = 0;
+        } else if (!redo) {
+            bits = full[w];
         } else if (base + 256 <= bloom_dev_bytes) {
             const uint4 *__restrict__ p = reinterpret_cast<const uint4 *>(bloom + base);
 #pragma unroll 4
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
                 bits |= (all ? 1u : 0u) << gI;
             }
         }
-        if (w < nwords) full[w] = bits;
+        if (w < nwords && redo) full[w] = bits;
         both = both && bits == 0xffffffffu;
     }
     // coarse level: one bit per EIGHT summary words = "all 2048 cells taken, and the cell after them" -- 4 KiB for the 64 MiB of reachable cells at
@@ -509,15 +521,28 @@ __global__ __launch_bounds__(256) void bloom_summary_kernel(const uint8_t *__res
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i) packed |= (uint32_t)((m >> (4 * i)) & 1ull) << i;
     if ((threadIdx.x & 63u) == 0 && (t >> 6) < n16) full2[t >> 6] = (uint16_t)packed;
+    // (a region's threads are neighbours in one wave: all of them have read the flag by now)
+    if (swept && redo && (t * 512) % (1u << kBloomRegionLog2) == 0) swept[region] = 0;
 }
 
-int launch_bloom_summary(mk_ctx *c)
+int launch_bloom_summary(mk_ctx *c, bool after_sweep)
 {
     if (!c->d_bloom) return MK_OK;
     const uint64_t nwords = (c->bloom_dev_bytes / 8 + 31) / 32 + 1, threads = (nwords + 1) / 2;
+    // after a sweep, with a summary that was current before it: the swept regions only (a young filter: all of them; a filter
+    // that has filled up: the few at the top of the range -- 19 us of reading 64 MiB per batch otherwise)
+    uint8_t *swept = nullptr;
+    if (c->d_bloom_touched) {
+        swept = c->d_bloom_touched + bloom_regions(c);
+        if (!after_sweep || c->bloom_full_stale) {
+            MK_HIP(hipMemsetAsync(swept, 0, bloom_regions(c), c->stream));   // (everything is redone: nothing is pending after it)
+            swept = nullptr;
+        }
+    }
     hipLaunchKernelGGL(bloom_summary_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_bloom,
-                       c->bloom_dev_bytes, c->d_bloom_full, nwords, (uint16_t *)c->d_bloom_full2, bloom_summary_bytes(c) / 2);
+                       c->bloom_dev_bytes, c->d_bloom_full, nwords, (uint16_t *)c->d_bloom_full2, bloom_summary_bytes(c) / 2, swept);
     MK_HIP(hipGetLastError());
+    c->bloom_full_stale = false;
     return MK_OK;
 }
 
@@ -564,7 +589,7 @@ int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const 
                        c->d_bloom, c->bloom_dev_bytes, c->d_bloom_order, c->d_bloom_touched, d_abort, c->d_bloom_full, kOvfCap, make_sp(c));
     MK_HIP(hipGetLastError());
     MK_TRY(launch_bloom_sweep(c));
-    return launch_bloom_summary(c);
+    return launch_bloom_summary(c, true);
 }
 
 __device__ __forceinline__ bool bloom_check(const uint8_t *__restrict__ bloom, uint64_t bloom_dev_bytes,
