@@ -462,6 +462,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
+// ---------------------------------------------------------------- the meta words, bin-major
+// A reduce workgroup wants the words of ONE bin from every scatter workgroup of its genome: in the order the scatter kernel
+// leaves them -- meta[(genome, workgroup)][bin], a workgroup's 16-byte stores -- that is 1,221 loads of four bytes from 1,221
+// lines at the head of every reduce workgroup, 20 M requests per 64 x 5 Mb batch and 0.15 of the reduce kernel's 0.49 ms
+// (measured with the words made up instead of loaded).  Written bin-major by the scatter kernel they were as many four-byte
+// STORES to as many lines and cost what they saved.  This pass turns them once, 64 x 64 words through LDS, rows in and rows
+// out: 160 MB of traffic per batch for metaT[(genome, bin)][workgroup], which the reduce workgroup reads as 39 lines.
+// (pitch: words per row of metaT, nwg rounded up to a multiple of four, so that rows start on 16 bytes.  VEC: nbins is a
+// multiple of four -- 16 bytes per lane both ways; one to three bins, -h 13 and below, take the word-by-word form.)
+template <bool VEC>
+__global__ __launch_bounds__(256) void meta_transpose_kernel(const uint32_t *__restrict__ meta, uint32_t *__restrict__ metaT,
+                                                             uint32_t nwg, uint32_t nbins, uint32_t pitch)
+{
+    __shared__ uint32_t tile[64][65];                                 // [workgroup][bin]; 65: a column is read across 64 banks
+    const uint32_t g = blockIdx.z, w0 = blockIdx.x * 64u, b0 = blockIdx.y * 64u;
+    const uint32_t *__restrict__ src = meta + (uint64_t)g * nwg * nbins;
+    uint32_t *__restrict__ dst = metaT + (uint64_t)g * nbins * pitch;
+    if (VEC) {
+        const uint32_t q = (threadIdx.x & 15u) * 4u, r0 = threadIdx.x >> 4;   // four words of a row; sixteen rows per step
+#pragma unroll
+        for (uint32_t r = r0; r < 64u; r += 16u)
+            if (w0 + r < nwg && b0 + q < nbins) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + (uint64_t)(w0 + r) * nbins + b0 + q);
+                tile[r][q] = v.x; tile[r][q + 1] = v.y; tile[r][q + 2] = v.z; tile[r][q + 3] = v.w;
+            }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = r0; r < 64u; r += 16u)
+            if (b0 + r < nbins && w0 + q < nwg)                       // (the row's last words may lie in its padding: pitch >= nwg rounded up)
+                *reinterpret_cast<uint4 *>(dst + (uint64_t)(b0 + r) * pitch + w0 + q) = make_uint4(tile[q][r], tile[q + 1][r], tile[q + 2][r], tile[q + 3][r]);
+    } else {
+        const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+        for (uint32_t r = ty; r < 64u; r += 4u)
+            if (w0 + r < nwg && b0 + tx < nbins) tile[r][tx] = src[(uint64_t)(w0 + r) * nbins + b0 + tx];
+        __syncthreads();
+        for (uint32_t r = ty; r < 64u; r += 4u)
+            if (b0 + r < nbins && w0 + tx < nwg) dst[(uint64_t)(b0 + r) * pitch + w0 + tx] = tile[tx][r];
+    }
+}
+
 // ---------------------------------------------------------------- reduce + fingerprints + sizes + Bloom pass A
 // One 512-thread workgroup per (genome, bin) -- 38 KiB of LDS, so four of them share a CU: the kernel is a chain of
 // latencies (meta words, then items) and what hides them is other workgroups.  The bin's runs -- one per scatter
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
 #pragma unroll
             for (uint32_t u = 0; u < kMetaPer; ++u) {                 // (all of a thread's words requested before the first is stored)
                 const uint32_t i = threadIdx.x + u * kThreads;
-                mw[u] = meta[((uint64_t)g * bs.nwg + c0 + min(i, cn - 1u)) * bs.nbins + bin];   // (no branch: see the item loads below)
+                mw[u] = meta[((uint64_t)g * bs.nbins + bin) * ((bs.nwg + 3u) & ~3u) + c0 + min(i, cn - 1u)];   // bin-major (meta_transpose_kernel); (no branch: see the item loads below)
             }
             if (!c0) init_shared();                                   // (under the loads' latency)
 #pragma unroll
@@ -809,9 +849,9 @@ static int build_setup(mk_ctx *c, int b, const uint64_t *h_off, uint32_t n, Buil
     while (bs.lpr < 64 && bs.lpr * ipl < reach) bs.lpr <<= 1;
     *key32 = c->W == 1 && max_len < (1ULL << 24);              // (a stored fingerprint is below the all-ones byte: no key equals "none")
     const uint64_t isz = c->W == 1 ? 4 : 5;                          // (W == 2: the main words, then the low position bytes)
-    // the dense item array (kSeg item places per scatter workgroup) and, behind it, one meta word per (workgroup, bin)
+    // the dense item array (kSeg item places per scatter workgroup) and, behind it, one meta word per (workgroup, bin), twice
     const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
-    const uint64_t need = item_bytes + (uint64_t)n * bs.nwg * bs.nbins * 4;
+    const uint64_t need = item_bytes + 2 * (uint64_t)n * (bs.nwg + 3) * bs.nbins * 4;   // (the words as the scatter kernel leaves them, and bin-major)
     if (need > (12ull << 30)) return MK_OK;                          // scratch budget
     mk_ctx::BuildSide &sd = c->side[b];
     if (need > sd.slots_bytes) {
@@ -924,6 +964,10 @@ static uint32_t *meta_of(const mk_ctx *c, const mk_ctx::BuildSide &sd, const Bui
     const uint64_t item_bytes = ((uint64_t)n * bs.nwg * kSeg * isz + 255) / 256 * 256;
     return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(sd.d_slots) + item_bytes);
 }
+static uint32_t *metaT_of(const mk_ctx *c, const mk_ctx::BuildSide &sd, const BuildShape &bs, uint32_t n)
+{
+    return meta_of(c, sd, bs, n) + (uint64_t)n * bs.nwg * bs.nbins;
+}
 // W == 2: the items' low position bytes lie behind the main words
 static uint8_t *low_of(const mk_ctx::BuildSide &sd, const BuildShape &bs, uint32_t n)
 {
@@ -956,6 +1000,12 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     if (c->W == 1) { if (kbig) MK_SCATTER(1, true); else MK_SCATTER(1, false); }
     else           { if (kbig) MK_SCATTER(2, true); else MK_SCATTER(2, false); }
 #undef MK_SCATTER
+    if (bs.nbins % 4 == 0)
+        hipLaunchKernelGGL(meta_transpose_kernel<true>, dim3((bs.nwg + 63) / 64, (bs.nbins + 63) / 64, n), dim3(256), 0, st ? st : c->front_stream,
+                           meta_of(c, sd, bs, n), metaT_of(c, sd, bs, n), bs.nwg, bs.nbins, (bs.nwg + 3u) & ~3u);
+    else
+        hipLaunchKernelGGL(meta_transpose_kernel<false>, dim3((bs.nwg + 63) / 64, (bs.nbins + 63) / 64, n), dim3(256), 0, st ? st : c->front_stream,
+                           meta_of(c, sd, bs, n), metaT_of(c, sd, bs, n), bs.nwg, bs.nbins, (bs.nwg + 3u) & ~3u);
     MK_HIP(hipGetLastError());
     *used = true;
     return MK_OK;
@@ -986,7 +1036,7 @@ int launch_query_tables(mk_ctx *c, const char *d_seq, const uint64_t *d_off, con
     const SketchParams sp = make_sp(c);
 #define MK_QREDUCE(Wv, K32)                                                                                                     \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, st,                                     \
-                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), meta_of(c, sd, bs, n), codes, except,   \
+                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), metaT_of(c, sd, bs, n), codes, except,   \
                        c->d_pk_off[b], sd.d_counters->dirty, (const uint8_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr,         \
                        (const uint32_t *)nullptr, (uint8_t *)nullptr, d_tables, (uint8_t *)nullptr, (uint32_t *)nullptr,        \
                        (unsigned long long *)nullptr, sp, bs)
@@ -1015,7 +1065,7 @@ int launch_build_back(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *d
     // slots beside them: measured and left -- 55.1k against 57.7k sketches/s, the two kernels are better off taking turns)
 #define MK_REDUCE(Wv, K32)                                                                                                      \
     hipLaunchKernelGGL((build_reduce_kernel<Wv, K32>), dim3(bs.nbins, n), dim3(512), 0, c->stream,                              \
-                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), meta_of(c, sd, bs, n), d_codes,         \
+                       reinterpret_cast<const uint32_t *>(sd.d_slots), low_of(sd, bs, n), metaT_of(c, sd, bs, n), d_codes,         \
                        d_except, d_code_off, sd.d_counters->dirty, c->d_bloom, c->bloom_dev_bytes,                             \
                        c->d_bloom_order, c->d_bloom_full, c->d_fpT, c->d_tables, c->d_bloom_touched,                           \
                        sd.d_counters->act, (unsigned long long *)sd.d_counters->card, sp, bs)
