@@ -580,6 +580,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
         for (uint32_t c0 = 0; c0 < nwg; c0 += kMetaChunk) {
             const uint32_t cn = min(kMetaChunk, nwg - c0);
             if (c0) __syncthreads();                                  // the previous chunk's words have been used
+            const item_t *__restrict__ chunk_items = items + ((uint64_t)g * bs.nwg + c0) * kSeg;
+            const uint8_t *__restrict__ chunk_low = low + ((uint64_t)g * bs.nwg + c0) * kSeg;
             uint32_t mw[kMetaPer];
 #pragma unroll
             for (uint32_t u = 0; u < kMetaPer; ++u) {                 // (all of a thread's words requested before the first is stored)
@@ -613,9 +615,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     place(q.m[u], a0, first, end);
                     // (a load may reach up to lpr * kIPL places past the run's start: inside the array, whose last workgroup
                     // is followed by the meta words)
-                    const uint64_t at = ((uint64_t)g * bs.nwg + c0 + min(r, cn - 1u)) * kSeg + a0 + j0;
-                    q.v[u] = *reinterpret_cast<const vec_t *>(items + at);
-                    if (W == 2) q.lo[u] = *reinterpret_cast<const uint32_t *>(low + at);         // (a0 + j0 is a multiple of four)
+                    // (a 32-bit offset from the chunk's first workgroup -- at most 1,280 x 4,096 items -- so that the address is the
+                    // load's scalar base plus one register instead of four 64-bit additions per lane)
+                    const uint32_t at = min(r, cn - 1u) * kSeg + a0 + j0;
+                    q.v[u] = *reinterpret_cast<const vec_t *>(reinterpret_cast<const unsigned char *>(chunk_items) + at * (uint32_t)sizeof(item_t));
+                    if (W == 2) q.lo[u] = *reinterpret_cast<const uint32_t *>(chunk_low + at);   // (a0 + j0 is a multiple of four)
                 }
             };
             auto consume = [&](uint32_t r0, const Stage &q) {
@@ -625,15 +629,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     uint32_t a0, first, end;
                     place(q.m[u], a0, first, end);
                     // the flagged items are the first ones of their run (rare once the filter has filled up: none)
-                    const uint32_t nf = q.m[u] & 127u, fend = nf == kAllFlagged ? end : first + nf;
+                    // (a run without flagged items has 0 here: the wave asks that alone before anything is made of it)
+                    const uint32_t nf = q.m[u] & 127u;
+                    auto flagged_end = [](uint32_t m) { const uint32_t f = m >> 20, n = m & 127u; return n == kAllFlagged ? f + ((m >> 7) & 0x1fffu) : f + n; };
                     // (lob: the item's low position byte, W == 2 only)
                     // The run's flagged items -- the first (fend - first) of it -- get their places in the list from ONE atomic per
                     // run, by the run's first lane (a young filter flags every item, 18,700 per workgroup: one atomic WITH return
                     // each on one LDS word cost 0.15 ms of LDS time per CU and batch; the meta word already says how many there are)
                     // (Once the filter has filled up no run of a wave-load has a flagged item -- the usual case of a large build: the
                     // whole wave then takes the form of the item loop without slots, bounds against `fend` and the list's store.)
-                    const bool noting = __ballot(fend != first) != 0ull;                // wave-uniform
+                    const bool noting = __ballot(nf != 0u) != 0ull;                     // wave-uniform (fend != first)
                     uint32_t nbase = 0;
+                    const uint32_t fend = noting ? flagged_end(q.m[u]) : first;
                     if (noting) {
                         const uint32_t nflag = fend - first;                        // (0 for a lane without a run)
                         if (nflag && lane % lpr == 0) nbase = atomicAdd(&n_noted, nflag);
@@ -685,9 +692,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((W == 1 && 
                     while (tails) {                                                             // (wave-uniform)
                         const uint32_t l = (uint32_t)__ffsll((long long)tails) - 1u;            // first lane of a sub-group with a tail
                         tails &= ~(((lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull))) << l);
-                        const uint32_t t_a0 = (uint32_t)__shfl((int)a0, (int)l), t_end = (uint32_t)__shfl((int)end, (int)l);
-                        const uint32_t t_fend = (uint32_t)__shfl((int)fend, (int)l), t_w = (uint32_t)__shfl((int)w, (int)l);
-                        const uint32_t t_first = (uint32_t)__shfl((int)first, (int)l), t_nbase = (uint32_t)__shfl((int)nbase, (int)l);
+                        // (the run's meta word says where it starts and ends and how many of it are flagged)
+                        const uint32_t t_m = (uint32_t)__shfl((int)q.m[u], (int)l), t_w = (uint32_t)__shfl((int)w, (int)l);
+                        const uint32_t t_nbase = (uint32_t)__shfl((int)nbase, (int)l);
+                        uint32_t t_a0, t_first, t_end;
+                        place(t_m, t_a0, t_first, t_end);
+                        const uint32_t t_fend = flagged_end(t_m);
                         for (uint32_t j = t_a0 + lpr * kIPL + lane * kIPL; j < t_end; j += 64u * kIPL) {
                             const uint64_t at = ((uint64_t)g * bs.nwg + t_w) * kSeg + j;
                             const vec_t x = *reinterpret_cast<const vec_t *>(items + at);
