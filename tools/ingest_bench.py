@@ -2,7 +2,9 @@
 """Steady-state rate of `miekki -l` (host parse + H2D + device build) on many FASTA files.
     python tools/ingest_bench.py [n_genomes] [threads] [distinct] [gz]
 The list names n_genomes files; only `distinct` different ones are written, the rest are
-symlinks to them (the page cache is warm either way; the device work per genome is the same).
+symlinks to them (the page cache is warm either way; the device work per genome is the same while the Bloom filter is
+young -- it stays young for ever when the same 64 genomes come again and again, and fills up within ~2,000 distinct ones:
+`distinct` = n_genomes is the collection a user has).
 gz: the files are gzip members (level 6, what NCBI ships and what the reference's zstr reader inflates on the fly,
 zstr.hpp:78-82): every reader thread then spends its time in zlib's inflate."""
 import gzip, os, re, shlex, subprocess, sys, tempfile, time
@@ -18,17 +20,28 @@ L = 5_000_000
 cli = os.environ.get("MIEKKI_CLI") or os.path.join(ROOT, "miekki_amd", "miekki")
 # MIEKKI_PREFIX: words put before the binary ("rocprofv3 --kernel-trace -d DIR{rep} -o t --": {rep} = the run's number)
 prefix = os.environ.get("MIEKKI_PREFIX", "")
+def write_genome(job):
+    g, fn = job
+    data = synth.fasta(f"genome{g}", synth.genome_bases(g, 0, L))
+    with open(fn, "wb") as f:
+        f.write(gzip.compress(data, 6) if GZ else data)
+
+
 with tempfile.TemporaryDirectory(prefix="mk_ing_", dir="/tmp") as d:
     t0 = time.time()
+    ext = ".fa.gz" if GZ else ".fa"
+    jobs = [(g, os.path.join(d, f"g{g}{ext}")) for g in range(min(D, G))]
+    if len(jobs) > 128:                                 # (many distinct genomes: a collection whose Bloom filter fills up, as a real one's does)
+        import multiprocessing
+        with multiprocessing.Pool(min(16, os.cpu_count() or 1)) as pool:
+            pool.map(write_genome, jobs, chunksize=8)
+    else:
+        for j in jobs:
+            write_genome(j)
     with open(os.path.join(d, "genomes.lst"), "w") as lst:
         for g in range(G):
-            ext = ".fa.gz" if GZ else ".fa"
             fn = os.path.join(d, f"g{g}{ext}")
-            if g < D:
-                data = synth.fasta(f"genome{g}", synth.genome_bases(g, 0, L))
-                with open(fn, "wb") as f:
-                    f.write(gzip.compress(data, 6) if GZ else data)
-            else:
+            if g >= D:
                 os.symlink(os.path.join(d, f"g{g % D}{ext}"), fn)
             lst.write(fn + "\n")
     with open(os.path.join(d, "q.fa"), "wb") as f:
