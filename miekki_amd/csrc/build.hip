@@ -329,23 +329,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     round_toward_zero();                                              // (the one conversion of this kernel: the fingerprint in hash16)
     constexpr uint32_t kIPV = 4;                                      // items per 16-byte store of the main array
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // (everything in the one dynamic block: with no static arrays before it the block starts at LDS address 0 and the offsets
-    // below are the instructions' own offset fields)
-    constexpr uint32_t kLead = (2 * (kSeg / 16 + 4) + 4) * 4;         // cw, xw, wave_sum: 2,096 bytes
-    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + kLead);     // kSeg + kIPV: the workgroup's items (main words), sorted by bin
-    uint8_t *stage_low = smem + kLead + (kSeg + kIPV) * 4;            // W == 2: their low position bytes, kSeg + 16
+    // (the positions' words, cw and xw below, and the Bloom summary lie IN the stage: the hash loop is the last to read them,
+    // two barriers before the first item is stored there -- 6 KiB that make the difference between six and eight workgroups
+    // per CU, five and seven at 2-byte fingerprints: the kernel runs 557 us at four, 507 at five, 480 at six, 460 at seven)
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem);             // kSeg + kIPV: the workgroup's items (main words), sorted by bin
+    uint8_t *stage_low = smem + (kSeg + kIPV) * 4;                    // W == 2: their low position bytes, kSeg + 16
     constexpr uint32_t kStageBytes = (kSeg + kIPV) * 4 + (W == 2 ? kSeg + 16 : 0);
     // 2 * nbins counters (per bin: flagged items, then settled ones; padded with zeros to a multiple of eight), later the
     // places where their runs start -- as LDS addresses in the stage -- and behind them one word that no k-mer counts in (the "dump
     // slot": where the items that do not exist go, below).
     const uint32_t nctr = 2 * bs.nbins, pad8 = (nctr + 7u) & ~7u;
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(smem + kLead + kStageBytes);   // (16-byte aligned)
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(smem + kStageBytes);   // (16-byte aligned)
     // the Bloom summary (one bit per 2048 cells: all taken), when there is one: 4 KiB at -b 33 -- as a snapshot of whatever
     // the array holds right now (the summary kernel of the batch before may be writing it: bits only ever get set)
-    uint32_t *sum32 = ctr + pad8 + 4;                                 // (at least one word)
-    uint32_t *cw = reinterpret_cast<uint32_t *>(smem);                // [kSeg / 16 + 4] the workgroup's positions, 16 per word
+    uint32_t *wave_sum = ctr + pad8 + 4;                              // [4] (behind the dump slot's 16 bytes)
+    constexpr uint32_t kWordsBytes = 2 * (kSeg / 16 + 4) * 4;         // cw, xw: 2,080 bytes
+    uint32_t *sum32 = reinterpret_cast<uint32_t *>(smem + ((kWordsBytes + 15u) & ~15u));   // (at least one word; at most 8 KiB: build_setup)
+    static_assert(((kWordsBytes + 15u) & ~15u) + 8192 <= kSeg * 4, "the positions' words and the summary fit in the stage");
+    uint32_t *cw = reinterpret_cast<uint32_t *>(smem);                // [kSeg / 16 + 4] the workgroup's positions, 16 per word (see above)
     uint32_t *xw = cw + kSeg / 16 + 4;                                // [kSeg / 16 + 4] their exception bits (low 16)
-    uint32_t *wave_sum = xw + kSeg / 16 + 4;                          // [4]
     const uint32_t g = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x;
     const uint64_t len = off[g + 1] - off[g];
     const uint64_t nk = len > sp.k ? len - sp.k : 0;                  // Miekki.cpp:162: the last k-mer is skipped
@@ -999,8 +1001,8 @@ int launch_build_front(mk_ctx *c, int b, const uint8_t *d_codes, const uint8_t *
     const SketchParams sp = make_sp(c);
     MK_TRY(ensure_bloom_summary_arrays(c));                       // (all zero until the first summary: everything flagged)
     const size_t stage_bytes = (kSeg + 4) * 4 + (c->W == 2 ? kSeg + 16 : 0);
-    // positions and wave sums, stage, counters, dump slot, summary
-    size_t lds = (2 * (kSeg / 16 + 4) + 4) * 4 + stage_bytes + (((size_t)2 * bs.nbins + 7) & ~(size_t)7) * 4 + 16 + std::max<size_t>(((size_t)bs.sum_words + 1) / 2 * 16, 16);
+    // stage (the positions' words and the Bloom summary in it), counters, dump slot, wave sums
+    size_t lds = stage_bytes + (((size_t)2 * bs.nbins + 7) & ~(size_t)7) * 4 + 32;
 #define MK_SCATTER(Wv, KB)                                                                                                      \
     hipLaunchKernelGGL((build_scatter_kernel<Wv, KB>), dim3(bs.nwg, n), dim3(256), lds, st ? st : c->front_stream, d_codes,     \
                        d_except,                                                                                                \
