@@ -128,8 +128,8 @@ def run_ranked(args, cwd, extra_env=None):
     return r.stdout                                              # (RCCL's version banner goes to stderr: mk_comm_create)
 
 
-# (rnd1 and rnd4 too until round 6: 11 s each, mostly RCCL starting up eight times; the multi-rank driver tests below keep both)
-@pytest.mark.parametrize("name", ["messy", "h20", "w16"])
+# (rnd1, rnd4 and h20 too until round 6: 11 s each, mostly RCCL starting up; the multi-rank driver tests below keep them)
+@pytest.mark.parametrize("name", ["messy", "w16"])
 def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name):
     """`miekki` with a communicator (RCCL called from the C++ host through the C ABI): -l with -a, -A, -e and -A -e must
     give the reference's files and banners."""
@@ -174,7 +174,7 @@ def test_one_process_per_gpu_form_like_the_reference(workdirs, golden_dir, name)
     assert (d / "out_ri2.txt").read_bytes() == (d / "out_ri.txt").read_bytes()
 
 
-@pytest.mark.parametrize("name,world", [("messy", 3), ("w16", 2), ("rnd1", 5), ("h20", 13)])
+@pytest.mark.parametrize("name,world", [("messy", 3), ("w16", 2), ("h20", 13)])
 def test_an_index_loads_in_slices_as_the_ranks_take_it(workdirs, golden_dir, tmp_path_factory, name, world):
     """-i with one process per GPU at a world of MORE than one, without the communicator (two ranks cannot share a GPU under
     RCCL): load_index(slice_rank, slice_world) for every rank of the world -- ranks beyond the genomes keep none -- and the
