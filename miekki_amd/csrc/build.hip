@@ -6,16 +6,18 @@
 // insert_sequences (Miekki.cpp:287-311) for whole batches of genomes:
 //   pack_kernel        characters -> codes + exception bits + "has exceptions" flag    (A1)
 //   seed_fix_kernel    the k-1 seed digits as str2numstrand / rcb make them            (A2)
-//   build_scatter_kernel   rolling k-mers, revhash64, partition + fingerprint; the items
-//                      (fingerprint, partition, position) of a workgroup's 4096 k-mers sorted
-//                      by BIN (the partition's high bits) in LDS and written as they lie --
-//                      a dense array plus one meta word per (workgroup, bin); k-mers whose
-//                      Bloom cell may still be empty are flagged and lead their run      (A3-A6, A9)
+//   build_scatter_kernel   the k-mers (windows of the packed digits), revhash64, partition +
+//                      fingerprint; the items (fingerprint, partition, position) of a
+//                      workgroup's 4096 k-mers sorted by BIN (the partition's high bits) in LDS
+//                      and written as they lie -- a dense array plus one meta word per
+//                      (workgroup, bin); k-mers whose Bloom cell may still be empty are flagged
+//                      and lead their run                                                (A3-A6, A9)
+//   meta_transpose_kernel  the meta words bin-major, as the reduce workgroups read them
 //   build_reduce_kernel    one workgroup per (genome, bin): per-partition minimum of
 //                      (fingerprint, position) in LDS, then for the winners: fingerprint
 //                      bytes, sketch_size / cardinality sums, Bloom pass A for the
 //                      flagged ones                                                     (A4, A7, A9)
-// followed by fp_transpose_kernel, bloom_kernel<true> and bloom_summary_kernel (sketch.hip).
+// followed by fp_transpose_kernel, bloom_sweep_kernel and bloom_summary_kernel (sketch.hip).
 // Runs of long queries take the same kernels (launch_query_tables): no flags, the reduce kernel leaves the keys in a table.
 //
 // Selection rule: in every partition the k-mer with the smallest
@@ -313,12 +315,14 @@ __device__ __forceinline__ void hash16(uint32_t w0, uint32_t w1, uint32_t w2, bo
     }
 }
 
-// What bounds this kernel is instruction issue (round 2: ~122 vector instructions per k-mer in its
-// predecessor, most of them around the hash loop, not in it; 77 here, PMC, at 3.6 cycles each).
+// What bounds this kernel is instruction issue and, behind it, the LDS round trips of its four random LDS accesses per
+// k-mer (round 2: ~122 vector instructions per k-mer in its predecessor, round 5: 73.5, most of the difference around the
+// hash loop, not in it; 51.6 here, PMC, at 4.4 cycles each -- profiles/r6_pmc_build_sq.txt).
 // So: the positions arrive packed -- a thread's 16 + k-1 digits are three LDS words, no
 // classification, no squeezing; the items of the whole workgroup are sorted by (bin, flagged |
-// settled) through ONE 4096-entry stage (4-byte items: 16 KiB; with the Bloom summary six
-// workgroups per CU) and leave as they lie, 16 bytes per lane -- no per-item address arithmetic.
+// settled) through ONE 4096-entry stage (4-byte items: 16 KiB, which also lends its first 6 KiB to the positions' words
+// and the Bloom summary while nothing is staged yet: eight workgroups per CU, and the waves are what hides the LDS) and
+// leave as they lie, 16 bytes per lane -- no per-item address arithmetic.
 template <int W, bool KBIG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void build_scatter_kernel(
     const uint8_t *__restrict__ codes, const uint8_t *__restrict__ except, const uint64_t *__restrict__ code_off,
