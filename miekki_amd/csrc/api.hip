@@ -11,6 +11,8 @@
 #include <memory>
 #include <mutex>
 
+#include <sys/mman.h>
+
 #include "mk_internal.hpp"
 
 namespace mk {
@@ -171,6 +173,47 @@ int ensure_build_counters(mk_ctx *c)
     MK_TRY(ensure_build_side(c, 0));
     use_build_side(c, 0);
     return MK_OK;
+}
+
+namespace {
+std::mutex g_pinned_m;
+std::vector<std::pair<void *, uint64_t>> g_registered;              // what pinned_alloc registered itself (pointer, bytes)
+}
+void *pinned_alloc(uint64_t bytes)
+{
+    constexpr uint64_t kHuge = 2ull << 20;
+    void *p = nullptr;
+    if (bytes >= kHuge) {
+        const uint64_t size = (bytes + kHuge - 1) / kHuge * kHuge;
+        if (posix_memalign(&p, kHuge, size) == 0 && p) {
+            (void)madvise(p, size, MADV_HUGEPAGE);                    // (advice: ordinary pages do as well, more slowly)
+            if (hipHostRegister(p, size, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_pinned_m);
+                g_registered.emplace_back(p, size);
+                return p;
+            }
+            (void)hipGetLastError();
+            free(p);
+            p = nullptr;
+        }
+    }
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pinned_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_m);
+        for (size_t i = 0; i < g_registered.size(); ++i)
+            if (g_registered[i].first == p) {
+                g_registered.erase(g_registered.begin() + (long)i);
+                (void)hipHostUnregister(p);
+                free(p);
+                return;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 uint64_t bloom_regions(const mk_ctx *c)
@@ -796,7 +839,8 @@ int mk_host_alloc(mk_ctx *c, uint64_t bytes, void **out)
     if (!c || !out) { set_error("null argument"); return MK_ERR_ARG; }
     *out = nullptr;
     MK_TRY(use_device(c, false));
-    MK_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    *out = pinned_alloc(bytes ? bytes : 1);
+    if (!*out) { set_error("no page-locked host memory for %llu bytes", (unsigned long long)bytes); return MK_ERR_NOMEM; }
     return MK_OK;
 }
 
@@ -804,7 +848,7 @@ void mk_host_free(mk_ctx *c, void *p)
 {
     if (!c || !p) return;
     (void)hipSetDevice(c->p.device);
-    (void)hipHostFree(p);
+    pinned_free(p);
 }
 
 static int append_synthetic(mk_ctx *c, uint64_t first_id, uint32_t n, uint64_t length, uint32_t strains, uint32_t rate_ppm);

@@ -1488,10 +1488,10 @@ static void *gz_stage_get(mk_ctx *c)
         else return nullptr;                                          // (every piece is in some caller's hands)
     }
     if (!got.p) {
-        if (hipHostMalloc(&got.p, kStagePiece, hipHostMallocDefault) != hipSuccess ||
+        if (!(got.p = pinned_alloc(kStagePiece)) ||
             hipEventCreateWithFlags(&got.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
-            if (got.p) (void)hipHostFree(got.p);
+            if (got.p) pinned_free(got.p);
             std::lock_guard<std::mutex> g(c->gz_m);
             --c->gz_stage_made;
             return nullptr;
@@ -1864,7 +1864,7 @@ void gz_release_staging(mk_ctx *c)
     for (hipStream_t &u : c->gz_up) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); u = nullptr; }
     for (auto &pc : c->gz_stage_busy) c->gz_stage_free.push_back(pc);
     c->gz_stage_busy.clear();
-    for (auto &pc : c->gz_stage_free) { (void)hipHostFree(pc.p); (void)hipEventDestroy(pc.ev); --c->gz_stage_made; }
+    for (auto &pc : c->gz_stage_free) { pinned_free(pc.p); (void)hipEventDestroy(pc.ev); --c->gz_stage_made; }
     c->gz_stage_free.clear();
 }
 

@@ -382,6 +382,12 @@ int launch_genome_sketch(mk_ctx *c, const char *d_seq, const uint64_t *d_off, co
 int launch_finalize(mk_ctx *c, const uint64_t *d_tables, uint32_t n, uint32_t g0, const uint32_t *d_abort);
 int launch_bloom_insert(mk_ctx *c, uint64_t *d_tables, const char *d_seq, const uint64_t *d_off,
                         const uint32_t *d_valid, uint32_t n, const uint32_t *d_abort);
+// Page-locked host memory for the ingest's buffers (api.hip): ordinary memory in transparent huge pages, registered with the
+// runtime -- a 16 MiB piece is 8 pages to pin instead of 4,096, and the page faults are the calling thread's own, where sixteen
+// reader threads asking hipHostMalloc for their first pieces stood in one queue for 70 ms (profiles/r6_cli_startup.txt).
+// hipHostMalloc when that does not work.  pinned_free takes either kind.
+void *pinned_alloc(uint64_t bytes);
+void pinned_free(void *p);
 int launch_bloom_summary(mk_ctx *c, bool after_sweep = false);   // after_sweep: only the regions the sweep has just changed, when the rest is current
 uint64_t bloom_regions(const mk_ctx *c);                          // flags per array of d_bloom_touched
 int launch_build_tail(mk_ctx *c, uint32_t n, uint32_t g0);     // matrix rows, Bloom pass B, summary (after a fused reduce kernel)
