@@ -1181,7 +1181,7 @@ int main(int argc, char **argv)
     // One process, its work done and written: leave.  Taking the contexts apart first -- dozens of page-locked pieces, the device's
     // blocks, the streams, one runtime call each -- is 60-80 ms of a run that may be 300 (profiles/r6_cli_startup.txt), for memory
     // the driver takes back anyway when the process ends.  Ranks leave in order: their communicator is shared.
-    if (!rank_mode && !getenv("MIEKKI_ORDERLY_EXIT")) {
+    if (!rank_mode) {
         cout.flush();
         exit(0);                                             // (not _exit: a profiler's exit handlers write its files)
     }
