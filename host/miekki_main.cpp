@@ -1182,6 +1182,7 @@ int main(int argc, char **argv)
     // blocks, the streams, one runtime call each -- is 60-80 ms of a run that may be 300 (profiles/r6_cli_startup.txt), for memory
     // the driver takes back anyway when the process ends.  Ranks leave in order: their communicator is shared.
     if (!rank_mode) {
+        for (mk_ctx *ctx : drv.group.contexts()) (void)mk_sync(ctx);   // (nothing of the library's is under way, on the device or on a thread)
         cout.flush();
         exit(0);                                             // (not _exit: a profiler's exit handlers write its files)
     }

@@ -655,6 +655,12 @@ int mk_sync(mk_ctx *c)
     if (!c) { set_error("null context"); return MK_ERR_ARG; }
     MK_TRY(use_device(c));
     MK_HIP(hipStreamSynchronize(c->stream));
+    {
+        // (and no thread of the library's own is at work for the context: the inflater makes its next blocks on one -- a caller
+        // that leaves by exit() after this must not meet it inside the runtime)
+        std::unique_lock<std::mutex> g(c->gz_m);
+        c->gz_cv.wait(g, [&] { return c->gz_making == 0; });
+    }
     return drain_timers(c);
 }
 
